@@ -1,0 +1,285 @@
+/*
+ * ipde_hip.h — C ABI of libipde_hip.so, the MI355X (gfx950) implementation of
+ * dbstein/ipde's hot path: boundary->target layer-potential sums, periodic FFT
+ * grid solves / spectral + 4th-order derivatives, and the Chebyshev x Fourier
+ * annular solves.
+ *
+ * Conventions (all entry points)
+ *   - return value is a status code (IPDE_OK == 0); no exceptions cross the ABI;
+ *     ipde_last_error(ctx) gives a human readable message for the last failure.
+ *   - all arrays are IEEE fp64 (complex = interleaved re,im fp64), C-contiguous.
+ *   - `loc` says where EVERY array pointer of that call lives: IPDE_HOST (the
+ *     library stages through its own device workspace) or IPDE_DEVICE (zero-copy,
+ *     work is queued on the context's stream; call ipde_ctx_sync before reading
+ *     results from another stream / the host).
+ *   - densities are ALREADY multiplied by the quadrature weights: the reference
+ *     multiplies `ch*src.weights` on the Python side of its own boundary
+ *     (ipde/solvers/internals/poisson.py:31, modified_helmholtz.py:32,
+ *     stokes.py:29) and so does our Python shim.
+ *   - one context per GPU per process (one process per GPU); calls on one context
+ *     are not re-entrant (the reference is single-threaded Python as well).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * the dbstein/ipde tree).
+ */
+#ifndef IPDE_HIP_H
+#define IPDE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ipde_ctx ipde_ctx;
+typedef struct ipde_fft_plan ipde_fft_plan;
+typedef struct ipde_annular_scalar ipde_annular_scalar;
+typedef struct ipde_annular_stokes ipde_annular_stokes;
+
+enum { IPDE_HOST = 0, IPDE_DEVICE = 1 };
+
+enum {
+    IPDE_OK = 0,
+    IPDE_ERR_INVALID = 1,   /* bad argument (null pointer, negative size, bad enum) */
+    IPDE_ERR_HIP = 2,       /* a HIP runtime call failed                             */
+    IPDE_ERR_FFT = 3,       /* a rocFFT call failed                                  */
+    IPDE_ERR_NOGPU = 4,     /* no usable gfx950 device                               */
+    IPDE_ERR_ALLOC = 5,     /* device allocation failed                              */
+    IPDE_ERR_NOCONV = 6     /* GMRES hit maxiter before reaching tol (result is
+                               still written; iters/resid report what was reached) */
+};
+
+/* flags for the layer-potential applies */
+enum {
+    IPDE_FLAG_NONE = 0,
+    /* skip source/target pairs at zero distance (a point set evaluated onto
+       itself); without it such a pair yields inf/nan exactly like the formula */
+    IPDE_FLAG_SKIP_COINCIDENT = 1,
+    /* force the reference-grade generic kernel (libdevice log / no LDS table) */
+    IPDE_FLAG_GENERIC_MATH = 2
+};
+
+/* ------------------------------------------------------------------------- */
+/* context                                                                   */
+
+const char* ipde_version(void);
+
+/* Owns: HIP stream, device workspaces, LDS math tables, rocFFT plan cache.
+   device_id < 0 selects the current device. */
+int ipde_ctx_create(int device_id, ipde_ctx** ctx);
+int ipde_ctx_destroy(ipde_ctx* ctx);
+int ipde_ctx_sync(ipde_ctx* ctx);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all
+   subsequent work; pass NULL to return to the context's own stream. */
+int ipde_ctx_set_stream(ipde_ctx* ctx, void* hip_stream);
+void* ipde_ctx_get_stream(ipde_ctx* ctx);
+const char* ipde_last_error(ipde_ctx* ctx);
+/* Average duration in ms of the dominant kernel of the LAST layer-potential
+   apply, measured with hipEvents on the context's stream (0 if timing is off). */
+/* Tuning knobs (kernel geometry variants); never changes results beyond rounding.
+   Names: "laplace_variant", "stokes_variant". */
+int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value);
+int ipde_ctx_enable_timing(ipde_ctx* ctx, int on);
+int ipde_ctx_last_kernel_ms(ipde_ctx* ctx, double* ms);
+
+/* ------------------------------------------------------------------------- */
+/* layer potentials                                        */
+
+/*
+ * Laplace single+double layer:
+ *   out_i = sum_j [ -(1/2pi) log|t_i-s_j| * w_sigma_j
+ *                   +(1/2pi) (n_j.(t_i-s_j))/|t_i-s_j|^2 * w_tau_j ]
+ * Replaces pybie2d Laplace_Layer_Apply(src, trg, charge=, dipstr=, backend='fly')
+ * as called by PoissonHelper._define_layer_apply
+ * (ipde/solvers/internals/poisson.py:27-36), the Grid_Evaluator closure
+ * (ipde/solvers/multi_boundary/poisson.py:57-62) and
+ * examples/interior_poisson.py:89.
+ * w_sigma NULL => no single layer; w_tau NULL => no double layer (then nx,ny may
+ * be NULL).  Sign of the SLP pinned by ipde/grid_evaluators/
+ * laplace_grid_evaluator.py:8-12; DLP sign by the interior jump D-I/2
+ * (examples/interior_poisson.py:19,84).
+ */
+int ipde_laplace_apply(ipde_ctx* ctx, int loc,
+                       int64_t ns, const double* sx, const double* sy,
+                       const double* w_sigma,
+                       const double* nx, const double* ny, const double* w_tau,
+                       int64_t nt, const double* tx, const double* ty,
+                       double* out, int flags);
+
+/*
+ * Modified Helmholtz (k^2 - Lap) single+double layer:
+ *   out_i = sum_j [ (1/2pi) K0(k r) w_sigma_j + (k/2pi) K1(k r) (n_j.d)/r w_tau_j ]
+ * Replaces pybie2d Modified_Helmholtz_Layer_Apply(src, trg, charge=, k=) as
+ * called by ModifiedHelmholtzHelper._define_layer_apply
+ * (ipde/solvers/internals/modified_helmholtz.py:28-37); SLP pinned by
+ * ipde/grid_evaluators/modified_helmholtz_grid_evaluator.py:8-9.
+ */
+int ipde_modhelm_apply(ipde_ctx* ctx, int loc, double k,
+                       int64_t ns, const double* sx, const double* sy,
+                       const double* w_sigma,
+                       const double* nx, const double* ny, const double* w_tau,
+                       int64_t nt, const double* tx, const double* ty,
+                       double* out, int flags);
+
+/*
+ * Stokes (mu=1) Stokeslet + stresslet with pressure:
+ *   SLP: u = (1/4pi) sum [ -log r f + (d.f) d / r^2 ] ,  p = (1/2pi) sum (d.f)/r^2
+ *   DLP: u = (1/pi)  sum (d.n)(d.g) d / r^4 ,
+ *        p = (1/pi)  sum [ -(n.g)/r^2 + 2 (d.n)(d.g)/r^4 ]
+ * with f=(wfx,wfy) and g=(wdx,wdy) weight-multiplied densities.
+ * Replaces StokesHelper._define_layer_apply (pyfmmlib2d SFMM with
+ * compute_target_stress=True; ipde/solvers/internals/stokes.py:25-35); pressure
+ * formulas restated in ipde/solvers/internals/stokes_save.py:29-81.
+ * wfx/wfy NULL => no SLP; wdx/wdy NULL => no DLP; out_p may be NULL.
+ */
+int ipde_stokes_apply(ipde_ctx* ctx, int loc,
+                      int64_t ns, const double* sx, const double* sy,
+                      const double* wfx, const double* wfy,
+                      const double* nx, const double* ny,
+                      const double* wdx, const double* wdy,
+                      int64_t nt, const double* tx, const double* ty,
+                      double* out_u, double* out_v, double* out_p, int flags);
+
+/* ------------------------------------------------------------------------- */
+/* periodic spectral grid operators                  */
+
+/*
+ * Plan for an (nx, ny) C-ordered real grid with periods Lx = nx*hx, Ly = ny*hy.
+ * Wavenumbers follow ipde/ebdy_collection.py:388-395:
+ *   kx = fftfreq(nx, hx/2pi) (shape (nx,1)), ky = fftfreq(ny, hy/2pi).
+ */
+int ipde_fft_plan2d_create(ipde_ctx* ctx, int64_t nx, int64_t ny,
+                           double hx, double hy, ipde_fft_plan** plan);
+int ipde_fft_plan2d_destroy(ipde_fft_plan* plan);
+
+/* numpy-compatible complex transforms: ipde.utilities.fft2/ifft2
+   (ipde/utilities.py:5-12).  direction: -1 forward, +1 inverse (scaled 1/(nx ny)). */
+int ipde_fft2_c2c(ipde_fft_plan* plan, int loc, int direction,
+                  const double* in_c, double* out_c);
+/* fft2 of a real grid returning the full (nx,ny) complex spectrum. */
+int ipde_fft2_r2c_full(ipde_fft_plan* plan, int loc, const double* in_r, double* out_c);
+
+/*
+ * PoissonSolver._grid_solve (ipde/solvers/multi_boundary/poisson.py:30-38)
+ * without the demean step (caller does ebdyc.demean_function):
+ *   uhat = fft2(f) * ilap, ilap = 1/(-kx^2-ky^2), ilap[0,0] = 0;  u = ifft2(uhat).real
+ * uhat (full (nx,ny) complex) may be NULL.
+ */
+int ipde_poisson_grid_solve(ipde_fft_plan* plan, int loc,
+                            const double* f, double* u, double* uhat);
+/* ModifiedHelmholtzSolver._grid_solve
+   (ipde/solvers/multi_boundary/modified_helmholtz.py:40-46): ihelm = 1/(k^2+kx^2+ky^2) */
+int ipde_modhelm_grid_solve(ipde_fft_plan* plan, int loc, double k,
+                            const double* f, double* u, double* uhat);
+/* StokesSolver._grid_solve (ipde/solvers/multi_boundary/stokes.py:34-50) */
+int ipde_stokes_grid_solve(ipde_fft_plan* plan, int loc,
+                           const double* fu, const double* fv,
+                           double* u, double* v, double* p);
+/*
+ * ipde.derivatives.fourier(f, ik) (ipde/derivatives.py:25-28) for ik = 1j*kx
+ * (axis 0) or 1j*ky (axis 1): out = ifft2(fft2(f)*ik).real
+ */
+int ipde_fourier_deriv(ipde_fft_plan* plan, int loc, const double* f, int axis, double* out);
+/* general symbol: out = ifft2(fft2(f) * sym).real with sym a full (nx,ny)
+   complex array (the reference accepts any broadcastable ik) */
+int ipde_fourier_multiply(ipde_fft_plan* plan, int loc, const double* f,
+                          const double* sym_c, double* out);
+/* ipde.derivatives.fd_x_4 / fd_y_4 (ipde/derivatives.py:3-23): axis 0 = x.
+   Rows/cols within 2 of the edge are zero unless periodic_fix. */
+int ipde_fd4(ipde_ctx* ctx, int loc, int64_t nx, int64_t ny, double h,
+             int axis, int periodic_fix, const double* f, double* out);
+
+/* batched 1-D complex FFT along the last axis of a (batch, n) array:
+   ipde.utilities.fft / ifft (ipde/utilities.py:5-12). direction -1 / +1 (scaled). */
+int ipde_fft1_c2c(ipde_ctx* ctx, int loc, int64_t batch, int64_t n, int direction,
+                  const double* in_c, double* out_c);
+
+/* ------------------------------------------------------------------------- */
+/* annular solvers                                        */
+
+/*
+ * AnnularModifiedHelmholtzSolver / AnnularPoissonSolver
+ * (ipde/annular/modified_helmholtz.py:90-203, ipde/annular/poisson.py:3-21) on the
+ * `annular_full` geometry (ns == n; ipde/solvers/internals/scalar.py:2-3).
+ * The small Chebyshev matrices and the per-mode inverse blocks are set-up data
+ * computed by the Python host exactly as the reference computes them
+ * (ChebyshevOperators, _construct) and handed over once:
+ *   R01 (M-1,M)  R12 (M-2,M-1)  R02 (M-2,M)  D01 (M-1,M)  D12 (M-2,M-1)
+ *   ibc, obc (M,)   = ia*ibc_dirichlet+ib*ibc_neumann, oa*obc_dirichlet+ob*obc_neumann
+ *   kinv (n,M,M) real = Stacked_KINVS.real (modified_helmholtz.py:150-153)
+ * all HOST pointers (set-up is host-side in the reference too).
+ */
+int ipde_annular_scalar_create(ipde_ctx* ctx, int M, int n, double helmholtz_k,
+                               const double* R01, const double* R12, const double* R02,
+                               const double* D01, const double* D12,
+                               const double* ibc, const double* obc,
+                               const double* kinv,
+                               ipde_annular_scalar** h);
+int ipde_annular_scalar_destroy(ipde_annular_scalar* h);
+/* RealAnnularGeometry fields used by _apply (ipde/annular/annular_full.py:87-108):
+   psi1, inv_psi1 (M-1,n), inv_psi2 (M-2,n); HOST or DEVICE per `loc`. */
+int ipde_annular_scalar_set_geometry(ipde_annular_scalar* h, int loc,
+                                     const double* psi1, const double* ipsi1,
+                                     const double* ipsi2);
+/* one operator application in Fourier space: out = _apply(uh)
+   (modified_helmholtz.py:172-186); uh,out complex (M,n) row-major */
+int ipde_annular_scalar_apply(ipde_annular_scalar* h, int loc,
+                              const double* uh_c, double* out_c);
+/* out = _optim_preconditioner(fh) (modified_helmholtz.py:157-159, :68-88) */
+int ipde_annular_scalar_precondition(ipde_annular_scalar* h, int loc,
+                                     const double* fh_c, double* out_c);
+/*
+ * solve (modified_helmholtz.py:187-203): f (M,n) real, ig, og (n,) real ->
+ * out (M,n) real.  Right-preconditioned restarted GMRES on the device; stops when
+ * ||r||/||b|| <= tol.  negate_f != 0 gives AnnularPoissonSolver.solve (f -> -f).
+ */
+int ipde_annular_scalar_solve(ipde_annular_scalar* h, int loc,
+                              const double* f, const double* ig, const double* og,
+                              int negate_f, double tol, int maxiter, int restart,
+                              double* out, int* iters, double* resid);
+
+/*
+ * AnnularStokesSolver (ipde/annular/stokes.py:73-541) on the `annular` geometry
+ * (ns == n-1, Nyquist mode dropped by mfft/mifft, ipde/utilities.py:78-99).
+ * Set-up data (HOST): R01,R12,R02,D01,D12 as above, ibcd, obcd (M,), VI1row0 (M-1,)
+ * = CO.VI1[0], kinv (ns,3M-1,3M-1) complex = Stacked_KINVS, mu.
+ */
+int ipde_annular_stokes_create(ipde_ctx* ctx, int M, int n, double mu,
+                               const double* R01, const double* R12, const double* R02,
+                               const double* D01, const double* D12,
+                               const double* ibcd, const double* obcd,
+                               const double* VI1row0,
+                               const double* kinv_c,
+                               ipde_annular_stokes** h);
+int ipde_annular_stokes_destroy(ipde_annular_stokes* h);
+/* RAG fields (ipde/annular/annular.py:87-108): psi0 (M,n), psi1, ipsi1 (M-1,n),
+   ipsi2, DR_psi2, ipsi_DR_ipsi_DT_psi2, ipsi_DT_ipsi_DR_psi2 (M-2,n) */
+int ipde_annular_stokes_set_geometry(ipde_annular_stokes* h, int loc,
+                                     const double* psi0, const double* psi1,
+                                     const double* ipsi1, const double* ipsi2,
+                                     const double* DR_psi2,
+                                     const double* ipsi_DR_ipsi_DT_psi2,
+                                     const double* ipsi_DT_ipsi_DR_psi2);
+/* out = _apply_optim_real(uuh) (stokes.py:321-385); vectors complex length
+   NB = 2*M*ns + (M-1)*ns */
+int ipde_annular_stokes_apply(ipde_annular_stokes* h, int loc,
+                              const double* uuh_c, double* out_c);
+/* out = _preconditioner(ffh) (stokes.py:200-210, :51-71) */
+int ipde_annular_stokes_precondition(ipde_annular_stokes* h, int loc,
+                                     const double* ffh_c, double* out_c);
+/* solve (stokes.py:519-541): fr, ft (M,n); irg,itg,org,otg (n,) ->
+   ur, ut (M,n), p (M,n) (= P10 . p_{M-1}); P10 (M,M-1) handed in (HOST). */
+int ipde_annular_stokes_solve(ipde_annular_stokes* h, int loc,
+                              const double* fr, const double* ft,
+                              const double* irg, const double* itg,
+                              const double* org, const double* otg,
+                              const double* P10_host,
+                              double tol, int maxiter, int restart,
+                              double* ur, double* ut, double* p,
+                              int* iters, double* resid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPDE_HIP_H */

@@ -1,0 +1,124 @@
+"""ctypes binding of libipde_hip.so (the C ABI declared in include/ipde_hip.h).
+
+The product has NO CPU fallback: if the library is missing or no gfx950 device is
+usable, importing/using this module raises.  torch is imported first on purpose:
+its bundled libamdhip64 / librocfft (sonames libamdhip64.so.7 / librocfft.so.0)
+must be the single HIP runtime of the process so that torch device pointers and
+our kernels live in the same runtime.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede loading libipde_hip.so, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libipde_hip.so")
+
+IPDE_HOST = 0
+IPDE_DEVICE = 1
+
+IPDE_OK = 0
+IPDE_ERR_NOCONV = 6
+FLAG_NONE = 0
+FLAG_SKIP_COINCIDENT = 1
+FLAG_GENERIC_MATH = 2
+
+_STATUS = {
+    1: "invalid argument",
+    2: "HIP runtime error",
+    3: "rocFFT error",
+    4: "no usable gfx950 device",
+    5: "device allocation failed",
+    6: "GMRES did not converge",
+}
+
+
+class IpdeHipError(RuntimeError):
+    pass
+
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+
+# name -> (restype, argtypes); pointer-to-double arguments are declared c_void_p so
+# that raw device addresses (ints) and numpy buffers can both be passed.
+SIGNATURES = {
+    "ipde_version": (ctypes.c_char_p, []),
+    "ipde_ctx_create": (_int, [_int, _c_void_pp]),
+    "ipde_ctx_destroy": (_int, [_vp]),
+    "ipde_ctx_sync": (_int, [_vp]),
+    "ipde_ctx_set_stream": (_int, [_vp, _vp]),
+    "ipde_ctx_get_stream": (_vp, [_vp]),
+    "ipde_last_error": (ctypes.c_char_p, [_vp]),
+    "ipde_ctx_set_option": (_int, [_vp, ctypes.c_char_p, _int]),
+    "ipde_ctx_enable_timing": (_int, [_vp, _int]),
+    "ipde_ctx_last_kernel_ms": (_int, [_vp, _c_double_p]),
+    "ipde_laplace_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
+                                  _vp, _int]),
+    "ipde_modhelm_apply": (_int, [_vp, _int, _dbl, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
+                                  _vp, _vp, _int]),
+    "ipde_stokes_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                 _vp, _vp, _vp, _vp, _vp, _int]),
+    "ipde_fft_plan2d_create": (_int, [_vp, _i64, _i64, _dbl, _dbl, _c_void_pp]),
+    "ipde_fft_plan2d_destroy": (_int, [_vp]),
+    "ipde_fft2_c2c": (_int, [_vp, _int, _int, _vp, _vp]),
+    "ipde_fft2_r2c_full": (_int, [_vp, _int, _vp, _vp]),
+    "ipde_poisson_grid_solve": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "ipde_modhelm_grid_solve": (_int, [_vp, _int, _dbl, _vp, _vp, _vp]),
+    "ipde_stokes_grid_solve": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
+    "ipde_fourier_deriv": (_int, [_vp, _int, _vp, _int, _vp]),
+    "ipde_fourier_multiply": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "ipde_fd4": (_int, [_vp, _int, _i64, _i64, _dbl, _int, _int, _vp, _vp]),
+    "ipde_fft1_c2c": (_int, [_vp, _int, _i64, _i64, _int, _vp, _vp]),
+    "ipde_annular_scalar_create": (_int, [_vp, _int, _int, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _c_void_pp]),
+    "ipde_annular_scalar_destroy": (_int, [_vp]),
+    "ipde_annular_scalar_set_geometry": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "ipde_annular_scalar_apply": (_int, [_vp, _int, _vp, _vp]),
+    "ipde_annular_scalar_precondition": (_int, [_vp, _int, _vp, _vp]),
+    "ipde_annular_scalar_solve": (_int, [_vp, _int, _vp, _vp, _vp, _int, _dbl, _int, _int, _vp,
+                                         ctypes.POINTER(_int), _c_double_p]),
+    "ipde_annular_stokes_create": (_int, [_vp, _int, _int, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _c_void_pp]),
+    "ipde_annular_stokes_destroy": (_int, [_vp]),
+    "ipde_annular_stokes_set_geometry": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ipde_annular_stokes_apply": (_int, [_vp, _int, _vp, _vp]),
+    "ipde_annular_stokes_precondition": (_int, [_vp, _int, _vp, _vp]),
+    "ipde_annular_stokes_solve": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int,
+                                         _int, _vp, _vp, _vp, ctypes.POINTER(_int), _c_double_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libipde_hip.so and attach signatures.  Raises IpdeHipError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IpdeHipError(
+            "libipde_hip.so not found at %s — build it with `python -m ipde_amd.build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, ctx_handle=None, allow=()):
+    if status == IPDE_OK or status in allow:
+        return status
+    msg = _STATUS.get(status, "status %d" % status)
+    if ctx_handle is not None and _lib is not None:
+        detail = _lib.ipde_last_error(ctx_handle)
+        if detail:
+            msg += ": " + detail.decode(errors="replace")
+    raise IpdeHipError(msg)

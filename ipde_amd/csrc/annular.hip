@@ -1,0 +1,1175 @@
+// Chebyshev x Fourier annular solvers on the device.
+//
+// Layout: every field is a (rows, n) row-major array, the tangential (Fourier /
+// theta) index is the fast one, so that "one thread per column" kernels are
+// coalesced and the batched 1-D rocFFTs run along contiguous rows.
+//   * operator apply   : small dense Chebyshev matrices mixed over rows (A is
+//                        wave-uniform -> scalar loads), pointwise metric factors,
+//                        4 batched FFT calls per apply;
+//   * preconditioner   : per-mode dense block K_i^{-1}; stored MODE-MINOR
+//                        ([row][col][mode]) so the one-thread-per-mode matvec
+//                        streams it fully coalesced.  HBM bound: bytes = |KINV|;
+//   * GMRES            : right preconditioned, restarted, Krylov basis resident
+//                        in HBM, CGS2 orthogonalisation (2 fused multi-dots),
+//                        one host sync per iteration (the Hessenberg column).
+#include "ipde_common.h"
+
+int ipde_fft1_exec(ipde_ctx* ctx, int64_t batch, int64_t n, int direction, const void* in,
+                   void* out);
+
+namespace {
+
+typedef double2 cd;
+
+__device__ __forceinline__ cd cmul(cd a, cd b) {
+    return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+
+// out[a, j] = alpha * sum_b A[a,b] * in[b, j] * (colfac ? colfac[j] : 1) + beta * out[a, j]
+// complex data, real A.  grid = (ceil(n/256), ra)
+__global__ __launch_bounds__(256) void mixc_kernel(cd* __restrict__ out, int ldo,
+                                                   const double* __restrict__ A, int ca,
+                                                   const cd* __restrict__ in, int ldi, int n,
+                                                   const cd* __restrict__ colfac, double alpha,
+                                                   double beta) {
+    int j = blockIdx.x * 256 + threadIdx.x;
+    int a = blockIdx.y;
+    if (j >= n) return;
+    const double* Ar = A + (size_t)a * ca;
+    double sr = 0.0, si = 0.0;
+    for (int b = 0; b < ca; ++b) {
+        cd v = in[(size_t)b * ldi + j];
+        double w = Ar[b];
+        sr = fma(w, v.x, sr);
+        si = fma(w, v.y, si);
+    }
+    cd s{sr, si};
+    if (colfac) s = cmul(s, colfac[j]);
+    cd o{alpha * s.x, alpha * s.y};
+    if (beta != 0.0) {
+        cd p = out[(size_t)a * ldo + j];
+        o.x = fma(beta, p.x, o.x);
+        o.y = fma(beta, p.y, o.y);
+    }
+    out[(size_t)a * ldo + j] = o;
+}
+
+// real-space variant on the REAL PART of complex input rows, real output rows:
+// out[a, j] = beta*out[a,j] + alpha * P[a,j] * sum_b A[a,b] * Q[b,j] * Re(in[b, j])
+// P, Q nullable real fields.
+__global__ __launch_bounds__(256) void mixr_kernel(double* __restrict__ out, int ldo,
+                                                   const double* __restrict__ A, int ca,
+                                                   const cd* __restrict__ in, int ldi, int n,
+                                                   const double* __restrict__ Q, int ldq,
+                                                   const double* __restrict__ P, int ldp,
+                                                   double alpha, double beta) {
+    int j = blockIdx.x * 256 + threadIdx.x;
+    int a = blockIdx.y;
+    if (j >= n) return;
+    const double* Ar = A + (size_t)a * ca;
+    double s = 0.0;
+    for (int b = 0; b < ca; ++b) {
+        double v = in[(size_t)b * ldi + j].x;
+        if (Q) v *= Q[(size_t)b * ldq + j];
+        s = fma(Ar[b], v, s);
+    }
+    if (P) s *= P[(size_t)a * ldp + j];
+    double o = alpha * s;
+    if (beta != 0.0) o = fma(beta, out[(size_t)a * ldo + j], o);
+    out[(size_t)a * ldo + j] = o;
+}
+
+// same, but the input rows are real arrays
+__global__ __launch_bounds__(256) void mixrr_kernel(double* __restrict__ out, int ldo,
+                                                    const double* __restrict__ A, int ca,
+                                                    const double* __restrict__ in, int ldi, int n,
+                                                    const double* __restrict__ P, int ldp,
+                                                    double alpha, double beta) {
+    int j = blockIdx.x * 256 + threadIdx.x;
+    int a = blockIdx.y;
+    if (j >= n) return;
+    const double* Ar = A + (size_t)a * ca;
+    double s = 0.0;
+    for (int b = 0; b < ca; ++b) s = fma(Ar[b], in[(size_t)b * ldi + j], s);
+    if (P) s *= P[(size_t)a * ldp + j];
+    double o = alpha * s;
+    if (beta != 0.0) o = fma(beta, out[(size_t)a * ldo + j], o);
+    out[(size_t)a * ldo + j] = o;
+}
+
+// complex rows times a real field (and a constant): x[a,j] *= s * F[a,j]
+__global__ __launch_bounds__(256) void cscale_field_kernel(cd* __restrict__ x, int rows, int n,
+                                                           const double* __restrict__ F, double s) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * n) return;
+    double f = s * F[idx];
+    cd v = x[idx];
+    x[idx] = cd{v.x * f, v.y * f};
+}
+
+// y[a,j] += alpha * x[a,j] (complex)
+__global__ __launch_bounds__(256) void caxpy_kernel(cd* __restrict__ y, const cd* __restrict__ x,
+                                                    int64_t n, double alpha) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    cd a = y[idx], b = x[idx];
+    y[idx] = cd{fma(alpha, b.x, a.x), fma(alpha, b.y, a.y)};
+}
+
+// real (rows,n) -> complex with zero imaginary part, times s
+__global__ __launch_bounds__(256) void r2c_copy_kernel(cd* __restrict__ y,
+                                                       const double* __restrict__ x, int64_t n,
+                                                       double s) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    y[idx] = cd{s * x[idx], 0.0};
+}
+__global__ __launch_bounds__(256) void c2r_real_kernel(double* __restrict__ y,
+                                                       const cd* __restrict__ x, int64_t n,
+                                                       double s) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    y[idx] = s * x[idx].x;
+}
+
+// Nyquist handling of ipde/utilities.py:78-99.  ns = n-1, N2 = n/2.
+// splat: (rows, ns) -> (rows, n) with a zero column at N2, times colfac[js] (nullable)
+__global__ __launch_bounds__(256) void splat_kernel(cd* __restrict__ out,
+                                                    const cd* __restrict__ in, int rows, int n,
+                                                    const cd* __restrict__ colfac) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * n) return;
+    int a = (int)(idx / n), j = (int)(idx - (int64_t)a * n);
+    const int N2 = n / 2, ns = n - 1;
+    cd v{0.0, 0.0};
+    if (j != N2) {
+        int js = j < N2 ? j : j - 1;
+        v = in[(size_t)a * ns + js];
+        if (colfac) v = cmul(v, colfac[js]);
+    }
+    out[idx] = v;
+}
+// desplat: (rows, n) -> (rows, ns) dropping column N2, times colfac[js], times s
+__global__ __launch_bounds__(256) void desplat_kernel(cd* __restrict__ out,
+                                                      const cd* __restrict__ in, int rows, int n,
+                                                      const cd* __restrict__ colfac, double s) {
+    const int ns = n - 1, N2 = n / 2;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * ns) return;
+    int a = (int)(idx / ns), js = (int)(idx - (int64_t)a * ns);
+    int j = js < N2 ? js : js + 1;
+    cd v = in[(size_t)a * n + j];
+    if (colfac) v = cmul(v, colfac[js]);
+    out[idx] = cd{s * v.x, s * v.y};
+}
+
+// ---- preconditioners -------------------------------------------------------
+// scalar: Kt real [M][M][n] mode-minor.  out[j, i] = sum_k Kt[j][k][i] x[k, i]
+// grid = (ceil(n/256), M)
+__global__ __launch_bounds__(256) void prec_scalar_kernel(cd* __restrict__ out,
+                                                          const double* __restrict__ Kt,
+                                                          const cd* __restrict__ x, int M, int n) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= n) return;
+    const double* K = Kt + (size_t)j * M * n + i;
+    double sr = 0.0, si = 0.0;
+    for (int k = 0; k < M; ++k) {
+        double w = K[(size_t)k * n];
+        cd v = x[(size_t)k * n + i];
+        sr = fma(w, v.x, sr);
+        si = fma(w, v.y, si);
+    }
+    out[(size_t)j * n + i] = cd{sr, si};
+}
+// complex blocks: Kt complex [B][B][ns] mode-minor, x/out as (B, ns) row-major
+__global__ __launch_bounds__(256) void prec_cplx_kernel(cd* __restrict__ out,
+                                                        const cd* __restrict__ Kt,
+                                                        const cd* __restrict__ x, int B, int ns) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= ns) return;
+    const cd* K = Kt + (size_t)j * B * ns + i;
+    double sr = 0.0, si = 0.0;
+    for (int k = 0; k < B; ++k) {
+        cd w = K[(size_t)k * ns];
+        cd v = x[(size_t)k * ns + i];
+        sr = fma(w.x, v.x, sr);
+        sr = fma(-w.y, v.y, sr);
+        si = fma(w.x, v.y, si);
+        si = fma(w.y, v.x, si);
+    }
+    out[(size_t)j * ns + i] = cd{sr, si};
+}
+
+// ---- GMRES vector kernels --------------------------------------------------
+// h[i] = <V_i, w> = sum conj(V_i) * w, i = blockIdx.x < nv.  One block per vector.
+__global__ __launch_bounds__(1024) void multidot_kernel(const cd* __restrict__ V, int64_t ld,
+                                                        const cd* __restrict__ w, int64_t n,
+                                                        cd* __restrict__ h) {
+    const cd* v = V + (size_t)blockIdx.x * ld;
+    double sr = 0.0, si = 0.0;
+    for (int64_t k = threadIdx.x; k < n; k += 1024) {
+        cd a = v[k], b = w[k];
+        sr = fma(a.x, b.x, sr);
+        sr = fma(a.y, b.y, sr);
+        si = fma(a.x, b.y, si);
+        si = fma(-a.y, b.x, si);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sr += __shfl_xor(sr, o);
+        si += __shfl_xor(si, o);
+    }
+    __shared__ double red[16][2];
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wv][0] = sr;
+        red[wv][1] = si;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < 16; ++i) {
+            a += red[i][0];
+            b += red[i][1];
+        }
+        h[blockIdx.x] = cd{a, b};
+    }
+}
+// w -= sum_i h[i] V_i
+__global__ __launch_bounds__(256) void multiaxpy_kernel(cd* __restrict__ w,
+                                                        const cd* __restrict__ V, int64_t ld,
+                                                        const cd* __restrict__ h, int nv,
+                                                        int64_t n) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    cd acc = w[k];
+    for (int i = 0; i < nv; ++i) {
+        cd c = h[i];
+        cd v = V[(size_t)i * ld + k];
+        acc.x -= c.x * v.x - c.y * v.y;
+        acc.y -= c.x * v.y + c.y * v.x;
+    }
+    w[k] = acc;
+}
+// y = sum_i c[i] V_i  (c on device)
+__global__ __launch_bounds__(256) void lincomb_kernel(cd* __restrict__ y, const cd* __restrict__ V,
+                                                      int64_t ld, const cd* __restrict__ c, int nv,
+                                                      int64_t n) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    cd acc{0.0, 0.0};
+    for (int i = 0; i < nv; ++i) {
+        cd ci = c[i];
+        cd v = V[(size_t)i * ld + k];
+        acc.x += ci.x * v.x - ci.y * v.y;
+        acc.y += ci.x * v.y + ci.y * v.x;
+    }
+    y[k] = acc;
+}
+__global__ __launch_bounds__(256) void cscale_copy_kernel(cd* __restrict__ y,
+                                                          const cd* __restrict__ x, int64_t n,
+                                                          double s) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    cd v = x[k];
+    y[k] = cd{s * v.x, s * v.y};
+}
+
+inline unsigned nb256(int64_t n) { return (unsigned)ceil_div64(n, 256); }
+
+// ---------------------------------------------------------------------------
+struct LinOp {
+    ipde_ctx* ctx = nullptr;
+    int64_t NB = 0;
+    virtual int apply(const cd* in, cd* out) = 0;
+    virtual int precond(const cd* in, cd* out) = 0;
+    virtual ~LinOp() {}
+};
+
+struct GmresWork {
+    cd* V = nullptr;   // (restart+1, NB)
+    cd* w = nullptr;   // NB
+    cd* z = nullptr;   // NB
+    cd* x = nullptr;   // NB
+    cd* t = nullptr;   // NB
+    cd* hdev = nullptr;  // 2*(restart+2)
+    int restart_cap = 0;
+    int64_t nb_cap = 0;
+};
+
+int gmres_reserve(ipde_ctx* ctx, GmresWork& g, int64_t NB, int restart) {
+    if (g.V && restart <= g.restart_cap && NB <= g.nb_cap) return IPDE_OK;
+    hipStreamSynchronize(ctx->stream);
+    for (cd** p : {&g.V, &g.w, &g.z, &g.x, &g.t, &g.hdev})
+        if (*p) {
+            hipFree(*p);
+            *p = nullptr;
+        }
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.V, (size_t)(restart + 1) * NB * sizeof(cd)));
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.w, NB * sizeof(cd)));
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.z, NB * sizeof(cd)));
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.x, NB * sizeof(cd)));
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.t, NB * sizeof(cd)));
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.hdev, (size_t)(2 * restart + 8) * sizeof(cd)));
+    g.restart_cap = restart;
+    g.nb_cap = NB;
+    return IPDE_OK;
+}
+void gmres_free(GmresWork& g) {
+    for (cd** p : {&g.V, &g.w, &g.z, &g.x, &g.t, &g.hdev})
+        if (*p) {
+            hipFree(*p);
+            *p = nullptr;
+        }
+}
+
+struct hc {
+    double re, im;
+};
+inline hc hmul(hc a, hc b) { return hc{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+inline hc hconj(hc a) { return hc{a.re, -a.im}; }
+inline double habs(hc a) { return hypot(a.re, a.im); }
+
+// Right-preconditioned restarted GMRES for A x = b (x0 = 0).  The result is left
+// in g.x.  Stops when ||r|| <= tol*||b||.  iters = total inner iterations.
+int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, int restart,
+                int* iters_out, double* resid_out) {
+    ipde_ctx* ctx = op.ctx;
+    const int64_t NB = op.NB;
+    hipStream_t st = ctx->stream;
+    if (restart < 1) restart = 1;
+    if (maxiter < 1) maxiter = 1;
+    IPDE_TRY(gmres_reserve(ctx, g, NB, restart));
+    IPDE_HIP_CHECK(ctx, hipMemsetAsync(g.x, 0, NB * sizeof(cd), st));
+    cd* hp = (cd*)ctx->h_pinned;  // pinned: [restart+2] entries used per transfer
+    // ||b||
+    hipLaunchKernelGGL(multidot_kernel, dim3(1), dim3(1024), 0, st, b, NB, b, NB, g.hdev);
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, g.hdev, sizeof(cd), hipMemcpyDeviceToHost, st));
+    IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const double bnorm = sqrt(hp[0].x);
+    int iters = 0;
+    double resid = 0.0;
+    int status = IPDE_OK;
+    if (!(bnorm > 0.0)) {
+        *iters_out = 0;
+        *resid_out = 0.0;
+        return IPDE_OK;
+    }
+    std::vector<hc> H((size_t)(restart + 1) * restart), cs(restart), sn(restart), gv(restart + 1);
+    bool converged = false;
+    bool first_cycle = true;
+    while (!converged && iters < maxiter) {
+        // r = b - A x   (x = 0 in the first cycle)
+        double beta;
+        if (first_cycle) {
+            hipLaunchKernelGGL(cscale_copy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.V, b, NB,
+                               1.0 / bnorm);
+            beta = bnorm;
+            first_cycle = false;
+        } else {
+            IPDE_TRY(op.apply(g.x, g.w));
+            hipLaunchKernelGGL(cscale_copy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.t, b, NB, 1.0);
+            hipLaunchKernelGGL(caxpy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.t,
+                               (const cd*)g.w, NB, -1.0);
+            hipLaunchKernelGGL(multidot_kernel, dim3(1), dim3(1024), 0, st, (const cd*)g.t, NB,
+                               (const cd*)g.t, NB, g.hdev);
+            IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, g.hdev, sizeof(cd), hipMemcpyDeviceToHost, st));
+            IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            beta = sqrt(hp[0].x);
+            if (beta <= tol * bnorm) {
+                resid = beta / bnorm;
+                converged = true;
+                break;
+            }
+            hipLaunchKernelGGL(cscale_copy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.V,
+                               (const cd*)g.t, NB, 1.0 / beta);
+        }
+        for (auto& v : gv) v = hc{0.0, 0.0};
+        gv[0] = hc{beta, 0.0};
+        int j = 0;
+        for (; j < restart && iters < maxiter; ++j) {
+            cd* vj = g.V + (size_t)j * NB;
+            IPDE_TRY(op.precond(vj, g.z));
+            IPDE_TRY(op.apply(g.z, g.w));
+            // CGS2
+            cd* h1 = g.hdev;
+            cd* h2 = g.hdev + (restart + 2);
+            hipLaunchKernelGGL(multidot_kernel, dim3(j + 1), dim3(1024), 0, st, (const cd*)g.V, NB,
+                               (const cd*)g.w, NB, h1);
+            hipLaunchKernelGGL(multiaxpy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.w,
+                               (const cd*)g.V, NB, (const cd*)h1, j + 1, NB);
+            hipLaunchKernelGGL(multidot_kernel, dim3(j + 1), dim3(1024), 0, st, (const cd*)g.V, NB,
+                               (const cd*)g.w, NB, h2);
+            hipLaunchKernelGGL(multiaxpy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.w,
+                               (const cd*)g.V, NB, (const cd*)h2, j + 1, NB);
+            hipLaunchKernelGGL(multidot_kernel, dim3(1), dim3(1024), 0, st, (const cd*)g.w, NB,
+                               (const cd*)g.w, NB, h1 + (j + 1));
+            IPDE_HIP_CHECK(ctx, hipGetLastError());
+            IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, g.hdev, (size_t)(2 * restart + 4) * sizeof(cd),
+                                               hipMemcpyDeviceToHost, st));
+            IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            hc* col = &H[(size_t)j * (restart + 1)];
+            for (int i = 0; i <= j; ++i)
+                col[i] = hc{hp[i].x + hp[restart + 2 + i].x, hp[i].y + hp[restart + 2 + i].y};
+            double hn = sqrt(fmax(hp[j + 1].x, 0.0));
+            col[j + 1] = hc{hn, 0.0};
+            if (hn > 0.0)
+                hipLaunchKernelGGL(cscale_copy_kernel, dim3(nb256(NB)), dim3(256), 0, st,
+                                   g.V + (size_t)(j + 1) * NB, (const cd*)g.w, NB, 1.0 / hn);
+            // Givens
+            for (int i = 0; i < j; ++i) {
+                hc a = col[i], bb = col[i + 1];
+                hc t1 = hmul(hconj(cs[i]), a);
+                hc t2 = hmul(hconj(sn[i]), bb);
+                hc n1{t1.re + t2.re, t1.im + t2.im};
+                hc t3 = hmul(sn[i], a);
+                hc t4 = hmul(cs[i], bb);
+                hc n2{-t3.re + t4.re, -t3.im + t4.im};
+                col[i] = n1;
+                col[i + 1] = n2;
+            }
+            {
+                hc a = col[j], bb = col[j + 1];
+                double den = hypot(habs(a), habs(bb));
+                if (den == 0.0) den = 1.0;
+                cs[j] = hc{a.re / den, a.im / den};
+                sn[j] = hc{bb.re / den, bb.im / den};
+                col[j] = hc{den, 0.0};
+                col[j + 1] = hc{0.0, 0.0};
+                hc gj = gv[j];
+                gv[j] = hmul(hconj(cs[j]), gj);
+                hc tmp = hmul(sn[j], gj);
+                gv[j + 1] = hc{-tmp.re, -tmp.im};
+            }
+            ++iters;
+            resid = habs(gv[j + 1]) / bnorm;
+            if (resid <= tol || hn == 0.0) {
+                converged = resid <= tol || hn == 0.0;
+                ++j;
+                break;
+            }
+        }
+        // solve the j x j triangular system, x += M^{-1} V y
+        int m = j;
+        std::vector<hc> y(m);
+        for (int i = m - 1; i >= 0; --i) {
+            hc s = gv[i];
+            for (int k = i + 1; k < m; ++k) {
+                hc t = hmul(H[(size_t)k * (restart + 1) + i], y[k]);
+                s.re -= t.re;
+                s.im -= t.im;
+            }
+            hc d = H[(size_t)i * (restart + 1) + i];
+            double dd = d.re * d.re + d.im * d.im;
+            if (dd == 0.0) {
+                y[i] = hc{0.0, 0.0};
+            } else {
+                y[i] = hc{(s.re * d.re + s.im * d.im) / dd, (s.im * d.re - s.re * d.im) / dd};
+            }
+        }
+        for (int i = 0; i < m; ++i) hp[i] = cd{y[i].re, y[i].im};
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(g.hdev, hp, (size_t)m * sizeof(cd),
+                                           hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(lincomb_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.t, (const cd*)g.V, NB,
+                           (const cd*)g.hdev, m, NB);
+        IPDE_TRY(op.precond(g.t, g.z));
+        hipLaunchKernelGGL(caxpy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.x, (const cd*)g.z, NB,
+                           1.0);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+        // the pinned buffer is reused by the next cycle
+        IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
+    if (!converged) status = IPDE_ERR_NOCONV;
+    *iters_out = iters;
+    *resid_out = resid;
+    return status;
+}
+
+int upload(ipde_ctx* ctx, double** d, const double* h, size_t n) {
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)d, n * sizeof(double)));
+    IPDE_HIP_CHECK(ctx, hipMemcpy(*d, h, n * sizeof(double), hipMemcpyHostToDevice));
+    return IPDE_OK;
+}
+
+int set_field(ipde_ctx* ctx, int loc, double* dst, const double* src, size_t n) {
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, n * sizeof(double),
+                                       loc == IPDE_HOST ? hipMemcpyHostToDevice
+                                                        : hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+    if (loc == IPDE_HOST) IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return IPDE_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// scalar (modified Helmholtz / Poisson) annular solver
+struct ipde_annular_scalar : public LinOp {
+    int M = 0, n = 0;
+    double k2 = 0.0;
+    double *R01 = nullptr, *R12 = nullptr, *D01 = nullptr, *D12 = nullptr, *R02 = nullptr;
+    double* Bmat = nullptr;  // (M, M): [k^2 R02; ibc; obc]
+    double* Kt = nullptr;    // [M][M][n]
+    cd* iks = nullptr;       // (n)
+    double *psi1 = nullptr, *ipsi1 = nullptr, *ipsi2 = nullptr;
+    cd *T = nullptr, *U = nullptr;  // 2(M-1) x n work
+    cd *bvec = nullptr;
+    double* rwork = nullptr;        // (M, n) real work
+    cd *hin = nullptr, *hout = nullptr;  // host-call staging
+    GmresWork gw;
+    bool have_geom = false;
+
+    int apply(const cd* uh, cd* out) override {
+        hipStream_t st = ctx->stream;
+        const int m1 = M - 1, m2 = M - 2;
+        dim3 b(256);
+        // T1 = R01 (uh * iks), T2 = D01 uh
+        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), m1), b, 0, st, T, n, (const double*)R01, M, uh,
+                           n, n, (const cd*)iks, 1.0, 0.0);
+        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), m1), b, 0, st, T + (size_t)m1 * n, n,
+                           (const double*)D01, M, uh, n, n, (const cd*)nullptr, 1.0, 0.0);
+        IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, +1, T, U));
+        hipLaunchKernelGGL(cscale_field_kernel, dim3(nb256((int64_t)m1 * n)), b, 0, st, U, m1, n,
+                           (const double*)ipsi1, 1.0 / n);
+        hipLaunchKernelGGL(cscale_field_kernel, dim3(nb256((int64_t)m1 * n)), b, 0, st,
+                           U + (size_t)m1 * n, m1, n, (const double*)psi1, 1.0 / n);
+        IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, -1, U, T));
+        // S = R12 (T1 * iks) + D12 T2   -> U[0:m2]
+        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), m2), b, 0, st, U, n, (const double*)R12, m1,
+                           (const cd*)T, n, n, (const cd*)iks, 1.0, 0.0);
+        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), m2), b, 0, st, U, n, (const double*)D12, m1,
+                           (const cd*)(T + (size_t)m1 * n), n, n, (const cd*)nullptr, 1.0, 1.0);
+        IPDE_TRY(ipde_fft1_exec(ctx, m2, n, +1, U, T));
+        hipLaunchKernelGGL(cscale_field_kernel, dim3(nb256((int64_t)m2 * n)), b, 0, st, T, m2, n,
+                           (const double*)ipsi2, 1.0 / n);
+        IPDE_TRY(ipde_fft1_exec(ctx, m2, n, -1, T, U));
+        // out = B uh ; out[0:m2] -= luh
+        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), M), b, 0, st, out, n, (const double*)Bmat, M,
+                           uh, n, n, (const cd*)nullptr, 1.0, 0.0);
+        hipLaunchKernelGGL(caxpy_kernel, dim3(nb256((int64_t)m2 * n)), b, 0, st, out, (const cd*)U,
+                           (int64_t)m2 * n, -1.0);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+        return IPDE_OK;
+    }
+    int precond(const cd* in, cd* out) override {
+        hipLaunchKernelGGL(prec_scalar_kernel, dim3(nb256(n), M), dim3(256), 0, ctx->stream, out,
+                           (const double*)Kt, in, M, n);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+        return IPDE_OK;
+    }
+    ~ipde_annular_scalar() override {
+        for (double** p : {&R01, &R12, &D01, &D12, &R02, &Bmat, &Kt, &psi1, &ipsi1, &ipsi2, &rwork})
+            if (*p) hipFree(*p);
+        for (cd** p : {&iks, &T, &U, &bvec, &hin, &hout})
+            if (*p) hipFree(*p);
+        gmres_free(gw);
+    }
+};
+
+extern "C" int ipde_annular_scalar_create(ipde_ctx* ctx, int M, int n, double helmholtz_k,
+                                          const double* R01, const double* R12, const double* R02,
+                                          const double* D01, const double* D12, const double* ibc,
+                                          const double* obc, const double* kinv,
+                                          ipde_annular_scalar** out) {
+    if (!ctx || !out) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, M >= 4 && M <= 256 && n >= 4);
+    IPDE_CHECK_ARG(ctx, R01 && R12 && R02 && D01 && D12 && ibc && obc && kinv);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ipde_annular_scalar* h = new ipde_annular_scalar();
+    h->ctx = ctx;
+    h->M = M;
+    h->n = n;
+    h->NB = (int64_t)M * n;
+    h->k2 = helmholtz_k * helmholtz_k;
+    const int m1 = M - 1, m2 = M - 2;
+    int st = IPDE_OK;
+    auto up = [&](double** d, const double* s, size_t cnt) {
+        if (st == IPDE_OK) st = upload(ctx, d, s, cnt);
+    };
+    up(&h->R01, R01, (size_t)m1 * M);
+    up(&h->R12, R12, (size_t)m2 * m1);
+    up(&h->R02, R02, (size_t)m2 * M);
+    up(&h->D01, D01, (size_t)m1 * M);
+    up(&h->D12, D12, (size_t)m2 * m1);
+    std::vector<double> B((size_t)M * M);
+    for (int a = 0; a < m2; ++a)
+        for (int b = 0; b < M; ++b) B[(size_t)a * M + b] = h->k2 * R02[(size_t)a * M + b];
+    for (int b = 0; b < M; ++b) {
+        B[(size_t)m2 * M + b] = ibc[b];
+        B[(size_t)m1 * M + b] = obc[b];
+    }
+    up(&h->Bmat, B.data(), B.size());
+    {   // mode-minor transpose of the inverse blocks: Kt[j][k][i] = kinv[i][j][k]
+        std::vector<double> Kt((size_t)M * M * n);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < M; ++j)
+                for (int k = 0; k < M; ++k)
+                    Kt[((size_t)j * M + k) * n + i] = kinv[((size_t)i * M + j) * M + k];
+        up(&h->Kt, Kt.data(), Kt.size());
+    }
+    {   // iks = 1j * fftfreq(n, 1/n)  (annular_full.py:67-71)
+        std::vector<double> v(2 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            int s = (i < (n + 1) / 2) ? i : i - n;
+            v[2 * i] = 0.0;
+            v[2 * i + 1] = (double)s;
+        }
+        up((double**)&h->iks, v.data(), v.size());
+    }
+    auto al = [&](void** d, size_t bytes) {
+        if (st == IPDE_OK && hipMalloc(d, bytes) != hipSuccess) st = IPDE_ERR_ALLOC;
+    };
+    al((void**)&h->psi1, (size_t)m1 * n * sizeof(double));
+    al((void**)&h->ipsi1, (size_t)m1 * n * sizeof(double));
+    al((void**)&h->ipsi2, (size_t)m2 * n * sizeof(double));
+    al((void**)&h->T, (size_t)2 * m1 * n * sizeof(cd));
+    al((void**)&h->U, (size_t)2 * m1 * n * sizeof(cd));
+    al((void**)&h->bvec, (size_t)M * n * sizeof(cd));
+    al((void**)&h->rwork, (size_t)(M + 2) * n * sizeof(double));
+    al((void**)&h->hin, (size_t)M * n * sizeof(cd));
+    al((void**)&h->hout, (size_t)M * n * sizeof(cd));
+    if (st != IPDE_OK) {
+        delete h;
+        return st;
+    }
+    *out = h;
+    return IPDE_OK;
+}
+
+extern "C" int ipde_annular_scalar_destroy(ipde_annular_scalar* h) {
+    if (!h) return IPDE_ERR_INVALID;
+    hipSetDevice(h->ctx->device);
+    hipStreamSynchronize(h->ctx->stream);
+    delete h;
+    return IPDE_OK;
+}
+
+extern "C" int ipde_annular_scalar_set_geometry(ipde_annular_scalar* h, int loc, const double* psi1,
+                                                const double* ipsi1, const double* ipsi2) {
+    if (!h) return IPDE_ERR_INVALID;
+    ipde_ctx* ctx = h->ctx;
+    IPDE_CHECK_ARG(ctx, psi1 && ipsi1 && ipsi2);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    IPDE_TRY(set_field(ctx, loc, h->psi1, psi1, (size_t)(h->M - 1) * h->n));
+    IPDE_TRY(set_field(ctx, loc, h->ipsi1, ipsi1, (size_t)(h->M - 1) * h->n));
+    IPDE_TRY(set_field(ctx, loc, h->ipsi2, ipsi2, (size_t)(h->M - 2) * h->n));
+    h->have_geom = true;
+    return IPDE_OK;
+}
+
+namespace {
+template <class H, class F>
+int run_vec_op(H* h, int loc, const double* in_c, double* out_c, int64_t NB, F f) {
+    ipde_ctx* ctx = h->ctx;
+    IPDE_CHECK_ARG(ctx, in_c && out_c);
+    IPDE_CHECK_ARG(ctx, loc == IPDE_HOST || loc == IPDE_DEVICE);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const cd* d_in = (const cd*)in_c;
+    cd* d_out = (cd*)out_c;
+    if (loc == IPDE_HOST) {
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(h->hin, in_c, NB * sizeof(cd), hipMemcpyHostToDevice,
+                                           ctx->stream));
+        d_in = h->hin;
+        d_out = h->hout;
+    }
+    IPDE_TRY(f(d_in, d_out));
+    if (loc == IPDE_HOST) {
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(out_c, h->hout, NB * sizeof(cd), hipMemcpyDeviceToHost,
+                                           ctx->stream));
+        IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return IPDE_OK;
+}
+}  // namespace
+
+extern "C" int ipde_annular_scalar_apply(ipde_annular_scalar* h, int loc, const double* uh_c,
+                                         double* out_c) {
+    if (!h) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(h->ctx, h->have_geom);
+    return run_vec_op(h, loc, uh_c, out_c, h->NB,
+                      [&](const cd* a, cd* b) { return h->apply(a, b); });
+}
+
+extern "C" int ipde_annular_scalar_precondition(ipde_annular_scalar* h, int loc,
+                                                const double* fh_c, double* out_c) {
+    if (!h) return IPDE_ERR_INVALID;
+    return run_vec_op(h, loc, fh_c, out_c, h->NB,
+                      [&](const cd* a, cd* b) { return h->precond(a, b); });
+}
+
+extern "C" int ipde_annular_scalar_solve(ipde_annular_scalar* h, int loc, const double* f,
+                                         const double* ig, const double* og, int negate_f,
+                                         double tol, int maxiter, int restart, double* out,
+                                         int* iters, double* resid) {
+    if (!h) return IPDE_ERR_INVALID;
+    ipde_ctx* ctx = h->ctx;
+    IPDE_CHECK_ARG(ctx, f && ig && og && out && iters && resid);
+    IPDE_CHECK_ARG(ctx, h->have_geom);
+    IPDE_CHECK_ARG(ctx, loc == IPDE_HOST || loc == IPDE_DEVICE);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int M = h->M, n = h->n, m2 = M - 2;
+    // real staging: rwork = [f (M,n) | ig | og]
+    double* rw = h->rwork;
+    auto kind = loc == IPDE_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(rw, f, (size_t)M * n * sizeof(double), kind, st));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(rw + (size_t)M * n, ig, n * sizeof(double), kind, st));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(rw + (size_t)(M + 1) * n, og, n * sizeof(double), kind, st));
+    // ff = [R02 f ; ig ; og] as real rows in U (used as real scratch), then complexify -> T
+    double* ffr = (double*)h->U;
+    hipLaunchKernelGGL(mixrr_kernel, dim3(nb256(n), m2), dim3(256), 0, st, ffr, n,
+                       (const double*)h->R02, M, (const double*)rw, n, n, (const double*)nullptr, 0,
+                       negate_f ? -1.0 : 1.0, 0.0);
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(ffr + (size_t)m2 * n, rw + (size_t)M * n,
+                                       2 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256((int64_t)M * n)), dim3(256), 0, st, h->T,
+                       (const double*)ffr, (int64_t)M * n, 1.0);
+    IPDE_TRY(ipde_fft1_exec(ctx, M, n, -1, h->T, h->bvec));
+    int st_g = gmres_solve(*h, h->gw, h->bvec, tol, maxiter, restart, iters, resid);
+    if (st_g != IPDE_OK && st_g != IPDE_ERR_NOCONV) return st_g;
+    // out = ifft(x).real
+    IPDE_TRY(ipde_fft1_exec(ctx, M, n, +1, h->gw.x, h->T));
+    double* d_out = loc == IPDE_HOST ? rw : out;
+    hipLaunchKernelGGL(c2r_real_kernel, dim3(nb256((int64_t)M * n)), dim3(256), 0, st, d_out,
+                       (const cd*)h->T, (int64_t)M * n, 1.0 / n);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    if (loc == IPDE_HOST) {
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(out, rw, (size_t)M * n * sizeof(double),
+                                           hipMemcpyDeviceToHost, st));
+        IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
+    if (st_g == IPDE_ERR_NOCONV)
+        IPDE_SET_ERR(ctx, "annular scalar GMRES: no convergence in %d iterations (resid %.3e)",
+                     *iters, *resid);
+    return st_g;
+}
+
+// ===========================================================================
+// Stokes annular solver (ns = n-1 modes)
+struct ipde_annular_stokes : public LinOp {
+    int M = 0, n = 0, ns = 0;
+    double mu = 1.0;
+    int64_t NU = 0, NP = 0;
+    double *R01 = nullptr, *R12 = nullptr, *R02 = nullptr, *D01 = nullptr, *D12 = nullptr;
+    double* BC = nullptr;    // (2, M): [ibcd; obcd]
+    double* VI1 = nullptr;   // (M-1)
+    cd* Kt = nullptr;        // [B][B][ns] complex
+    cd* iks = nullptr;       // (ns)
+    double *psi0 = nullptr, *psi1 = nullptr, *ipsi1 = nullptr, *ipsi2 = nullptr;
+    double *combo1 = nullptr, *combo2 = nullptr, *c3 = nullptr, *c4 = nullptr, *DRpsi2 = nullptr;
+    cd *A = nullptr, *Bw = nullptr;   // complex work, (6M) x n each
+    double* Rw = nullptr;             // real work (4M) x n
+    cd *xs = nullptr, *ys = nullptr;  // preconditioner stacking (B, ns)
+    cd* bvec = nullptr;
+    cd *hin = nullptr, *hout = nullptr;
+    double* rstage = nullptr;
+    GmresWork gw;
+    bool have_geom = false;
+
+    int apply(const cd* uuh, cd* out) override;
+    int precond(const cd* in, cd* out) override {
+        // unknown ordering [ur (M,ns); ut (M,ns); p (M-1,ns)] is already the (B, ns)
+        // row-major stacking the block matvec wants (stokes.py:200-210 transposes
+        // only because its blocks are stored mode-major)
+        const int B = 3 * M - 1;
+        hipLaunchKernelGGL(prec_cplx_kernel, dim3(nb256(ns), B), dim3(256), 0, ctx->stream, out,
+                           (const cd*)Kt, in, B, ns);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+        return IPDE_OK;
+    }
+    ~ipde_annular_stokes() override {
+        for (double** p : {&R01, &R12, &R02, &D01, &D12, &BC, &VI1, &psi0, &psi1, &ipsi1, &ipsi2,
+                           &combo1, &combo2, &c3, &c4, &DRpsi2, &Rw, &rstage})
+            if (*p) hipFree(*p);
+        for (cd** p : {&Kt, &iks, &A, &Bw, &xs, &ys, &bvec, &hin, &hout})
+            if (*p) hipFree(*p);
+        gmres_free(gw);
+    }
+};
+
+namespace {
+// out[j] += sum_b w[b] * in[b, 0]  for column 0 only: the pressure-mean fix
+// fph[:,0] += (VI1 . ph)[0,0]   (stokes.py:383)
+__global__ void pressure_mean_kernel(cd* __restrict__ fph, int ld, int rows,
+                                     const double* __restrict__ w, const cd* __restrict__ ph,
+                                     int ldp) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sr = 0.0, si = 0.0;
+    for (int b = 0; b < rows; ++b) {
+        cd v = ph[(size_t)b * ldp];
+        sr = fma(w[b], v.x, sr);
+        si = fma(w[b], v.y, si);
+    }
+    for (int a = 0; a < rows; ++a) {
+        cd v = fph[(size_t)a * ld];
+        fph[(size_t)a * ld] = cd{v.x + sr, v.y + si};
+    }
+}
+// y[a,j] = alpha * F[a,j] * x[a,j] + beta * y[a,j]   (real)
+__global__ __launch_bounds__(256) void rfield_axpby_kernel(double* __restrict__ y,
+                                                           const double* __restrict__ x,
+                                                           const double* __restrict__ F, int64_t n,
+                                                           double alpha, double beta) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    double v = alpha * x[idx];
+    if (F) v *= F[idx];
+    if (beta != 0.0) v = fma(beta, y[idx], v);
+    y[idx] = v;
+}
+}  // namespace
+
+// _apply_optim_real (ipde/annular/stokes.py:321-385)
+int ipde_annular_stokes::apply(const cd* uuh, cd* out) {
+    hipStream_t st = ctx->stream;
+    const int m1 = M - 1, m2 = M - 2;
+    const dim3 b(256);
+    const cd* urh = uuh;
+    const cd* uth = uuh + NU;
+    const cd* ph = uuh + 2 * NU;
+    cd* frh = out;
+    cd* fth = out + NU;
+    cd* fph = out + 2 * NU;
+    const size_t Mn = (size_t)M * n;
+    // --- inverse transforms: A rows [ur(M) | ut(M) | p(M-1) | dur(M) | dut(M) | dp(M-1)]
+    cd* a_ur = A;
+    cd* a_ut = A + Mn;
+    cd* a_p = A + 2 * Mn;
+    cd* a_dur = a_p + (size_t)m1 * n;
+    cd* a_dut = a_dur + Mn;
+    cd* a_dp = a_dut + Mn;
+    hipLaunchKernelGGL(splat_kernel, dim3(nb256(Mn)), b, 0, st, a_ur, urh, M, n, (const cd*)nullptr);
+    hipLaunchKernelGGL(splat_kernel, dim3(nb256(Mn)), b, 0, st, a_ut, uth, M, n, (const cd*)nullptr);
+    hipLaunchKernelGGL(splat_kernel, dim3(nb256((int64_t)m1 * n)), b, 0, st, a_p, ph, m1, n,
+                       (const cd*)nullptr);
+    hipLaunchKernelGGL(splat_kernel, dim3(nb256(Mn)), b, 0, st, a_dur, urh, M, n, (const cd*)iks);
+    hipLaunchKernelGGL(splat_kernel, dim3(nb256(Mn)), b, 0, st, a_dut, uth, M, n, (const cd*)iks);
+    hipLaunchKernelGGL(splat_kernel, dim3(nb256((int64_t)m1 * n)), b, 0, st, a_dp, ph, m1, n,
+                       (const cd*)iks);
+    const int rowsA = 4 * M + 2 * m1;
+    IPDE_TRY(ipde_fft1_exec(ctx, rowsA, n, +1, A, Bw));
+    const double in = 1.0 / n;  // ifft scaling, folded into the first real-space use
+    cd* ur = Bw;
+    cd* ut = Bw + Mn;
+    cd* p = Bw + 2 * Mn;
+    cd* dur = p + (size_t)m1 * n;
+    cd* dut = dur + Mn;
+    cd* dp = dut + Mn;
+    // --- tangential second derivatives: X = [ (R01 dur)*ipsi1 ; (R01 dut)*ipsi1 ] (real rows)
+    double* X = Rw;                         // 2*m1 rows
+    double* W2 = Rw + (size_t)2 * m1 * n;   // m1 rows: R01 dut (unscaled by ipsi1)
+    double* Fr = W2 + (size_t)m1 * n;       // m2 rows: physical-space ur equation
+    double* Ft = Fr + (size_t)m2 * n;       // m2 rows
+    double* Fp = Ft + (size_t)m2 * n;       // m1 rows
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m1), b, 0, st, X, n, (const double*)R01, M,
+                       (const cd*)dur, n, n, (const double*)nullptr, 0, (const double*)ipsi1, n, in, 0.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m1), b, 0, st, X + (size_t)m1 * n, n,
+                       (const double*)R01, M, (const cd*)dut, n, n, (const double*)nullptr, 0,
+                       (const double*)ipsi1, n, in, 0.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m1), b, 0, st, W2, n, (const double*)R01, M,
+                       (const cd*)dut, n, n, (const double*)nullptr, 0, (const double*)nullptr, 0, in,
+                       0.0);
+    // forward, * iks (Nyquist dropped), inverse
+    cd* C1 = A;                              // reuse A: 2*m1 rows complex
+    cd* C2 = A + (size_t)2 * m1 * n;
+    hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, C1,
+                       (const double*)X, (int64_t)2 * m1 * n, 1.0);
+    IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, -1, C1, C2));
+    // mfft -> *iks -> mifft == zero the Nyquist column and multiply by i k
+    cd* C3 = C2 + (size_t)2 * m1 * n;        // (2 m1, ns)
+    hipLaunchKernelGGL(desplat_kernel, dim3(nb256((int64_t)2 * m1 * ns)), b, 0, st, C3,
+                       (const cd*)C2, 2 * m1, n, (const cd*)iks, 1.0);
+    hipLaunchKernelGGL(splat_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, C1, (const cd*)C3,
+                       2 * m1, n, (const cd*)nullptr);
+    IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, +1, C1, C2));
+    cd* urt2 = C2;                           // real part = d/dt (ur_t * ipsi1), unscaled by 1/n
+    cd* utt2 = C2 + (size_t)m1 * n;
+    // --- ur equation: Fr = mu*(-lap_ur + t1 + t2 + t3) + t4
+    //   lap_ur = (D12 (D01 ur * psi1) + R12 urt2) * ipsi2
+    double* G = Fp + (size_t)m1 * n;         // m1 rows scratch: D01 ur * psi1
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m1), b, 0, st, G, n, (const double*)D01, M,
+                       (const cd*)ur, n, n, (const double*)nullptr, 0, (const double*)psi1, n, in, 0.0);
+    hipLaunchKernelGGL(mixrr_kernel, dim3(nb256(n), m2), b, 0, st, Fr, n, (const double*)D12, m1,
+                       (const double*)G, n, n, (const double*)ipsi2, n, -mu, 0.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Fr, n, (const double*)R12, m1,
+                       (const cd*)urt2, n, n, (const double*)nullptr, 0, (const double*)ipsi2, n,
+                       -mu * in, 1.0);
+    //   t1 = R02 dut * combo1 ; t2 = R02 ur * combo2 ; t3 = R02 ut * c3 ; t4 = D12 p
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Fr, n, (const double*)R02, M,
+                       (const cd*)dut, n, n, (const double*)nullptr, 0, (const double*)combo1, n,
+                       mu * in, 1.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Fr, n, (const double*)R02, M,
+                       (const cd*)ur, n, n, (const double*)nullptr, 0, (const double*)combo2, n,
+                       mu * in, 1.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Fr, n, (const double*)R02, M,
+                       (const cd*)ut, n, n, (const double*)nullptr, 0, (const double*)c3, n, mu * in,
+                       1.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Fr, n, (const double*)D12, m1,
+                       (const cd*)p, n, n, (const double*)nullptr, 0, (const double*)nullptr, 0, in,
+                       1.0);
+    // --- ut equation: Ft = mu*(-lap_ut - t1 + t2 - t3) + t4
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m1), b, 0, st, G, n, (const double*)D01, M,
+                       (const cd*)ut, n, n, (const double*)nullptr, 0, (const double*)psi1, n, in, 0.0);
+    hipLaunchKernelGGL(mixrr_kernel, dim3(nb256(n), m2), b, 0, st, Ft, n, (const double*)D12, m1,
+                       (const double*)G, n, n, (const double*)ipsi2, n, -mu, 0.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Ft, n, (const double*)R12, m1,
+                       (const cd*)utt2, n, n, (const double*)nullptr, 0, (const double*)ipsi2, n,
+                       -mu * in, 1.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Ft, n, (const double*)R02, M,
+                       (const cd*)dur, n, n, (const double*)nullptr, 0, (const double*)combo1, n,
+                       -mu * in, 1.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Ft, n, (const double*)R02, M,
+                       (const cd*)ut, n, n, (const double*)nullptr, 0, (const double*)combo2, n,
+                       mu * in, 1.0);
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Ft, n, (const double*)R02, M,
+                       (const cd*)ur, n, n, (const double*)nullptr, 0, (const double*)c4, n, -mu * in,
+                       1.0);
+    //   t4 = R12 (mifftr(ph*iks)) * ipsi2
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m2), b, 0, st, Ft, n, (const double*)R12, m1,
+                       (const cd*)dp, n, n, (const double*)nullptr, 0, (const double*)ipsi2, n, in,
+                       1.0);
+    // --- div equation: Fp = (D01 (ur*psi0) + W2) * ipsi1
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), m1), b, 0, st, Fp, n, (const double*)D01, M,
+                       (const cd*)ur, n, n, (const double*)psi0, n, (const double*)ipsi1, n, in, 0.0);
+    hipLaunchKernelGGL(rfield_axpby_kernel, dim3(nb256((int64_t)m1 * n)), b, 0, st, Fp,
+                       (const double*)W2, (const double*)ipsi1, (int64_t)m1 * n, 1.0, 1.0);
+    // --- forward transforms of [Fr; Ft; Fp], drop Nyquist, scatter into out
+    const int rowsF = 2 * m2 + m1;
+    hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256((int64_t)rowsF * n)), b, 0, st, A,
+                       (const double*)Fr, (int64_t)rowsF * n, 1.0);
+    cd* FH = A + (size_t)rowsF * n;
+    IPDE_TRY(ipde_fft1_exec(ctx, rowsF, n, -1, A, FH));
+    hipLaunchKernelGGL(desplat_kernel, dim3(nb256((int64_t)m2 * ns)), b, 0, st, frh, (const cd*)FH,
+                       m2, n, (const cd*)nullptr, 1.0);
+    hipLaunchKernelGGL(desplat_kernel, dim3(nb256((int64_t)m2 * ns)), b, 0, st, fth,
+                       (const cd*)(FH + (size_t)m2 * n), m2, n, (const cd*)nullptr, 1.0);
+    hipLaunchKernelGGL(desplat_kernel, dim3(nb256((int64_t)m1 * ns)), b, 0, st, fph,
+                       (const cd*)(FH + (size_t)2 * m2 * n), m1, n, (const cd*)nullptr, 1.0);
+    // boundary rows (computed in Fourier space on the unknowns themselves)
+    hipLaunchKernelGGL(mixc_kernel, dim3(nb256(ns), 2), b, 0, st, frh + (size_t)m2 * ns, ns,
+                       (const double*)BC, M, urh, ns, ns, (const cd*)nullptr, 1.0, 0.0);
+    hipLaunchKernelGGL(mixc_kernel, dim3(nb256(ns), 2), b, 0, st, fth + (size_t)m2 * ns, ns,
+                       (const double*)BC, M, uth, ns, ns, (const cd*)nullptr, 1.0, 0.0);
+    hipLaunchKernelGGL(pressure_mean_kernel, dim3(1), dim3(64), 0, st, fph, ns, m1,
+                       (const double*)VI1, ph, ns);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
+extern "C" int ipde_annular_stokes_create(ipde_ctx* ctx, int M, int n, double mu, const double* R01,
+                                          const double* R12, const double* R02, const double* D01,
+                                          const double* D12, const double* ibcd, const double* obcd,
+                                          const double* VI1row0, const double* kinv_c,
+                                          ipde_annular_stokes** out) {
+    if (!ctx || !out) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, M >= 4 && M <= 128 && n >= 4 && (n % 2) == 0);
+    IPDE_CHECK_ARG(ctx, R01 && R12 && R02 && D01 && D12 && ibcd && obcd && VI1row0 && kinv_c);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ipde_annular_stokes* h = new ipde_annular_stokes();
+    h->ctx = ctx;
+    h->M = M;
+    h->n = n;
+    h->ns = n - 1;
+    h->mu = mu;
+    const int ns = n - 1, m1 = M - 1, m2 = M - 2, B = 3 * M - 1;
+    h->NU = (int64_t)M * ns;
+    h->NP = (int64_t)m1 * ns;
+    h->NB = 2 * h->NU + h->NP;
+    int st = IPDE_OK;
+    auto up = [&](double** d, const double* s, size_t cnt) {
+        if (st == IPDE_OK) st = upload(ctx, d, s, cnt);
+    };
+    up(&h->R01, R01, (size_t)m1 * M);
+    up(&h->R12, R12, (size_t)m2 * m1);
+    up(&h->R02, R02, (size_t)m2 * M);
+    up(&h->D01, D01, (size_t)m1 * M);
+    up(&h->D12, D12, (size_t)m2 * m1);
+    std::vector<double> bc(2 * (size_t)M);
+    for (int i = 0; i < M; ++i) {
+        bc[i] = ibcd[i];
+        bc[M + i] = obcd[i];
+    }
+    up(&h->BC, bc.data(), bc.size());
+    up(&h->VI1, VI1row0, m1);
+    {   // Kt[j][k][i] = kinv[i][j][k] (complex)
+        std::vector<double> Kt((size_t)2 * B * B * ns);
+        for (int i = 0; i < ns; ++i)
+            for (int j = 0; j < B; ++j)
+                for (int k = 0; k < B; ++k) {
+                    size_t s = (((size_t)i * B + j) * B + k) * 2;
+                    size_t d = (((size_t)j * B + k) * ns + i) * 2;
+                    Kt[d] = kinv_c[s];
+                    Kt[d + 1] = kinv_c[s + 1];
+                }
+        up((double**)&h->Kt, Kt.data(), Kt.size());
+    }
+    {   // iks = 1j*ks, ks = fftfreq(n,1/n) without the Nyquist entry (annular.py:67-71)
+        std::vector<double> v(2 * (size_t)ns);
+        const int N2 = n / 2;
+        for (int js = 0; js < ns; ++js) {
+            int j = js < N2 ? js : js + 1;
+            int s = (j < (n + 1) / 2) ? j : j - n;
+            v[2 * js] = 0.0;
+            v[2 * js + 1] = (double)s;
+        }
+        up((double**)&h->iks, v.data(), v.size());
+    }
+    auto al = [&](void** d, size_t bytes) {
+        if (st == IPDE_OK && hipMalloc(d, bytes) != hipSuccess) st = IPDE_ERR_ALLOC;
+    };
+    al((void**)&h->psi0, (size_t)M * n * 8);
+    al((void**)&h->psi1, (size_t)m1 * n * 8);
+    al((void**)&h->ipsi1, (size_t)m1 * n * 8);
+    al((void**)&h->ipsi2, (size_t)m2 * n * 8);
+    al((void**)&h->combo1, (size_t)m2 * n * 8);
+    al((void**)&h->combo2, (size_t)m2 * n * 8);
+    al((void**)&h->c3, (size_t)m2 * n * 8);
+    al((void**)&h->c4, (size_t)m2 * n * 8);
+    al((void**)&h->DRpsi2, (size_t)m2 * n * 8);
+    al((void**)&h->A, (size_t)(6 * M + 8) * n * sizeof(cd));
+    al((void**)&h->Bw, (size_t)(6 * M + 8) * n * sizeof(cd));
+    al((void**)&h->Rw, (size_t)(8 * M + 8) * n * 8);
+    al((void**)&h->bvec, (size_t)h->NB * sizeof(cd));
+    al((void**)&h->hin, (size_t)h->NB * sizeof(cd));
+    al((void**)&h->hout, (size_t)h->NB * sizeof(cd));
+    al((void**)&h->rstage, (size_t)(3 * M + 8) * n * 8);
+    if (st != IPDE_OK) {
+        delete h;
+        return st;
+    }
+    *out = h;
+    return IPDE_OK;
+}
+
+extern "C" int ipde_annular_stokes_destroy(ipde_annular_stokes* h) {
+    if (!h) return IPDE_ERR_INVALID;
+    hipSetDevice(h->ctx->device);
+    hipStreamSynchronize(h->ctx->stream);
+    delete h;
+    return IPDE_OK;
+}
+
+namespace {
+// combo1 = 2 DR ipsi2^2 ; combo2 = DR^2 ipsi2^2   (stokes.py:521-522)
+__global__ __launch_bounds__(256) void combos_kernel(double* __restrict__ c1, double* __restrict__ c2,
+                                                     const double* __restrict__ DR,
+                                                     const double* __restrict__ ipsi2, int64_t n) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    double d = DR[idx], q = ipsi2[idx];
+    c1[idx] = 2.0 * d * q * q;
+    c2[idx] = d * d * q * q;
+}
+}  // namespace
+
+extern "C" int ipde_annular_stokes_set_geometry(ipde_annular_stokes* h, int loc, const double* psi0,
+                                                const double* psi1, const double* ipsi1,
+                                                const double* ipsi2, const double* DR_psi2,
+                                                const double* c3, const double* c4) {
+    if (!h) return IPDE_ERR_INVALID;
+    ipde_ctx* ctx = h->ctx;
+    IPDE_CHECK_ARG(ctx, psi0 && psi1 && ipsi1 && ipsi2 && DR_psi2 && c3 && c4);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n = h->n, M = h->M;
+    IPDE_TRY(set_field(ctx, loc, h->psi0, psi0, M * n));
+    IPDE_TRY(set_field(ctx, loc, h->psi1, psi1, (M - 1) * n));
+    IPDE_TRY(set_field(ctx, loc, h->ipsi1, ipsi1, (M - 1) * n));
+    IPDE_TRY(set_field(ctx, loc, h->ipsi2, ipsi2, (M - 2) * n));
+    IPDE_TRY(set_field(ctx, loc, h->DRpsi2, DR_psi2, (M - 2) * n));
+    IPDE_TRY(set_field(ctx, loc, h->c3, c3, (M - 2) * n));
+    IPDE_TRY(set_field(ctx, loc, h->c4, c4, (M - 2) * n));
+    hipLaunchKernelGGL(combos_kernel, dim3(nb256((M - 2) * n)), dim3(256), 0, ctx->stream, h->combo1,
+                       h->combo2, (const double*)h->DRpsi2, (const double*)h->ipsi2,
+                       (int64_t)((M - 2) * n));
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    h->have_geom = true;
+    return IPDE_OK;
+}
+
+extern "C" int ipde_annular_stokes_apply(ipde_annular_stokes* h, int loc, const double* uuh_c,
+                                         double* out_c) {
+    if (!h) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(h->ctx, h->have_geom);
+    return run_vec_op(h, loc, uuh_c, out_c, h->NB,
+                      [&](const cd* a, cd* b) { return h->apply(a, b); });
+}
+
+extern "C" int ipde_annular_stokes_precondition(ipde_annular_stokes* h, int loc,
+                                                const double* ffh_c, double* out_c) {
+    if (!h) return IPDE_ERR_INVALID;
+    return run_vec_op(h, loc, ffh_c, out_c, h->NB,
+                      [&](const cd* a, cd* b) { return h->precond(a, b); });
+}
+
+extern "C" int ipde_annular_stokes_solve(ipde_annular_stokes* h, int loc, const double* fr,
+                                         const double* ft, const double* irg, const double* itg,
+                                         const double* org, const double* otg,
+                                         const double* P10_host, double tol, int maxiter,
+                                         int restart, double* ur, double* ut, double* p, int* iters,
+                                         double* resid) {
+    if (!h) return IPDE_ERR_INVALID;
+    ipde_ctx* ctx = h->ctx;
+    IPDE_CHECK_ARG(ctx, fr && ft && irg && itg && org && otg && P10_host && ur && ut && p);
+    IPDE_CHECK_ARG(ctx, iters && resid && h->have_geom);
+    IPDE_CHECK_ARG(ctx, loc == IPDE_HOST || loc == IPDE_DEVICE);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int M = h->M, n = h->n, ns = h->ns, m1 = M - 1, m2 = M - 2;
+    const size_t Mn = (size_t)M * n;
+    auto kind = loc == IPDE_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    // stage: rstage = [fr (M,n) | ft (M,n) | irg | org | itg | otg]
+    double* rs = h->rstage;
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(rs, fr, Mn * 8, kind, st));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(rs + Mn, ft, Mn * 8, kind, st));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(rs + 2 * Mn, irg, (size_t)n * 8, kind, st));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(rs + 2 * Mn + n, org, (size_t)n * 8, kind, st));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(rs + 2 * Mn + 2 * n, itg, (size_t)n * 8, kind, st));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(rs + 2 * Mn + 3 * n, otg, (size_t)n * 8, kind, st));
+    // ffr = [R02 fr ; irg ; org], fft = [R02 ft ; itg ; otg]  as real rows in Rw (2M rows)
+    double* ff = h->Rw;
+    hipLaunchKernelGGL(mixrr_kernel, dim3(nb256(n), m2), dim3(256), 0, st, ff, n,
+                       (const double*)h->R02, M, (const double*)rs, n, n, (const double*)nullptr, 0,
+                       1.0, 0.0);
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(ff + (size_t)m2 * n, rs + 2 * Mn, 2 * (size_t)n * 8,
+                                       hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(mixrr_kernel, dim3(nb256(n), m2), dim3(256), 0, st, ff + Mn, n,
+                       (const double*)h->R02, M, (const double*)(rs + Mn), n, n,
+                       (const double*)nullptr, 0, 1.0, 0.0);
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(ff + Mn + (size_t)m2 * n, rs + 2 * Mn + 2 * n,
+                                       2 * (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256(2 * Mn)), dim3(256), 0, st, h->A,
+                       (const double*)ff, (int64_t)(2 * Mn), 1.0);
+    cd* FH = h->A + 2 * Mn;
+    IPDE_TRY(ipde_fft1_exec(ctx, 2 * M, n, -1, h->A, FH));
+    hipLaunchKernelGGL(desplat_kernel, dim3(nb256(2 * (int64_t)M * ns)), dim3(256), 0, st, h->bvec,
+                       (const cd*)FH, 2 * M, n, (const cd*)nullptr, 1.0);
+    IPDE_HIP_CHECK(ctx, hipMemsetAsync(h->bvec + 2 * h->NU, 0, h->NP * sizeof(cd), st));
+    int st_g = gmres_solve(*h, h->gw, h->bvec, tol, maxiter, restart, iters, resid);
+    if (st_g != IPDE_OK && st_g != IPDE_ERR_NOCONV) return st_g;
+    // ur = mifft(urh).real, ut = ..., p = P10 . mifft(ph).real
+    const int rows = 2 * M + m1;
+    hipLaunchKernelGGL(splat_kernel, dim3(nb256((int64_t)rows * n)), dim3(256), 0, st, h->A,
+                       (const cd*)h->gw.x, rows, n, (const cd*)nullptr);
+    IPDE_TRY(ipde_fft1_exec(ctx, rows, n, +1, h->A, h->Bw));
+    double* o = h->Rw;  // [ur | ut | p] (3M rows)
+    hipLaunchKernelGGL(c2r_real_kernel, dim3(nb256(2 * Mn)), dim3(256), 0, st, o,
+                       (const cd*)h->Bw, (int64_t)(2 * Mn), 1.0 / n);
+    // P10 upload (M x m1) into the tail of rstage
+    double* dP10 = rs;
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(dP10, P10_host, (size_t)M * m1 * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mixr_kernel, dim3(nb256(n), M), dim3(256), 0, st, o + 2 * Mn, n,
+                       (const double*)dP10, m1, (const cd*)(h->Bw + 2 * Mn), n, n,
+                       (const double*)nullptr, 0, (const double*)nullptr, 0, 1.0 / n, 0.0);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    auto okind = loc == IPDE_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(ur, o, Mn * 8, okind, st));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(ut, o + Mn, Mn * 8, okind, st));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(p, o + 2 * Mn, Mn * 8, okind, st));
+    IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (st_g == IPDE_ERR_NOCONV)
+        IPDE_SET_ERR(ctx, "annular Stokes GMRES: no convergence in %d iterations (resid %.3e)",
+                     *iters, *resid);
+    return st_g;
+}

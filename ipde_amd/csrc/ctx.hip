@@ -1,0 +1,220 @@
+// Context, workspaces, host staging and math-table construction.
+#include "ipde_common.h"
+#include <cmath>
+
+extern "C" const char* ipde_version(void) { return "ipde_hip 0.1 (gfx950)"; }
+
+int ipde_devbuf_reserve(ipde_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return IPDE_OK;
+    if (b.p) {
+        // the buffer may still be in use by queued work
+        IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        IPDE_HIP_CHECK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&b.p, cap);
+    if (e != hipSuccess) {
+        IPDE_SET_ERR(ctx, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        b.p = nullptr;
+        return IPDE_ERR_ALLOC;
+    }
+    b.cap = cap;
+    return IPDE_OK;
+}
+
+int ipde_stage_in(ipde_ctx* ctx, int loc, int slot, const double* p, size_t n,
+                  const double** dptr) {
+    if (p == nullptr) {
+        *dptr = nullptr;
+        return IPDE_OK;
+    }
+    if (loc == IPDE_DEVICE) {
+        *dptr = p;
+        return IPDE_OK;
+    }
+    DevBuf& b = ctx->stage[slot];
+    IPDE_TRY(ipde_devbuf_reserve(ctx, b, n * sizeof(double)));
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(b.p, p, n * sizeof(double), hipMemcpyHostToDevice,
+                                       ctx->stream));
+    *dptr = (const double*)b.p;
+    return IPDE_OK;
+}
+
+int ipde_stage_out(ipde_ctx* ctx, int loc, int slot, double* p, size_t n, double** dptr) {
+    if (p == nullptr) {
+        *dptr = nullptr;
+        return IPDE_OK;
+    }
+    if (loc == IPDE_DEVICE) {
+        *dptr = p;
+        return IPDE_OK;
+    }
+    DevBuf& b = ctx->stage[slot];
+    IPDE_TRY(ipde_devbuf_reserve(ctx, b, n * sizeof(double)));
+    *dptr = (double*)b.p;
+    return IPDE_OK;
+}
+
+int ipde_stage_finish(ipde_ctx* ctx, int loc, int slot, double* p, size_t n) {
+    if (p == nullptr || loc == IPDE_DEVICE) return IPDE_OK;
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(p, ctx->stage[slot].p, n * sizeof(double),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+    IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return IPDE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// log table: for every key kappa = hi32(x) >> (20 - B) in the covered range the
+// entry holds R ~ 1/center(interval) and T = -log(R), so that
+//   log(x) = T + log1p(x*R - 1),  |x*R - 1| <= 2^-(B+1) (+ rounding).
+// Built on the host in long double and uploaded once.
+int ipde_build_log_table(ipde_ctx* ctx) {
+    LogTable& t = ctx->logtab;
+    t.mant_bits = 8;
+    t.exp_lo = -24;
+    t.exp_hi = 4;
+    const int B = t.mant_bits;
+    t.key_lo = (1023 + t.exp_lo) << B;
+    t.nkeys = (t.exp_hi - t.exp_lo) << B;
+    std::vector<double> h((size_t)t.nkeys * 2);
+    for (int i = 0; i < t.nkeys; ++i) {
+        uint64_t key = (uint64_t)(t.key_lo + i);
+        uint64_t lo_bits = key << (52 - B);
+        uint64_t hi_bits = (key + 1) << (52 - B);
+        double xlo, xhi;
+        memcpy(&xlo, &lo_bits, 8);
+        memcpy(&xhi, &hi_bits, 8);
+        long double c = 0.5L * ((long double)xlo + (long double)xhi);
+        double R = (double)(1.0L / c);
+        double T = (double)(-logl((long double)R));
+        h[2 * i] = R;
+        h[2 * i + 1] = T;
+    }
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&t.d_tab, h.size() * sizeof(double)));
+    IPDE_HIP_CHECK(ctx, hipMemcpy(t.d_tab, h.data(), h.size() * sizeof(double),
+                                  hipMemcpyHostToDevice));
+    return IPDE_OK;
+}
+
+extern "C" int ipde_ctx_create(int device_id, ipde_ctx** out) {
+    if (!out) return IPDE_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return IPDE_ERR_NOGPU;
+    if (device_id < 0) {
+        if (hipGetDevice(&device_id) != hipSuccess) return IPDE_ERR_NOGPU;
+    }
+    if (device_id >= ndev) return IPDE_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return IPDE_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return IPDE_ERR_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "ipde_hip: device %d is %s, this library is built for gfx950 only\n",
+                device_id, prop.gcnArchName);
+        return IPDE_ERR_NOGPU;
+    }
+    ipde_ctx* ctx = new ipde_ctx();
+    ctx->device = device_id;
+    ctx->num_cu = prop.multiProcessorCount;
+    // a BLOCKING stream: it orders itself against the legacy default stream, which is
+    // where a host framework (torch) allocates and fills the buffers it hands us
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamDefault) != hipSuccess) {
+        delete ctx;
+        return IPDE_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    hipEventCreate(&ctx->ev0);
+    hipEventCreate(&ctx->ev1);
+    ctx->h_pinned_bytes = 1 << 16;
+    if (hipHostMalloc((void**)&ctx->h_pinned, ctx->h_pinned_bytes) != hipSuccess) {
+        delete ctx;
+        return IPDE_ERR_ALLOC;
+    }
+    int s = ipde_build_log_table(ctx);
+    if (s == IPDE_OK) s = ipde_build_k_table(ctx);
+    if (s != IPDE_OK) {
+        fprintf(stderr, "ipde_hip: table construction failed: %s\n", ctx->err.c_str());
+        delete ctx;
+        return s;
+    }
+    *out = ctx;
+    return IPDE_OK;
+}
+
+void ipde_fft1_plans_destroy(ipde_ctx* ctx);  // spectral.hip
+
+extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    ipde_fft1_plans_destroy(ctx);
+    auto freebuf = [](DevBuf& b) {
+        if (b.p) hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    };
+    freebuf(ctx->src_pack);
+    for (auto& b : ctx->stage) freebuf(b);
+    freebuf(ctx->partial);
+    freebuf(ctx->scratch);
+    for (auto& b : ctx->fftwork) freebuf(b);
+    if (ctx->logtab.d_tab) hipFree(ctx->logtab.d_tab);
+    if (ctx->d_ktab) hipFree(ctx->d_ktab);
+    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return IPDE_OK;
+}
+
+extern "C" int ipde_ctx_sync(ipde_ctx* ctx) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return IPDE_OK;
+}
+
+extern "C" int ipde_ctx_set_stream(ipde_ctx* ctx, void* s) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return IPDE_OK;
+}
+
+extern "C" void* ipde_ctx_get_stream(ipde_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" const char* ipde_last_error(ipde_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return IPDE_ERR_INVALID;
+    if (!strcmp(name, "laplace_variant")) {
+        ctx->opt_laplace_variant = value;
+    } else if (!strcmp(name, "stokes_variant")) {
+        ctx->opt_stokes_variant = value;
+    } else {
+        IPDE_SET_ERR(ctx, "unknown option '%s'", name);
+        return IPDE_ERR_INVALID;
+    }
+    return IPDE_OK;
+}
+
+extern "C" int ipde_ctx_enable_timing(ipde_ctx* ctx, int on) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    ctx->timing = on;
+    return IPDE_OK;
+}
+
+extern "C" int ipde_ctx_last_kernel_ms(ipde_ctx* ctx, double* ms) {
+    if (!ctx || !ms) return IPDE_ERR_INVALID;
+    if (ctx->timing && ctx->last_kernel_ms < 0.0) {
+        IPDE_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+        float f = 0.f;
+        IPDE_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+        ctx->last_kernel_ms = (double)f;
+    }
+    *ms = ctx->last_kernel_ms;
+    return IPDE_OK;
+}

@@ -1,0 +1,103 @@
+// Internal shared declarations for libipde_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/ipde_hip.h"
+
+// A growable device buffer owned by the context (never freed between calls so
+// that the hot path does no hipMalloc).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+// LDS log/reciprocal table, see mathtab.h.
+struct LogTable {
+    double* d_tab = nullptr;  // nkeys * 2 doubles: {R, -log(R)}
+    int mant_bits = 0;
+    int key_lo = 0;           // first key = (hi32(x) >> (20-mant_bits)) covered
+    int nkeys = 0;
+    int exp_lo = 0, exp_hi = 0;  // covers x in [2^exp_lo, 2^exp_hi)
+};
+
+struct ipde_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // workspaces
+    DevBuf src_pack;     // packed source records
+    DevBuf stage[16];    // host-staging buffers for IPDE_HOST calls
+    DevBuf partial;      // split-source partial sums
+    DevBuf scratch;      // reductions (bbox etc.)
+    DevBuf fftwork[8];
+    double* h_pinned = nullptr;  // small pinned host buffer for scalars
+    size_t h_pinned_bytes = 0;
+    LogTable logtab;
+    // modified-Helmholtz K0/K1 piecewise table
+    double* d_ktab = nullptr;
+    // timing
+    int timing = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_kernel_ms = 0.0;
+    // 1-D batched fft plan cache: key (batch, n)
+    std::map<std::pair<int64_t, int64_t>, void*> fft1_plans;
+    int num_cu = 256;
+    // tuning knobs (ipde_ctx_set_option)
+    int opt_laplace_variant = 0;
+    int opt_stokes_variant = 0;
+};
+
+#define IPDE_SET_ERR(ctx, ...)                                      \
+    do {                                                            \
+        char _b[512];                                               \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                      \
+        if (ctx) (ctx)->err = _b;                                   \
+    } while (0)
+
+#define IPDE_HIP_CHECK(ctx, call)                                                      \
+    do {                                                                               \
+        hipError_t _e = (call);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            IPDE_SET_ERR(ctx, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,            \
+                         hipGetErrorString(_e));                                       \
+            return IPDE_ERR_HIP;                                                       \
+        }                                                                              \
+    } while (0)
+
+#define IPDE_CHECK_ARG(ctx, cond)                                                      \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            IPDE_SET_ERR(ctx, "%s:%d: invalid argument: %s", __FILE__, __LINE__, #cond); \
+            return IPDE_ERR_INVALID;                                                   \
+        }                                                                              \
+    } while (0)
+
+#define IPDE_TRY(expr)                  \
+    do {                                \
+        int _s = (expr);                \
+        if (_s != IPDE_OK) return _s;   \
+    } while (0)
+
+// ensure capacity (grow-only). Returns IPDE_OK / IPDE_ERR_ALLOC.
+int ipde_devbuf_reserve(ipde_ctx* ctx, DevBuf& b, size_t bytes);
+
+// Resolve an input array to a device pointer: for IPDE_DEVICE returns the
+// pointer itself, for IPDE_HOST copies into ctx->stage[slot].
+int ipde_stage_in(ipde_ctx* ctx, int loc, int slot, const double* p, size_t n_doubles,
+                  const double** dptr);
+// Resolve an output array: device pointer to write into.
+int ipde_stage_out(ipde_ctx* ctx, int loc, int slot, double* p, size_t n_doubles,
+                   double** dptr);
+// After the kernels: copy staged outputs back (no-op for IPDE_DEVICE).
+int ipde_stage_finish(ipde_ctx* ctx, int loc, int slot, double* p, size_t n_doubles);
+
+int ipde_build_log_table(ipde_ctx* ctx);
+int ipde_build_k_table(ipde_ctx* ctx);
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,316 @@
+// Laplace single/double layer dense sums for gfx950.
+//
+// Record rows: [0] x*s [1] y*s [2] q' = -w_sigma/(4 pi)
+//              [3] ax' = s*nx*w_tau/(2 pi) [4] ay' = s*ny*w_tau/(2 pi)
+//   out_i = sum_j q'_j log(d2_ij) + (a'_j . d_ij)/d2_ij   (+ corr for the scaling)
+//
+// Roofline: fp64 VALU bound.  Per source/target pair the table kernel issues
+//   4 (dx,dy,d2) + 1 (z) + 5 (log1p poly + T) + 1 (accumulate) fp64 ops for the
+//   SLP, + 2 (a.d) + 6 (1/d2 from the same table entry) + 1 for the DLP,
+// plus 4 int32 ops and one ds_read_b128 (the {R, -log R} table entry).
+// Algorithmic HBM traffic is 24 B per target (read x,y, write u) — irrelevant.
+#include "layer_pack.h"
+
+namespace {
+
+constexpr int MODE_SLP = 1, MODE_DLP = 2, MODE_BOTH = 3;
+
+// ---------------------------------------------------------------------------
+// generic (libdevice log / IEEE division, no table): reference-grade path, the
+// SKIP_COINCIDENT path, and the fallback for table misses
+template <int MODE, bool SKIP>
+__device__ __forceinline__ double laplace_pair_generic(double dx, double dy, double q, double ax,
+                                                       double ay, double acc) {
+    double d2 = fma(dy, dy, dx * dx);
+    if (SKIP && d2 == 0.0) return acc;
+    if (MODE & MODE_SLP) acc = fma(q, log(d2), acc);
+    if (MODE & MODE_DLP) {
+        double ad = fma(ay, dy, ax * dx);
+        acc = fma(ad, 1.0 / d2, acc);
+    }
+    return acc;
+}
+
+template <int MODE, bool SKIP, int R>
+__device__ __forceinline__ void laplace_generic_loop(const double* __restrict__ rec, int j0, int j1,
+                                                     const double (&x)[R], const double (&y)[R],
+                                                     double (&acc)[R]) {
+    for (int j = j0; j < j1; ++j) {
+        double sx = rec[ipde_rec_index(j, 0)], sy = rec[ipde_rec_index(j, 1)];
+        double q = rec[ipde_rec_index(j, 2)];
+        double ax = rec[ipde_rec_index(j, 3)], ay = rec[ipde_rec_index(j, 4)];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            acc[r] = laplace_pair_generic<MODE, SKIP>(x[r] - sx, y[r] - sy, q, ax, ay, acc[r]);
+    }
+}
+
+template <int MODE, bool SKIP, int R, int NT>
+__global__ __launch_bounds__(NT) void laplace_generic_kernel(
+    const double* __restrict__ rec, int ns_pad, int chunk, const double* __restrict__ tx,
+    const double* __restrict__ ty, int64_t nt, double* __restrict__ out,
+    const ApplyParams* __restrict__ prm) {
+    const int j0 = blockIdx.y * chunk;
+    const int j1 = min(ns_pad, j0 + chunk);
+    const double s1 = ldexp(1.0, prm->sh);
+    double x[R], y[R], acc[R];
+    int64_t base = (int64_t)blockIdx.x * (R * NT) + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t i = min(base + (int64_t)r * NT, nt - 1);
+        x[r] = tx[i] * s1;
+        y[r] = ty[i] * s1;
+        acc[r] = 0.0;
+    }
+    laplace_generic_loop<MODE, SKIP, R>(rec, j0, j1, x, y, acc);
+    const double corr = (blockIdx.y == 0) ? prm->corr : 0.0;
+    double* o = out + (size_t)blockIdx.y * nt;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t i = base + (int64_t)r * NT;
+        if (i < nt) o[i] = acc[r] + corr;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// table kernel: R targets per lane, U sources of a batch in flight -> R*U
+// independent lookup + polynomial chains, written phase by phase so that the
+// ds_reads of a group are issued back to back and the fp64 chains interleave.
+template <int MODE, int R, int NT, int U>
+__global__ __launch_bounds__(NT) void laplace_table_kernel(
+    const double* __restrict__ rec, int ns_pad, int chunk, const double* __restrict__ tx,
+    const double* __restrict__ ty, int64_t nt, double* __restrict__ out,
+    const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab, unsigned key_lo,
+    unsigned nkeys, int shift) {
+    extern __shared__ double2 ltab[];
+    for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
+    __syncthreads();
+    const unsigned nkeys_m1 = nkeys - 1;
+
+    const int j0 = blockIdx.y * chunk;
+    const int j1 = min(ns_pad, j0 + chunk);
+    const double s1 = ldexp(1.0, prm->sh);
+    double x[R], y[R], acc[R];
+    int64_t base = (int64_t)blockIdx.x * (R * NT) + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t i = min(base + (int64_t)r * NT, nt - 1);
+        x[r] = tx[i] * s1;
+        y[r] = ty[i] * s1;
+        acc[r] = 0.0;
+    }
+    unsigned worst = 0;
+    for (int b = j0 / IPDE_SRC_PAD; b < j1 / IPDE_SRC_PAD; ++b) {
+        SrcRow sx, sy, sq, sax, say;
+        sx.load(rec, b, 0);
+        sy.load(rec, b, 1);
+        if (MODE & MODE_SLP) sq.load(rec, b, 2);
+        if (MODE & MODE_DLP) {
+            sax.load(rec, b, 3);
+            say.load(rec, b, 4);
+        }
+#pragma unroll
+        for (int u0 = 0; u0 < IPDE_SRC_PAD; u0 += U) {
+            double dx[U][R], dy[U][R], d2[U][R], z[U][R];
+            double2 e[U][R];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    dx[u][r] = x[r] - sx.v[u0 + u];
+                    dy[u][r] = y[r] - sy.v[u0 + u];
+                    d2[u][r] = fma(dy[u][r], dy[u][r], dx[u][r] * dx[u][r]);
+                    unsigned idx = ((unsigned)__double2hiint(d2[u][r]) >> shift) - key_lo;
+                    worst = max(worst, idx);
+                    e[u][r] = ltab[min(idx, nkeys_m1)];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) z[u][r] = fma(d2[u][r], e[u][r].x, -1.0);
+            if (MODE & MODE_SLP) {
+                double p[U][R];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) p[u][r] = fma(z[u][r], 0.2, -0.25);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) p[u][r] = fma(p[u][r], z[u][r], 1.0 / 3.0);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) p[u][r] = fma(p[u][r], z[u][r], -0.5);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) p[u][r] = fma(p[u][r], z[u][r], 1.0);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) p[u][r] = fma(p[u][r], z[u][r], e[u][r].y);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] = fma(sq.v[u0 + u], p[u][r], acc[r]);
+            }
+            if (MODE & MODE_DLP) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        double ad = fma(say.v[u0 + u], dy[u][r], sax.v[u0 + u] * dx[u][r]);
+                        acc[r] = fma(ad, tab_rcp_from(e[u][r].x, z[u][r]), acc[r]);
+                    }
+            }
+        }
+    }
+    if (worst > nkeys_m1) {
+        // some pair of this lane fell outside the table (d^2 == 0, tiny or huge):
+        // redo the lane's targets with the generic math.  Rare by construction.
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        laplace_generic_loop<MODE, false, R>(rec, j0, j1, x, y, acc);
+    }
+    const double corr = (blockIdx.y == 0) ? prm->corr : 0.0;
+    double* o = out + (size_t)blockIdx.y * nt;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t i = base + (int64_t)r * NT;
+        if (i < nt) o[i] = acc[r] + corr;
+    }
+}
+
+template <int MODE, int R, int NT, int U>
+int launch_table_variant(ipde_ctx* ctx, dim3 grid, const double* rec, const LayerGeom& g,
+                         const double* tx, const double* ty, int64_t nt, double* dst,
+                         const ApplyParams* prm) {
+    const LogTable& lt = ctx->logtab;
+    size_t lds = (size_t)lt.nkeys * sizeof(double2);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_table_kernel<MODE, R, NT, U>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((laplace_table_kernel<MODE, R, NT, U>), grid, dim3(NT), lds, ctx->stream, rec,
+                       g.ns_pad, g.chunk, tx, ty, nt, dst, prm, (const double2*)lt.d_tab,
+                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, 20 - lt.mant_bits);
+    return IPDE_OK;
+}
+
+template <int MODE>
+int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* tx,
+                   const double* ty, int64_t nt, double* out, const ApplyParams* prm, int flags) {
+    const bool generic = (flags & (IPDE_FLAG_GENERIC_MATH | IPDE_FLAG_SKIP_COINCIDENT)) != 0;
+    const bool skip = (flags & IPDE_FLAG_SKIP_COINCIDENT) != 0;
+    const int variant = generic ? -1 : ctx->opt_laplace_variant;
+    int NTv = 256, Rv = 2;
+    switch (variant) {
+        case 0: NTv = 512; Rv = 4; break;
+        case 1: NTv = 1024; Rv = 4; break;
+        case 2: NTv = 512; Rv = 8; break;
+        case 3: NTv = 1024; Rv = 2; break;
+        case 4: NTv = 768; Rv = 4; break;
+        case 5: NTv = 512; Rv = 4; break;
+        default: break;
+    }
+    const LayerGeom g = ipde_layer_geom(ns, nt, NTv * Rv, ctx->num_cu);
+    double* dst = out;
+    if (g.nchunk > 1) {
+        IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, (size_t)g.nchunk * nt * sizeof(double)));
+        dst = (double*)ctx->partial.p;
+    }
+    dim3 grid((unsigned)g.gx, (unsigned)g.nchunk);
+    if (ctx->timing) hipEventRecord(ctx->ev0, ctx->stream);
+    if (generic) {
+        if (skip)
+            hipLaunchKernelGGL((laplace_generic_kernel<MODE, true, 2, 256>), grid, dim3(256), 0,
+                               ctx->stream, rec, g.ns_pad, g.chunk, tx, ty, nt, dst, prm);
+        else
+            hipLaunchKernelGGL((laplace_generic_kernel<MODE, false, 2, 256>), grid, dim3(256), 0,
+                               ctx->stream, rec, g.ns_pad, g.chunk, tx, ty, nt, dst, prm);
+    } else {
+        int st;
+        switch (variant) {
+            case 1: st = launch_table_variant<MODE, 4, 1024, 1>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 2: st = launch_table_variant<MODE, 8, 512, 1>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 3: st = launch_table_variant<MODE, 2, 1024, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 4: st = launch_table_variant<MODE, 4, 768, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 5: st = launch_table_variant<MODE, 4, 512, 1>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            default: st = launch_table_variant<MODE, 4, 512, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+        }
+        IPDE_TRY(st);
+    }
+    if (ctx->timing) {
+        hipEventRecord(ctx->ev1, ctx->stream);
+        ctx->last_kernel_ms = -1.0;  // resolved lazily in ipde_ctx_last_kernel_ms
+    }
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    if (g.nchunk > 1) {
+        hipLaunchKernelGGL(ipde_reduce_partials, dim3((unsigned)ceil_div64(nt, 256)), dim3(256), 0,
+                           ctx->stream, (const double*)dst, g.nchunk, nt, out);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return IPDE_OK;
+}
+
+}  // namespace
+
+extern "C" int ipde_laplace_apply(ipde_ctx* ctx, int loc, int64_t ns, const double* sx,
+                                  const double* sy, const double* w_sigma, const double* nx,
+                                  const double* ny, const double* w_tau, int64_t nt,
+                                  const double* tx, const double* ty, double* out, int flags) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, loc == IPDE_HOST || loc == IPDE_DEVICE);
+    IPDE_CHECK_ARG(ctx, ns >= 0 && nt >= 0 && ns < (1LL << 30));
+    IPDE_CHECK_ARG(ctx, w_sigma != nullptr || w_tau != nullptr);
+    IPDE_CHECK_ARG(ctx, w_tau == nullptr || (nx != nullptr && ny != nullptr));
+    if (nt == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, tx && ty && out);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    double* d_out;
+    IPDE_TRY(ipde_stage_out(ctx, loc, 7, out, nt, &d_out));
+    if (ns == 0) {
+        IPDE_HIP_CHECK(ctx, hipMemsetAsync(d_out, 0, nt * sizeof(double), ctx->stream));
+        return ipde_stage_finish(ctx, loc, 7, out, nt);
+    }
+    IPDE_CHECK_ARG(ctx, sx && sy);
+    const double *d_sx, *d_sy, *d_q, *d_nx, *d_ny, *d_tau, *d_tx, *d_ty;
+    IPDE_TRY(ipde_stage_in(ctx, loc, 0, sx, ns, &d_sx));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 1, sy, ns, &d_sy));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 2, w_sigma, ns, &d_q));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 3, w_tau ? nx : nullptr, ns, &d_nx));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 4, w_tau ? ny : nullptr, ns, &d_ny));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 5, w_tau, ns, &d_tau));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 8, tx, nt, &d_tx));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 9, ty, nt, &d_ty));
+    PackArgs pa{};
+    pa.sx = d_sx;
+    pa.sy = d_sy;
+    pa.ch[0] = d_q;
+    pa.mul[0] = -0.25 / M_PI;
+    pa.ch[1] = d_nx;
+    pa.mulby[1] = d_tau;
+    pa.mul[1] = 0.5 / M_PI;
+    pa.pw[1] = 1;
+    pa.ch[2] = d_ny;
+    pa.mulby[2] = d_tau;
+    pa.mul[2] = 0.5 / M_PI;
+    pa.pw[2] = 1;
+    pa.corr_ch = 0;
+    pa.corr2_ch = -1;
+    const bool generic = (flags & (IPDE_FLAG_GENERIC_MATH | IPDE_FLAG_SKIP_COINCIDENT)) != 0;
+    pa.use_scale = generic ? 0 : 1;
+    pa.exp_hi = ctx->logtab.exp_hi;
+    const double* rec;
+    const ApplyParams* prm;
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, d_tx, d_ty, nt, &rec, &prm));
+    int mode = (w_sigma ? MODE_SLP : 0) | (w_tau ? MODE_DLP : 0);
+    int st;
+    if (mode == MODE_SLP)
+        st = launch_laplace<MODE_SLP>(ctx, rec, ns, d_tx, d_ty, nt, d_out, prm, flags);
+    else if (mode == MODE_DLP)
+        st = launch_laplace<MODE_DLP>(ctx, rec, ns, d_tx, d_ty, nt, d_out, prm, flags);
+    else
+        st = launch_laplace<MODE_BOTH>(ctx, rec, ns, d_tx, d_ty, nt, d_out, prm, flags);
+    IPDE_TRY(st);
+    return ipde_stage_finish(ctx, loc, 7, out, nt);
+}

@@ -1,0 +1,134 @@
+"""Context handling and array marshalling for the C ABI.
+
+Arrays may be numpy (host; the library stages them through its own device
+workspace) or torch CUDA tensors (device; zero-copy).  torch is used for device
+memory only — every computation on this path is a kernel of libipde_hip.so.
+"""
+import ctypes
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_contexts = {}
+_lock = threading.Lock()
+
+
+class Context:
+    """One per GPU per process (wraps ipde_ctx)."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.IpdeHipError("no GPU visible: ipde_amd has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.ipde_ctx_create(self.device, ctypes.byref(h)))
+        self.handle = h
+        self._plans = {}
+
+    # -- misc ---------------------------------------------------------------
+    def check(self, status, allow=()):
+        return _lib.check(status, self.handle, allow)
+
+    def sync(self):
+        self.check(self.lib.ipde_ctx_sync(self.handle))
+
+    def use_torch_stream(self, stream=None):
+        """Queue all subsequent work on a torch stream (default: torch's current)."""
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        self.check(self.lib.ipde_ctx_set_stream(self.handle, ctypes.c_void_p(s.cuda_stream)))
+
+    def set_option(self, name, value):
+        self.check(self.lib.ipde_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def enable_timing(self, on=True):
+        self.check(self.lib.ipde_ctx_enable_timing(self.handle, int(bool(on))))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_double()
+        self.check(self.lib.ipde_ctx_last_kernel_ms(self.handle, ctypes.byref(ms)))
+        return ms.value
+
+    def torch_device(self):
+        return torch.device("cuda", self.device)
+
+    def close(self):
+        if self.handle:
+            for p in list(self._plans.values()):
+                p.close()
+            self._plans.clear()
+            self.lib.ipde_ctx_destroy(self.handle)
+            self.handle = None
+
+
+def get_context(device=None):
+    """Process-wide context of a device (created on first use)."""
+    if device is None:
+        if not torch.cuda.is_available():
+            raise _lib.IpdeHipError("no GPU visible: ipde_amd has no CPU fallback")
+        device = torch.cuda.current_device()
+    with _lock:
+        ctx = _contexts.get(device)
+        if ctx is None or not ctx.handle:
+            ctx = Context(device)
+            _contexts[device] = ctx
+        return ctx
+
+
+# ---------------------------------------------------------------------------
+def is_device_array(a):
+    return isinstance(a, torch.Tensor) and a.is_cuda
+
+
+def location_of(*arrays):
+    """IPDE_DEVICE if the (non-None) arrays are torch CUDA tensors, IPDE_HOST if they
+    are host arrays; mixing is an error."""
+    dev = [is_device_array(a) for a in arrays if a is not None]
+    if dev and all(dev):
+        return _lib.IPDE_DEVICE
+    if any(dev):
+        raise ValueError("mixing host arrays and device tensors in one call")
+    return _lib.IPDE_HOST
+
+
+def as_f64(a, loc):
+    """Contiguous fp64 view/copy of `a` in the representation matching `loc`."""
+    if a is None:
+        return None
+    if loc == _lib.IPDE_DEVICE:
+        if a.dtype != torch.float64 and a.dtype != torch.complex128:
+            a = a.to(torch.float64)
+        return a.contiguous()
+    a = np.asarray(a)
+    if a.dtype != np.float64 and a.dtype != np.complex128:
+        a = a.astype(np.float64)
+    return np.ascontiguousarray(a)
+
+
+def ptr(a):
+    """Raw address for the C ABI (None -> NULL)."""
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return ctypes.c_void_p(a.data_ptr())
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def empty_like_loc(shape, loc, ctx, dtype="f8"):
+    if loc == _lib.IPDE_DEVICE:
+        td = torch.float64 if dtype == "f8" else torch.complex128
+        return torch.empty(shape, dtype=td, device=ctx.torch_device())
+    return np.empty(shape, dtype=np.float64 if dtype == "f8" else np.complex128)
+
+
+def to_device(a, ctx=None):
+    """numpy -> torch CUDA tensor (fp64 / complex128), device memory only."""
+    ctx = ctx or get_context()
+    if is_device_array(a):
+        return a
+    return torch.as_tensor(np.ascontiguousarray(a), device=ctx.torch_device())

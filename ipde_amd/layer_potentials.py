@@ -1,0 +1,196 @@
+"""Layer-potential applies on the MI355X.
+
+High-level functions keep the call shape of the pybie2d functions the reference
+binds (`Laplace_Layer_Apply`, `Modified_Helmholtz_Layer_Apply`; reference
+ipde/solvers/internals/poisson.py:12,35, modified_helmholtz.py:3,37) and of the
+Stokes `Layer_Apply(src, trg, f) -> (u, v, p)` closure
+(ipde/solvers/internals/stokes.py:25-35): `source` is any object with
+.x, .y, .weights (and .normal_x, .normal_y for double layers), `target` any object
+with .x, .y; densities are NOT yet multiplied by the weights.
+
+Targets may carry device-resident coordinates (see `DeviceTargets`): then the
+result is a torch CUDA tensor and nothing crosses PCIe except the (tiny) source
+arrays.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .device import get_context, location_of, as_f64, ptr, empty_like_loc, to_device
+
+__all__ = [
+    "laplace_apply", "modified_helmholtz_apply", "stokes_apply",
+    "Laplace_Layer_Apply", "Modified_Helmholtz_Layer_Apply", "Stokes_Layer_Apply",
+    "DeviceTargets", "make_laplace_layer_apply", "make_modified_helmholtz_layer_apply",
+    "make_stokes_layer_apply",
+]
+
+
+class DeviceTargets:
+    """A target point set kept resident in HBM (the solver evaluates onto the same
+    `grid_pnai` / `radial_targ` / `grid_and_radial_pts` sets in every solve;
+    reference ipde/ebdy_collection.py:426-429,488-491)."""
+
+    def __init__(self, x, y=None, ctx=None):
+        if y is None:  # a PointSet-like object
+            x, y = x.x, x.y
+        self.ctx = ctx or get_context()
+        self.x = to_device(np.asarray(x, dtype=np.float64).ravel(), self.ctx) \
+            if not isinstance(x, torch.Tensor) else x.to(torch.float64).contiguous().view(-1)
+        self.y = to_device(np.asarray(y, dtype=np.float64).ravel(), self.ctx) \
+            if not isinstance(y, torch.Tensor) else y.to(torch.float64).contiguous().view(-1)
+        self.N = int(self.x.shape[0])
+
+
+def _match(a, loc, ctx):
+    """Bring a (small) source-side array to the location of the targets."""
+    if a is None:
+        return None
+    if loc == _lib.IPDE_DEVICE:
+        if isinstance(a, torch.Tensor):
+            return a.to(device=ctx.torch_device(), dtype=torch.float64).contiguous()
+        return to_device(np.asarray(a, dtype=np.float64), ctx)
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return as_f64(a, loc)
+
+
+def _flags(skip_coincident, generic_math):
+    return (_lib.FLAG_SKIP_COINCIDENT if skip_coincident else 0) | \
+           (_lib.FLAG_GENERIC_MATH if generic_math else 0)
+
+
+def laplace_apply(sx, sy, tx, ty, w_sigma=None, nx=None, ny=None, w_tau=None,
+                  skip_coincident=False, generic_math=False, ctx=None, out=None):
+    """ipde_laplace_apply: densities already weight-multiplied (C-ABI convention)."""
+    ctx = ctx or get_context()
+    loc = location_of(tx, ty)
+    tx, ty = as_f64(tx, loc), as_f64(ty, loc)
+    sx, sy, w_sigma, nx, ny, w_tau = (_match(a, loc, ctx) for a in (sx, sy, w_sigma, nx, ny, w_tau))
+    nt, ns = int(tx.shape[0]), int(sx.shape[0])
+    if out is None:
+        out = empty_like_loc((nt,), loc, ctx)
+    ctx.check(ctx.lib.ipde_laplace_apply(ctx.handle, loc, ns, ptr(sx), ptr(sy), ptr(w_sigma),
+                                         ptr(nx), ptr(ny), ptr(w_tau), nt, ptr(tx), ptr(ty),
+                                         ptr(out), _flags(skip_coincident, generic_math)))
+    return out
+
+
+def modified_helmholtz_apply(sx, sy, tx, ty, k, w_sigma=None, nx=None, ny=None, w_tau=None,
+                             skip_coincident=False, ctx=None, out=None):
+    ctx = ctx or get_context()
+    loc = location_of(tx, ty)
+    tx, ty = as_f64(tx, loc), as_f64(ty, loc)
+    sx, sy, w_sigma, nx, ny, w_tau = (_match(a, loc, ctx) for a in (sx, sy, w_sigma, nx, ny, w_tau))
+    nt, ns = int(tx.shape[0]), int(sx.shape[0])
+    if out is None:
+        out = empty_like_loc((nt,), loc, ctx)
+    ctx.check(ctx.lib.ipde_modhelm_apply(ctx.handle, loc, float(k), ns, ptr(sx), ptr(sy),
+                                         ptr(w_sigma), ptr(nx), ptr(ny), ptr(w_tau), nt, ptr(tx),
+                                         ptr(ty), ptr(out), _flags(skip_coincident, False)))
+    return out
+
+
+def stokes_apply(sx, sy, tx, ty, wfx=None, wfy=None, nx=None, ny=None, wdx=None, wdy=None,
+                 pressure=True, skip_coincident=False, generic_math=False, ctx=None):
+    ctx = ctx or get_context()
+    loc = location_of(tx, ty)
+    tx, ty = as_f64(tx, loc), as_f64(ty, loc)
+    sx, sy, wfx, wfy, nx, ny, wdx, wdy = (_match(a, loc, ctx)
+                                          for a in (sx, sy, wfx, wfy, nx, ny, wdx, wdy))
+    nt, ns = int(tx.shape[0]), int(sx.shape[0])
+    u = empty_like_loc((nt,), loc, ctx)
+    v = empty_like_loc((nt,), loc, ctx)
+    p = empty_like_loc((nt,), loc, ctx) if pressure else None
+    ctx.check(ctx.lib.ipde_stokes_apply(ctx.handle, loc, ns, ptr(sx), ptr(sy), ptr(wfx), ptr(wfy),
+                                        ptr(nx), ptr(ny), ptr(wdx), ptr(wdy), nt, ptr(tx), ptr(ty),
+                                        ptr(u), ptr(v), ptr(p),
+                                        _flags(skip_coincident, generic_math)))
+    return u, v, p
+
+
+# ---------------------------------------------------------------------------
+def _xy(obj):
+    return obj.x, obj.y
+
+
+def _weighted(density, weights):
+    if density is None:
+        return None
+    return np.asarray(density, dtype=np.float64) * np.asarray(weights, dtype=np.float64)
+
+
+def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=None, **kwargs):
+    """out = SLP[charge] + DLP[dipstr] evaluated at target (pybie2d call shape;
+    reference ipde/solvers/internals/poisson.py:35, examples/interior_poisson.py:89).
+    target None: source onto itself, the coincident pairs skipped."""
+    self_eval = target is None
+    trg = source if self_eval else target
+    tx, ty = _xy(trg)
+    if charge is None and dipstr is None:
+        raise ValueError("need a charge and/or a dipstr density")
+    return laplace_apply(source.x, source.y, tx, ty,
+                         w_sigma=_weighted(charge, source.weights),
+                         nx=None if dipstr is None else source.normal_x,
+                         ny=None if dipstr is None else source.normal_y,
+                         w_tau=_weighted(dipstr, source.weights),
+                         skip_coincident=self_eval)
+
+
+def Modified_Helmholtz_Layer_Apply(source, target=None, k=1.0, charge=None, dipstr=None,
+                                   backend=None, **kwargs):
+    """(reference ipde/solvers/internals/modified_helmholtz.py:37)"""
+    self_eval = target is None
+    trg = source if self_eval else target
+    tx, ty = _xy(trg)
+    if charge is None and dipstr is None:
+        raise ValueError("need a charge and/or a dipstr density")
+    return modified_helmholtz_apply(source.x, source.y, tx, ty, k,
+                                    w_sigma=_weighted(charge, source.weights),
+                                    nx=None if dipstr is None else source.normal_x,
+                                    ny=None if dipstr is None else source.normal_y,
+                                    w_tau=_weighted(dipstr, source.weights),
+                                    skip_coincident=self_eval)
+
+
+def Stokes_Layer_Apply(source, target=None, forces=None, dipstr=None, pressure=True, **kwargs):
+    """Returns (u, v, p) like the reference's Stokes Layer_Apply closure
+    (ipde/solvers/internals/stokes.py:25-35).  forces / dipstr have shape (2, N)."""
+    self_eval = target is None
+    trg = source if self_eval else target
+    tx, ty = _xy(trg)
+    if forces is None and dipstr is None:
+        raise ValueError("need a forces and/or a dipstr density")
+    w = np.asarray(source.weights, dtype=np.float64)
+    f = None if forces is None else np.asarray(forces, dtype=np.float64).reshape(2, -1) * w
+    g = None if dipstr is None else np.asarray(dipstr, dtype=np.float64).reshape(2, -1) * w
+    return stokes_apply(source.x, source.y, tx, ty,
+                        wfx=None if f is None else f[0], wfy=None if f is None else f[1],
+                        nx=None if g is None else source.normal_x,
+                        ny=None if g is None else source.normal_y,
+                        wdx=None if g is None else g[0], wdy=None if g is None else g[1],
+                        pressure=pressure, skip_coincident=self_eval)
+
+
+# -- the `Layer_Apply(src, trg, ch)` closures the solver helpers store ---------
+def make_laplace_layer_apply():
+    """Drop-in for PoissonHelper._define_layer_apply (internals/poisson.py:27-36)."""
+    def func(src, trg, ch):
+        return Laplace_Layer_Apply(src, trg, charge=ch)
+    return func
+
+
+def make_modified_helmholtz_layer_apply(k):
+    """Drop-in for ModifiedHelmholtzHelper._define_layer_apply
+    (internals/modified_helmholtz.py:28-37)."""
+    def func(src, trg, ch):
+        return Modified_Helmholtz_Layer_Apply(src, trg, charge=ch, k=k)
+    return func
+
+
+def make_stokes_layer_apply():
+    """Drop-in for StokesHelper._define_layer_apply (internals/stokes.py:25-35):
+    f is (2, N) unweighted; returns (u, v, p)."""
+    def func(src, trg, f):
+        return Stokes_Layer_Apply(src, trg, forces=f)
+    return func

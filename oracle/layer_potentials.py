@@ -1,0 +1,143 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement (numpy, fp64) of the layer-potential
+sums on ipde's hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this; the product (ipde_amd/) never does.
+
+PARITY UNPINNED for this file: the arithmetic lives in third-party packages that
+are neither under the reference tree nor installed (pybie2d `*_Layer_Apply`,
+pyfmmlib2d `SFMM`, fmm2dpy; no version pinned anywhere, reference setup.py:26).
+What the reference tree itself pins, and what this file follows:
+
+  Laplace SLP   -log(r)/(2 pi)            ipde/grid_evaluators/laplace_grid_evaluator.py:8-12,
+                                          ipde/solvers/multi_boundary/poisson.py:12-17,
+                                          ipde/solvers/internals/poisson.py:30-32
+  Laplace DLP   (n.(t-s))/(2 pi r^2)      sign from the interior jump D - I/2,
+                                          examples/interior_poisson.py:19,84
+  MH SLP        K0(k r)/(2 pi)            ipde/grid_evaluators/modified_helmholtz_grid_evaluator.py:8-9,
+                                          ipde/solvers/internals/modified_helmholtz.py:31-34
+  MH DLP        k K1(k r) (n.d)/(2 pi r)  (normal derivative of the SLP kernel w.r.t. the source)
+  Stokes SLP/DLP with pressure            ipde/solvers/internals/stokes_save.py:29-81,
+                                          ipde/solvers/internals/stokes.py:25-35
+
+The functions take densities that are NOT yet multiplied by the quadrature
+weights, exactly like the reference's `Layer_Apply(src, trg, ch)` closures
+(ipde/solvers/internals/poisson.py:27-36), and multiply `ch*weights` themselves.
+K0/K1 are scipy.special.k0/k1 — the very functions the reference calls.
+"""
+import numpy as np
+from scipy.special import k0 as _k0, k1 as _k1
+
+_CHUNK = 2048  # targets per block: (2048 x ns) fp64 temporaries
+
+
+def _blocks(nt):
+    for a in range(0, nt, _CHUNK):
+        yield a, min(nt, a + _CHUNK)
+
+
+def laplace_layer_apply(sx, sy, tx, ty, charge=None, dipstr=None, weights=None,
+                        nx=None, ny=None, skip_coincident=False):
+    """u_i = sum_j [-(1/2pi) log r_ij charge_j + (1/2pi) (n_j.d_ij)/r_ij^2 dipstr_j] w_j"""
+    sx, sy, tx, ty = (np.asarray(a, dtype=float) for a in (sx, sy, tx, ty))
+    w = np.ones_like(sx) if weights is None else np.asarray(weights, dtype=float)
+    out = np.zeros(tx.shape[0])
+    q = None if charge is None else np.asarray(charge, dtype=float) * w
+    if dipstr is not None:
+        tau = np.asarray(dipstr, dtype=float) * w
+        ax, ay = np.asarray(nx, dtype=float) * tau, np.asarray(ny, dtype=float) * tau
+    for a, b in _blocks(tx.shape[0]):
+        dx = tx[a:b, None] - sx[None, :]
+        dy = ty[a:b, None] - sy[None, :]
+        d2 = dx * dx + dy * dy
+        mask = None
+        if skip_coincident:
+            mask = d2 == 0.0
+            d2 = np.where(mask, 1.0, d2)
+        acc = np.zeros(b - a)
+        if q is not None:
+            L = np.log(d2)
+            if mask is not None:
+                L[mask] = 0.0
+            acc += (L @ q) * (-0.25 / np.pi)
+        if dipstr is not None:
+            G = (dx * ax[None, :] + dy * ay[None, :]) / d2
+            if mask is not None:
+                G[mask] = 0.0
+            acc += G.sum(axis=1) * (0.5 / np.pi)
+        out[a:b] = acc
+    return out
+
+
+def modified_helmholtz_layer_apply(sx, sy, tx, ty, k, charge=None, dipstr=None, weights=None,
+                                   nx=None, ny=None, skip_coincident=False):
+    """u_i = sum_j [(1/2pi) K0(k r) charge_j + (k/2pi) K1(k r) (n_j.d)/r dipstr_j] w_j"""
+    sx, sy, tx, ty = (np.asarray(a, dtype=float) for a in (sx, sy, tx, ty))
+    w = np.ones_like(sx) if weights is None else np.asarray(weights, dtype=float)
+    out = np.zeros(tx.shape[0])
+    q = None if charge is None else np.asarray(charge, dtype=float) * w
+    if dipstr is not None:
+        tau = np.asarray(dipstr, dtype=float) * w
+        ax, ay = np.asarray(nx, dtype=float) * tau, np.asarray(ny, dtype=float) * tau
+    for a, b in _blocks(tx.shape[0]):
+        dx = tx[a:b, None] - sx[None, :]
+        dy = ty[a:b, None] - sy[None, :]
+        r = np.hypot(dx, dy)
+        mask = None
+        if skip_coincident:
+            mask = r == 0.0
+            r = np.where(mask, 1.0, r)
+        acc = np.zeros(b - a)
+        if q is not None:
+            G = _k0(k * r)
+            if mask is not None:
+                G[mask] = 0.0
+            acc += (G @ q) * (0.5 / np.pi)
+        if dipstr is not None:
+            G = _k1(k * r) * (dx * ax[None, :] + dy * ay[None, :]) / r
+            if mask is not None:
+                G[mask] = 0.0
+            acc += G.sum(axis=1) * (0.5 * k / np.pi)
+        out[a:b] = acc
+    return out
+
+
+def stokes_layer_apply(sx, sy, tx, ty, force=None, dipstr=None, weights=None, nx=None, ny=None,
+                       skip_coincident=False):
+    """Stokeslet (force, shape (2,ns)) + stresslet (dipstr, shape (2,ns)), mu = 1.
+    Returns (u, v, p)."""
+    sx, sy, tx, ty = (np.asarray(a, dtype=float) for a in (sx, sy, tx, ty))
+    w = np.ones_like(sx) if weights is None else np.asarray(weights, dtype=float)
+    nt = tx.shape[0]
+    u, v, p = np.zeros(nt), np.zeros(nt), np.zeros(nt)
+    if force is not None:
+        f = np.asarray(force, dtype=float).reshape(2, -1) * w
+    if dipstr is not None:
+        g = np.asarray(dipstr, dtype=float).reshape(2, -1) * w
+        nxa, nya = np.asarray(nx, dtype=float), np.asarray(ny, dtype=float)
+    for a, b in _blocks(nt):
+        dx = tx[a:b, None] - sx[None, :]
+        dy = ty[a:b, None] - sy[None, :]
+        d2 = dx * dx + dy * dy
+        mask = None
+        if skip_coincident:
+            mask = d2 == 0.0
+            d2 = np.where(mask, 1.0, d2)
+        ir2 = 1.0 / d2
+        if mask is not None:
+            ir2[mask] = 0.0
+        if force is not None:
+            mlogr = -0.5 * np.log(d2)
+            if mask is not None:
+                mlogr[mask] = 0.0
+            df = (dx * f[0][None, :] + dy * f[1][None, :]) * ir2
+            u[a:b] += (mlogr @ f[0] + (df * dx).sum(axis=1)) * (0.25 / np.pi)
+            v[a:b] += (mlogr @ f[1] + (df * dy).sum(axis=1)) * (0.25 / np.pi)
+            p[a:b] += df.sum(axis=1) * (0.5 / np.pi)
+        if dipstr is not None:
+            dn = dx * nxa[None, :] + dy * nya[None, :]
+            dg = dx * g[0][None, :] + dy * g[1][None, :]
+            ng = (nxa * g[0] + nya * g[1])[None, :]
+            wq = dn * dg * ir2 * ir2
+            u[a:b] += (wq * dx).sum(axis=1) / np.pi
+            v[a:b] += (wq * dy).sum(axis=1) / np.pi
+            p[a:b] += (-ng * ir2 + 2.0 * wq).sum(axis=1) / np.pi
+    return u, v, p

@@ -1,0 +1,239 @@
+"""Parity of the HIP layer-potential kernels against the CPU oracle (GPU box).
+
+Tolerances (BASELINE.json north_star): <= 1e-12 of max|u| for Laplace / modified
+Helmholtz, <= 1e-10 for Stokes.  All calls go through the C ABI.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import layer_potentials as olp
+from util import Curve, Points, grid_targets, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+TOL_STOKES = 1e-10
+
+
+@pytest.fixture(scope="module")
+def lp():
+    from ipde_amd import layer_potentials
+    return layer_potentials
+
+
+@pytest.fixture(scope="module")
+def setup():
+    c = Curve(512, a=0.2, f=5)
+    trg, h = grid_targets(c, 96)
+    rng = np.random.default_rng(0)
+    return c, trg, rng.standard_normal(c.N), rng.standard_normal(c.N), \
+        rng.standard_normal((2, c.N)), rng.standard_normal((2, c.N))
+
+
+@pytest.mark.parametrize("mode", ["slp", "dlp", "both"])
+@pytest.mark.parametrize("generic", [False, True])
+def test_laplace_parity(lp, setup, mode, generic):
+    c, trg, sig, tau, _, _ = setup
+    ch = sig if mode in ("slp", "both") else None
+    dp = tau if mode in ("dlp", "both") else None
+    ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=ch, dipstr=dp, weights=c.weights,
+                                  nx=c.normal_x, ny=c.normal_y)
+    w = c.weights
+    got = lp.laplace_apply(c.x, c.y, trg.x, trg.y,
+                           w_sigma=None if ch is None else ch * w,
+                           nx=None if dp is None else c.normal_x,
+                           ny=None if dp is None else c.normal_y,
+                           w_tau=None if dp is None else dp * w, generic_math=generic)
+    assert rel_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+def test_laplace_kernel_variants_agree(lp, ctx, setup, variant):
+    c, trg, sig, tau, _, _ = setup
+    ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=sig, dipstr=tau,
+                                  weights=c.weights, nx=c.normal_x, ny=c.normal_y)
+    ctx.set_option("laplace_variant", variant)
+    try:
+        got = lp.Laplace_Layer_Apply(c, trg, charge=sig, dipstr=tau)
+    finally:
+        ctx.set_option("laplace_variant", 0)
+    assert rel_err(got, ref) < TOL
+
+
+def test_laplace_high_level_call_shape(lp, setup):
+    c, trg, sig, _, _, _ = setup
+    f = lp.make_laplace_layer_apply()
+    got = f(c, trg, sig)
+    ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=sig, weights=c.weights)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float64 and got.shape == (trg.N,)
+    assert rel_err(got, ref) < TOL
+
+
+def test_laplace_device_resident_targets(lp, setup):
+    import torch
+    c, trg, sig, tau, _, _ = setup
+    dt = lp.DeviceTargets(trg)
+    got = lp.Laplace_Layer_Apply(c, dt, charge=sig, dipstr=tau)
+    assert isinstance(got, torch.Tensor) and got.is_cuda
+    ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=sig, dipstr=tau,
+                                  weights=c.weights, nx=c.normal_x, ny=c.normal_y)
+    assert rel_err(got.cpu().numpy(), ref) < TOL
+
+
+def test_laplace_gauss_identity_on_gpu(lp):
+    c = Curve(800, a=0.2, f=5)
+    trg, _ = grid_targets(c, 128, clearance=6.0)
+    u = lp.Laplace_Layer_Apply(c, trg, dipstr=np.ones(c.N))
+    inside = np.hypot(trg.x, trg.y) < c.radius_at(np.arctan2(trg.y, trg.x))
+    assert np.max(np.abs(u[inside] + 1.0)) < 1e-11
+    assert np.max(np.abs(u[~inside])) < 1e-11
+
+
+@pytest.mark.parametrize("scale,center", [(1.0, (0, 0)), (1e-3, (5.0, -2.0)), (250.0, (1e3, 4e3))])
+def test_laplace_scale_and_shift_invariance_of_accuracy(lp, scale, center):
+    """The kernel rescales coordinates by a power of two for its table; results
+    must stay at parity in any unit system."""
+    c = Curve(256, a=0.2, f=5, scale=scale, center=center)
+    rng = np.random.default_rng(7)
+    sig, tau = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    th = rng.uniform(0, 2 * np.pi, 5000)
+    rr = scale * rng.uniform(0.0, 0.7, 5000)
+    tx, ty = center[0] + rr * np.cos(th), center[1] + rr * np.sin(th)
+    ref = olp.laplace_layer_apply(c.x, c.y, tx, ty, charge=sig, dipstr=tau, weights=c.weights,
+                                  nx=c.normal_x, ny=c.normal_y)
+    got = lp.Laplace_Layer_Apply(c, Points(tx, ty), charge=sig, dipstr=tau)
+    assert rel_err(got, ref) < TOL
+
+
+def test_laplace_table_miss_falls_back(lp):
+    """Targets extremely close to (and far from) the sources leave the LDS table:
+    the kernel must detect it and still be right."""
+    c = Curve(128, a=0.1, f=3)
+    rng = np.random.default_rng(11)
+    sig = rng.standard_normal(c.N)
+    eps = 1e-9
+    tx = np.concatenate([c.x[:50] - eps * c.normal_x[:50], rng.uniform(-1.0, 1.0, 3000) * 0.5])
+    ty = np.concatenate([c.y[:50] - eps * c.normal_y[:50], rng.uniform(-1.0, 1.0, 3000) * 0.5])
+    ref = olp.laplace_layer_apply(c.x, c.y, tx, ty, charge=sig, weights=c.weights)
+    got = lp.Laplace_Layer_Apply(c, Points(tx, ty), charge=sig)
+    assert rel_err(got, ref) < TOL
+
+
+def test_laplace_self_evaluation_and_edge_sizes(lp):
+    c = Curve(200, a=0.2, f=5)
+    sig = np.cos(3 * c.t)
+    got = lp.Laplace_Layer_Apply(c, None, charge=sig)
+    ref = olp.laplace_layer_apply(c.x, c.y, c.x, c.y, charge=sig, weights=c.weights,
+                                  skip_coincident=True)
+    assert np.all(np.isfinite(got)) and rel_err(got, ref) < TOL
+    # ragged sizes: 1 target, 1 source, sizes that are not multiples of anything
+    for ns, nt in [(1, 1), (7, 3), (9, 1025), (513, 4097)]:
+        rng = np.random.default_rng(ns * 1000 + nt)
+        sx, sy, q = rng.uniform(-1, 1, ns), rng.uniform(-1, 1, ns), rng.standard_normal(ns)
+        tx, ty = rng.uniform(2, 3, nt), rng.uniform(2, 3, nt)
+        ref = olp.laplace_layer_apply(sx, sy, tx, ty, charge=q)
+        got = lp.laplace_apply(sx, sy, tx, ty, w_sigma=q)
+        assert rel_err(got, ref) < TOL
+    # empty target set
+    out = lp.laplace_apply(c.x, c.y, np.zeros(0), np.zeros(0), w_sigma=sig)
+    assert out.shape == (0,)
+
+
+def test_laplace_linearity_full_size(lp):
+    """Size-independent property at the BASELINE size (2048^2 grid x 4096 nodes):
+    u[a*s1 + b*s2] == a*u[s1] + b*u[s2] on device-resident targets, plus a spot
+    check of 4096 random targets against the oracle."""
+    import torch
+    c = Curve(4096, a=0.2, f=5)
+    trg, h = grid_targets(c, 2048)
+    dt = lp.DeviceTargets(trg)
+    rng = np.random.default_rng(0)
+    s1, s2 = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    u1 = lp.Laplace_Layer_Apply(c, dt, charge=s1)
+    u2 = lp.Laplace_Layer_Apply(c, dt, charge=s2)
+    u3 = lp.Laplace_Layer_Apply(c, dt, charge=2.0 * s1 - 0.5 * s2)
+    lin = 2.0 * u1 - 0.5 * u2
+    scale = float(torch.max(torch.abs(u3)))
+    assert float(torch.max(torch.abs(u3 - lin))) < 1e-12 * scale
+    idx = rng.choice(trg.N, 4096, replace=False)
+    ref = oracle.c_laplace_apply(c.x, c.y, trg.x[idx], trg.y[idx], w_sigma=s1 * c.weights)
+    got = u1.cpu().numpy()[idx]
+    assert np.max(np.abs(got - ref)) < 1e-12 * float(torch.max(torch.abs(u1)))
+
+
+@pytest.mark.parametrize("k", [0.5, 10.0, 40.0])
+@pytest.mark.parametrize("mode", ["slp", "dlp", "both"])
+def test_modhelm_parity(lp, setup, k, mode):
+    c, trg, sig, tau, _, _ = setup
+    ch = sig if mode in ("slp", "both") else None
+    dp = tau if mode in ("dlp", "both") else None
+    ref = olp.modified_helmholtz_layer_apply(c.x, c.y, trg.x, trg.y, k, charge=ch, dipstr=dp,
+                                             weights=c.weights, nx=c.normal_x, ny=c.normal_y)
+    got = lp.Modified_Helmholtz_Layer_Apply(c, trg, k=k, charge=ch, dipstr=dp)
+    assert rel_err(got, ref) < TOL
+
+
+def test_modhelm_closure_and_self(lp, setup):
+    c, trg, sig, _, _, _ = setup
+    f = lp.make_modified_helmholtz_layer_apply(3.0)
+    ref = olp.modified_helmholtz_layer_apply(c.x, c.y, trg.x, trg.y, 3.0, charge=sig,
+                                             weights=c.weights)
+    assert rel_err(f(c, trg, sig), ref) < TOL
+    got = lp.Modified_Helmholtz_Layer_Apply(c, None, k=3.0, charge=sig)
+    ref = olp.modified_helmholtz_layer_apply(c.x, c.y, c.x, c.y, 3.0, charge=sig,
+                                             weights=c.weights, skip_coincident=True)
+    assert rel_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize("mode", ["slp", "dlp", "both"])
+@pytest.mark.parametrize("generic", [False, True])
+def test_stokes_parity(lp, setup, mode, generic):
+    c, trg, _, _, f, g = setup
+    ff = f if mode in ("slp", "both") else None
+    gg = g if mode in ("dlp", "both") else None
+    ur, vr, pr = olp.stokes_layer_apply(c.x, c.y, trg.x, trg.y, force=ff, dipstr=gg,
+                                        weights=c.weights, nx=c.normal_x, ny=c.normal_y)
+    w = c.weights
+    u, v, p = lp.stokes_apply(c.x, c.y, trg.x, trg.y,
+                              wfx=None if ff is None else ff[0] * w,
+                              wfy=None if ff is None else ff[1] * w,
+                              nx=None if gg is None else c.normal_x,
+                              ny=None if gg is None else c.normal_y,
+                              wdx=None if gg is None else gg[0] * w,
+                              wdy=None if gg is None else gg[1] * w, generic_math=generic)
+    assert rel_err(u, ur) < TOL_STOKES and rel_err(v, vr) < TOL_STOKES
+    assert rel_err(p, pr) < TOL_STOKES
+
+
+def test_stokes_closure_identities_and_scaling(lp):
+    c = Curve(600, a=0.2, f=5, scale=37.0, center=(100.0, -50.0))
+    trg, _ = grid_targets(Curve(600, a=0.2, f=5), 64, clearance=6.0)
+    trg = Points(trg.x * 37.0 + 100.0, trg.y * 37.0 - 50.0)
+    n = np.vstack([c.normal_x, c.normal_y])
+    u, v, p = lp.make_stokes_layer_apply()(c, trg, n)
+    xc, yc = (trg.x - 100.0) / 37.0, (trg.y + 50.0) / 37.0
+    inside = np.hypot(xc, yc) < (1.0 + 0.2 * np.cos(5 * np.arctan2(yc, xc)))
+    assert max(np.max(np.abs(u)), np.max(np.abs(v))) < 1e-9 * 37.0
+    assert np.max(np.abs(p[inside] + 1.0)) < 1e-9 and np.max(np.abs(p[~inside])) < 1e-9
+    rng = np.random.default_rng(4)
+    f, g = rng.standard_normal((2, c.N)), rng.standard_normal((2, c.N))
+    ur, vr, pr = olp.stokes_layer_apply(c.x, c.y, trg.x, trg.y, force=f, dipstr=g,
+                                        weights=c.weights, nx=c.normal_x, ny=c.normal_y)
+    u, v, p = lp.Stokes_Layer_Apply(c, trg, forces=f, dipstr=g)
+    assert rel_err(u, ur) < TOL_STOKES and rel_err(v, vr) < TOL_STOKES
+    assert rel_err(p, pr) < TOL_STOKES
+
+
+def test_small_target_set_source_split_is_deterministic(lp):
+    """Interface-sized target sets (N targets x N sources) take the split-source
+    path; partials are summed in a fixed order -> bitwise reproducible."""
+    c = Curve(4096, a=0.2, f=5)
+    inner = Curve(4096, a=0.2, f=5, scale=0.9)
+    rng = np.random.default_rng(9)
+    sig = rng.standard_normal(c.N)
+    a = lp.Laplace_Layer_Apply(c, inner, charge=sig)
+    b = lp.Laplace_Layer_Apply(c, inner, charge=sig)
+    assert np.array_equal(a, b)
+    ref = oracle.c_laplace_apply(c.x, c.y, inner.x, inner.y, w_sigma=sig * c.weights)
+    assert rel_err(a, ref) < TOL
