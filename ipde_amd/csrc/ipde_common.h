@@ -49,7 +49,7 @@ struct ipde_ctx {
     std::map<std::pair<int64_t, int64_t>, void*> fft1_plans;
     int num_cu = 256;
     // tuning knobs (ipde_ctx_set_option)
-    int opt_laplace_variant = 0;
+    int opt_laplace_variant = 1;
     int opt_stokes_variant = 0;
 };
 

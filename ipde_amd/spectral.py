@@ -1,0 +1,156 @@
+"""Periodic spectral grid operators on the device.
+
+`GridPlan` wraps an ipde_fft_plan (rocFFT D2Z/Z2D plans + fused symbol kernels)
+for an (nx, ny) C-ordered grid with spacings (hx, hy).  Arrays may be numpy
+(staged) or torch CUDA tensors (zero-copy); the result matches the input kind.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .device import get_context, location_of, as_f64, ptr, empty_like_loc
+
+
+class GridPlan:
+    def __init__(self, nx, ny, hx, hy, ctx=None):
+        self.ctx = ctx or get_context()
+        self.nx, self.ny, self.hx, self.hy = int(nx), int(ny), float(hx), float(hy)
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx.lib.ipde_fft_plan2d_create(self.ctx.handle, self.nx, self.ny,
+                                                           self.hx, self.hy, ctypes.byref(h)))
+        self.handle = h
+        self.shape = (self.nx, self.ny)
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.ipde_fft_plan2d_destroy(self.handle)
+            self.handle = None
+
+    # -- helpers --------------------------------------------------------------
+    def _real_in(self, f):
+        loc = location_of(f)
+        f = as_f64(f, loc)
+        if tuple(f.shape) != self.shape:
+            raise ValueError("grid shape %s does not match the plan %s" % (tuple(f.shape), self.shape))
+        return loc, f
+
+    # -- grid solves ----------------------------------------------------------
+    def poisson_solve(self, f, want_uhat=False):
+        """u = ifft2(fft2(f) * ilap).real  (multi_boundary/poisson.py:30-38; f demeaned
+        by the caller).  Returns (uhat, u) like the reference when want_uhat."""
+        loc, f = self._real_in(f)
+        u = empty_like_loc(self.shape, loc, self.ctx)
+        uh = empty_like_loc(self.shape, loc, self.ctx, "c16") if want_uhat else None
+        self.ctx.check(self.ctx.lib.ipde_poisson_grid_solve(self.handle, loc, ptr(f), ptr(u), ptr(uh)))
+        return (uh, u) if want_uhat else u
+
+    def modhelm_solve(self, f, k, want_uhat=False):
+        """(multi_boundary/modified_helmholtz.py:40-46)"""
+        loc, f = self._real_in(f)
+        u = empty_like_loc(self.shape, loc, self.ctx)
+        uh = empty_like_loc(self.shape, loc, self.ctx, "c16") if want_uhat else None
+        self.ctx.check(self.ctx.lib.ipde_modhelm_grid_solve(self.handle, loc, float(k), ptr(f),
+                                                            ptr(u), ptr(uh)))
+        return (uh, u) if want_uhat else u
+
+    def stokes_solve(self, fu, fv):
+        """(uc, vc, pc) of multi_boundary/stokes.py:34-45 (fu, fv demeaned by the caller)"""
+        loc = location_of(fu, fv)
+        fu, fv = as_f64(fu, loc), as_f64(fv, loc)
+        u, v, p = (empty_like_loc(self.shape, loc, self.ctx) for _ in range(3))
+        self.ctx.check(self.ctx.lib.ipde_stokes_grid_solve(self.handle, loc, ptr(fu), ptr(fv),
+                                                           ptr(u), ptr(v), ptr(p)))
+        return u, v, p
+
+    # -- derivatives ----------------------------------------------------------
+    def dx(self, f):
+        return self._deriv(f, 0)
+
+    def dy(self, f):
+        return self._deriv(f, 1)
+
+    def _deriv(self, f, axis):
+        loc, f = self._real_in(f)
+        out = empty_like_loc(self.shape, loc, self.ctx)
+        self.ctx.check(self.ctx.lib.ipde_fourier_deriv(self.handle, loc, ptr(f), axis, ptr(out)))
+        return out
+
+    def fourier_multiply(self, f, sym):
+        """ifft2(fft2(f) * sym).real for an arbitrary complex symbol array."""
+        loc, f = self._real_in(f)
+        if loc == _lib.IPDE_HOST:
+            sym = np.ascontiguousarray(np.broadcast_to(np.asarray(sym, dtype=np.complex128), self.shape))
+        else:
+            import torch
+            if not isinstance(sym, torch.Tensor):
+                sym = torch.as_tensor(np.ascontiguousarray(
+                    np.broadcast_to(np.asarray(sym, dtype=np.complex128), self.shape)), device=f.device)
+            sym = sym.to(torch.complex128).expand(self.shape).contiguous()
+        out = empty_like_loc(self.shape, loc, self.ctx)
+        self.ctx.check(self.ctx.lib.ipde_fourier_multiply(self.handle, loc, ptr(f), ptr(sym), ptr(out)))
+        return out
+
+    # -- plain transforms (ipde.utilities.fft2 / ifft2) ------------------------
+    def fft2(self, a):
+        loc = location_of(a)
+        if (loc == _lib.IPDE_HOST and np.isrealobj(a)) or (loc == _lib.IPDE_DEVICE and not a.is_complex()):
+            a = as_f64(a, loc)
+            out = empty_like_loc(self.shape, loc, self.ctx, "c16")
+            self.ctx.check(self.ctx.lib.ipde_fft2_r2c_full(self.handle, loc, ptr(a), ptr(out)))
+            return out
+        return self._c2c(a, -1)
+
+    def ifft2(self, a):
+        return self._c2c(a, +1)
+
+    def _c2c(self, a, direction):
+        loc = location_of(a)
+        if loc == _lib.IPDE_HOST:
+            a = np.ascontiguousarray(a, dtype=np.complex128)
+        else:
+            import torch
+            a = a.to(torch.complex128).contiguous()
+        out = empty_like_loc(self.shape, loc, self.ctx, "c16")
+        self.ctx.check(self.ctx.lib.ipde_fft2_c2c(self.handle, loc, direction, ptr(a), ptr(out)))
+        return out
+
+
+def get_plan(nx, ny, hx, hy, ctx=None):
+    """Cached GridPlan (rocFFT plan creation is expensive; shapes repeat)."""
+    ctx = ctx or get_context()
+    key = (int(nx), int(ny), float(hx), float(hy))
+    p = ctx._plans.get(key)
+    if p is None or not p.handle:
+        p = GridPlan(nx, ny, hx, hy, ctx)
+        ctx._plans[key] = p
+    return p
+
+
+def fd4(f, h, axis, periodic_fix=False, ctx=None):
+    """4th-order centred difference along axis 0 (x) or 1 (y)."""
+    ctx = ctx or get_context()
+    loc = location_of(f)
+    f = as_f64(f, loc)
+    nx, ny = int(f.shape[0]), int(f.shape[1])
+    out = empty_like_loc((nx, ny), loc, ctx)
+    ctx.check(ctx.lib.ipde_fd4(ctx.handle, loc, nx, ny, float(h), int(axis), int(bool(periodic_fix)),
+                               ptr(f), ptr(out)))
+    return out
+
+
+def fft1(a, direction, ctx=None):
+    """Batched 1-D complex FFT along the last axis of a 2-D (batch, n) array."""
+    ctx = ctx or get_context()
+    loc = location_of(a)
+    if loc == _lib.IPDE_HOST:
+        a = np.ascontiguousarray(a, dtype=np.complex128)
+    else:
+        import torch
+        a = a.to(torch.complex128).contiguous()
+    shape = tuple(a.shape)
+    batch = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
+    n = int(shape[-1])
+    out = empty_like_loc(shape, loc, ctx, "c16")
+    ctx.check(ctx.lib.ipde_fft1_c2c(ctx.handle, loc, batch, n, int(direction), ptr(a), ptr(out)))
+    return out

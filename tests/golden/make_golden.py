@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by IMPORTING the reference
+(/root/reference) in the build container.  The fixtures are data only (seeded
+inputs + the reference's outputs); no reference source is copied.
+
+    python tests/golden/make_golden.py
+
+What can be imported:
+  * ipde.derivatives                      — numpy only, imports as is;
+  * ipde.utilities, ipde.annular.*        — need three packages the image lacks:
+      numexpr            (only `import numexpr as ne`; never called on this path)
+      numba              (`njit`/`prange` decorators on the batched matvecs)
+      personal_utilities.scipy_gmres.right_gmres   (absent upstream module)
+    They are satisfied with in-process stand-ins registered in sys.modules below
+    (identity decorators; `range` for prange; a small right-preconditioned GMRES).
+    The stand-ins only make the modules importable; every number stored here is
+    produced by the reference's own code.  Because the GMRES is ours, only
+    OPERATOR-level outputs (matrices, apply, preconditioner) are exact goldens;
+    the solve outputs are stored with the manufactured solution they must
+    reproduce and are compared at solver tolerance.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_standins():
+    ne = types.ModuleType("numexpr")
+    ne.evaluate = lambda expr, **kw: (_ for _ in ()).throw(RuntimeError("numexpr stand-in"))
+    sys.modules.setdefault("numexpr", ne)
+
+    nb = types.ModuleType("numba")
+
+    def njit(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return args[0]
+        return lambda f: f
+    nb.njit = njit
+    nb.jit = njit
+    nb.prange = range
+    nb.float64 = float
+    nb.int64 = int
+    nb.boolean = bool
+    sys.modules.setdefault("numba", nb)
+
+    pu = types.ModuleType("personal_utilities")
+    sg = types.ModuleType("personal_utilities.scipy_gmres")
+
+    def right_gmres(A, b, M=None, tol=1e-12, maxiter=200, restart=50, verbose=False, **kw):
+        """x = M y with A M y = b (restarted GMRES, modified Gram-Schmidt)."""
+        n = b.shape[0]
+        x = np.zeros(n, dtype=complex)
+        bn = np.linalg.norm(b)
+        res = []
+        if bn == 0:
+            return x, 0, res
+        it = 0
+        while it < maxiter:
+            r = b - A.matvec(x) if it else b.copy()
+            beta = np.linalg.norm(r)
+            if beta <= tol * bn:
+                break
+            V = [r / beta]
+            Z = []
+            H = np.zeros((restart + 1, restart), dtype=complex)
+            g = np.zeros(restart + 1, dtype=complex)
+            g[0] = beta
+            k = 0
+            for k in range(restart):
+                z = M.matvec(V[k]) if M is not None else V[k]
+                z = np.array(z, dtype=complex, copy=True)
+                Z.append(z)
+                w = np.array(A.matvec(z), dtype=complex, copy=True)
+                for i in range(k + 1):
+                    H[i, k] = np.vdot(V[i], w)
+                    w -= H[i, k] * V[i]
+                H[k + 1, k] = np.linalg.norm(w)
+                V.append(w / H[k + 1, k])
+                y, *_ = np.linalg.lstsq(H[:k + 2, :k + 1], g[:k + 2], rcond=None)
+                rr = np.linalg.norm(H[:k + 2, :k + 1] @ y - g[:k + 2])
+                res.append(rr / bn)
+                it += 1
+                if rr <= tol * bn or it >= maxiter:
+                    break
+            x = x + sum(yi * zi for yi, zi in zip(y, Z))
+            if res[-1] <= tol:
+                break
+        return x, 0, res
+    sg.right_gmres = right_gmres
+    sg.gmres = right_gmres
+    pu.scipy_gmres = sg
+    sys.modules.setdefault("personal_utilities", pu)
+    sys.modules.setdefault("personal_utilities.scipy_gmres", sg)
+
+
+def golden_derivatives():
+    from ipde.derivatives import fd_x_4, fd_y_4, fourier
+    rng = np.random.default_rng(101)
+    out = {}
+    for tag, (nx, ny) in {"even": (48, 40), "odd": (45, 37)}.items():
+        f = rng.standard_normal((nx, ny))
+        hx, hy = 2 * np.pi / nx * 1.3, 2 * np.pi / ny * 0.7
+        kx = np.fft.fftfreq(nx, hx / (2 * np.pi))[:, None]
+        ky = np.fft.fftfreq(ny, hy / (2 * np.pi))
+        out[tag + "_f"] = f
+        out[tag + "_h"] = np.array([hx, hy])
+        out[tag + "_fdx"] = fd_x_4(f, hx)
+        out[tag + "_fdy"] = fd_y_4(f, hy)
+        out[tag + "_fdx_p"] = fd_x_4(f, hx, periodic_fix=True)
+        out[tag + "_fdy_p"] = fd_y_4(f, hy, periodic_fix=True)
+        out[tag + "_dx"] = fourier(f, 1j * kx)
+        out[tag + "_dy"] = fourier(f, 1j * ky)
+        sym = rng.standard_normal((nx, ny)) + 1j * rng.standard_normal((nx, ny))
+        out[tag + "_sym"] = sym
+        out[tag + "_gen"] = fourier(f, sym)
+    np.savez_compressed(os.path.join(OUT, "derivatives.npz"), **out)
+    print("derivatives.npz", len(out))
+
+
+def _annulus_fields(n, seed):
+    """speed / curvature of a smooth star-like closed curve (analytic)."""
+    t = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    a, f = 0.15, 3
+    r = 1 + a * np.cos(f * t)
+    rp = -a * f * np.sin(f * t)
+    rpp = -a * f * f * np.cos(f * t)
+    speed = np.sqrt(r * r + rp * rp)
+    curvature = (r * r + 2 * rp * rp - r * rpp) / speed ** 3
+    return t, speed, curvature
+
+
+def golden_annular_scalar():
+    from ipde.annular.annular_full import ApproximateAnnularGeometry, RealAnnularGeometry
+    from ipde.annular.modified_helmholtz import AnnularModifiedHelmholtzSolver
+    from ipde.annular.poisson import AnnularPoissonSolver
+    rng = np.random.default_rng(202)
+    out = {}
+    n, M, width, radius = 64, 10, 0.25, 1.0
+    AAG = ApproximateAnnularGeometry(n, M, width, radius)
+    CO = AAG.CO
+    for name in ["D00", "D01", "D12", "R01", "R12", "R02", "P10", "ibc_dirichlet", "obc_dirichlet",
+                 "ibc_neumann", "obc_neumann", "VI1"]:
+        out["CO_" + name] = getattr(CO, name)
+    out["params"] = np.array([n, M, width, radius])
+    out["rv0"], out["rv1"], out["rv2"] = AAG.rv0, AAG.rv1, AAG.rv2
+    out["ratio"] = np.array([AAG.ratio])
+    t, speed, curvature = _annulus_fields(n, 0)
+    RAG = RealAnnularGeometry(speed, curvature, AAG)
+    out["speed"], out["curvature"] = speed, curvature
+    for name in ["psi0", "psi1", "psi2", "inv_psi0", "inv_psi1", "inv_psi2", "DR_psi2",
+                 "ipsi_DR_ipsi_DT_psi2", "ipsi_DT_ipsi_DR_psi2"]:
+        out["RAG_" + name] = getattr(RAG, name)
+    for tag, k in [("mh", 2.5), ("po", 0.0)]:
+        S = AnnularModifiedHelmholtzSolver(AAG, k) if tag == "mh" else AnnularPoissonSolver(AAG)
+        S.RAG = RAG
+        out[tag + "_k"] = np.array([k])
+        out[tag + "_kinv"] = S.Stacked_KINVS
+        uh = rng.standard_normal(M * n) + 1j * rng.standard_normal(M * n)
+        out[tag + "_uh"] = uh
+        out[tag + "_apply"] = np.array(S._apply(uh.copy()))
+        out[tag + "_prec"] = np.array(S._optim_preconditioner(uh.copy())).copy()
+        # manufactured solve on the real geometry: u = exp(sin x) cos(2y) style field
+        rv = AAG.rv0
+        # boundary-fitted coordinates: point = X(t) + r * n(t), inward r in [-width, 0]
+        rr = 1 + 0.15 * np.cos(3 * t)
+        bx, by = rr * np.cos(t), rr * np.sin(t)
+        rp = -0.45 * np.sin(3 * t)
+        xp = rp * np.cos(t) - rr * np.sin(t)
+        yp = rp * np.sin(t) + rr * np.cos(t)
+        sp = np.hypot(xp, yp)
+        nxv, nyv = yp / sp, -xp / sp
+        X = bx[None, :] + rv[:, None] * nxv[None, :]
+        Y = by[None, :] + rv[:, None] * nyv[None, :]
+        kk = 1.3
+        sol = np.exp(np.sin(kk * X)) * np.sin(kk * Y)
+        lap = kk ** 2 * np.exp(np.sin(kk * X)) * np.sin(kk * Y) * (np.cos(kk * X) ** 2 - np.sin(kk * X) - 1.0)
+        force = (k * k * sol - lap) if tag == "mh" else lap
+        Xi = bx - width * nxv
+        Yi = by - width * nyv
+        ig = np.exp(np.sin(kk * Xi)) * np.sin(kk * Yi)
+        og = np.exp(np.sin(kk * bx)) * np.sin(kk * by)
+        # geometry convention: ibc acts at r = -width... (the solver's own ibc/obc rows decide)
+        ig_row = CO.ibc_dirichlet.dot(sol)[0]
+        og_row = CO.obc_dirichlet.dot(sol)[0]
+        es = S.solve(RAG, force, ig_row, og_row, tol=1e-13, maxiter=200, restart=60)
+        out[tag + "_force"] = force
+        out[tag + "_ig"] = ig_row
+        out[tag + "_og"] = og_row
+        out[tag + "_sol_exact"] = sol
+        out[tag + "_sol_ref"] = es
+        out[tag + "_iters"] = np.array([S.iterations_last_call])
+        print(tag, "ref solve err vs manufactured:", np.abs(es - sol).max(), "iters", S.iterations_last_call)
+    np.savez_compressed(os.path.join(OUT, "annular_scalar.npz"), **out)
+    print("annular_scalar.npz", len(out))
+
+
+def golden_annular_stokes():
+    from ipde.annular.annular import ApproximateAnnularGeometry, RealAnnularGeometry
+    from ipde.annular.stokes import AnnularStokesSolver
+    rng = np.random.default_rng(303)
+    out = {}
+    n, M, width, radius = 48, 8, 0.3, 1.0
+    AAG = ApproximateAnnularGeometry(n, M, width, radius)
+    t, speed, curvature = _annulus_fields(n, 0)
+    RAG = RealAnnularGeometry(speed, curvature, AAG)
+    S = AnnularStokesSolver(AAG, mu=1.0)
+    out["params"] = np.array([n, M, width, radius])
+    out["speed"], out["curvature"] = speed, curvature
+    out["ks"] = AAG.ks
+    for name in ["psi0", "psi1", "inv_psi1", "inv_psi2", "DR_psi2", "ipsi_DR_ipsi_DT_psi2",
+                 "ipsi_DT_ipsi_DR_psi2"]:
+        out["RAG_" + name] = getattr(RAG, name)
+    out["kinv"] = S.Stacked_KINVS
+    # set the state solve() would set, then apply to (a) a random complex vector and
+    # (b) a Hermitian-consistent one (the transform of real fields), the case that
+    # occurs inside GMRES
+    S.RAG = RAG
+    S.combo1 = 2 * RAG.DR_psi2 * RAG.inv_psi2 ** 2
+    S.combo2 = RAG.DR_psi2 ** 2 * RAG.inv_psi2 ** 2
+    S.ik = AAG.k * 1j
+    S.iks = AAG.ks * 1j
+    NB = S.NB
+    v = rng.standard_normal(NB) + 1j * rng.standard_normal(NB)
+    out["vec_random"] = v
+    out["apply_random"] = np.array(S._apply_optim_real(v.copy()))
+    out["prec_random"] = np.array(S._preconditioner(v.copy()))
+    from ipde.utilities import mfft
+    ur = rng.standard_normal((M, n))
+    ut = rng.standard_normal((M, n))
+    p = rng.standard_normal((M - 1, n))
+    vh = np.concatenate([mfft(ur).ravel(), mfft(ut).ravel(), mfft(p).ravel()])
+    out["vec_herm"] = vh
+    out["apply_herm"] = np.array(S._apply_optim_real(vh.copy()))
+    # a full solve with smooth forcing (tolerance-level golden)
+    rv = AAG.rv0
+    T = t[None, :] + 0 * rv[:, None]
+    fr = np.cos(2 * T) * (1 + rv[:, None])
+    ft = np.sin(3 * T) * (1 - 0.5 * rv[:, None])
+    irg, itg = 0.1 * np.cos(t), 0.2 * np.sin(2 * t)
+    org, otg = -0.3 * np.sin(t), 0.1 * np.cos(3 * t)
+    # compatibility: net flux through the two boundaries must vanish for div u = 0;
+    # use zero-mean normal data (cos/sin are zero-mean)
+    urs, uts, ps = S.solve(RAG, fr, ft, irg, itg, org, otg, tol=1e-12, maxiter=300, restart=100)
+    out["fr"], out["ft"] = fr, ft
+    out["irg"], out["itg"], out["org"], out["otg"] = irg, itg, org, otg
+    out["sol_ur"], out["sol_ut"], out["sol_p"] = urs, uts, ps
+    out["P10"] = AAG.CO.P10
+    print("stokes golden: |ur| %.3e |ut| %.3e |p| %.3e" % (np.abs(urs).max(), np.abs(uts).max(),
+                                                       np.abs(ps).max()))
+    np.savez_compressed(os.path.join(OUT, "annular_stokes.npz"), **out)
+    print("annular_stokes.npz", len(out))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present; fixtures can only be regenerated where it is")
+    _install_standins()
+    sys.path.insert(0, REF)
+    golden_derivatives()
+    golden_annular_scalar()
+    golden_annular_stokes()

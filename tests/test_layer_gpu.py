@@ -57,7 +57,7 @@ def test_laplace_kernel_variants_agree(lp, ctx, setup, variant):
     try:
         got = lp.Laplace_Layer_Apply(c, trg, charge=sig, dipstr=tau)
     finally:
-        ctx.set_option("laplace_variant", 0)
+        ctx.set_option("laplace_variant", 1)
     assert rel_err(got, ref) < TOL
 
 
