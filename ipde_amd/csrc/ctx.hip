@@ -72,15 +72,19 @@ int ipde_stage_finish(ipde_ctx* ctx, int loc, int slot, double* p, size_t n) {
 // Built on the host in long double and uploaded once.
 int ipde_build_log_table(ipde_ctx* ctx) {
     LogTable& t = ctx->logtab;
+    // 32 binades x 256 mantissa intervals = 8192 entries (128 KiB of LDS).  An entry
+    // sits at position (key mod 8192): the kernels index with a shift and a mask
+    // only, and validate the covered range once per lane from min/max of hi32(x).
     t.mant_bits = 8;
-    t.exp_lo = -24;
     t.exp_hi = 4;
+    t.exp_lo = t.exp_hi - 32;
     const int B = t.mant_bits;
     t.key_lo = (1023 + t.exp_lo) << B;
     t.nkeys = (t.exp_hi - t.exp_lo) << B;
     std::vector<double> h((size_t)t.nkeys * 2);
-    for (int i = 0; i < t.nkeys; ++i) {
-        uint64_t key = (uint64_t)(t.key_lo + i);
+    for (int n = 0; n < t.nkeys; ++n) {
+        uint64_t key = (uint64_t)(t.key_lo + n);
+        const int i = (int)(key & (uint64_t)(t.nkeys - 1));
         uint64_t lo_bits = key << (52 - B);
         uint64_t hi_bits = (key + 1) << (52 - B);
         double xlo, xhi;
@@ -89,7 +93,7 @@ int ipde_build_log_table(ipde_ctx* ctx) {
         long double c = 0.5L * ((long double)xlo + (long double)xhi);
         double R = (double)(1.0L / c);
         double T = (double)(-logl((long double)R));
-        h[2 * i] = R;
+        h[2 * i] = 0.5 * R;  // Rh = R/2 (exact), see layer_common.h
         h[2 * i + 1] = T;
     }
     IPDE_HIP_CHECK(ctx, hipMalloc((void**)&t.d_tab, h.size() * sizeof(double)));

@@ -52,27 +52,68 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------
-// Table-driven log: log(x) = T + log1p(z), z = x*R - 1, |z| <= 2^-(B+1).
-// The entry {R, T} is one ds_read_b128.  Degree-5 Taylor of log1p(z)/z is
-// accurate to z^6/6 <= 2^-54/6 for B = 8.
-__device__ __forceinline__ double log1p_poly5(double z, double T) {
-    double p = fma(z, 0.2, -0.25);
-    p = fma(p, z, 1.0 / 3.0);
-    p = fma(p, z, -0.5);
-    p = fma(p, z, 1.0);
-    return fma(p, z, T);
+// Table-driven log / reciprocal.  For every key = hi32(x) >> 12 (sign, exponent and
+// the top IPDE_TAB_B = 8 mantissa bits of x) of the 32 covered binades the table
+// holds {Rh, T} with R ~ 1/centre(interval), Rh = R/2, T = -log R, stored at
+// position (key mod 8192).  With y = x*Rh - 1/2 (= z/2, z = x*R - 1, |z| <= 2^-9):
+//   log(x) = T + log1p(2y),   1/x = 2 Rh / (1 + 2y).
+// log1p is the degree-5 Taylor polynomial economised to degree 4 on |z| <= a = 2^-9
+// (z^5 -> (20 a^2 z^3 - 5 a^4 z)/16; max error a^5/80 = 3.6e-16 absolute, one
+// rounding of a log value of O(1..10)):
+//   log1p(z) ~ z (1 - a^4/16) - z^2/2 + z^3 (1/3 + a^2/4) - z^4/4
+// written in y so that every Horner step is ONE v_fma_f64 whose constants are
+// inline constants (-4, -2, -0.5) or a single SGPR pair (gfx9 constant-bus limit 1).
+#define IPDE_TAB_B 8
+#define IPDE_TAB_SHIFT (20 - IPDE_TAB_B)
+#define IPDE_TAB_BINADES 32
+#define IPDE_TAB_NKEYS (IPDE_TAB_BINADES << IPDE_TAB_B)
+
+__device__ __forceinline__ double tab_y(double x, double Rh) { return fma(x, Rh, -0.5); }
+
+#define IPDE_LOG_K3 (8.0 * (1.0 / 3.0 + 0x1p-20))
+#define IPDE_LOG_K1 (2.0 * (1.0 - 0x1p-40))
+
+__device__ __forceinline__ double log_from_y(double y, double T) {
+    double p = fma(y, -4.0, IPDE_LOG_K3);
+    p = fma(y, p, -2.0);
+    p = fma(y, p, IPDE_LOG_K1);
+    return fma(y, p, T);
 }
 
-// 1/x from the same table entry: 1/x = R/(1+z), |z| <= 2^-9:
-//   1/(1+z) = (1-z)(1+z^2)(1+z^4) + O(z^8)
-__device__ __forceinline__ double tab_rcp_from(double R, double z) {
-    double g = fma(z, -1.0, 1.0);
+// 1/x = 2 Rh (1 - z)(1 + z^2)(1 + z^4) + O(z^8), z = 2y
+__device__ __forceinline__ double rcp_from_y(double Rh, double y) {
+    double g = fma(y, -4.0, 2.0);  // 2 (1 - z)
+    double z = y + y;
     double z2 = z * z;
     g = fma(z2, g, g);
     double z4 = z2 * z2;
     g = fma(z4, g, g);
-    return R * g;
+    return Rh * g;
 }
+
+// Table addressing: one v_bfe_u32 + one v_lshl_add_u32, plus min3/max3 tracking of
+// hi32(x) so that the covered range is validated ONCE per lane after the source loop.
+struct TabAddr {
+    unsigned hmin, hmax;
+    __device__ __forceinline__ TabAddr() : hmin(0xFFFFFFFFu), hmax(0u) {}
+    __device__ __forceinline__ double2 lookup(const double2* ltab, double x) {
+        unsigned hi = (unsigned)__double2hiint(x);
+        hmin = min(hmin, hi);
+        hmax = max(hmax, hi);
+        // hipcc lowers the C form to v_lshrrev + v_and (+ v_lshl_add for the address);
+        // the bit-field extract is one instruction.  Plain VALU op: no wait counters,
+        // VALU->VALU dependencies are hardware-interlocked.
+        unsigned idx;
+        static_assert(IPDE_TAB_SHIFT == 12 && IPDE_TAB_B + 5 == 13, "literal operands below");
+        asm("v_bfe_u32 %0, %1, 12, 13" : "=v"(idx) : "v"(hi));
+        return ltab[idx];
+    }
+    // every x seen so far was inside the covered binades?
+    __device__ __forceinline__ bool all_inside(unsigned key_lo) const {
+        return (hmin >> IPDE_TAB_SHIFT) >= key_lo &&
+               (hmax >> IPDE_TAB_SHIFT) < key_lo + IPDE_TAB_NKEYS;
+    }
+};
 
 // Launch geometry shared by the three kernel families: big target sets give every
 // lane R targets and every block all sources; small target sets split the

@@ -5,9 +5,11 @@
 //   out_i = sum_j q'_j log(d2_ij) + (a'_j . d_ij)/d2_ij   (+ corr for the scaling)
 //
 // Roofline: fp64 VALU bound.  Per source/target pair the table kernel issues
-//   4 (dx,dy,d2) + 1 (z) + 5 (log1p poly + T) + 1 (accumulate) fp64 ops for the
+//   4 (dx,dy,d2) + 1 (z) + 4 (log1p poly + T) + 1 (accumulate) fp64 ops for the
 //   SLP, + 2 (a.d) + 6 (1/d2 from the same table entry) + 1 for the DLP,
-// plus 4 int32 ops and one ds_read_b128 (the {R, -log R} table entry).
+// plus 3 int32 ops (shift, mask, min3/max3 range tracking) and one ds_read_b128
+// (the {R, -log R} table entry).  Measured: every VALU instruction, int32 or fp64,
+// costs one quad-cycle of the SIMD here, so instruction count is what matters.
 // Algorithmic HBM traffic is 24 B per target (read x,y, write u) — irrelevant.
 #include "layer_pack.h"
 
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(NT) void laplace_table_kernel(
     extern __shared__ double2 ltab[];
     for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
     __syncthreads();
-    const unsigned nkeys_m1 = nkeys - 1;
+    TabAddr ta;
 
     const int j0 = blockIdx.y * chunk;
     const int j1 = min(ns_pad, j0 + chunk);
@@ -99,7 +101,6 @@ __global__ __launch_bounds__(NT) void laplace_table_kernel(
         y[r] = ty[i] * s1;
         acc[r] = 0.0;
     }
-    unsigned worst = 0;
     for (int b = j0 / IPDE_SRC_PAD; b < j1 / IPDE_SRC_PAD; ++b) {
         SrcRow sx, sy, sq, sax, say;
         sx.load(rec, b, 0);
@@ -120,36 +121,31 @@ __global__ __launch_bounds__(NT) void laplace_table_kernel(
                     dx[u][r] = x[r] - sx.v[u0 + u];
                     dy[u][r] = y[r] - sy.v[u0 + u];
                     d2[u][r] = fma(dy[u][r], dy[u][r], dx[u][r] * dx[u][r]);
-                    unsigned idx = ((unsigned)__double2hiint(d2[u][r]) >> shift) - key_lo;
-                    worst = max(worst, idx);
-                    e[u][r] = ltab[min(idx, nkeys_m1)];
+                    e[u][r] = ta.lookup(ltab, d2[u][r]);
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int r = 0; r < R; ++r) z[u][r] = fma(d2[u][r], e[u][r].x, -1.0);
+                for (int r = 0; r < R; ++r) z[u][r] = tab_y(d2[u][r], e[u][r].x);
             if (MODE & MODE_SLP) {
+                // log_from_y, written phase by phase (z[][] holds y = z/2 here)
                 double p[U][R];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) p[u][r] = fma(z[u][r], 0.2, -0.25);
+                    for (int r = 0; r < R; ++r) p[u][r] = fma(z[u][r], -4.0, IPDE_LOG_K3);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) p[u][r] = fma(p[u][r], z[u][r], 1.0 / 3.0);
+                    for (int r = 0; r < R; ++r) p[u][r] = fma(z[u][r], p[u][r], -2.0);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) p[u][r] = fma(p[u][r], z[u][r], -0.5);
+                    for (int r = 0; r < R; ++r) p[u][r] = fma(z[u][r], p[u][r], IPDE_LOG_K1);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) p[u][r] = fma(p[u][r], z[u][r], 1.0);
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int r = 0; r < R; ++r) p[u][r] = fma(p[u][r], z[u][r], e[u][r].y);
+                    for (int r = 0; r < R; ++r) p[u][r] = fma(z[u][r], p[u][r], e[u][r].y);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -161,12 +157,12 @@ __global__ __launch_bounds__(NT) void laplace_table_kernel(
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         double ad = fma(say.v[u0 + u], dy[u][r], sax.v[u0 + u] * dx[u][r]);
-                        acc[r] = fma(ad, tab_rcp_from(e[u][r].x, z[u][r]), acc[r]);
+                        acc[r] = fma(ad, rcp_from_y(e[u][r].x, z[u][r]), acc[r]);
                     }
             }
         }
     }
-    if (worst > nkeys_m1) {
+    if (!ta.all_inside(key_lo)) {
         // some pair of this lane fell outside the table (d^2 == 0, tiny or huge):
         // redo the lane's targets with the generic math.  Rare by construction.
 #pragma unroll
@@ -210,6 +206,9 @@ int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
         case 3: NTv = 1024; Rv = 2; break;
         case 4: NTv = 768; Rv = 4; break;
         case 5: NTv = 512; Rv = 4; break;
+        case 6: NTv = 1024; Rv = 4; break;
+        case 7: NTv = 1024; Rv = 2; break;
+        case 8: NTv = 1024; Rv = 3; break;
         default: break;
     }
     const LayerGeom g = ipde_layer_geom(ns, nt, NTv * Rv, ctx->num_cu);
@@ -235,6 +234,9 @@ int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
             case 3: st = launch_table_variant<MODE, 2, 1024, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
             case 4: st = launch_table_variant<MODE, 4, 768, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
             case 5: st = launch_table_variant<MODE, 4, 512, 1>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 6: st = launch_table_variant<MODE, 4, 1024, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 7: st = launch_table_variant<MODE, 2, 1024, 4>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 8: st = launch_table_variant<MODE, 3, 1024, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
             default: st = launch_table_variant<MODE, 4, 512, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
         }
         IPDE_TRY(st);

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NT) void stokes_table_kernel(
     extern __shared__ double2 ltab[];
     for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
     __syncthreads();
-    const unsigned nkeys_m1 = nkeys - 1;
+    TabAddr ta;
     const int j0 = blockIdx.y * chunk;
     const int j1 = min(ns_pad, j0 + chunk);
     const double s1 = ldexp(1.0, prm->sh);
@@ -137,7 +137,6 @@ __global__ __launch_bounds__(NT) void stokes_table_kernel(
         y[r] = ty[i] * s1;
         acc[r] = StokesAcc{0, 0, 0, 0, 0};
     }
-    unsigned worst = 0;
     // half batches (4 sources): every channel row is one s_load_dwordx8, all issued
     // before the first table lookup of the group (see layer_common.h)
     for (int hb = j0 / 4; hb < j1 / 4; ++hb) {
@@ -172,22 +171,20 @@ __global__ __launch_bounds__(NT) void stokes_table_kernel(
                     dx[u][r] = x[r] - sx[u0 + u];
                     dy[u][r] = y[r] - sy[u0 + u];
                     d2[u][r] = fma(dy[u][r], dy[u][r], dx[u][r] * dx[u][r]);
-                    unsigned idx = ((unsigned)__double2hiint(d2[u][r]) >> shift) - key_lo;
-                    worst = max(worst, idx);
-                    e[u][r] = ltab[min(idx, nkeys_m1)];
+                    e[u][r] = ta.lookup(ltab, d2[u][r]);
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    double z = fma(d2[u][r], e[u][r].x, -1.0);
-                    double rinv = tab_rcp_from(e[u][r].x, z);
-                    double L = (MODE & MODE_SLP) ? log1p_poly5(z, e[u][r].y) : 0.0;
+                    double yy = tab_y(d2[u][r], e[u][r].x);
+                    double rinv = rcp_from_y(e[u][r].x, yy);
+                    double L = (MODE & MODE_SLP) ? log_from_y(yy, e[u][r].y) : 0.0;
                     stokes_pair<MODE>(dx[u][r], dy[u][r], L, rinv, s[u0 + u], acc[r]);
                 }
         }
     }
-    if (worst > nkeys_m1) {
+    if (!ta.all_inside(key_lo)) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = StokesAcc{0, 0, 0, 0, 0};
         stokes_generic_loop<MODE, false, R>(rec, j0, j1, x, y, acc);

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench contract): every kernel family
+of the hot path at the BASELINE sizes, device-resident inputs, HIP-event kernel
+times from the library.  Prints one JSON object.
+
+    python tools/bench_kernels.py [--quick]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def timeit(fn, sync, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    import torch
+    from util import Curve, grid_targets
+    from ipde_amd.device import get_context
+    from ipde_amd import layer_potentials as lp
+    from ipde_amd.spectral import GridPlan, fd4
+
+    ctx = get_context()
+    sync = torch.cuda.synchronize
+    out = {}
+    ng, nb = (1024, 2048) if args.quick else (2048, 4096)
+    c = Curve(nb, a=0.2, f=5)
+    trg, h = grid_targets(c, ng)
+    dt = lp.DeviceTargets(trg)
+    rng = np.random.default_rng(0)
+    sig, tau = rng.standard_normal(nb), rng.standard_normal(nb)
+    f2, g2 = rng.standard_normal((2, nb)), rng.standard_normal((2, nb))
+    pairs = float(nb) * dt.N
+    ctx.enable_timing(True)
+
+    def rec(name, fn, flops_per_pair):
+        fn()
+        sync()
+        fn()
+        ms = ctx.last_kernel_ms()
+        out[name] = {"kernel_ms": ms, "pairs_per_s": pairs / (ms * 1e-3),
+                     "algorithmic_tflops": pairs * flops_per_pair / (ms * 1e-3) / 1e12}
+
+    rec("laplace_slp", lambda: lp.Laplace_Layer_Apply(c, dt, charge=sig), 8)
+    rec("laplace_dlp", lambda: lp.Laplace_Layer_Apply(c, dt, dipstr=tau), 12)
+    rec("laplace_slp_dlp", lambda: lp.Laplace_Layer_Apply(c, dt, charge=sig, dipstr=tau), 15)
+    rec("modhelm_slp_k10", lambda: lp.Modified_Helmholtz_Layer_Apply(c, dt, k=10.0, charge=sig), 10)
+    rec("modhelm_dlp_k10", lambda: lp.Modified_Helmholtz_Layer_Apply(c, dt, k=10.0, dipstr=tau), 15)
+    rec("stokes_slp", lambda: lp.Stokes_Layer_Apply(c, dt, forces=f2), 20)
+    rec("stokes_dlp", lambda: lp.Stokes_Layer_Apply(c, dt, dipstr=g2), 25)
+    ctx.enable_timing(False)
+    # interface-sized apply (split-source path): N x N
+    inner = Curve(nb, a=0.2, f=5, scale=0.95)
+    di = lp.DeviceTargets(inner)
+    t = timeit(lambda: lp.Laplace_Layer_Apply(c, di, charge=sig), sync, reps=20)
+    out["laplace_slp_interface_NxN"] = {"wall_ms": t * 1e3, "pairs_per_s": nb * nb / t}
+
+    # spectral
+    n = ng
+    hh = 3.0 / n
+    plan = GridPlan(n, n, hh, hh)
+    f = torch.randn(n, n, dtype=torch.float64, device="cuda")
+    f -= f.mean()
+    g = torch.randn(n, n, dtype=torch.float64, device="cuda")
+    N = float(n * n)
+    for name, fn, nfft, fields in [
+        ("poisson_grid_solve", lambda: plan.poisson_solve(f), 2, 1),
+        ("modhelm_grid_solve", lambda: plan.modhelm_solve(f, 10.0), 2, 1),
+        ("stokes_grid_solve", lambda: plan.stokes_solve(f, g), 5, 2.5),
+        ("fourier_dx", lambda: plan.dx(f), 2, 1),
+    ]:
+        t = timeit(fn, sync, reps=10)
+        out[name] = {"wall_ms": t * 1e3,
+                     "algorithmic_GBps": fields * 16.0 * N / t / 1e9,
+                     "rocfft_GFLOPs": nfft * 2.5 * N * np.log2(N) / t / 1e9}
+    t = timeit(lambda: fd4(f, hh, 0), sync, reps=10)
+    out["fd_x_4"] = {"wall_ms": t * 1e3, "algorithmic_GBps": 16.0 * N / t / 1e9}
+
+    # annular solves at the BASELINE boundary size
+    from ipde_amd.annular.annular_full import ApproximateAnnularGeometry as AAGf, RealAnnularGeometry
+    from ipde_amd.annular.annular import ApproximateAnnularGeometry as AAGd
+    from ipde_amd.annular.poisson import AnnularPoissonSolver
+    from ipde_amd.annular.stokes import AnnularStokesSolver
+    M = 20
+    width = M * c.dt * c.speed.min()
+    tt = c.t
+    r = 1 + 0.2 * np.cos(5 * tt)
+    rp = -1.0 * np.sin(5 * tt)
+    rpp = -5.0 * np.cos(5 * tt)
+    curv = (r * r + 2 * rp * rp - r * rpp) / c.speed ** 3
+    aag = AAGf(nb, M, width, 1.0)
+    rag = RealAnnularGeometry(c.speed, curv, aag)
+    t0 = time.perf_counter()
+    S = AnnularPoissonSolver(aag)
+    out["annular_poisson_setup_ms"] = (time.perf_counter() - t0) * 1e3
+    fr = np.cos(3 * tt)[None, :] * (1 + aag.rv0[:, None])
+    S.solve(rag, fr, 0.0, 0.0, tol=1e-12, maxiter=100, restart=50)
+    t0 = time.perf_counter()
+    S.solve(rag, fr, 0.0, 0.0, tol=1e-12, maxiter=100, restart=50)
+    out["annular_poisson_solve"] = {"wall_ms": (time.perf_counter() - t0) * 1e3,
+                                    "iters": S.iterations_last_call, "resid": S.residual_last_call}
+    if not args.quick:
+        aagd = AAGd(nb, M, width, 1.0)
+        ragd = RealAnnularGeometry(c.speed, curv, aagd)
+        t0 = time.perf_counter()
+        SS = AnnularStokesSolver(aagd, 1.0)
+        out["annular_stokes_setup_ms"] = (time.perf_counter() - t0) * 1e3
+        ft = np.sin(2 * tt)[None, :] * (1 - aagd.rv0[:, None])
+        z = np.zeros(nb)
+        SS.solve(ragd, fr, ft, z, z, z, z, tol=1e-10, maxiter=200, restart=100)
+        t0 = time.perf_counter()
+        SS.solve(ragd, fr, ft, z, z, z, z, tol=1e-10, maxiter=200, restart=100)
+        out["annular_stokes_solve"] = {"wall_ms": (time.perf_counter() - t0) * 1e3,
+                                       "iters": SS.iterations_last_call,
+                                       "resid": SS.residual_last_call}
+    out["config"] = {"grid": ng, "boundary_nodes": nb, "targets": dt.N, "M": M}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
