@@ -33,6 +33,7 @@ struct ApplyParams {
     double corr2;  // second constant (Stokes v component)
     double inv_s;  // 2^-sh
     double inv_s2; // 2^-2sh
+    double scale;  // coordinate scale actually applied (2^sh, or PackArgs::fixed_scale)
 };
 
 __device__ __forceinline__ double wave_min(double v) {

@@ -1,23 +1,36 @@
 // Modified Helmholtz (k^2 - Lap) single/double layer dense sums.
 //
 //   SLP: (1/2pi) K0(k r) w_sigma          DLP: (k/2pi) K1(k r) (n.d)/r w_tau
-// Record rows: [0] x [1] y [2] q' = w_sigma/(2 pi)
-//              [3] ax' = nx*w_tau*k^2/(2 pi) [4] ay'
-// With y = k^2 d^2 the DLP needs only K1(x)/x (x = k r), so that the small-argument
-// branch never takes a square root:
-//   K0(x)   = -log(x) I0s(y) + B0(y)
-//   K1(x)/x = [1 + y (log(x) J1(y) + C1(y))] / y                      (x <= 2)
-//   K0(x)   = exp(-x)/sqrt(x) G0(t),  K1(x)/x = exp(-x)/sqrt(x) G1(t)/x  (x > 2)
-// with t = 4/x - 1 and G0, G1 Chebyshev series (coefficients: bessel_coeffs.h,
-// generated by gen_bessel_coeffs.py).  fp64 VALU bound; no coordinate scaling
-// (the kernel is not scale invariant).
+//
+// Coordinates are scaled by k on the way in (pack kernel / target load), so that
+// y = |t' - s'|^2 = (k r)^2 comes straight out of the distance computation and
+//   SLP term = q' K0(sqrt y),                 q' = w_sigma/(2 pi)
+//   DLP term = (a'.d') K1(sqrt y)/sqrt y,     a' = n w_tau k/(2 pi)
+// Record rows: [0] k x [1] k y [2] q' [3] ax' [4] ay'.
+//
+// Table kernel (the fast path).  F0(y) = K0(sqrt y) and F1(y) = K1(sqrt y)/sqrt y are
+// smooth on log-spaced intervals (the only singularity is y = 0), so each of the
+// 32 covered binades [2^-21, 2^11) is cut into 2^5 intervals by the top 5 mantissa
+// bits of y; per interval the LDS table holds R ~ 1/centre and the 8 coefficients
+// of a degree-7 polynomial in z = y R - 1 (|z| <= 2^-6), fitted at Chebyshev nodes
+// from long-double std::cyl_bessel_k at context creation.  Degree 7 keeps the
+// ABSOLUTE error below 2e-18 for every k r (the (p+1)-th log-derivative of K0 peaks
+// at k r ~ p+1) and the relative error below 1e-15 for k r <= 45.  y outside the
+// table (k r < 7e-4 or > 45, or r = 0) is detected per lane and that lane's targets
+// are redone with the series / Chebyshev code below (bessel_coeffs.h).
+//   per pair: 4 (dx,dy,y) + 1 (z) + 7 (Horner) + 1 (accumulate) fp64 ops
+//             (+2 for the DLP's a.d), 3 int32 ops, 5 ds_read_b128 (80-byte entry).
+// Roofline: fp64 VALU / LDS-read co-bound; algorithmic HBM traffic 24 B per target.
 #include "layer_pack.h"
 #include "bessel_coeffs.h"
+#include <cmath>
 
 namespace {
 
 constexpr int MODE_SLP = 1, MODE_DLP = 2;
 
+// ---------------------------------------------------------------------------
+// reference-grade evaluation (no table): series for x <= 2, Chebyshev for x > 2
 __device__ __constant__ double c_i0s[IPDE_K_I0S_N];
 __device__ __constant__ double c_b0[IPDE_K_B0_N];
 __device__ __constant__ double c_j1[IPDE_K_J1_N];
@@ -46,7 +59,9 @@ __device__ __forceinline__ double clenshaw(const double* c, double t) {
     return fma(t, b1, c[0]) - b2;
 }
 
-// returns K0(x) in k0 and K1(x)/x in k1x for y = x^2 > 0
+// K0(x) and K1(x)/x for y = x^2 > 0:
+//   x <= 2:  K0 = -log(x) I0s(y) + B0(y),  K1/x = [1 + y (log(x) J1(y) + C1(y))]/y
+//   x  > 2:  K0 = exp(-x)/sqrt(x) G0(t),   K1/x = exp(-x)/sqrt(x) G1(t)/x,  t = 4/x - 1
 template <int MODE>
 __device__ __forceinline__ void bessel_k01(double y, double& k0, double& k1x) {
     if (y <= IPDE_BESSEL_XS * IPDE_BESSEL_XS) {
@@ -67,22 +82,10 @@ __device__ __forceinline__ void bessel_k01(double y, double& k0, double& k1x) {
     }
 }
 
-template <int MODE, bool SKIP, int R, int NT>
-__global__ __launch_bounds__(NT) void modhelm_kernel(
-    const double* __restrict__ rec, int ns_pad, int chunk, double k2,
-    const double* __restrict__ tx, const double* __restrict__ ty, int64_t nt,
-    double* __restrict__ out) {
-    const int j0 = blockIdx.y * chunk;
-    const int j1 = min(ns_pad, j0 + chunk);
-    double x[R], y[R], acc[R];
-    int64_t base = (int64_t)blockIdx.x * (R * NT) + threadIdx.x;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int64_t i = min(base + (int64_t)r * NT, nt - 1);
-        x[r] = tx[i];
-        y[r] = ty[i];
-        acc[r] = 0.0;
-    }
+template <int MODE, bool SKIP, int R>
+__device__ __forceinline__ void modhelm_generic_loop(const double* __restrict__ rec, int j0, int j1,
+                                                     const double (&x)[R], const double (&y)[R],
+                                                     double (&acc)[R]) {
     for (int j = j0; j < j1; ++j) {
         double sx = rec[ipde_rec_index(j, 0)], sy = rec[ipde_rec_index(j, 1)];
         double q = rec[ipde_rec_index(j, 2)];
@@ -93,49 +96,236 @@ __global__ __launch_bounds__(NT) void modhelm_kernel(
             double d2 = fma(dy, dy, dx * dx);
             if (SKIP && d2 == 0.0) continue;
             double k0 = 0.0, k1x = 0.0;
-            bessel_k01<MODE>(k2 * d2, k0, k1x);
+            bessel_k01<MODE>(d2, k0, k1x);
             if (MODE & MODE_SLP) acc[r] = fma(q, k0, acc[r]);
             if (MODE & MODE_DLP) acc[r] = fma(fma(ay, dy, ax * dx), k1x, acc[r]);
         }
     }
+}
+
+template <int R, int NT>
+__device__ __forceinline__ void modhelm_store(const double (&acc)[R], int64_t base, int64_t nt,
+                                              double* __restrict__ out, int accumulate) {
     double* o = out + (size_t)blockIdx.y * nt;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int64_t i = base + (int64_t)r * NT;
-        if (i < nt) o[i] = acc[r];
+        if (i < nt) o[i] = accumulate ? o[i] + acc[r] : acc[r];
     }
 }
 
+template <int MODE, bool SKIP, int R, int NT>
+__global__ __launch_bounds__(NT) void modhelm_generic_kernel(
+    const double* __restrict__ rec, int ns_pad, int chunk, const double* __restrict__ tx,
+    const double* __restrict__ ty, int64_t nt, double* __restrict__ out,
+    const ApplyParams* __restrict__ prm, int accumulate) {
+    const int j0 = blockIdx.y * chunk;
+    const int j1 = min(ns_pad, j0 + chunk);
+    const double s1 = prm->scale;
+    double x[R], y[R], acc[R];
+    int64_t base = (int64_t)blockIdx.x * (R * NT) + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t i = min(base + (int64_t)r * NT, nt - 1);
+        x[r] = tx[i] * s1;
+        y[r] = ty[i] * s1;
+        acc[r] = 0.0;
+    }
+    modhelm_generic_loop<MODE, SKIP, R>(rec, j0, j1, x, y, acc);
+    modhelm_store<R, NT>(acc, base, nt, out, accumulate);
+}
+
+// ---------------------------------------------------------------------------
+// table kernel
+#define KT_B 5
+#define KT_SHIFT (20 - KT_B)
+#define KT_BINADES 32
+#define KT_NKEYS (KT_BINADES << KT_B)    // 1024 entries
+#define KT_ENTRY 10                      // doubles per entry: R, a0..a7, pad  (80 B)
+#define KT_EXP_LO (-21)
+
+template <int MODE, int R, int NT, int U>
+__global__ __launch_bounds__(NT) void modhelm_table_kernel(
+    const double* __restrict__ rec, int ns_pad, int chunk, const double* __restrict__ tx,
+    const double* __restrict__ ty, int64_t nt, double* __restrict__ out,
+    const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab, int accumulate) {
+    extern __shared__ double2 ltab[];  // KT_NKEYS * 5 double2
+    for (unsigned i = threadIdx.x; i < KT_NKEYS * (KT_ENTRY / 2); i += NT) ltab[i] = gtab[i];
+    __syncthreads();
+    const unsigned key_lo = (unsigned)((1023 + KT_EXP_LO) << KT_B);
+    unsigned hmin = 0xFFFFFFFFu, hmax = 0u;
+
+    const int j0 = blockIdx.y * chunk;
+    const int j1 = min(ns_pad, j0 + chunk);
+    const double s1 = prm->scale;
+    double x[R], y[R], acc[R];
+    int64_t base = (int64_t)blockIdx.x * (R * NT) + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t i = min(base + (int64_t)r * NT, nt - 1);
+        x[r] = tx[i] * s1;
+        y[r] = ty[i] * s1;
+        acc[r] = 0.0;
+    }
+    for (int b = j0 / IPDE_SRC_PAD; b < j1 / IPDE_SRC_PAD; ++b) {
+        SrcRow sx, sy, sq, sax, say;
+        sx.load(rec, b, 0);
+        sy.load(rec, b, 1);
+        if (MODE & MODE_SLP) sq.load(rec, b, 2);
+        if (MODE & MODE_DLP) {
+            sax.load(rec, b, 3);
+            say.load(rec, b, 4);
+        }
+#pragma unroll
+        for (int u0 = 0; u0 < IPDE_SRC_PAD; u0 += U) {
+            double dx[U][R], dy[U][R], d2[U][R];
+            double2 e[U][R][5];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    dx[u][r] = x[r] - sx.v[u0 + u];
+                    dy[u][r] = y[r] - sy.v[u0 + u];
+                    d2[u][r] = fma(dy[u][r], dy[u][r], dx[u][r] * dx[u][r]);
+                    unsigned hi = (unsigned)__double2hiint(d2[u][r]);
+                    hmin = min(hmin, hi);
+                    hmax = max(hmax, hi);
+                    unsigned idx;
+                    static_assert(KT_SHIFT == 15 && KT_B + 5 == 10, "literal operands below");
+                    asm("v_bfe_u32 %0, %1, 15, 10" : "=v"(idx) : "v"(hi));
+                    // 24-bit multiply-add is full rate (v_mul_lo_u32 is quarter rate)
+                    const double2* ep = (const double2*)((const char*)ltab +
+                                                         __umul24(idx, KT_ENTRY * 8u));
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) e[u][r][c] = ep[c];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double2* c = e[u][r];
+                    double z = fma(d2[u][r], c[0].x, -1.0);
+                    double p = fma(c[4].x, z, c[3].y);   // a7 z + a6
+                    p = fma(p, z, c[3].x);               // a5
+                    p = fma(p, z, c[2].y);               // a4
+                    p = fma(p, z, c[2].x);               // a3
+                    p = fma(p, z, c[1].y);               // a2
+                    p = fma(p, z, c[1].x);               // a1
+                    p = fma(p, z, c[0].y);               // a0
+                    if (MODE == MODE_SLP) {
+                        acc[r] = fma(sq.v[u0 + u], p, acc[r]);
+                    } else {
+                        double ad = fma(say.v[u0 + u], dy[u][r], sax.v[u0 + u] * dx[u][r]);
+                        acc[r] = fma(ad, p, acc[r]);
+                    }
+                }
+        }
+    }
+    const bool inside = (hmin >> KT_SHIFT) >= key_lo && (hmax >> KT_SHIFT) < key_lo + KT_NKEYS;
+    if (!inside) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        modhelm_generic_loop<MODE, false, R>(rec, j0, j1, x, y, acc);
+    }
+    modhelm_store<R, NT>(acc, base, nt, out, accumulate);
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_acc(const double* __restrict__ part,
+                                                           int nchunk, int64_t nt,
+                                                           double* __restrict__ out,
+                                                           int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt) return;
+    double s = accumulate ? out[i] : 0.0;
+    for (int c = 0; c < nchunk; ++c) s += part[(size_t)c * nt + i];
+    out[i] = s;
+}
+
+// one pass (MODE_SLP or MODE_DLP); accumulate != 0 adds into `out`
 template <int MODE>
-int launch_modhelm(ipde_ctx* ctx, const double* rec, int64_t ns, double k, const double* tx,
-                   const double* ty, int64_t nt, double* out, int flags) {
+int launch_modhelm(ipde_ctx* ctx, const double* rec, int64_t ns, const double* tx, const double* ty,
+                   int64_t nt, double* out, const ApplyParams* prm, int flags, int accumulate) {
     const bool skip = (flags & IPDE_FLAG_SKIP_COINCIDENT) != 0;
-    constexpr int NT = 256, R = 2;
-    const LayerGeom g = ipde_layer_geom(ns, nt, NT * R, 2 * ctx->num_cu);
+    const bool generic = skip || (flags & IPDE_FLAG_GENERIC_MATH) != 0;
+    constexpr int NT_T = 1024, R_T = 2, U_T = 1;
+    constexpr int NT_G = 256, R_G = 2;
+    const LayerGeom g = generic ? ipde_layer_geom(ns, nt, NT_G * R_G, 2 * ctx->num_cu)
+                                : ipde_layer_geom(ns, nt, NT_T * R_T, ctx->num_cu);
     double* dst = out;
+    int acc_main = accumulate;
     if (g.nchunk > 1) {
         IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, (size_t)g.nchunk * nt * sizeof(double)));
         dst = (double*)ctx->partial.p;
+        acc_main = 0;
     }
     dim3 grid((unsigned)g.gx, (unsigned)g.nchunk);
-    if (ctx->timing) hipEventRecord(ctx->ev0, ctx->stream);
-    if (skip)
-        hipLaunchKernelGGL((modhelm_kernel<MODE, true, R, NT>), grid, dim3(NT), 0, ctx->stream, rec,
-                           g.ns_pad, g.chunk, k * k, tx, ty, nt, dst);
-    else
-        hipLaunchKernelGGL((modhelm_kernel<MODE, false, R, NT>), grid, dim3(NT), 0, ctx->stream, rec,
-                           g.ns_pad, g.chunk, k * k, tx, ty, nt, dst);
+    if (ctx->timing && !accumulate) hipEventRecord(ctx->ev0, ctx->stream);
+    if (generic) {
+        if (skip)
+            hipLaunchKernelGGL((modhelm_generic_kernel<MODE, true, R_G, NT_G>), grid, dim3(NT_G), 0,
+                               ctx->stream, rec, g.ns_pad, g.chunk, tx, ty, nt, dst, prm, acc_main);
+        else
+            hipLaunchKernelGGL((modhelm_generic_kernel<MODE, false, R_G, NT_G>), grid, dim3(NT_G), 0,
+                               ctx->stream, rec, g.ns_pad, g.chunk, tx, ty, nt, dst, prm, acc_main);
+    } else {
+        const double* tab = ctx->d_ktab + (MODE == MODE_SLP ? 0 : (size_t)KT_NKEYS * KT_ENTRY);
+        size_t lds = (size_t)KT_NKEYS * KT_ENTRY * sizeof(double);
+        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute(
+                                (const void*)modhelm_table_kernel<MODE, R_T, NT_T, U_T>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((modhelm_table_kernel<MODE, R_T, NT_T, U_T>), grid, dim3(NT_T), lds,
+                           ctx->stream, rec, g.ns_pad, g.chunk, tx, ty, nt, dst, prm,
+                           (const double2*)tab, acc_main);
+    }
     if (ctx->timing) {
         hipEventRecord(ctx->ev1, ctx->stream);
         ctx->last_kernel_ms = -1.0;
     }
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     if (g.nchunk > 1) {
-        hipLaunchKernelGGL(ipde_reduce_partials, dim3((unsigned)ceil_div64(nt, 256)), dim3(256), 0,
-                           ctx->stream, (const double*)dst, g.nchunk, nt, out);
+        hipLaunchKernelGGL(reduce_partials_acc, dim3((unsigned)ceil_div64(nt, 256)), dim3(256), 0,
+                           ctx->stream, (const double*)dst, g.nchunk, nt, out, accumulate);
         IPDE_HIP_CHECK(ctx, hipGetLastError());
     }
     return IPDE_OK;
+}
+
+// ---- host: table construction ---------------------------------------------
+// degree-7 fit of F on x = c (1 + z), |z| <= a, at 8 Chebyshev nodes
+template <class F>
+void fit_interval(long double c, long double a, F f, double* coef /*8*/) {
+    const int n = 8;
+    long double v[n], b[n];
+    for (int i = 0; i < n; ++i) {
+        long double u = cosl(M_PIl * (i + 0.5L) / n);
+        v[i] = f(c * (1.0L + a * u));
+    }
+    for (int k = 0; k < n; ++k) {
+        long double s = 0.0L;
+        for (int i = 0; i < n; ++i) s += v[i] * cosl(M_PIl * k * (i + 0.5L) / n);
+        b[k] = s * 2.0L / n;
+    }
+    b[0] *= 0.5L;
+    // Chebyshev -> monomial in u via T_{k+1} = 2 u T_k - T_{k-1}
+    long double mono[n] = {0}, Tkm1[n] = {0}, Tk[n] = {0};
+    Tkm1[0] = 1.0L;  // T0
+    Tk[1] = 1.0L;    // T1
+    for (int j = 0; j < n; ++j) mono[j] += b[0] * Tkm1[j] + b[1] * Tk[j];
+    for (int k = 2; k < n; ++k) {
+        long double Tn[n] = {0};
+        for (int j = 0; j + 1 < n; ++j) Tn[j + 1] += 2.0L * Tk[j];
+        for (int j = 0; j < n; ++j) Tn[j] -= Tkm1[j];
+        for (int j = 0; j < n; ++j) {
+            mono[j] += b[k] * Tn[j];
+            Tkm1[j] = Tk[j];
+            Tk[j] = Tn[j];
+        }
+    }
+    long double s = 1.0L;
+    for (int j = 0; j < n; ++j) {
+        coef[j] = (double)(mono[j] / s);  // u = z / a
+        s *= a;
+    }
 }
 
 }  // namespace
@@ -147,6 +337,36 @@ int ipde_build_k_table(ipde_ctx* ctx) {
     IPDE_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_c1), ipde_k_c1, sizeof(ipde_k_c1)));
     IPDE_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_g0), ipde_k_g0, sizeof(ipde_k_g0)));
     IPDE_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_g1), ipde_k_g1, sizeof(ipde_k_g1)));
+    // piecewise tables of F0(y) = K0(sqrt y), F1(y) = K1(sqrt y)/sqrt y
+    std::vector<double> h((size_t)2 * KT_NKEYS * KT_ENTRY, 0.0);
+    const uint64_t key_lo = (uint64_t)((1023 + KT_EXP_LO) << KT_B);
+    auto F0 = [](long double y) { return std::cyl_bessel_kl(0.0L, sqrtl(y)); };
+    auto F1 = [](long double y) {
+        long double x = sqrtl(y);
+        return std::cyl_bessel_kl(1.0L, x) / x;
+    };
+    for (int n = 0; n < KT_NKEYS; ++n) {
+        uint64_t key = key_lo + (uint64_t)n;
+        size_t pos = (size_t)(key & (uint64_t)(KT_NKEYS - 1));
+        uint64_t lo_bits = key << (52 - KT_B), hi_bits = (key + 1) << (52 - KT_B);
+        double xlo, xhi;
+        memcpy(&xlo, &lo_bits, 8);
+        memcpy(&xhi, &hi_bits, 8);
+        double R = (double)(2.0L / ((long double)xlo + (long double)xhi));
+        long double c = 1.0L / (long double)R;  // the centre the kernel actually uses
+        long double a = fmaxl(fabsl((long double)xlo / c - 1.0L), fabsl((long double)xhi / c - 1.0L));
+        for (int t = 0; t < 2; ++t) {
+            double* e = &h[((size_t)t * KT_NKEYS + pos) * KT_ENTRY];
+            e[0] = R;
+            if (t == 0)
+                fit_interval(c, a, F0, e + 1);
+            else
+                fit_interval(c, a, F1, e + 1);
+        }
+    }
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_ktab, h.size() * sizeof(double)));
+    IPDE_HIP_CHECK(ctx, hipMemcpy(ctx->d_ktab, h.data(), h.size() * sizeof(double),
+                                  hipMemcpyHostToDevice));
     return IPDE_OK;
 }
 
@@ -186,24 +406,23 @@ extern "C" int ipde_modhelm_apply(ipde_ctx* ctx, int loc, double k, int64_t ns, 
     pa.mul[0] = 0.5 / M_PI;
     pa.ch[1] = d_nx;
     pa.mulby[1] = d_tau;
-    pa.mul[1] = 0.5 * k * k / M_PI;
+    pa.mul[1] = 0.5 * k / M_PI;
     pa.ch[2] = d_ny;
     pa.mulby[2] = d_tau;
-    pa.mul[2] = 0.5 * k * k / M_PI;
+    pa.mul[2] = 0.5 * k / M_PI;
     pa.corr_ch = -1;
     pa.corr2_ch = -1;
     pa.use_scale = 0;
+    pa.fixed_scale = k;
     const double* rec;
     const ApplyParams* prm;
     IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, d_tx, d_ty, nt, &rec, &prm));
-    int mode = (w_sigma ? MODE_SLP : 0) | (w_tau ? MODE_DLP : 0);
-    int st;
-    if (mode == MODE_SLP)
-        st = launch_modhelm<MODE_SLP>(ctx, rec, ns, k, d_tx, d_ty, nt, d_out, flags);
-    else if (mode == MODE_DLP)
-        st = launch_modhelm<MODE_DLP>(ctx, rec, ns, k, d_tx, d_ty, nt, d_out, flags);
-    else
-        st = launch_modhelm<3>(ctx, rec, ns, k, d_tx, d_ty, nt, d_out, flags);
-    IPDE_TRY(st);
+    int accumulate = 0;
+    if (w_sigma) {
+        IPDE_TRY(launch_modhelm<MODE_SLP>(ctx, rec, ns, d_tx, d_ty, nt, d_out, prm, flags, 0));
+        accumulate = 1;
+    }
+    if (w_tau)
+        IPDE_TRY(launch_modhelm<MODE_DLP>(ctx, rec, ns, d_tx, d_ty, nt, d_out, prm, flags, accumulate));
     return ipde_stage_finish(ctx, loc, 7, out, nt);
 }

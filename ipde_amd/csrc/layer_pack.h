@@ -52,6 +52,7 @@ struct PackArgs {
     int use_scale;           // 0: sh = 0
     int exp_hi;              // table upper exponent
     int stokes_ng;           // 1: channel 6 = ch4*ch2 + ch5*ch3 (n.g' of the stresslet)
+    double fixed_scale;      // != 0: scale coordinates by this factor instead of 2^sh
 };
 
 // single block of 1024 threads; ns_alloc = whole batches (multiple of 8) >= ns
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
         sh = s_sh;
         __syncthreads();
     }
-    const double s1 = ldexp(1.0, sh);
+    const double s1 = a.fixed_scale != 0.0 ? a.fixed_scale : ldexp(1.0, sh);
     double sum1 = 0.0, sum2 = 0.0;
     for (int64_t i = tid; i < ns_alloc; i += 1024) {
         const bool real = i < ns;
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
         prm->corr2 = -two_ln2 * (double)sh * t2;
         prm->inv_s = ldexp(1.0, -sh);
         prm->inv_s2 = ldexp(1.0, -2 * sh);
+        prm->scale = s1;
     }
 }
 

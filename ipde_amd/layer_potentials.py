@@ -77,7 +77,7 @@ def laplace_apply(sx, sy, tx, ty, w_sigma=None, nx=None, ny=None, w_tau=None,
 
 
 def modified_helmholtz_apply(sx, sy, tx, ty, k, w_sigma=None, nx=None, ny=None, w_tau=None,
-                             skip_coincident=False, ctx=None, out=None):
+                             skip_coincident=False, generic_math=False, ctx=None, out=None):
     ctx = ctx or get_context()
     loc = location_of(tx, ty)
     tx, ty = as_f64(tx, loc), as_f64(ty, loc)
@@ -87,7 +87,7 @@ def modified_helmholtz_apply(sx, sy, tx, ty, k, w_sigma=None, nx=None, ny=None, 
         out = empty_like_loc((nt,), loc, ctx)
     ctx.check(ctx.lib.ipde_modhelm_apply(ctx.handle, loc, float(k), ns, ptr(sx), ptr(sy),
                                          ptr(w_sigma), ptr(nx), ptr(ny), ptr(w_tau), nt, ptr(tx),
-                                         ptr(ty), ptr(out), _flags(skip_coincident, False)))
+                                         ptr(ty), ptr(out), _flags(skip_coincident, generic_math)))
     return out
 
 

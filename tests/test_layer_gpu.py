@@ -174,6 +174,21 @@ def test_modhelm_parity(lp, setup, k, mode):
     assert rel_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("k", [0.05, 3.0, 200.0])
+def test_modhelm_generic_path_and_table_misses(lp, setup, k):
+    """k*r far below / above the LDS table (k r < 7e-4 or > 45) must fall back to
+    the series / Chebyshev code per lane; generic_math forces that code everywhere."""
+    c, trg, sig, tau, _, _ = setup
+    ref = olp.modified_helmholtz_layer_apply(c.x, c.y, trg.x, trg.y, k, charge=sig, dipstr=tau,
+                                             weights=c.weights, nx=c.normal_x, ny=c.normal_y)
+    w = c.weights
+    for generic in (False, True):
+        got = lp.modified_helmholtz_apply(c.x, c.y, trg.x, trg.y, k, w_sigma=sig * w,
+                                          nx=c.normal_x, ny=c.normal_y, w_tau=tau * w,
+                                          generic_math=generic)
+        assert rel_err(got, ref) < TOL, (k, generic)
+
+
 def test_modhelm_closure_and_self(lp, setup):
     c, trg, sig, _, _, _ = setup
     f = lp.make_modified_helmholtz_layer_apply(3.0)
