@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Interior Poisson problem on a 5-arm star — the same steps as the reference's
+examples/interior_poisson.py (construct boundary :41, EmbeddedBoundary :47, grid :49,
+bump :51, manufactured solution :59-61, PoissonSolver :80-81, homogeneous correction
+:84-92, max error :95-96) on the MI355X stack.
+
+    python examples/interior_poisson.py [--nb 800] [--M 20] [--hard]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from ipde_amd.ebdy_collection import EmbeddedBoundaryCollection  # noqa: E402
+from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
+from ipde_amd.embedded_function import EmbeddedFunction, BoundaryFunction  # noqa: E402
+from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
+from ipde_amd.layer_potentials import Laplace_Layer_Apply, DeviceTargets  # noqa: E402
+from ipde_amd.pybie2d_compat import (star, Global_Smooth_Boundary as GSB,  # noqa: E402
+                                     Laplace_Layer_Singular_Form, Laplace_Layer_Form)
+from ipde_amd.qfs import QFS_Evaluator  # noqa: E402
+from ipde_amd.solvers.multi_boundary.poisson import PoissonSolver  # noqa: E402
+
+Singular_DLP = lambda src, _: Laplace_Layer_Singular_Form(src, ifdipole=True) - 0.5 * np.eye(src.N)
+Naive_SLP = lambda src, trg: Laplace_Layer_Form(src, trg, ifcharge=True)
+
+
+def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, grid_upsample=1,
+        Ns=None, verbose=False, timings=None):
+    T = {} if timings is None else timings
+    t0 = time.perf_counter()
+    MOL = SlepianMollifier(1.5 * M)
+    bdy = GSB(c=star(nb, a=0.2, f=5))
+    bh = bdy.dt * bdy.speed.min()
+    ebdy = EmbeddedBoundary(bdy, True, M, bh / grid_upsample, pad_zone=0, heaviside=MOL.step,
+                            qfs_tolerance=1e-14, coordinate_tolerance=1e-14)
+    ebdyc = EmbeddedBoundaryCollection([ebdy, ])
+    grid = ebdyc.generate_grid(bh / grid_upsample, Ns=Ns)
+    ebdyc.ready_bump(MOL.bump, (grid.x_bounds[1] - ebdy.radial_width, grid.y_bounds[1] - ebdy.radial_width),
+                     ebdyc[0].radial_width)
+    if problem == 'easy':
+        solution_func = lambda x, y: -np.cos(x) * np.exp(np.sin(x)) * np.sin(y)
+        force_func = lambda x, y: (2.0 * np.cos(x) + 3.0 * np.cos(x) * np.sin(x) - np.cos(x) ** 3) \
+            * np.exp(np.sin(x)) * np.sin(y)
+    else:
+        k = 10 * np.pi / 3
+        solution_func = lambda x, y: np.exp(np.sin(k * x)) * np.sin(k * y)
+        force_func = lambda x, y: k ** 2 * np.exp(np.sin(k * x)) * np.sin(k * y) \
+            * (np.cos(k * x) ** 2 - np.sin(k * x) - 1.0)
+    f = EmbeddedFunction(ebdyc)
+    f.define_via_function(force_func)
+    ua = EmbeddedFunction(ebdyc)
+    ua.define_via_function(solution_func)
+    bc = BoundaryFunction(ebdyc)
+    bc.define_via_function(solution_func)
+    solver = PoissonSolver(ebdyc, solver_type=solver_type)
+    T['setup_s'] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    ue = solver(f, tol=solver_tol, verbose=verbose, maxiter=100, restart=20)
+    T['inhomogeneous_solve_s'] = time.perf_counter() - t0
+
+    # homogeneous correction: double-layer density on the boundary, evaluated through QFS
+    t0 = time.perf_counter()
+    A = Laplace_Layer_Singular_Form(bdy, ifdipole=True) - 0.5 * np.eye(bdy.N)
+    qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [Singular_DLP, ], Naive_SLP, on_surface=True, form_b2c=False)
+    import scipy.linalg
+    Alu = scipy.linalg.lu_factor(A)
+    targets = DeviceTargets(ebdyc.grid_and_radial_pts)
+    T['homogeneous_form_s'] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    bv = solver.get_boundary_values(ue.get_radial_value_list())
+    tau = scipy.linalg.lu_solve(Alu, np.concatenate((bc - bv).bdy_value_list))
+    sigma = qfs([tau, ])
+    out = Laplace_Layer_Apply(ebdyc.bdy_inward_sources, targets, charge=sigma).cpu().numpy()
+    gslp, rslpl = ebdyc.divide_grid_and_radial(out)
+    ue[0] += rslpl[0].reshape(ebdyc[0].radial_shape)
+    ue['grid'] += gslp
+    T['homogeneous_apply_s'] = time.perf_counter() - t0
+
+    err = np.abs(np.asarray(ue) - np.asarray(ua))
+    T['dof'] = int(ebdyc.dof)
+    T['grid'] = list(grid.shape)
+    T['gmres_iterations'] = solver.iteration_counts
+    return float(err.max()), float(np.abs(np.asarray(ua)).max()), solver, ue, T
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nb", type=int, default=800)
+    ap.add_argument("--M", type=int, default=20)
+    ap.add_argument("--hard", action="store_true")
+    a = ap.parse_args()
+    T = {}
+    err, scale, *_ = run(a.nb, a.M, 'hard' if a.hard else 'easy', verbose=True, timings=T)
+    print('Error: {:0.2e}'.format(err), ' (|u|max %.3f)' % scale)
+    print(T)

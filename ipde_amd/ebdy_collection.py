@@ -1,0 +1,197 @@
+"""EmbeddedBoundaryCollection — the attribute contract of ipde/ebdy_collection.py
+(reference :230-829) read by the multi-boundary solvers and the examples: grid
+registration for all boundaries, `phys` / `in_annulus` / `phys_not_in_annulus` masks,
+Fourier operators, point sets (`grid_phys`, `grid_pna`, `grid_pnai`, `all_iv`,
+`radial_pts`, `grid_and_radial_pts`), source collections, splitters, grid <->
+interface / radial interpolation, demeaning with a bump.  Host numpy set-up; the
+interpolations and derivatives evaluate on the device.
+"""
+import numpy as np
+
+from .embedded_function import EmbeddedFunction
+from .near import points_inside_curve
+from .pybie2d_compat import Grid, PointSet
+from .utilities import affine_transformation
+
+
+def merge_sources(src_list):
+    """(reference :22-31)"""
+    p = PointSet(c=np.concatenate([src.c for src in src_list]))
+    p.weights = np.concatenate([src.weights for src in src_list])
+    p.normal_x = np.concatenate([src.normal_x for src in src_list])
+    p.normal_y = np.concatenate([src.normal_y for src in src_list])
+    return p
+
+
+class EmbeddedBoundaryCollection(object):
+    def __init__(self, ebdy_list):
+        self.ebdys = list(ebdy_list)
+        self.N = len(self.ebdys)
+        self.bumpy_readied = False
+        self.bump_location = None
+        self.grid = None
+
+    def __iter__(self):
+        return iter(self.ebdys)
+
+    def __len__(self):
+        return self.N
+
+    def __getitem__(self, ind):
+        return self.ebdys[ind]
+
+    # -- grid generation (reference :279-339) ------------------------------------
+    def generate_grid(self, h=None, Ns=None, force_square=False, danger_zone_distance=None):
+        iebdy = self[0]
+        if not iebdy.interior:
+            raise Exception('Generate grid may only be used if the first boundary is interior.')
+        ibdy = iebdy.bdy
+        cheat_space = iebdy.radial_width
+        xmin = ibdy.x.min() - cheat_space
+        ymin = ibdy.y.min() - cheat_space
+        xmax = ibdy.x.max() + 2 * cheat_space
+        ymax = ibdy.y.max() + 2 * cheat_space
+        self.bump_location = [ibdy.x.max() + cheat_space, ibdy.y.max() + cheat_space]
+        xran, yran = xmax - xmin, ymax - ymin
+        if h is None:
+            h = iebdy.radial_width / iebdy.M
+        if Ns is None:
+            Nx = 2 * int(0.5 * np.ceil(xran / h))
+            Ny = 2 * int(0.5 * np.ceil(yran / h))
+        else:
+            Nx, Ny = Ns
+            if xmin + Nx * h < xmin + xran:
+                raise Exception('Provided value of Nx is too small')
+            if ymin + Ny * h < ymin + yran:
+                raise Exception('Provided value of Ny is too small')
+        if force_square:
+            Nx = Ny = max(Nx, Ny)
+        grid = Grid([xmin, xmin + Nx * h], Nx, [ymin, ymin + Ny * h], Ny,
+                    x_endpoints=[True, False], y_endpoints=[True, False])
+        assert np.abs(grid.xh - h) < 1e-13 * max(1.0, abs(h)), 'Gridspacing not what was requested'
+        self.register_grid(grid)
+        self.bumpy_readied = False
+        return grid
+
+    # -- registration (reference :352-526) ------------------------------------------
+    def register_grid(self, grid, danger_zone_distance=None, verbose=False):
+        self.grid = grid
+        phys = np.zeros(grid.shape, dtype=bool) if self.ebdys[0].interior \
+            else np.ones(grid.shape, dtype=bool)
+        for ebdy in self:
+            IX, IY, r, t = ebdy.register_grid(grid, verbose=verbose)
+            rfull = np.full(grid.shape, np.nan)
+            found = np.zeros(grid.shape, dtype=bool)
+            rfull[IX, IY] = r
+            found[IX, IY] = True
+            inside = points_inside_curve(ebdy.bdy, grid.xg, grid.yg, rfull, found)
+            if ebdy.interior:
+                phys = np.logical_or(phys, inside) if ebdy is self.ebdys[0] \
+                    else np.logical_and(phys, inside)
+            else:
+                phys = np.logical_and(phys, np.logical_not(inside))
+        self.phys = phys
+        self.ext = np.logical_not(phys)
+        self.phys_inds = np.zeros(grid.shape, dtype=int)
+        self.phys_n = int(np.sum(phys))
+        self.phys_inds[phys] = np.arange(self.phys_n)
+        # Fourier operators (reference :388-395)
+        kxv = np.fft.fftfreq(grid.Nx, grid.xh / (2 * np.pi))
+        kyv = np.fft.fftfreq(grid.Ny, grid.yh / (2 * np.pi))
+        self.kx, self.ky = kxv[:, None], kyv
+        self.ikx, self.iky = 1j * self.kx, 1j * self.ky
+        self.lap = -self.kx * self.kx - self.ky * self.ky
+        ia = np.zeros(grid.shape, dtype=bool)
+        for ebdy in self:
+            ia[ebdy.grid_ia_xind, ebdy.grid_ia_yind] = True
+        self.in_annulus = ia
+        self.phys_not_in_annulus = np.logical_and(phys, np.logical_not(ia))
+        for ebdy in self:
+            ebdy.register_ia_inds(self.phys_inds)
+        self.grid_step = phys.astype(float)
+        for ebdy in self:
+            self.grid_step[ebdy.grid_ia_xind, ebdy.grid_ia_yind] *= ebdy.grid_to_radial_step
+        # point sets
+        self.grid_phys = PointSet(grid.xg[phys], grid.yg[phys])
+        self.radial_x = np.concatenate([e.radial_x.ravel() for e in self])
+        self.radial_y = np.concatenate([e.radial_y.ravel() for e in self])
+        self.radial_pts = PointSet(self.radial_x, self.radial_y)
+        self.grid_and_radial_pts = PointSet(np.concatenate([self.grid_phys.x, self.radial_x]),
+                                            np.concatenate([self.grid_phys.y, self.radial_y]))
+        pna = self.phys_not_in_annulus
+        self.grid_pna = PointSet(grid.xg[pna], grid.yg[pna])
+        self.grid_pna_num = self.grid_pna.N
+        self.all_bvx = np.concatenate([e.bdy.x for e in self])
+        self.all_bvy = np.concatenate([e.bdy.y for e in self])
+        self.all_bv = PointSet(self.all_bvx, self.all_bvy)
+        self.all_ivx = np.concatenate([e.interface.x for e in self])
+        self.all_ivy = np.concatenate([e.interface.y for e in self])
+        self.all_iv = PointSet(self.all_ivx, self.all_ivy)
+        self.grid_pnai = PointSet(np.concatenate([self.grid_pna.x, self.all_ivx]),
+                                  np.concatenate([self.grid_pna.y, self.all_ivy]))
+        self.grid_source = merge_sources([e.interface_grid_source for e in self])
+        self.radial_source = merge_sources([e.interface_radial_source for e in self])
+        self.bdy_inward_sources = merge_sources([e.bdy_inward_source for e in self])
+        self.bdy_outward_sources = merge_sources([e.bdy_outward_source for e in self])
+        self.bdy_Ns = [e.bdy.N for e in self]
+        self.splitter = np.cumsum(self.bdy_Ns)[:-1]
+        self.radial_Ns = [e.bdy.N * e.M for e in self]
+        self.rsplitter = np.cumsum(self.radial_Ns)[:-1]
+        self.interfaces_x_transf = np.concatenate([e.interface_x_transf for e in self])
+        self.interfaces_y_transf = np.concatenate([e.interface_y_transf for e in self])
+        self.grid_dof = self.grid_phys.N
+        self.radial_dof_list = [int(np.prod(e.radial_shape)) for e in self]
+        self.radial_dof = int(np.sum(self.radial_dof_list))
+        self.dof = self.grid_dof + self.radial_dof
+
+    # -- splitters (reference :528-570) -----------------------------------------------
+    def v2l(self, v):
+        return np.split(np.asarray(v), self.splitter)
+
+    def v2r(self, v):
+        return [w.reshape(e.radial_shape) for w, e in zip(np.split(np.asarray(v), self.rsplitter), self)]
+
+    def divide_grid_and_radial(self, v):
+        g, w = np.split(np.asarray(v), [self.grid_phys.N])
+        return g, self.v2r(w)
+
+    def divide_pnai(self, v):
+        g, w = np.split(np.asarray(v), [self.grid_pna.N])
+        return g, self.v2l(w)
+
+    # -- interpolation (reference :585-660) ---------------------------------------------
+    def interpolate_grid_to_interface(self, f, order=np.inf, cutoff=None):
+        """Spectral interpolation of a periodic grid function to all interface nodes."""
+        from .interp import periodic_interp2d
+        fh = np.fft.fft2(f)
+        return periodic_interp2d(fh, self.interfaces_x_transf, self.interfaces_y_transf).real.cpu().numpy()
+
+    def interpolate_radial_to_grid1(self, fr_list, f):
+        for fr, ebdy in zip(fr_list, self):
+            ebdy.interpolate_radial_to_grid1(fr, f)
+        return f
+
+    # -- demeaning (reference :795-812) ----------------------------------------------------
+    def ready_bump(self, bump, bump_loc=None, bump_width=None):
+        if bump_width is None:
+            bump_width = self[0].radial_width
+        if bump_loc is None:
+            if self.bump_location is None:
+                raise Exception('if ebdyc has no bump_location, need to give bump_loc')
+            bump_loc = self.bump_location
+        grr = np.hypot(self.grid.xg - bump_loc[0], self.grid.yg - bump_loc[1])
+        bumpy = bump(affine_transformation(grr, 0, bump_width, 0, 1))
+        self.bumpy = bumpy / self.grid_integral(bumpy)
+        self.bumpy_readied = True
+
+    def demean_function(self, f):
+        return f - self.grid_integral(f) * self.bumpy
+
+    def grid_integral(self, f):
+        return np.sum(f) * self.grid.xh * self.grid.yh
+
+    def volume_integral(self, f):
+        integral = self.grid_integral(f.get_smoothed_grid_value())
+        for fr, ebdy in zip(f, self):
+            integral += ebdy.radial_integral(fr)
+        return integral

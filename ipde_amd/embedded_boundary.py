@@ -1,0 +1,199 @@
+"""EmbeddedBoundary — the attribute contract of ipde/embedded_boundary.py (reference
+:55-557) that the solvers and the example scripts read, rebuilt on our own geometry,
+QFS and interpolation modules.  A smooth closed boundary, its interface curve at
+distance M*h along the normal, the boundary-fitted (Chebyshev-Gauss x periodic)
+radial grid between them, the classification of background-grid points and the
+cut-off functions coupling the two grids.  Host numpy (one-time set-up); the
+radial -> grid interpolation evaluates on the device (ipde_amd.interp).
+"""
+import numpy as np
+
+from .heavisides import SlepianMollifier
+from .near import local_coordinates
+from .pybie2d_compat import Global_Smooth_Boundary as GSB, PointSet
+from .qfs import QFS_Boundary
+from .utilities import affine_transformation, get_chebyshev_nodes
+
+
+def setit(n, dictionary, default):
+    return dictionary[n] if n in dictionary else default
+
+
+class EmbeddedBoundary(object):
+    def __init__(self, bdy, interior, M, h, **kwargs):
+        """bdy: Global_Smooth_Boundary; interior: bool; M: radial modes; h: radial grid
+        spacing (radial_width = M*h).  kwargs as the reference (:106-112): pad_zone,
+        heaviside, qfs_tolerance, coordinate_tolerance, ... (unknown ones are kept)."""
+        self.bdy = bdy
+        self.interior = interior
+        self.M = M
+        self.h = h
+        self.pad_zone = setit('pad_zone', kwargs, 0)
+        self.coordinate_tolerance = setit('coordinate_tolerance', kwargs, 1e-14)
+        self.qfs_tolerance = setit('qfs_tolerance', kwargs, 1e-12)
+        self.qfs_fsuf = setit('qfs_fsuf', kwargs, None)
+        self.qfs_FF = setit('qfs_FF', kwargs, 0.0)
+        self.heaviside = kwargs['heaviside'] if 'heaviside' in kwargs \
+            else SlepianMollifier(2 * self.M).step
+        self.radial_width = self.M * self.h
+        self.heaviside_width = self.radial_width - self.pad_zone * self.h
+        self.kwargs = kwargs
+        self._generate_radial_grid()
+        self._generate_qfs_boundaries()
+
+    # -- radial grid (reference :280-358) ---------------------------------------
+    def _generate_radial_grid(self):
+        bdy = self.bdy
+        X, Y, N = bdy.x, bdy.y, bdy.N
+        NX, NY = bdy.normal_x, bdy.normal_y
+        sign = -1 if self.interior else 1
+        self.interface = GSB(x=X + sign * self.radial_width * NX, y=Y + sign * self.radial_width * NY)
+        lb = -self.radial_width if self.interior else 0.0
+        ub = 0.0 if self.interior else self.radial_width
+        rc, rv, rat = get_chebyshev_nodes(lb, ub, self.M)
+        self.radial_rv = rv
+        self.radial_tv = bdy.t
+        self.radial_r, self.radial_t = np.meshgrid(rv, bdy.t, indexing='ij')
+        self.radial_x = X + self.radial_r * NX
+        self.radial_y = Y + self.radial_r * NY
+        self.radial_shape = (self.M, N)
+        self.radial_k = np.fft.fftfreq(N, bdy.dt / (2 * np.pi))
+        self.radial_speed = bdy.speed * (1.0 + bdy.curvature * self.radial_r)
+        self.inverse_radial_speed = 1.0 / self.radial_speed
+        V0 = np.polynomial.chebyshev.chebvander(rc, self.M - 1)
+        VI0 = np.linalg.inv(V0)
+        DC01 = np.polynomial.chebyshev.chebder(np.eye(self.M)) / rat
+        DC00 = np.vstack([DC01, np.zeros(self.M)])
+        self.D00 = V0 @ DC00 @ VI0
+        e_hi = (np.polynomial.chebyshev.chebvander(1, self.M - 1) @ VI0)[0]
+        e_lo = (np.polynomial.chebyshev.chebvander(-1, self.M - 1) @ VI0)[0]
+        self.chebyshev_interp_f_to_bdy = e_hi if self.interior else e_lo
+        self.chebyshev_interp_f_to_interface = e_lo if self.interior else e_hi
+        self.chebyshev_interp_df_dn_to_bdy = self.chebyshev_interp_f_to_bdy @ self.D00
+        self.bdy_centroid_x, self.bdy_centroid_y = np.mean(X), np.mean(Y)
+        self.approximate_radius = np.mean(np.hypot(X - self.bdy_centroid_x, Y - self.bdy_centroid_y))
+        self.radial_targ = PointSet(self.radial_x.ravel(), self.radial_y.ravel())
+        # Fejer-1 weights on the Chebyshev-Gauss nodes for radial integrals
+        self.radial_quadrature_weights = bdy.dt * _fejer1(self.M)[:, None] * self.radial_width / 2.0 \
+            * self.radial_speed
+        self._minx = X.min() if self.interior else self.interface.x.min()
+        self._maxx = X.max() if self.interior else self.interface.x.max()
+        self._miny = Y.min() if self.interior else self.interface.y.min()
+        self._maxy = Y.max() if self.interior else self.interface.y.max()
+
+    def _generate_qfs_boundaries(self):
+        """(reference :534-551)"""
+        eps, fsuf, FF = self.qfs_tolerance, self.qfs_fsuf, self.qfs_FF
+        self.bdy_qfs = QFS_Boundary(self.bdy, eps=eps, forced_source_upsampling_factor=fsuf, FF=FF)
+        self.interface_qfs = QFS_Boundary(self.interface, eps=eps,
+                                          forced_source_upsampling_factor=fsuf, FF=FF)
+        q = self.interface_qfs
+        self.interface_grid_source = q.interior_source_bdy if self.interior else q.exterior_source_bdy
+        self.interface_radial_source = q.exterior_source_bdy if self.interior else q.interior_source_bdy
+        q = self.bdy_qfs
+        self.bdy_outward_source = q.exterior_source_bdy if self.interior else q.interior_source_bdy
+        self.bdy_inward_source = q.interior_source_bdy if self.interior else q.exterior_source_bdy
+
+    # -- grid registration (reference :185-270) ----------------------------------
+    def check_if_r_in_annulus(self, r):
+        if self.interior:
+            w1, w2 = r <= 0, r >= -self.radial_width
+        else:
+            w1, w2 = r >= 0, r <= self.radial_width
+        return np.logical_and(w1, w2), np.logical_not(w2), np.logical_not(w1)
+
+    def register_grid(self, grid, verbose=False):
+        """Find the grid points in the annulus, their (r, t) coordinates and the
+        cut-off functions.  Returns (r, t, found) on the whole grid for the collection's
+        inside/outside classification."""
+        self.grid = grid
+        # candidates: bounding box of the curve +/- width
+        pad = 1.6 * self.radial_width + 3 * max(grid.xh, grid.yh)
+        ix = np.where((grid.xv >= self.bdy.x.min() - pad) & (grid.xv <= self.bdy.x.max() + pad))[0]
+        iy = np.where((grid.yv >= self.bdy.y.min() - pad) & (grid.yv <= self.bdy.y.max() + pad))[0]
+        IX, IY = np.meshgrid(ix, iy, indexing='ij')
+        IX, IY = IX.ravel(), IY.ravel()
+        r, t, found = local_coordinates(self.bdy, grid.xv[IX], grid.yv[IY], self.radial_width,
+                                        tol=self.coordinate_tolerance)
+        self._near = (IX[found], IY[found], r[found], t[found])
+        ia, _, _ = self.check_if_r_in_annulus(r[found])
+        self.grid_ia_xind = IX[found][ia]
+        self.grid_ia_yind = IY[found][ia]
+        self.grid_ia_x = grid.xv[self.grid_ia_xind]
+        self.grid_ia_y = grid.yv[self.grid_ia_yind]
+        self.grid_ia_r = r[found][ia]
+        self.grid_ia_t = t[found][ia]
+        lb = -self.radial_width if self.interior else 0.0
+        ub = 0.0 if self.interior else self.radial_width
+        self.grid_ia_xi = affine_transformation(self.grid_ia_r, lb, ub, -1.0, 1.0)
+        self.interface_x_transf = affine_transformation(self.interface.x, grid.x_bounds[0],
+                                                        grid.x_bounds[1], 0.0, 2 * np.pi)
+        self.interface_y_transf = affine_transformation(self.interface.y, grid.y_bounds[0],
+                                                        grid.y_bounds[1], 0.0, 2 * np.pi)
+        # regularised Heaviside functions coupling the grids (reference :239-247)
+        lbh = -self.heaviside_width if self.interior else self.heaviside_width
+        grts = affine_transformation(self.grid_ia_r, lbh, 0, -1, 1)
+        self.grid_to_radial_step = 1.0 - self.heaviside(grts)
+        arts = affine_transformation(self.radial_rv, lbh, 0, -1, 1)
+        self.radial_cutoff = self.heaviside(arts)
+        return self._near
+
+    def register_ia_inds(self, phys_inds):
+        self.ia_inds = phys_inds[self.grid_ia_xind, self.grid_ia_yind]
+
+    # -- radial <-> boundary / grid ------------------------------------------------
+    def interpolate_radial_to_boundary(self, f):
+        return self.chebyshev_interp_f_to_bdy.dot(f)
+
+    def interpolate_radial_to_interface(self, f):
+        return self.chebyshev_interp_f_to_interface.dot(f)
+
+    def interpolate_radial_to_boundary_normal_derivative(self, f):
+        return self.chebyshev_interp_df_dn_to_bdy.dot(f)
+
+    def interpolate_radial_to_points(self, fr, xi, t):
+        """fr (M, N) on the radial grid -> values at local coordinates (xi in [-1,1], t)
+        (reference :419-434; here an exact Chebyshev x Fourier evaluation on the device)."""
+        from .interp import chebyshev_fourier_eval
+        return chebyshev_fourier_eval(fr, xi, t)
+
+    def interpolate_radial_to_grid1(self, fr, f):
+        vals = self.interpolate_radial_to_points(fr, self.grid_ia_xi, self.grid_ia_t)
+        f[self.grid_ia_xind, self.grid_ia_yind] = vals.cpu().numpy()
+
+    # -- derivatives on the radial grid (reference :463-483) -------------------------
+    def _radial_grid_t_derivative(self, f):
+        return np.fft.ifft(np.fft.fft(f) * 1j * self.radial_k).real
+
+    def _radial_grid_tau_derivative(self, f):
+        return self._radial_grid_t_derivative(f) * self.inverse_radial_speed
+
+    def _radial_grid_r_derivative(self, f):
+        return self.D00.dot(f)
+
+    def radial_grid_derivatives(self, f):
+        bdy = self.bdy
+        ft = self._radial_grid_tau_derivative(f)
+        fr = self._radial_grid_r_derivative(f)
+        return fr * bdy.normal_x + ft * bdy.tangent_x, fr * bdy.normal_y + ft * bdy.tangent_y
+
+    def convert_uv_to_rt(self, fu, fv):
+        bdy = self.bdy
+        return fu * bdy.normal_x + fv * bdy.normal_y, fu * bdy.tangent_x + fv * bdy.tangent_y
+
+    def convert_rt_to_uv(self, fr, ft):
+        bdy = self.bdy
+        return fr * bdy.normal_x + ft * bdy.tangent_x, fr * bdy.normal_y + ft * bdy.tangent_y
+
+    def radial_integral(self, fr):
+        return np.sum(fr * self.radial_cutoff[:, None] * self.radial_quadrature_weights)
+
+
+def _fejer1(n):
+    """Fejer's first rule weights on the n Chebyshev-Gauss nodes of [-1, 1]."""
+    k = np.arange(n)
+    theta = (2 * k + 1) * np.pi / (2 * n)
+    w = np.ones(n)
+    for j in range(1, n // 2 + 1):
+        w -= 2.0 * np.cos(2 * j * theta) / (4 * j * j - 1)
+    return w * 2.0 / n

@@ -1,0 +1,30 @@
+"""ipde/grid_evaluators/laplace_grid_evaluator.py API (reference :35-45), exact sum."""
+import numpy as np
+
+from .scalar_grid_evaluator import (ScalarGridBackend, ScalarFreespaceGridEvaluator,
+                                    ScalarPeriodicGridEvaluator)
+from ..layer_potentials import laplace_apply
+
+scale = -1.0 / (2 * np.pi)
+
+
+def gf(r):
+    """Green's function the evaluator sums (reference :8-12)."""
+    return scale * np.log(r)
+
+
+class LaplaceGridBackend(ScalarGridBackend):
+    def __init__(self, h, spread_width, funcgen_tol=1e-10, inline_core=True):
+        super().__init__(h, spread_width, {}, funcgen_tol, inline_core)
+
+
+class LaplaceFreespaceGridEvaluator(ScalarFreespaceGridEvaluator):
+    def __init__(self, backend, xv, yv):
+        super().__init__(backend, xv, yv)
+
+    def _apply(self, sx, sy, ch):
+        return laplace_apply(sx, sy, self.targets.x, self.targets.y, w_sigma=ch)
+
+
+class LaplacePeriodicGridEvaluator(ScalarPeriodicGridEvaluator):
+    pass

@@ -1,0 +1,24 @@
+"""ipde/grid_evaluators/modified_helmholtz_grid_evaluator.py API (reference :19-30)."""
+import numpy as np
+
+from .scalar_grid_evaluator import (ScalarGridBackend, ScalarFreespaceGridEvaluator,
+                                    ScalarPeriodicGridEvaluator)
+from ..layer_potentials import modified_helmholtz_apply
+
+
+class ModifiedHelmholtzGridBackend(ScalarGridBackend):
+    def __init__(self, h, spread_width, helmholtz_k, funcgen_tol=1e-10, inline_core=True):
+        super().__init__(h, spread_width, {'helmholtz_k': helmholtz_k}, funcgen_tol, inline_core)
+
+
+class ModifiedHelmholtzFreespaceGridEvaluator(ScalarFreespaceGridEvaluator):
+    def __init__(self, backend, xv, yv):
+        super().__init__(backend, xv, yv)
+        self.k = backend.kernel_kwargs['helmholtz_k']
+
+    def _apply(self, sx, sy, ch):
+        return modified_helmholtz_apply(sx, sy, self.targets.x, self.targets.y, self.k, w_sigma=ch)
+
+
+class ModifiedHelmholtzPeriodicGridEvaluator(ScalarPeriodicGridEvaluator):
+    pass

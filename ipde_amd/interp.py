@@ -1,0 +1,84 @@
+"""Spectral evaluation at scattered points ("type-2 NUFFT" by dense matrix products).
+
+Own replacement for the finufft / near_finder calls that sit on either side of the
+hot path (reference multi_boundary/scalar.py:80-88 `periodic_interp2d`;
+embedded_boundary.py:419-434 `interpolate_radial_to_points`).  The number of points
+is O(boundary nodes) or O(grid points in the annulus), so the exact evaluation
+     f(x_p, y_p) = sum_{kx,ky} F[kx,ky] e^{i (kx x_p + ky y_p)}
+is two dense complex128 matrix products — library GEMMs (rocBLAS through
+torch.matmul, the MFMA f64 path) — instead of a spreading NUFFT: exact to rounding,
+no tolerance parameter.  torch is used for the GEMM and device memory only.
+"""
+import numpy as np
+import torch
+
+from .device import get_context
+
+
+def _dev(a, ctx, dtype):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=ctx.torch_device(), dtype=dtype)
+    return torch.as_tensor(np.ascontiguousarray(a), device=ctx.torch_device()).to(dtype)
+
+
+def periodic_interp2d(fh, x, y, ctx=None, chunk=16384):
+    """Evaluate the Fourier series with fft2-ordered coefficients fh (K, Nx, Ny) (or
+    (Nx, Ny)) at the points (x, y) given in [0, 2 pi) units of the periodic box.
+    Returns a (K, P) (or (P,)) complex torch tensor on the device:
+        out[k, p] = (1/(Nx Ny)) sum fh[k, a, b] exp(i (kx_a x_p + ky_b y_p))"""
+    ctx = ctx or get_context()
+    fh = _dev(fh, ctx, torch.complex128)
+    squeeze = fh.dim() == 2
+    if squeeze:
+        fh = fh[None]
+    K, Nx, Ny = fh.shape
+    x = _dev(x, ctx, torch.float64)
+    y = _dev(y, ctx, torch.float64)
+    kx = torch.fft.fftfreq(Nx, 1.0 / Nx, dtype=torch.float64, device=fh.device)
+    ky = torch.fft.fftfreq(Ny, 1.0 / Ny, dtype=torch.float64, device=fh.device)
+    P = x.shape[0]
+    out = torch.empty((K, P), dtype=torch.complex128, device=fh.device)
+    f2 = fh.reshape(K * Nx, Ny)
+    for a in range(0, P, chunk):
+        b = min(P, a + chunk)
+        Ey = torch.exp(1j * ky[:, None] * y[None, a:b])          # (Ny, p)
+        A = (f2 @ Ey).reshape(K, Nx, b - a)                       # GEMM
+        Ex = torch.exp(1j * kx[:, None] * x[None, a:b])          # (Nx, p)
+        out[:, a:b] = (A * Ex[None]).sum(dim=1)
+    out /= float(Nx * Ny)
+    return out[0] if squeeze else out
+
+
+def chebyshev_fourier_eval(fr, xi, t, ctx=None, chunk=16384):
+    """Evaluate a function given on (M Chebyshev-Gauss nodes, lowest first) x
+    (N equispaced t) at scattered (xi in [-1, 1], t).  fr: (M, N) real.
+    Returns a real (P,) torch tensor on the device."""
+    ctx = ctx or get_context()
+    fr = _dev(fr, ctx, torch.float64)
+    M, N = fr.shape
+    xi = _dev(xi, ctx, torch.float64)
+    t = _dev(t, ctx, torch.float64)
+    # Chebyshev coefficients along r: c = V^{-1} f  (nodes ascending)
+    xc = np.polynomial.chebyshev.chebgauss(M)[0][::-1].copy()
+    VI = np.linalg.inv(np.polynomial.chebyshev.chebvander(xc, M - 1))
+    c = _dev(VI, ctx, torch.float64) @ fr                         # (M, N)
+    ch = torch.fft.fft(c, dim=1) / N                              # (M, N) complex
+    k = torch.fft.fftfreq(N, 1.0 / N, dtype=torch.float64, device=fr.device)
+    P = t.shape[0]
+    out = torch.empty(P, dtype=torch.float64, device=fr.device)
+    for a in range(0, P, chunk):
+        b = min(P, a + chunk)
+        Et = torch.exp(1j * k[:, None] * t[None, a:b])           # (N, p)
+        B = (ch @ Et).real                                        # (M, p) GEMM
+        # T_m(xi) by the three-term recurrence
+        x = xi[a:b]
+        T0 = torch.ones_like(x)
+        T1 = x.clone()
+        acc = B[0] * T0
+        if M > 1:
+            acc = acc + B[1] * T1
+        for m in range(2, M):
+            T0, T1 = T1, 2 * x * T1 - T0
+            acc = acc + B[m] * T1
+        out[a:b] = acc
+    return out

@@ -1,0 +1,117 @@
+"""Grid points near a closed curve: closest-point ("local") coordinates and inside
+tests.  Own replacement for the near_finder calls of the reference
+(`gridpoints_near_curve_update`, `points_inside_curve_update`; reference
+ipde/embedded_boundary.py:185-214, ipde/ebdy_collection.py:376-382).  Host numpy,
+one-time set-up per geometry.
+
+For a point p within `width` of the curve X(t) we want (r, t):  p = X(t) + r n(t),
+n the outward unit normal (r < 0 inside a ccw curve).  The curve is trigonometrically
+upsampled 8x once (FFT) together with X' and X''; Newton's method on
+g(t) = (p - X(t)) . X'(t) then evaluates X, X', X'' by 12-point local Lagrange
+interpolation of the upsampled samples — at >= 16 samples per shortest resolved
+wavelength the interpolation error is ~1e-14 relative — so each iteration is O(1)
+per point instead of O(N).
+"""
+import numpy as np
+from scipy.spatial import cKDTree
+
+from .pybie2d_compat import fourier_resample
+
+_UP = 8        # upsampling of the curve
+_NL = 12       # Lagrange stencil width
+
+
+class CurveEvaluator(object):
+    """X(t), X'(t), X''(t) at arbitrary t from an equispaced closed-curve sampling."""
+
+    def __init__(self, bdy):
+        self.N = bdy.N
+        self.Nf = _UP * bdy.N
+        c = bdy.c
+        k = np.fft.fftfreq(bdy.N, 1.0 / bdy.N)
+        ch = np.fft.fft(c)
+        if bdy.N % 2 == 0:
+            ch = ch.copy()
+            ch[bdy.N // 2] = 0.0   # the Nyquist mode has no consistent derivative
+        c0 = np.fft.ifft(ch)
+        c1 = np.fft.ifft(ch * 1j * k)
+        c2 = np.fft.ifft(ch * (1j * k) ** 2)
+        self.f = np.stack([fourier_resample(a, self.Nf) for a in (c0, c1, c2)])  # (3, Nf)
+        self.hf = 2 * np.pi / self.Nf
+        # barycentric weights of _NL equispaced nodes
+        j = np.arange(_NL)
+        w = np.ones(_NL)
+        for a in range(_NL):
+            w[a] = 1.0 / np.prod((j[a] - np.delete(j, a)).astype(float))
+        self.w = w
+
+    def __call__(self, t):
+        """returns complex X, X', X'' at t (array)"""
+        s = np.asarray(t) / self.hf
+        i0 = np.floor(s).astype(np.int64) - (_NL // 2 - 1)
+        u = s - i0                                  # position within the stencil [0, _NL-1]
+        idx = (i0[:, None] + np.arange(_NL)[None, :]) % self.Nf
+        d = u[:, None] - np.arange(_NL)[None, :]
+        exact = np.abs(d) < 1e-14
+        d = np.where(exact, 1.0, d)
+        wt = self.w[None, :] / d
+        hit = exact.any(axis=1)
+        wt = np.where(hit[:, None], exact.astype(float), wt)
+        wt /= wt.sum(axis=1, keepdims=True)
+        vals = self.f[:, idx]                        # (3, P, _NL)
+        out = np.einsum('kpj,pj->kp', vals, wt)
+        return out[0], out[1], out[2]
+
+
+def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30):
+    """(r, t, found) of the points (px, py); found = within ~1.5*width of the curve and
+    Newton converged.  r is the signed distance along the outward normal."""
+    px = np.asarray(px, dtype=float)
+    py = np.asarray(py, dtype=float)
+    ev = CurveEvaluator(bdy)
+    fine = ev.f[0]
+    tree = cKDTree(np.column_stack([fine.real, fine.imag]))
+    dist, j = tree.query(np.column_stack([px, py]), distance_upper_bound=1.5 * width + 2 * bdy.max_h)
+    found = np.isfinite(dist)
+    r = np.full(px.shape, np.nan)
+    t = np.full(px.shape, np.nan)
+    if not found.any():
+        return r, t, found
+    p = px[found] + 1j * py[found]
+    tt = j[found] * ev.hf
+    for _ in range(maxiter):
+        X, Xp, Xpp = ev(tt)
+        d = p - X
+        g = d.real * Xp.real + d.imag * Xp.imag
+        gp = -(Xp.real ** 2 + Xp.imag ** 2) + d.real * Xpp.real + d.imag * Xpp.imag
+        # guard: if the Newton derivative is not negative definite fall back to the
+        # Gauss-Newton step (always a descent direction for |p - X|^2)
+        gp = np.where(gp < -1e-300, gp, -(Xp.real ** 2 + Xp.imag ** 2))
+        dt = -g / gp
+        dt = np.clip(dt, -0.25 * width / np.abs(Xp) - ev.hf, 0.25 * width / np.abs(Xp) + ev.hf)
+        tt = tt + dt
+        if np.max(np.abs(dt)) < tol:
+            break
+    X, Xp, _ = ev(tt)
+    sp = np.abs(Xp)
+    nx, ny = Xp.imag / sp, -Xp.real / sp
+    d = p - X
+    r[found] = d.real * nx + d.imag * ny
+    t[found] = np.mod(tt, 2 * np.pi)
+    return r, t, found
+
+
+def points_inside_curve(bdy, px, py, r=None, found=None):
+    """Boolean: inside the closed curve.  Points with local coordinates are decided by
+    the sign of r (exact to coordinate tolerance); the rest by a polygon test on the
+    8x upsampled curve (they are at least ~1.5 widths away, far beyond the polygon's
+    sagitta)."""
+    from matplotlib.path import Path
+    px = np.asarray(px, dtype=float)
+    py = np.asarray(py, dtype=float)
+    fine = fourier_resample(bdy.c, _UP * bdy.N)
+    inside = Path(np.column_stack([fine.real, fine.imag])).contains_points(
+        np.column_stack([px.ravel(), py.ravel()])).reshape(px.shape)
+    if r is not None:
+        inside = np.where(found, r < 0.0, inside)
+    return inside

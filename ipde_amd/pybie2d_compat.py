@@ -1,0 +1,200 @@
+"""Own minimal stand-ins for the part of the pybie2d surface that ipde's scripts and
+solvers touch.  pybie2d is not part of the reference tree; these
+classes follow the ATTRIBUTE CONTRACT the reference reads
+(`.x .y .c .N .t .dt .speed .curvature .normal_x .normal_y .tangent_x .tangent_y
+.weights .get_stacked_boundary()`; reference ipde/embedded_boundary.py:280-358,
+ipde/solvers/internals/scalar.py:31-35, ipde/ebdy_collection.py:22-31) with standard
+spectral differentiation of a closed curve sampled at equispaced parameter values.
+Host numpy: one-time geometry set-up.
+"""
+import numpy as np
+
+
+def star(N, x=0.0, y=0.0, r=1.0, a=0.5, f=3, rot=0.0):
+    """Complex points of the star curve  (x+iy) + r (1 + a cos(f (t - rot))) e^{it}
+    (the call shape of pybie2d.misc.curve_descriptions.star; reference
+    examples/interior_poisson.py:41 uses star(nb, a=0.2, f=5))."""
+    t = np.linspace(0.0, 2 * np.pi, N, endpoint=False)
+    return (x + 1j * y) + (r + r * a * np.cos(f * (t - rot))) * np.exp(1j * t)
+
+
+def squish(N, x=0.0, y=0.0, r=1.0, b=1.0, rot=0.0):
+    """Ellipse-like closed curve (semi-axes r, r*b)."""
+    t = np.linspace(0.0, 2 * np.pi, N, endpoint=False)
+    return (x + 1j * y) + np.exp(1j * rot) * (r * np.cos(t) + 1j * r * b * np.sin(t))
+
+
+class PointSet(object):
+    def __init__(self, x=None, y=None, c=None):
+        if c is not None:
+            c = np.asarray(c)
+            x, y = c.real, c.imag
+        self.x = np.ascontiguousarray(x, dtype=float).ravel()
+        self.y = np.ascontiguousarray(y, dtype=float).ravel()
+        self.c = self.x + 1j * self.y
+        self.N = self.x.shape[0]
+
+    def get_stacked_boundary(self, T=True):
+        s = np.vstack([self.x, self.y])
+        return s if T else s.T
+
+
+class Global_Smooth_Boundary(PointSet):
+    """Smooth closed curve, counter-clockwise, equispaced in its parameter t."""
+
+    def __init__(self, x=None, y=None, c=None):
+        super().__init__(x, y, c)
+        N = self.N
+        self.t, self.dt = np.linspace(0.0, 2 * np.pi, N, endpoint=False, retstep=True)
+        self.k = np.fft.fftfreq(N, 1.0 / N)
+        self.ik = 1j * self.k
+        ch = np.fft.fft(self.c)
+        self.cp = np.fft.ifft(ch * self.ik)
+        self.cpp = np.fft.ifft(ch * self.ik ** 2)
+        self.speed = np.abs(self.cp)
+        self.tangent_c = self.cp / self.speed
+        self.tangent_x, self.tangent_y = self.tangent_c.real.copy(), self.tangent_c.imag.copy()
+        self.normal_c = -1j * self.tangent_c          # outward for a ccw curve
+        self.normal_x, self.normal_y = self.normal_c.real.copy(), self.normal_c.imag.copy()
+        self.curvature = (self.cp.real * self.cpp.imag - self.cp.imag * self.cpp.real) / self.speed ** 3
+        self.weights = self.speed * self.dt
+        self.max_h = np.max(self.weights)
+        self.area = 0.5 * np.sum((self.x * self.normal_x + self.y * self.normal_y) * self.weights)
+
+    def generate_resampled_boundary(self, new_N):
+        return Global_Smooth_Boundary(c=fourier_resample(self.c, new_N))
+
+
+GSB = Global_Smooth_Boundary
+
+
+def fourier_resample(f, new_N):
+    """Trigonometric resampling of a periodic sequence to new_N points."""
+    N = f.shape[0]
+    fh = np.fft.fft(f)
+    out = np.zeros(new_N, dtype=complex)
+    if new_N >= N:
+        h = N // 2
+        out[:h] = fh[:h]                          # k = 0 .. h-1
+        if N % 2 == 0:
+            out[h] = 0.5 * fh[h]                  # split the Nyquist mode
+            out[new_N - h] += 0.5 * fh[h]
+            if h > 1:
+                out[new_N - h + 1:] = fh[h + 1:]  # k = -(h-1) .. -1
+        else:
+            out[h] = fh[h]
+            out[new_N - h:] = fh[h + 1:]
+    else:
+        h = (new_N - 1) // 2                      # keep |k| <= h
+        out[:h + 1] = fh[:h + 1]
+        if h > 0:
+            out[new_N - h:] = fh[N - h:]
+    res = np.fft.ifft(out) * (new_N / N)
+    return res if np.iscomplexobj(f) else res.real
+
+
+class Grid(object):
+    def __init__(self, x_bounds, Nx, y_bounds, Ny, mask=None, x_endpoints=(True, True),
+                 y_endpoints=(True, True)):
+        self.x_bounds, self.y_bounds = list(x_bounds), list(y_bounds)
+        self.Nx, self.Ny = int(Nx), int(Ny)
+        self.xv = self._axis(x_bounds, self.Nx, x_endpoints)
+        self.yv = self._axis(y_bounds, self.Ny, y_endpoints)
+        self.xh = self.xv[1] - self.xv[0]
+        self.yh = self.yv[1] - self.yv[0]
+        self.xg, self.yg = np.meshgrid(self.xv, self.yv, indexing='ij')
+        self.shape = (self.Nx, self.Ny)
+        self.N = self.Nx * self.Ny
+        self.mask = mask
+
+    @staticmethod
+    def _axis(b, n, ends):
+        if ends[0] and ends[1]:
+            return np.linspace(b[0], b[1], n, endpoint=True)
+        if ends[0]:
+            return np.linspace(b[0], b[1], n, endpoint=False)
+        v = np.linspace(b[0], b[1], n + 1, endpoint=ends[1])
+        return v[1:]
+
+
+class BoundaryCollection(object):
+    """Concatenation of source curves (reference multi_boundary/scalar.py:34-39)."""
+
+    def __init__(self):
+        self.boundaries = []
+        self.sides = []
+
+    def add(self, bdy, side):
+        self.boundaries.append(bdy)
+        self.sides.append(side)
+
+    def amass_information(self):
+        cat = lambda name: np.concatenate([np.asarray(getattr(b, name)) for b in self.boundaries])
+        self.x, self.y = cat('x'), cat('y')
+        self.c = self.x + 1j * self.y
+        self.weights = cat('weights')
+        self.normal_x, self.normal_y = cat('normal_x'), cat('normal_y')
+        self.N = self.x.shape[0]
+        self.Ns = [b.N for b in self.boundaries]
+
+    def get_stacked_boundary(self, T=True):
+        s = np.vstack([self.x, self.y])
+        return s if T else s.T
+
+
+# ---------------------------------------------------------------------------
+# dense layer matrices (host; set-up of QFS and of the example-level boundary solve)
+def Laplace_Layer_Form(source, target=None, ifcharge=False, ifdipole=False):
+    """Dense matrix of the Laplace SLP and/or DLP from `source` to `target`
+    (off-surface; weights included).  Conventions of ipde_amd.layer_potentials."""
+    if target is None:
+        target = source
+    dx = target.x[:, None] - source.x[None, :]
+    dy = target.y[:, None] - source.y[None, :]
+    d2 = dx * dx + dy * dy
+    out = np.zeros_like(d2)
+    if ifcharge:
+        out += (-0.25 / np.pi) * np.log(d2) * source.weights[None, :]
+    if ifdipole:
+        out += (0.5 / np.pi) * (dx * source.normal_x[None, :] + dy * source.normal_y[None, :]) / d2 \
+            * source.weights[None, :]
+    return out
+
+
+def _kress_log_weights(N):
+    """R_j with  int_0^{2pi} log(4 sin^2((t_i-s)/2)) f(s) ds ~ sum_j R_{|i-j|} f(s_j)
+    for trigonometric f (Kress' quadrature for the periodic log singularity)."""
+    m = np.arange(1, N // 2)
+    j = np.arange(N)
+    R = -(4 * np.pi / N) * (np.cos(np.outer(j, m) * (2 * np.pi / N)) @ (1.0 / m)
+                            + np.cos(np.pi * j) / N)
+    return R
+
+
+def Laplace_Layer_Singular_Form(bdy, ifcharge=False, ifdipole=False):
+    """On-surface Nystrom matrices of the Laplace SLP (Kress log split) and DLP (smooth
+    kernel, diagonal -curvature/(4 pi) * weight) on a Global_Smooth_Boundary.  The DLP
+    here is the principal value; interior limit = D - I/2 (reference
+    examples/interior_poisson.py:19)."""
+    N = bdy.N
+    out = np.zeros((N, N))
+    dx = bdy.x[:, None] - bdy.x[None, :]
+    dy = bdy.y[:, None] - bdy.y[None, :]
+    d2 = dx * dx + dy * dy
+    if ifcharge:
+        dt = bdy.t[:, None] - bdy.t[None, :]
+        s2 = 4 * np.sin(dt / 2) ** 2
+        np.fill_diagonal(d2, 1.0)
+        np.fill_diagonal(s2, 1.0)
+        smooth = -0.25 / np.pi * np.log(d2 / s2)
+        np.fill_diagonal(smooth, -0.5 / np.pi * np.log(bdy.speed))
+        R = _kress_log_weights(N)
+        idx = np.abs(np.arange(N)[:, None] - np.arange(N)[None, :])
+        out += (-0.25 / np.pi) * R[idx] * bdy.speed[None, :] + smooth * bdy.weights[None, :]
+        np.fill_diagonal(d2, 0.0)
+    if ifdipole:
+        with np.errstate(divide='ignore', invalid='ignore'):
+            D = (0.5 / np.pi) * (dx * bdy.normal_x[None, :] + dy * bdy.normal_y[None, :]) / d2
+        np.fill_diagonal(D, -bdy.curvature / (4 * np.pi))
+        out += D * bdy.weights[None, :]
+    return out

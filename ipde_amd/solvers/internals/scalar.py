@@ -1,0 +1,90 @@
+"""ScalarHelper — per-boundary helper of the scalar solvers, mirrors
+ipde/solvers/internals/scalar.py:5-116: owns the annular solver, the interface QFS
+pair and the `Layer_Apply` closure (the plug point of the GPU kernels)."""
+import numpy as np
+
+from ...annular.annular_full import ApproximateAnnularGeometry, RealAnnularGeometry
+
+
+class ScalarHelper(object):
+    def __init__(self, ebdy, helper=None, grid_backend='hip'):
+        self.ebdy = ebdy
+        self.grid_backend = grid_backend
+        self.interior = self.ebdy.interior
+        if helper is None:
+            self.AAG = ApproximateAnnularGeometry(self.ebdy.bdy.N, self.ebdy.M,
+                                                  self.ebdy.radial_width, self.ebdy.approximate_radius)
+            self._define_annular_solver()
+        else:
+            self.annular_solver = helper.annular_solver
+            self.AAG = self.annular_solver.AAG
+        self._set_boundary_estimators()
+        self._get_RAG()
+        self._get_qfs()
+        self._define_layer_apply()
+
+    def _define_annular_solver(self):
+        raise NotImplementedError
+
+    def _get_qfs(self):
+        raise NotImplementedError
+
+    def _define_layer_apply(self):
+        raise NotImplementedError
+
+    def _get_RAG(self):
+        bb = self.ebdy.bdy if self.interior else self.ebdy.interface
+        self.RAG = RealAnnularGeometry(bb.speed, bb.curvature, self.annular_solver.AAG)
+
+    def _set_boundary_estimators(self):
+        CO = self.annular_solver.AAG.CO
+        if self.interior:
+            self._bv_estimator, self._bn_estimator = CO.obc_dirichlet[0], CO.obc_neumann[0]
+            self._iv_estimator, self._in_estimator = CO.ibc_dirichlet[0], CO.ibc_neumann[0]
+        else:
+            self._bv_estimator, self._bn_estimator = CO.ibc_dirichlet[0], CO.ibc_neumann[0]
+            self._iv_estimator, self._in_estimator = CO.obc_dirichlet[0], CO.obc_neumann[0]
+
+    def get_boundary_values(self, ur):
+        return self._bv_estimator.dot(ur)
+
+    def get_boundary_normal_derivatives(self, ur):
+        return self._bn_estimator.dot(ur)
+
+    def get_interface_values(self, ur):
+        return self._iv_estimator.dot(ur)
+
+    def get_interface_normal_derivatives(self, ur):
+        return self._in_estimator.dot(ur)
+
+    def __call__(self, fr, bv, bx, by, **kwargs):
+        """kwargs go to the annular solver (reference :68-94)."""
+        ebdy = self.ebdy
+        ucn = bx * ebdy.interface.normal_x + by * ebdy.interface.normal_y
+        zer = np.zeros_like(bv)
+        ur = np.asarray(self.annular_solver.solve(self.RAG, fr, zer, zer, **kwargs))
+        self.iterations_last_call = self.annular_solver.iterations_last_call
+        urn = self.get_interface_normal_derivatives(ur)
+        slp = urn - ucn
+        dlp = np.array(bv, copy=True)
+        if not self.interior:
+            slp *= -1.0
+            dlp *= -1.0
+        sigma_g = self.interface_qfs_g([slp, dlp])
+        sigma_r = self.interface_qfs_r([slp, dlp])
+        self.ur = ur
+        self.sigma_r = sigma_r
+        self.sigma_g = sigma_g
+        return sigma_g
+
+    def correct(self, ub):
+        """(reference :95-116)"""
+        src = self.interface_qfs_g.source
+        w = self.Layer_Apply(src, self.ebdy.interface, self.sigma_g)
+        ub = ub - w
+        sigma_r_adj = self.interface_qfs_r.u2s(ub)
+        sigma_r_tot = sigma_r_adj + self.sigma_r
+        src = self.interface_qfs_r.source
+        rslp = self.Layer_Apply(src, self.ebdy.radial_targ, sigma_r_tot)
+        self.ur = self.ur + np.asarray(rslp).reshape(self.ur.shape)
+        return self.ur

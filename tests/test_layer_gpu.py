@@ -252,3 +252,32 @@ def test_small_target_set_source_split_is_deterministic(lp):
     assert np.array_equal(a, b)
     ref = oracle.c_laplace_apply(c.x, c.y, inner.x, inner.y, w_sigma=sig * c.weights)
     assert rel_err(a, ref) < TOL
+
+
+def test_grid_evaluator_class_api():
+    """The reference's *GridBackend / *FreespaceGridEvaluator call shape
+    (grid_evaluators/laplace_grid_evaluator.py:35-45), exact sums, same input checks."""
+    from ipde_amd.grid_evaluators.laplace_grid_evaluator import (LaplaceGridBackend,
+                                                                 LaplaceFreespaceGridEvaluator)
+    from ipde_amd.grid_evaluators.modified_helmholtz_grid_evaluator import (
+        ModifiedHelmholtzGridBackend, ModifiedHelmholtzFreespaceGridEvaluator)
+    c = Curve(300, a=0.2, f=5)
+    n = 80
+    xv = np.linspace(-1.5, 1.5, n, endpoint=False) + 0.0123   # no node on a source
+    h = xv[1] - xv[0]
+    rng = np.random.default_rng(2)
+    ch = rng.standard_normal(c.N) * c.weights
+    xg, yg = np.meshgrid(xv, xv, indexing="ij")
+    ev = LaplaceFreespaceGridEvaluator(LaplaceGridBackend(h, 20), xv, xv)
+    got = ev(c.get_stacked_boundary(), ch)
+    ref = olp.laplace_layer_apply(c.x, c.y, xg.ravel(), yg.ravel(), charge=ch).reshape(n, n)
+    assert got.shape == (n, n) and rel_err(got, ref) < TOL
+    evm = ModifiedHelmholtzFreespaceGridEvaluator(ModifiedHelmholtzGridBackend(h, 20, 10.0), xv, xv)
+    got = evm(c.get_stacked_boundary(), ch)
+    ref = olp.modified_helmholtz_layer_apply(c.x, c.y, xg.ravel(), yg.ravel(), 10.0,
+                                             charge=ch).reshape(n, n)
+    assert rel_err(got, ref) < TOL
+    with pytest.raises(Exception):
+        LaplaceFreespaceGridEvaluator(LaplaceGridBackend(h * 1.01, 20), xv, xv)
+    with pytest.raises(Exception):
+        LaplaceFreespaceGridEvaluator(LaplaceGridBackend(h, 20), xv, xv[:-1])

@@ -1,0 +1,33 @@
+"""The full interior Poisson pipeline (BASELINE configs[0] plumbing, reference
+examples/interior_poisson.py) on the device stack: FFT grid solve -> interface data ->
+annular GMRES -> QFS -> dense layer sums -> radial/grid merge -> boundary correction.
+Acceptance: the manufactured-solution error reaches the plateau the reference records
+for this script (poisson_for_paper.py:118-124: ~1e-13..4e-13 relative)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+
+def test_interior_poisson_manufactured_solution():
+    import interior_poisson
+    T = {}
+    err, scale, solver, ue, T = interior_poisson.run(nb=600, M=16, timings=T)
+    print(T, err, scale)
+    assert err / scale < 1e-10
+    assert max(solver.iteration_counts) < 40
+
+
+def test_interior_poisson_converges_with_resolution():
+    import interior_poisson
+    errs = []
+    for nb in (200, 400, 800):
+        err, scale, *_ = interior_poisson.run(nb=nb, M=16)
+        errs.append(err / scale)
+    print(errs)
+    assert errs[2] < 1e-11 and errs[2] < errs[0]
