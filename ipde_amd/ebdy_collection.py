@@ -9,7 +9,7 @@ interpolations and derivatives evaluate on the device.
 import numpy as np
 
 from .embedded_function import EmbeddedFunction
-from .near import points_inside_curve
+from .near import grid_inside_curve
 from .pybie2d_compat import Grid, PointSet
 from .utilities import affine_transformation
 
@@ -80,11 +80,7 @@ class EmbeddedBoundaryCollection(object):
             else np.ones(grid.shape, dtype=bool)
         for ebdy in self:
             IX, IY, r, t = ebdy.register_grid(grid, verbose=verbose)
-            rfull = np.full(grid.shape, np.nan)
-            found = np.zeros(grid.shape, dtype=bool)
-            rfull[IX, IY] = r
-            found[IX, IY] = True
-            inside = points_inside_curve(ebdy.bdy, grid.xg, grid.yg, rfull, found)
+            inside = grid_inside_curve(grid.shape, IX, IY, r)
             if ebdy.interior:
                 phys = np.logical_or(phys, inside) if ebdy is self.ebdys[0] \
                     else np.logical_and(phys, inside)

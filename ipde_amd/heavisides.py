@@ -11,6 +11,7 @@ once at set-up on O(annulus) points.
 """
 import numpy as np
 import scipy.signal
+from scipy.interpolate import InterpolatedUnivariateSpline
 from numpy.polynomial import chebyshev as C
 
 _cache = {}
@@ -25,7 +26,11 @@ def _build(r, nsamp=1000, deg=200):
     x = np.linspace(-1.0, 1.0, nsamp)
     w = scipy.signal.windows.dpss(nsamp, 0.25 * float(r))
     w = 0.5 * (w + w[::-1])  # exact evenness
-    bump_c = C.chebfit(x, w, deg)
+    # quintic spline through the samples (as the reference's construction), then
+    # Chebyshev interpolation at deg+1 Chebyshev points (square, well conditioned)
+    spl = InterpolatedUnivariateSpline(x, w, k=5)
+    xc = np.cos(np.pi * (np.arange(deg + 1) + 0.5) / (deg + 1))
+    bump_c = C.chebfit(xc, spl(xc), deg)
     bump_c[1::2] = 0.0       # even function
     step_c = C.chebint(bump_c, lbnd=-1.0)
     total = C.chebval(1.0, step_c)

@@ -102,10 +102,10 @@ def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30):
 
 
 def points_inside_curve(bdy, px, py, r=None, found=None):
-    """Boolean: inside the closed curve.  Points with local coordinates are decided by
-    the sign of r (exact to coordinate tolerance); the rest by a polygon test on the
-    8x upsampled curve (they are at least ~1.5 widths away, far beyond the polygon's
-    sagitta)."""
+    """Boolean: inside the closed curve, for scattered points.  Points with local
+    coordinates are decided by the sign of r (exact to coordinate tolerance); the rest
+    by a polygon test on the 8x upsampled curve.  O(points x vertices): use
+    `grid_inside_curve` for whole grids."""
     from matplotlib.path import Path
     px = np.asarray(px, dtype=float)
     py = np.asarray(py, dtype=float)
@@ -115,3 +115,18 @@ def points_inside_curve(bdy, px, py, r=None, found=None):
     if r is not None:
         inside = np.where(found, r < 0.0, inside)
     return inside
+
+
+def grid_inside_curve(shape, IX, IY, r):
+    """Inside mask of a whole grid from the near-band coordinates alone: cells with
+    coordinates are decided by the sign of r; every other cell inherits the state of
+    the last decided cell before it in its row (rows start outside: the grid has a
+    margin around the curve).  The band (>= 1.5 annulus widths either side) is far
+    thicker than a cell, so a row cannot pass from outside to inside without crossing
+    it.  O(grid)."""
+    state = np.full(shape, -1, dtype=np.int8)
+    state[IX, IY] = (r < 0.0).astype(np.int8)
+    idx = np.where(state >= 0, np.arange(shape[1], dtype=np.int64)[None, :], -1)
+    idx = np.maximum.accumulate(idx, axis=1)
+    filled = np.take_along_axis(state, np.maximum(idx, 0), axis=1)
+    return np.where(idx >= 0, filled, 0).astype(bool)

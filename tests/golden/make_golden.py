@@ -256,6 +256,20 @@ def golden_annular_stokes():
     print("annular_stokes.npz", len(out))
 
 
+def golden_slepian():
+    """Values of the reference's precomputed step/bump tables (values only, not the
+    14 847-line coefficient table)."""
+    from ipde.slepian.chebeval_bump_step import SlepianMollifier
+    x = np.linspace(-1, 1, 41)
+    out = {"x": x}
+    for r in (10, 30, 40):
+        m = SlepianMollifier(r)
+        out["step_%d" % r] = np.array([m.step(np.array([xi])) for xi in x]).ravel()
+        out["bump_%d" % r] = np.array([m.bump(np.array([xi])) for xi in x]).ravel()
+    np.savez(os.path.join(OUT, "slepian_values.npz"), **out)
+    print("slepian_values.npz", len(out))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be regenerated where it is")
@@ -264,3 +278,4 @@ if __name__ == "__main__":
     golden_derivatives()
     golden_annular_scalar()
     golden_annular_stokes()
+    golden_slepian()

@@ -1,0 +1,127 @@
+"""Host-side geometry / set-up modules (pure numpy): curve differentiation,
+closest-point coordinates, inside classification, Slepian cut-offs, Kress
+quadrature, QFS.  CPU only."""
+import os
+
+import numpy as np
+
+from ipde_amd.heavisides import SlepianMollifier
+from ipde_amd.near import local_coordinates, points_inside_curve, grid_inside_curve
+from ipde_amd.pybie2d_compat import (star, Global_Smooth_Boundary as GSB, Grid, PointSet,
+                                     Laplace_Layer_Form, Laplace_Layer_Singular_Form,
+                                     fourier_resample)
+from ipde_amd.qfs import Laplace_QFS, QFS_Boundary
+from oracle import layer_potentials as olp
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_global_smooth_boundary_star():
+    N = 512
+    b = GSB(c=star(N, a=0.2, f=5))
+    t = b.t
+    r, rp, rpp = 1 + 0.2 * np.cos(5 * t), -np.sin(5 * t), -5 * np.cos(5 * t)
+    speed = np.sqrt(r * r + rp * rp)
+    curv = (r * r + 2 * rp * rp - r * rpp) / speed ** 3
+    assert np.max(np.abs(b.speed - speed)) < 1e-11
+    assert np.max(np.abs(b.curvature - curv)) < 1e-9
+    # outward normal of a ccw curve, unit length, perimeter / area
+    assert np.all(b.normal_x * b.x + b.normal_y * b.y > 0)
+    assert np.max(np.abs(np.hypot(b.normal_x, b.normal_y) - 1)) < 1e-14
+    assert abs(b.area - np.pi * (1 + 0.02)) < 1e-12     # pi (1 + a^2/2)
+
+
+def test_fourier_resample_roundtrip():
+    t = np.linspace(0, 2 * np.pi, 64, endpoint=False)
+    f = np.exp(np.sin(t)) + 0.3 * np.cos(5 * t)
+    up = fourier_resample(f, 256)
+    tu = np.linspace(0, 2 * np.pi, 256, endpoint=False)
+    assert np.max(np.abs(up - (np.exp(np.sin(tu)) + 0.3 * np.cos(5 * tu)))) < 1e-13
+    assert np.max(np.abs(fourier_resample(up, 64) - f)) < 1e-13
+
+
+def test_slepian_mollifier_matches_reference_tables():
+    """golden values evaluated from the reference's precomputed Chebyshev tables
+    (ipde/slepian/heaviside_coefficients.py via chebeval_bump_step.SlepianMollifier)"""
+    g = np.load(os.path.join(G, "slepian_values.npz"))
+    for r in (30, 40):
+        m = SlepianMollifier(r)
+        assert np.max(np.abs(m.step(g["x"]) - g["step_%d" % r])) < 1e-11
+        assert np.max(np.abs(m.bump(g["x"]) - g["bump_%d" % r])) < 1e-8
+    m = SlepianMollifier(30)
+    assert m.step(np.array([-1.5, -1.0, 1.0, 2.0])).tolist() == [0.0, 0.0, 1.0, 1.0]
+    x = np.linspace(-0.99, 0.99, 50)
+    assert np.max(np.abs(m.step(x) + m.step(-x) - 1.0)) < 1e-13   # odd about 1/2
+
+
+def test_local_coordinates_and_inside():
+    N = 2000
+    b = GSB(c=star(N, a=0.2, f=5))
+    rng = np.random.default_rng(0)
+    width = 20 * b.dt * b.speed.min()
+    t = rng.uniform(0, 2 * np.pi, 5000)
+    r = rng.uniform(-width, 0.3 * width, 5000)
+    rr, rp = 1 + 0.2 * np.cos(5 * t), -np.sin(5 * t)
+    X = rr * np.exp(1j * t)
+    Xp = (rp + 1j * rr) * np.exp(1j * t)
+    p = X + r * (-1j * Xp / np.abs(Xp))
+    rf, tf, found = local_coordinates(b, p.real, p.imag, width)
+    assert found.all()
+    assert np.max(np.abs(rf - r)) < 1e-13
+    assert np.max(np.abs(np.angle(np.exp(1j * (tf - t))))) < 1e-12
+    assert np.array_equal(points_inside_curve(b, p.real, p.imag, rf, found), r < 0)
+    # far points are reported as not found
+    _, _, f2 = local_coordinates(b, np.array([0.0, 3.0]), np.array([0.0, 3.0]), width)
+    assert not f2.any()
+
+
+def test_grid_inside_scan_fill_equals_polygon_test():
+    b = GSB(c=star(600, a=0.2, f=5))
+    width = 16 * b.dt * b.speed.min()
+    grid = Grid([-1.6037, 1.5963], 200, [-1.6011, 1.5989], 200, x_endpoints=[True, False],
+                y_endpoints=[True, False])   # no node exactly on the curve
+    IX, IY = np.meshgrid(np.arange(200), np.arange(200), indexing="ij")
+    r, t, found = local_coordinates(b, grid.xg.ravel(), grid.yg.ravel(), width)
+    mask = grid_inside_curve(grid.shape, IX.ravel()[found], IY.ravel()[found], r[found])
+    assert np.array_equal(mask, points_inside_curve(b, grid.xg, grid.yg))
+
+
+def test_kress_single_layer_and_dlp_limits():
+    """On-surface Nystrom matrices against closed forms on the unit circle:
+    S[cos m t] = cos(m t)/(2m),  (D - I/2)[1] = -1 (Gauss)."""
+    b = GSB(c=star(128, a=0.0, f=1))
+    S = Laplace_Layer_Singular_Form(b, ifcharge=True)
+    for m in (1, 3, 7):
+        assert np.max(np.abs(S @ np.cos(m * b.t) - np.cos(m * b.t) / (2 * m))) < 1e-13
+    bs = GSB(c=star(400, a=0.2, f=5))
+    D = Laplace_Layer_Singular_Form(bs, ifdipole=True)
+    assert np.max(np.abs((D - 0.5 * np.eye(bs.N)) @ np.ones(bs.N) + 1.0)) < 1e-12
+
+
+def test_qfs_reproduces_layer_potentials_on_both_sides():
+    N = 600
+    b = GSB(c=star(N, a=0.2, f=5))
+    sig = np.exp(np.cos(b.t)) * np.sin(2 * b.t) + 0.3
+    tau = np.cos(3 * b.t) + np.sin(b.t) ** 2
+    bf = b.generate_resampled_boundary(12 * N)
+    sf, tf = fourier_resample(sig, 12 * N), fourier_resample(tau, 12 * N)
+    th = np.random.default_rng(0).uniform(0, 2 * np.pi, 200)
+    h = b.dt * b.speed.max()
+    rr = 1 + 0.2 * np.cos(5 * th)
+    X = rr * np.exp(1j * th)
+    Xp = (-np.sin(5 * th) + 1j * rr) * np.exp(1j * th)
+    n = -1j * Xp / np.abs(Xp)
+    q = QFS_Boundary(b, eps=1e-14)
+    for interior, p in ((True, X - 2 * h * n), (False, X + 2 * h * n)):
+        ref = olp.laplace_layer_apply(bf.x, bf.y, p.real, p.imag, charge=sf, dipstr=tf,
+                                      weights=bf.weights, nx=bf.normal_x, ny=bf.normal_y)
+        Q = Laplace_QFS(b, interior, True, True, qfs_boundary=q)
+        mu = Q([sig, tau])
+        got = olp.laplace_layer_apply(Q.source.x, Q.source.y, p.real, p.imag, charge=mu,
+                                      weights=Q.source.weights)
+        assert np.max(np.abs(got - ref)) < 1e-12 * np.max(np.abs(ref))
+        # u2s: source density reproducing given boundary values (the collocation
+        # system is ill-conditioned, so check the values it reproduces, not mu itself)
+        A = Laplace_Layer_Form(Q.source, b, ifcharge=True)
+        ub = A @ mu
+        assert np.max(np.abs(A @ Q.u2s(ub) - ub)) < 1e-11 * np.max(np.abs(ub))
