@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Interior modified-Helmholtz problem (k^2 - Lap) u = f on a star domain — the flow of
+the reference's examples/interior_modified_helmholtz.py / multi_modified_helmholtz_*.py
+(manufactured solution exp(sin kx) sin ky, inhomogeneous solve, double-layer boundary
+correction through QFS) on the MI355X stack.
+
+    python examples/interior_modified_helmholtz.py [--nb 800] [--M 20] [--k 10]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.linalg
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from ipde_amd.ebdy_collection import EmbeddedBoundaryCollection  # noqa: E402
+from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
+from ipde_amd.embedded_function import EmbeddedFunction, BoundaryFunction  # noqa: E402
+from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
+from ipde_amd.layer_potentials import Modified_Helmholtz_Layer_Apply, DeviceTargets  # noqa: E402
+from ipde_amd.pybie2d_compat import (star, Global_Smooth_Boundary as GSB,  # noqa: E402
+                                     Modified_Helmholtz_Layer_Form as MH_Layer_Form,
+                                     Modified_Helmholtz_Layer_Singular_Form as MH_Singular_Form)
+from ipde_amd.qfs import QFS_Evaluator  # noqa: E402
+from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver  # noqa: E402
+
+
+def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False, timings=None):
+    T = {} if timings is None else timings
+    t0 = time.perf_counter()
+    MOL = SlepianMollifier(1.5 * M)
+    bdy = GSB(c=star(nb, a=0.2, f=5))
+    bh = bdy.dt * bdy.speed.min()
+    ebdy = EmbeddedBoundary(bdy, True, M, bh, pad_zone=0, heaviside=MOL.step, qfs_tolerance=1e-14)
+    ebdyc = EmbeddedBoundaryCollection([ebdy, ])
+    grid = ebdyc.generate_grid(bh, Ns=Ns)
+    kk = 2 * np.pi / 3
+    solution_func = lambda x, y: np.exp(np.sin(kk * x)) * np.sin(kk * y)
+    force_func = lambda x, y: helmholtz_k ** 2 * solution_func(x, y) \
+        - kk ** 2 * np.exp(np.sin(kk * x)) * np.sin(kk * y) * (np.cos(kk * x) ** 2 - np.sin(kk * x) - 1.0)
+    f = EmbeddedFunction(ebdyc)
+    f.define_via_function(force_func)
+    ua = EmbeddedFunction(ebdyc)
+    ua.define_via_function(solution_func)
+    bc = BoundaryFunction(ebdyc)
+    bc.define_via_function(solution_func)
+    solver = ModifiedHelmholtzSolver(ebdyc, k=helmholtz_k)
+    T['setup_s'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ue = solver(f, tol=solver_tol, verbose=verbose, maxiter=100, restart=20)
+    T['inhomogeneous_solve_s'] = time.perf_counter() - t0
+    # homogeneous correction with a double layer on the boundary (interior: D - I/2)
+    t0 = time.perf_counter()
+    K = lambda src, _: MH_Singular_Form(src, k=helmholtz_k, ifdipole=True) - 0.5 * np.eye(src.N)
+    Naive_SLP = lambda src, trg: MH_Layer_Form(src, trg, k=helmholtz_k, ifcharge=True)
+    A = K(bdy, bdy)
+    qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [K, ], Naive_SLP, on_surface=True, form_b2c=False)
+    Alu = scipy.linalg.lu_factor(A)
+    targets = DeviceTargets(ebdyc.grid_and_radial_pts)
+    T['homogeneous_form_s'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    bv = solver.get_boundary_values(ue.get_radial_value_list())
+    tau = scipy.linalg.lu_solve(Alu, np.concatenate((bc - bv).bdy_value_list))
+    sigma = qfs([tau, ])
+    out = Modified_Helmholtz_Layer_Apply(ebdyc.bdy_inward_sources, targets, k=helmholtz_k,
+                                         charge=sigma).cpu().numpy()
+    gslp, rslpl = ebdyc.divide_grid_and_radial(out)
+    ue[0] += rslpl[0].reshape(ebdyc[0].radial_shape)
+    ue['grid'] += gslp
+    T['homogeneous_apply_s'] = time.perf_counter() - t0
+    err = np.abs(np.asarray(ue) - np.asarray(ua))
+    T['dof'] = int(ebdyc.dof)
+    T['grid'] = list(grid.shape)
+    T['gmres_iterations'] = solver.iteration_counts
+    return float(err.max()), float(np.abs(np.asarray(ua)).max()), solver, ue, T
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nb", type=int, default=800)
+    ap.add_argument("--M", type=int, default=20)
+    ap.add_argument("--k", type=float, default=10.0)
+    a = ap.parse_args()
+    T = {}
+    err, scale, *_ = run(a.nb, a.M, a.k, verbose=True, timings=T)
+    print('Error: {:0.2e}'.format(err), ' (|u|max %.3f)' % scale)
+    print(T)

@@ -198,3 +198,69 @@ def Laplace_Layer_Singular_Form(bdy, ifcharge=False, ifdipole=False):
         np.fill_diagonal(D, -bdy.curvature / (4 * np.pi))
         out += D * bdy.weights[None, :]
     return out
+
+
+# ---------------------------------------------------------------------------
+# modified Helmholtz (k^2 - Lap): kernels of ipde_amd.layer_potentials
+def Modified_Helmholtz_Layer_Form(source, target=None, k=1.0, ifcharge=False, ifdipole=False):
+    """Dense off-surface matrix: (1/2pi) K0(k r) w  and/or  (k/2pi) K1(k r) (n.d)/r w."""
+    from scipy.special import k0, k1
+    if target is None:
+        target = source
+    dx = target.x[:, None] - source.x[None, :]
+    dy = target.y[:, None] - source.y[None, :]
+    r = np.hypot(dx, dy)
+    out = np.zeros_like(r)
+    if ifcharge:
+        out += (0.5 / np.pi) * k0(k * r) * source.weights[None, :]
+    if ifdipole:
+        nd = dx * source.normal_x[None, :] + dy * source.normal_y[None, :]
+        out += (0.5 * k / np.pi) * k1(k * r) * nd / r * source.weights[None, :]
+    return out
+
+
+def Modified_Helmholtz_Layer_Singular_Form(bdy, k=1.0, ifcharge=False, ifdipole=False):
+    """On-surface Nystrom matrices with a LOCALISED Kress logarithmic split:
+       K0(k r)/(2 pi)                = -(1/4pi) I0(k r) psi(r) L + remainder,
+       (k/2pi) K1(k r) (n.d)/r       =  (k/4pi) I1(k r) psi(r) (n.d)/r L + remainder,
+    L = log(4 sin^2((t-s)/2)).  The analytic log-coefficients I0, I1 grow like e^{k r};
+    used globally they make the split cancel catastrophically once k*diameter >~ 20
+    (error ~ eps I0(k diam)).  psi is a C-infinity cut-off (Slepian step) equal to 1 for
+    k r <= 2 and 0 beyond k r = 6 (at least 24 nodes wide), so the remainder is still
+    smooth, the coefficient stays below I0(6) ~ 67, and beyond the cut-off the plain
+    trapezoid rule acts on the smooth kernel.  Diagonal limits:
+    -(log(k speed/2) + gamma)/(2 pi) for the SLP remainder, -curvature/(4 pi) for the DLP
+    remainder.  The DLP is the principal value (interior limit D - I/2)."""
+    from scipy.special import k0, k1, i0, i1
+    from .heavisides import SlepianMollifier
+    N = bdy.N
+    dx = bdy.x[:, None] - bdy.x[None, :]
+    dy = bdy.y[:, None] - bdy.y[None, :]
+    r = np.hypot(dx, dy)
+    np.fill_diagonal(r, 1.0)
+    dt = bdy.t[:, None] - bdy.t[None, :]
+    L = 4 * np.sin(dt / 2) ** 2
+    np.fill_diagonal(L, 1.0)
+    L = np.log(L)
+    R = _kress_log_weights(N)[np.abs(np.arange(N)[:, None] - np.arange(N)[None, :])]
+    r1 = 2.0 / k
+    r2 = max(6.0 / k, r1 + 24 * bdy.max_h)
+    psi = 1.0 - SlepianMollifier(30).step(2.0 * (r - r1) / (r2 - r1) - 1.0)
+    np.fill_diagonal(psi, 1.0)
+    near = psi > 0.0
+    kr = np.where(near, k * r, 0.0)          # keeps I0/I1 from overflowing far away
+    out = np.zeros((N, N))
+    if ifcharge:
+        S1 = -(0.25 / np.pi) * i0(kr) * psi
+        S2 = (0.5 / np.pi) * k0(k * r) - S1 * L
+        np.fill_diagonal(S1, -(0.25 / np.pi))
+        np.fill_diagonal(S2, -(0.5 / np.pi) * (np.log(0.5 * k * bdy.speed) + np.euler_gamma))
+        out += (S1 * R + S2 * bdy.dt) * bdy.speed[None, :]
+    if ifdipole:
+        nd = dx * bdy.normal_x[None, :] + dy * bdy.normal_y[None, :]
+        D1 = (0.25 * k / np.pi) * i1(kr) * psi * nd / r
+        D2 = (0.5 * k / np.pi) * k1(k * r) * nd / r - D1 * L
+        np.fill_diagonal(D1, 0.0)
+        np.fill_diagonal(D2, -bdy.curvature / (4 * np.pi))
+        out += (D1 * R + D2 * bdy.dt) * bdy.speed[None, :]
+    return out

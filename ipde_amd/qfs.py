@@ -1,7 +1,8 @@
-"""Quadrature by fundamental solutions (QFS) for the Laplace interface/boundary
-potentials — own restatement of what the reference obtains from the absent `qfs`
-package (`Laplace_QFS`, `QFS_Evaluator`; reference
-ipde/solvers/internals/poisson.py:22-26, examples/interior_poisson.py:87-88).
+"""Quadrature by fundamental solutions (QFS) for the interface/boundary potentials —
+own restatement of what the reference obtains from the absent `qfs` package
+(`Laplace_QFS`, `Modified_Helmholtz_QFS`, `QFS_Evaluator`; reference
+ipde/solvers/internals/poisson.py:22-26, internals/modified_helmholtz.py:22-27,
+examples/interior_poisson.py:87-88).
 
 Given a smooth closed curve G with N nodes and a side of evaluation, the layer
 potential  S_G[sigma] + D_G[tau]  restricted to that side is reproduced by a plain
@@ -9,20 +10,21 @@ single layer on a SOURCE CURVE shifted to the other side by delta(t) = alpha h(t
 (h = local node spacing).  The source strengths mu solve the collocation system
         S_{G <- src} mu = (S_G sigma + (D_G -/+ I/2) tau)|_G
 whose right-hand side is the one-sided limit computed with spectrally accurate
-on-surface quadrature (Kress' log split for S, smooth kernel for D;
-ipde_amd.pybie2d_compat.Laplace_Layer_Singular_Form).  Evaluating the point sources
-at any target at distance >= 0 from G on the evaluation side is then a smooth sum
-whose trapezoid error is ~exp(-2 pi alpha) — this is what lets the dense GPU kernel
-(`Layer_Apply`) serve near and far targets alike.  The collocation matrix is
-ill-conditioned (e^{pi alpha}) but the solve is backward stable and the data are
-resolved, so the potential keeps ~1e-13 accuracy.  Host LAPACK: set-up (LU) once,
-O(N^2) per call.
+on-surface quadrature (Kress' log split; ipde_amd.pybie2d_compat.*_Singular_Form).
+Evaluating the point sources at any target at distance >= 0 from G on the evaluation
+side is then a smooth sum whose trapezoid error is ~exp(-2 pi alpha) — this is what
+lets the dense GPU kernel (`Layer_Apply`) serve near and far targets alike.  The
+collocation matrix is ill-conditioned (e^{pi alpha}) but the solve is backward stable
+and the data are resolved, so the potential keeps ~1e-14 accuracy (measured on the
+5-arm star: alpha = 5 reproduces S+D to 4e-15 down to one node spacing from G).
+Host LAPACK: set-up (LU) once, O(N^2) per call.
 """
 import numpy as np
 import scipy.linalg
 
-from .pybie2d_compat import (Global_Smooth_Boundary, PointSet, Laplace_Layer_Form,
-                             Laplace_Layer_Singular_Form, fourier_resample)
+from .pybie2d_compat import (Global_Smooth_Boundary, Laplace_Layer_Form,
+                             Laplace_Layer_Singular_Form, Modified_Helmholtz_Layer_Form,
+                             Modified_Helmholtz_Layer_Singular_Form)
 
 
 class QFS_Boundary(object):
@@ -35,8 +37,6 @@ class QFS_Boundary(object):
         self.bdy = bdy
         self.eps = eps
         if alpha is None:
-            # measured on the 5-arm star: alpha = 5 reproduces S+D to 4e-15 down to one
-            # node spacing from the curve (alpha = 4: 1e-12)
             alpha = max(4.0, -np.log(eps) / (2 * np.pi) + 1.0) + FF
         self.alpha = alpha
         fs = 1 if forced_source_upsampling_factor is None else int(forced_source_upsampling_factor)
@@ -47,17 +47,17 @@ class QFS_Boundary(object):
         self.exterior_source_bdy = Global_Smooth_Boundary(c=fine.c - shift * fine.normal_c)
 
 
-class Laplace_QFS(object):
-    """qfs = Laplace_QFS(bdy, interior, slp, dlp);  qfs([sigma, tau]) -> mu on
-    qfs.source;  qfs.u2s(u) -> mu reproducing boundary values u."""
+class _QFS(object):
+    """qfs([sigma, tau]) -> mu on qfs.source;  qfs.u2s(u) -> mu reproducing boundary
+    values u.  Subclasses provide the off-surface and on-surface forms."""
 
-    def __init__(self, bdy, interior, slp=True, dlp=True, qfs_boundary=None, eps=1e-12):
+    def __init__(self, bdy, interior, slp, dlp, qfs_boundary=None, eps=1e-12):
         self.bdy = bdy
         self.interior = interior
         q = qfs_boundary if qfs_boundary is not None else QFS_Boundary(bdy, eps=eps)
         self.source = q.interior_source_bdy if interior else q.exterior_source_bdy
         self.slp, self.dlp = slp, dlp
-        A = Laplace_Layer_Form(self.source, bdy, ifcharge=True)     # (N, Ns)
+        A = self._s2b(self.source, bdy)                              # (N, Ns)
         if A.shape[0] == A.shape[1]:
             self._lu = scipy.linalg.lu_factor(A)
             self._solve = lambda u: scipy.linalg.lu_solve(self._lu, u)
@@ -67,9 +67,8 @@ class Laplace_QFS(object):
             self._pinv = (Vt[keep].T / s[keep]) @ U[:, keep].T
             self._solve = lambda u: self._pinv @ u
         jump = -0.5 if interior else 0.5
-        self._S = Laplace_Layer_Singular_Form(bdy, ifcharge=True) if slp else None
-        self._D = (Laplace_Layer_Singular_Form(bdy, ifdipole=True) + jump * np.eye(bdy.N)) \
-            if dlp else None
+        self._S = self._singular(bdy, True, False) if slp else None
+        self._D = (self._singular(bdy, False, True) + jump * np.eye(bdy.N)) if dlp else None
 
     def boundary_limit(self, densities):
         """one-sided limit on the curve of S[sigma] + D[tau]"""
@@ -88,6 +87,35 @@ class Laplace_QFS(object):
 
     def u2s(self, u):
         return self._solve(np.asarray(u, dtype=float))
+
+
+class Laplace_QFS(_QFS):
+    def __init__(self, bdy, interior, slp=True, dlp=True, qfs_boundary=None, eps=1e-12):
+        super().__init__(bdy, interior, slp, dlp, qfs_boundary, eps)
+
+    def _s2b(self, src, trg):
+        return Laplace_Layer_Form(src, trg, ifcharge=True)
+
+    def _singular(self, bdy, c, d):
+        return Laplace_Layer_Singular_Form(bdy, ifcharge=c, ifdipole=d)
+
+
+class Modified_Helmholtz_QFS(_QFS):
+    """(reference internals/modified_helmholtz.py:22-27 call shape)"""
+
+    def __init__(self, bdy, interior, slp=True, dlp=True, k=1.0, source_upsample_factor=1.0,
+                 closer_source=True, qfs_boundary=None, eps=1e-12):
+        self.k = k
+        if qfs_boundary is None and source_upsample_factor and source_upsample_factor > 1:
+            qfs_boundary = QFS_Boundary(bdy, eps=eps,
+                                        forced_source_upsampling_factor=int(np.ceil(source_upsample_factor)))
+        super().__init__(bdy, interior, slp, dlp, qfs_boundary, eps)
+
+    def _s2b(self, src, trg):
+        return Modified_Helmholtz_Layer_Form(src, trg, k=self.k, ifcharge=True)
+
+    def _singular(self, bdy, c, d):
+        return Modified_Helmholtz_Layer_Singular_Form(bdy, k=self.k, ifcharge=c, ifdipole=d)
 
 
 class QFS_Evaluator(object):

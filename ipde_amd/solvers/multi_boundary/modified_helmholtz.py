@@ -1,0 +1,72 @@
+"""ModifiedHelmholtzSolver — mirrors ipde/solvers/multi_boundary/modified_helmholtz.py:8-67."""
+import numpy as np
+
+from .scalar import ScalarSolver
+from ..internals.modified_helmholtz import ModifiedHelmholtzHelper
+from ...grid_evaluators.modified_helmholtz_grid_evaluator import (
+    ModifiedHelmholtzFreespaceGridEvaluator, ModifiedHelmholtzGridBackend)
+
+
+class ModifiedHelmholtzSolver(ScalarSolver):
+    def __init__(self, ebdyc, k, solver_type='spectral', helpers=None, grid_backend='hip',
+                 source_upsample_factor=1.0):
+        self.k = k
+        self.source_upsample_factor = source_upsample_factor
+        super().__init__(ebdyc, solver_type, helpers, grid_backend)
+
+    def _get_helper_combatibility(self, ebdy, helper):
+        """0: start over; 1: the annular solver can be reused; 2: reuse the helper"""
+        if helper is None:
+            return 0
+        if self.k != helper.k:
+            return 0
+        if ebdy.bdy.N != helper.ebdy.bdy.N:
+            return 0
+        if self.source_upsample_factor != helper.source_upsample_factor:
+            return 0
+        if helper.ebdy is not ebdy:
+            return 1
+        return 2
+
+    def _get_helper(self, ebdy, helper):
+        c = self._get_helper_combatibility(ebdy, helper)
+        if c == 0:
+            return ModifiedHelmholtzHelper(ebdy, k=self.k,
+                                           source_upsample_factor=self.source_upsample_factor,
+                                           grid_backend=self.grid_backend)
+        elif c == 1:
+            return ModifiedHelmholtzHelper(ebdy, helper, k=self.k,
+                                           source_upsample_factor=self.source_upsample_factor,
+                                           grid_backend=self.grid_backend)
+        return helper
+
+    def _grid_solve(self, fc):
+        import torch
+        fd = torch.as_tensor(np.ascontiguousarray(fc), device="cuda")
+        uch, uc = self.plan.modhelm_solve(fd, self.k, want_uhat=True)
+        return uch, uc
+
+    def _get_specific_operators(self):
+        self.lap = -self.kx * self.kx - self.ky * self.ky
+        self.helm = self.k ** 2 - self.lap
+        self.ihelm = 1.0 / self.helm
+
+    def _define_grid_evaluator(self):
+        if type(self.grid_backend) in [ModifiedHelmholtzGridBackend,
+                                       ModifiedHelmholtzFreespaceGridEvaluator]:
+            if type(self.grid_backend) == ModifiedHelmholtzGridBackend:
+                self.ewald_evaluator = ModifiedHelmholtzFreespaceGridEvaluator(
+                    self.grid_backend, self.grid.xv, self.grid.yv)
+            else:
+                self.ewald_evaluator = self.grid_backend
+
+            def evaluator(ch):
+                return self.ewald_evaluator(self.grid_sources.get_stacked_boundary(),
+                                            ch * self.grid_sources.weights)
+            self.Grid_Evaluator = evaluator
+            self.split_grid_evaluation = True
+        else:
+            def evaluator(ch):
+                return self.Layer_Apply(self.grid_sources, self._grid_pnai_dev, ch).cpu().numpy()
+            self.Grid_Evaluator = evaluator
+            self.split_grid_evaluation = False

@@ -31,3 +31,13 @@ def test_interior_poisson_converges_with_resolution():
         errs.append(err / scale)
     print(errs)
     assert errs[2] < 1e-11 and errs[2] < errs[0]
+
+
+@pytest.mark.parametrize("k", [1.0, 10.0])
+def test_interior_modified_helmholtz_manufactured_solution(k):
+    """(reference examples/interior_modified_helmholtz.py; recorded plateau
+    interior_modified_helmholtz_using_multi.py:28-29 ~4.5e-13)"""
+    import interior_modified_helmholtz as imh
+    err, scale, solver, ue, T = imh.run(nb=800, M=16, helmholtz_k=k)
+    print(k, err, scale, T)
+    assert err / scale < 1e-11
