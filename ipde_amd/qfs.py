@@ -58,35 +58,87 @@ class _QFS(object):
         self.source = q.interior_source_bdy if interior else q.exterior_source_bdy
         self.slp, self.dlp = slp, dlp
         A = self._s2b(self.source, bdy)                              # (N, Ns)
-        if A.shape[0] == A.shape[1]:
-            self._lu = scipy.linalg.lu_factor(A)
-            self._solve = lambda u: scipy.linalg.lu_solve(self._lu, u)
-        else:
-            U, s, Vt = np.linalg.svd(A, full_matrices=False)
-            keep = s > s[0] * 1e-14
-            self._pinv = (Vt[keep].T / s[keep]) @ U[:, keep].T
-            self._solve = lambda u: self._pinv @ u
         jump = -0.5 if interior else 0.5
-        self._S = self._singular(bdy, True, False) if slp else None
-        self._D = (self._singular(bdy, False, True) + jump * np.eye(bdy.N)) if dlp else None
+        S = self._singular(bdy, True, False) if slp else None
+        D = (self._singular(bdy, False, True) + jump * np.eye(bdy.N)) if dlp else None
+        self._dev = _device()
+        if self._dev is not None and A.shape[0] == A.shape[1]:
+            # factor and solve on the GPU (rocSOLVER through torch): the per-solve cost of
+            # three 4096^2 host LU back-substitutions was the largest single item of a
+            # warm 2048^2 Poisson solve
+            import torch
+            self._A = torch.as_tensor(A, device=self._dev)
+            self._LU, self._piv = torch.linalg.lu_factor(self._A)
+            self._S = None if S is None else torch.as_tensor(S, device=self._dev)
+            self._D = None if D is None else torch.as_tensor(D, device=self._dev)
+        else:
+            self._dev = None
+            self._S, self._D = S, D
+            if A.shape[0] == A.shape[1]:
+                self._lu = scipy.linalg.lu_factor(A)
+                self._solve_host = lambda u: scipy.linalg.lu_solve(self._lu, u)
+            else:
+                U, sv, Vt = np.linalg.svd(A, full_matrices=False)
+                keep = sv > sv[0] * 1e-14
+                self._pinv = (Vt[keep].T / sv[keep]) @ U[:, keep].T
+                self._solve_host = lambda u: self._pinv @ u
+
+    def _solve(self, u):
+        if self._dev is None:
+            return self._solve_host(np.asarray(u, dtype=float))
+        import torch
+        ud = u if isinstance(u, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(u, dtype=float),
+                                                                  device=self._dev)
+        x = _refined_lu_solve(self._A, self._LU, self._piv, ud)
+        return x if isinstance(u, torch.Tensor) else x.cpu().numpy()
 
     def boundary_limit(self, densities):
         """one-sided limit on the curve of S[sigma] + D[tau]"""
         densities = list(densities)
-        u = np.zeros(self.bdy.N)
+        if self._dev is not None:
+            import torch
+            densities = [torch.as_tensor(np.ascontiguousarray(d, dtype=float), device=self._dev)
+                         for d in densities]
+            u = torch.zeros(self.bdy.N, dtype=torch.float64, device=self._dev)
+        else:
+            u = np.zeros(self.bdy.N)
         i = 0
         if self.slp:
-            u += self._S @ densities[i]
+            u = u + self._S @ densities[i]
             i += 1
         if self.dlp:
-            u += self._D @ densities[i]
+            u = u + self._D @ densities[i]
         return u
 
     def __call__(self, densities):
-        return self._solve(self.boundary_limit(densities))
+        x = self._solve(self.boundary_limit(densities))
+        return x.cpu().numpy() if self._dev is not None else x
 
     def u2s(self, u):
         return self._solve(np.asarray(u, dtype=float))
+
+
+def _refined_lu_solve(A, LU, piv, b, steps=2):
+    """GPU LU solve + iterative refinement.  The library triangular solves (rocBLAS TRSM
+    with inverted diagonal blocks) are not backward stable on these collocation matrices
+    (cond ~1e12: residual 1.5e-9 vs 6e-15 for host LAPACK, measured); two refinement
+    steps with the fp64 residual bring it to 2e-15."""
+    import torch
+    x = torch.linalg.lu_solve(LU, piv, b[:, None])[:, 0]
+    for _ in range(steps):
+        r = b - A @ x
+        x = x + torch.linalg.lu_solve(LU, piv, r[:, None])[:, 0]
+    return x
+
+
+def _device():
+    """torch device for the QFS dense algebra, or None on a machine without a GPU (the
+    host path keeps the CPU geometry tests running; it is set-up math, not the hot path)."""
+    try:
+        import torch
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    except Exception:
+        return None
 
 
 class Laplace_QFS(_QFS):
@@ -133,8 +185,20 @@ class QFS_Evaluator(object):
         self.source = qfs_boundary.interior_source_bdy if interior else qfs_boundary.exterior_source_bdy
         self.b2c_mats = [f(self.bdy, self.bdy) for f in b2c_funcs]
         A = s2c_func(self.source, self.bdy)
-        self._lu = scipy.linalg.lu_factor(A)
+        self._dev = _device()
+        if self._dev is not None:
+            import torch
+            self._A = torch.as_tensor(A, device=self._dev)
+            self._LU, self._piv = torch.linalg.lu_factor(self._A)
+            self.b2c_mats = [torch.as_tensor(B, device=self._dev) for B in self.b2c_mats]
+        else:
+            self._lu = scipy.linalg.lu_factor(A)
 
     def __call__(self, densities):
+        if self._dev is not None:
+            import torch
+            u = sum(B @ torch.as_tensor(np.ascontiguousarray(d, dtype=float), device=self._dev)
+                    for B, d in zip(self.b2c_mats, densities))
+            return _refined_lu_solve(self._A, self._LU, self._piv, u).cpu().numpy()
         u = sum(B @ np.asarray(d) for B, d in zip(self.b2c_mats, densities))
         return scipy.linalg.lu_solve(self._lu, u)

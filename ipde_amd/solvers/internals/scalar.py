@@ -22,6 +22,10 @@ class ScalarHelper(object):
         self._get_RAG()
         self._get_qfs()
         self._define_layer_apply()
+        # fixed target sets of correct(): resident in HBM
+        from ...layer_potentials import DeviceTargets
+        self._interface_dev = DeviceTargets(self.ebdy.interface)
+        self._radial_dev = DeviceTargets(self.ebdy.radial_targ)
 
     def _define_annular_solver(self):
         raise NotImplementedError
@@ -80,11 +84,11 @@ class ScalarHelper(object):
     def correct(self, ub):
         """(reference :95-116)"""
         src = self.interface_qfs_g.source
-        w = self.Layer_Apply(src, self.ebdy.interface, self.sigma_g)
+        w = self.Layer_Apply(src, self._interface_dev, self.sigma_g).cpu().numpy()
         ub = ub - w
         sigma_r_adj = self.interface_qfs_r.u2s(ub)
         sigma_r_tot = sigma_r_adj + self.sigma_r
         src = self.interface_qfs_r.source
-        rslp = self.Layer_Apply(src, self.ebdy.radial_targ, sigma_r_tot)
-        self.ur = self.ur + np.asarray(rslp).reshape(self.ur.shape)
+        rslp = self.Layer_Apply(src, self._radial_dev, sigma_r_tot).cpu().numpy()
+        self.ur = self.ur + rslp.reshape(self.ur.shape)
         return self.ur

@@ -41,9 +41,8 @@ class ModifiedHelmholtzSolver(ScalarSolver):
         return helper
 
     def _grid_solve(self, fc):
-        import torch
-        fd = torch.as_tensor(np.ascontiguousarray(fc), device="cuda")
-        uch, uc = self.plan.modhelm_solve(fd, self.k, want_uhat=True)
+        """fc: device (Nx, Ny) -> (uch, uc) on the device"""
+        uch, uc = self.plan.modhelm_solve(fc.contiguous(), self.k, want_uhat=True)
         return uch, uc
 
     def _get_specific_operators(self):
@@ -67,6 +66,6 @@ class ModifiedHelmholtzSolver(ScalarSolver):
             self.split_grid_evaluation = True
         else:
             def evaluator(ch):
-                return self.Layer_Apply(self.grid_sources, self._grid_pnai_dev, ch).cpu().numpy()
+                return self.Layer_Apply(self.grid_sources, self._grid_pnai_dev, ch)
             self.Grid_Evaluator = evaluator
             self.split_grid_evaluation = False

@@ -15,11 +15,16 @@ class PoissonSolver(ScalarSolver):
         return PoissonHelper(ebdy, helper, grid_backend=self.grid_backend)
 
     def _grid_solve(self, fc):
-        """uch = fft2(fc) * ilap (full spectrum, device resident), uc = ifft2(uch).real"""
+        """fc: device (Nx, Ny).  Demean with the bump (ebdy_collection.py:808-810), then
+        uch = fft2(fc) * ilap (full spectrum), uc = ifft2(uch).real — all on the device."""
         import torch
-        fc = self.ebdyc.demean_function(fc)
-        fd = torch.as_tensor(np.ascontiguousarray(fc), device="cuda")
-        uch, uc = self.plan.poisson_solve(fd, want_uhat=True)
+        bumpy = self.ebdyc.bumpy
+        if getattr(self, "_bumpy_src", None) is not bumpy:
+            self._bumpy_d = torch.as_tensor(np.ascontiguousarray(bumpy), device=fc.device)
+            self._bumpy_src = bumpy
+        integral = fc.sum() * (self.grid.xh * self.grid.yh)
+        fc = fc - integral * self._bumpy_d
+        uch, uc = self.plan.poisson_solve(fc.contiguous(), want_uhat=True)
         return uch, uc
 
     def _get_specific_operators(self):
@@ -42,6 +47,6 @@ class PoissonSolver(ScalarSolver):
             # the reference's default branch (:57-62): one dense sum onto grid_pnai,
             # here with the target set resident on the device
             def evaluator(ch):
-                return self.Layer_Apply(self.grid_sources, self._grid_pnai_dev, ch).cpu().numpy()
+                return self.Layer_Apply(self.grid_sources, self._grid_pnai_dev, ch)
             self.Grid_Evaluator = evaluator
             self.split_grid_evaluation = False

@@ -2,12 +2,18 @@
 ipde/solvers/multi_boundary/scalar.py:7-119 step for step:
   FFT grid solve -> values/gradient on the interfaces -> per-boundary annular solves
   and QFS densities -> Grid_Evaluator (dense GPU sum) -> correct() -> radial->grid.
+
+The grid-sized arrays never leave HBM during a solve: the forcing's physical values go
+up once (pinned), the masks / cut-offs / index sets are resident, every grid update is
+a device gather/scatter, and only the physical values of the answer come back.  Small
+per-boundary vectors (N or M*N doubles) travel as numpy, as in the reference.
 """
 import numpy as np
+import torch
 
 from ...derivatives import fd_x_4, fd_y_4
 from ...embedded_function import EmbeddedFunction, BoundaryFunction
-from ...interp import periodic_interp2d
+from ...interp import periodic_interp2d, chebyshev_fourier_eval
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...spectral import get_plan
@@ -21,6 +27,7 @@ class ScalarSolver(object):
         if helpers is None:
             helpers = [None, ] * self.ebdyc.N
         self.helpers = [self._get_helper(ebdy, helper) for ebdy, helper in zip(self.ebdyc, helpers)]
+        self.AS_list = self.helpers
         self.grid = self.ebdyc.grid
         self.kx, self.ky = self.ebdyc.kx, self.ebdyc.ky
         self.ikx, self.iky = self.ebdyc.ikx, self.ebdyc.iky
@@ -32,6 +39,7 @@ class ScalarSolver(object):
         self.grid_step = self.ebdyc.grid_step
         self._define_layer_apply()
         self._collect_grid_sources()
+        self._make_device_state()
         self._define_grid_evaluator()
 
     def _collect_grid_sources(self):
@@ -39,8 +47,30 @@ class ScalarSolver(object):
         for helper in self.helpers:
             self.grid_sources.add(helper.interface_qfs_g.source, 'i' if helper.interior else 'e')
         self.grid_sources.amass_information()
+
+    def _make_device_state(self):
+        """Resident copies of everything grid-sized the solve touches."""
+        e = self.ebdyc
+        dev = self.plan.ctx.torch_device()
+        self._dev = dev
+        flat = lambda mask: torch.as_tensor(np.flatnonzero(mask.ravel()), device=dev)
+        self._phys_idx = flat(e.phys)
+        self._pna_idx = flat(e.phys_not_in_annulus)
+        self._grid_step_d = torch.as_tensor(np.ascontiguousarray(e.grid_step), device=dev)
+        self._phys_d = torch.as_tensor(e.phys.astype(float), device=dev)
+        self._ikx_d = torch.as_tensor(np.ascontiguousarray(self.ikx), device=dev)
+        self._iky_d = torch.as_tensor(np.ascontiguousarray(self.iky), device=dev)
+        self._ifx_d = torch.as_tensor(e.interfaces_x_transf, device=dev)
+        self._ify_d = torch.as_tensor(e.interfaces_y_transf, device=dev)
+        self._ia = []
+        for ebdy in e:
+            idx = torch.as_tensor(ebdy.grid_ia_xind * self.grid.Ny + ebdy.grid_ia_yind, device=dev)
+            self._ia.append((idx, torch.as_tensor(ebdy.grid_ia_xi, device=dev),
+                             torch.as_tensor(ebdy.grid_ia_t, device=dev)))
         # the solver evaluates onto the same target set in every solve: keep it in HBM
-        self._grid_pnai_dev = DeviceTargets(self.ebdyc.grid_pnai)
+        self._grid_pnai_dev = DeviceTargets(e.grid_pnai)
+        self._pin_in = torch.empty(e.grid_phys.N, dtype=torch.float64, pin_memory=True)
+        self._pin_out = torch.empty(e.grid_phys.N, dtype=torch.float64, pin_memory=True)
 
     def _get_helper(self, ebdy, helper):
         raise NotImplementedError
@@ -70,48 +100,54 @@ class ScalarSolver(object):
         return bv
 
     def evaluate_to_grid_pnai(self, sigmag):
-        """(reference :63-71)"""
+        """(reference :63-71) -> device tensor over grid_pnai"""
         if self.split_grid_evaluation:
             grid_out = self.Grid_Evaluator(sigmag)
-            grid_pna = grid_out[self.ebdyc.phys_not_in_annulus]
+            grid_out = grid_out if isinstance(grid_out, torch.Tensor) \
+                else torch.as_tensor(grid_out, device=self._dev)
+            grid_pna = grid_out.reshape(-1)[self._pna_idx]
             interface_out = self.Layer_Apply(self.grid_sources, self.ebdyc.all_iv, sigmag)
-            return np.concatenate([grid_pna, interface_out])
+            return torch.cat([grid_pna, torch.as_tensor(interface_out, device=self._dev)])
         return self.Grid_Evaluator(sigmag)
 
     def __call__(self, f, **kwargs):
         """f: EmbeddedFunction -> EmbeddedFunction (reference :72-117)."""
-        _, fc, fr_list = f.get_components()
+        e = self.ebdyc
+        Nx, Ny = self.grid.shape
+        fr_list = f.get_radial_value_list()
+        # fc = (grid values) * grid_step on the full grid  (embedded_function.py:135-138)
+        self._pin_in.numpy()[:] = f['grid']
+        fg = torch.zeros(Nx * Ny, dtype=torch.float64, device=self._dev)
+        fg[self._phys_idx] = self._pin_in.to(self._dev, non_blocking=True)
+        fc = fg.view(Nx, Ny) * self._grid_step_d
         uch, uc = self._grid_solve(fc)
+        uc = uc.contiguous()
         if self.interpolation_order == np.inf:
-            # values and gradient on all interface nodes from the spectrum (:80-88);
-            # the three fields share one set of exponential matrices
-            import torch
-            uch_d = uch if isinstance(uch, torch.Tensor) else torch.as_tensor(uch, device="cuda")
-            ikx = torch.as_tensor(self.ikx, device=uch_d.device)
-            iky = torch.as_tensor(self.iky, device=uch_d.device)
-            stack = torch.stack([uch_d, ikx * uch_d, iky * uch_d])
-            all_bvs = periodic_interp2d(stack, self.ebdyc.interfaces_x_transf,
-                                        self.ebdyc.interfaces_y_transf).real.cpu().numpy()
-            bvs, bxs, bys = all_bvs[0], all_bvs[1], all_bvs[2]
+            # values and gradient on all interface nodes from the spectrum (:80-88); the
+            # three fields share one set of exponential matrices
+            stack = torch.stack([uch, self._ikx_d * uch, self._iky_d * uch])
+            all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d).real.cpu().numpy()
         else:
-            bvs = self.ebdyc.interpolate_grid_to_interface(uc)
-            bxs = self.ebdyc.interpolate_grid_to_interface(np.asarray(self.dx(uc)))
-            bys = self.ebdyc.interpolate_grid_to_interface(np.asarray(self.dy(uc)))
-        uc = np.array(uc.cpu().numpy() if hasattr(uc, "cpu") else uc, copy=True)
-        bvl, bxl, byl = self.ebdyc.v2l(bvs), self.ebdyc.v2l(bxs), self.ebdyc.v2l(bys)
+            stack = torch.stack([torch.fft.fft2(g) for g in (uc, self.dx(uc), self.dy(uc))])
+            all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d).real.cpu().numpy()
+        bvl, bxl, byl = e.v2l(all_bvs[0]), e.v2l(all_bvs[1]), e.v2l(all_bvs[2])
         sigmag_list = []
         for helper, fr, bv, bx, by in zip(self.helpers, fr_list, bvl, bxl, byl):
             sigmag_list.append(helper(fr, bv, bx, by, **kwargs))
         self.iteration_counts = [helper.iterations_last_call for helper in self.helpers]
         sigmag = np.concatenate(sigmag_list)
-        out = np.asarray(self.evaluate_to_grid_pnai(sigmag))
-        gu, bus = self.ebdyc.divide_pnai(out)
-        uc[self.ebdyc.phys_not_in_annulus] += gu
+        out = self.evaluate_to_grid_pnai(sigmag)                 # device, len(grid_pnai)
+        n_pna = e.grid_pna.N
+        ucf = uc.view(-1)
+        ucf[self._pna_idx] += out[:n_pna]
+        bus = e.v2l(out[n_pna:].cpu().numpy())
         urs = [helper.correct(bu) for helper, bu in zip(self.helpers, bus)]
-        self.ebdyc.interpolate_radial_to_grid1(urs, uc)
-        uc *= self.ebdyc.phys
-        ue = EmbeddedFunction(self.ebdyc)
-        ue.load_data(uc, urs)
+        for ur, (idx, xi, t) in zip(urs, self._ia):
+            ucf[idx] = chebyshev_fourier_eval(ur, xi, t)
+        ucf *= self._phys_d.view(-1)
+        self._pin_out.copy_(ucf[self._phys_idx], non_blocking=False)
+        ue = EmbeddedFunction(e)
+        ue.load_data(self._pin_out.numpy(), urs)
         return ue
 
     def _define_layer_apply(self):

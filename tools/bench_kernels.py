@@ -68,6 +68,10 @@ def main():
     rec("stokes_slp", lambda: lp.Stokes_Layer_Apply(c, dt, forces=f2), 20)
     rec("stokes_dlp", lambda: lp.Stokes_Layer_Apply(c, dt, dipstr=g2), 25)
     ctx.enable_timing(False)
+    # PCIe-inclusive: host numpy in / out through the library's staging path
+    w = sig * c.weights
+    t = timeit(lambda: lp.laplace_apply(c.x, c.y, trg.x, trg.y, w_sigma=w), sync, reps=5)
+    out["laplace_slp_host_arrays_pcie_inclusive"] = {"wall_ms": t * 1e3, "pairs_per_s": pairs / t}
     # interface-sized apply (split-source path): N x N
     inner = Curve(nb, a=0.2, f=5, scale=0.95)
     di = lp.DeviceTargets(inner)
