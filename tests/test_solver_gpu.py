@@ -41,3 +41,12 @@ def test_interior_modified_helmholtz_manufactured_solution(k):
     err, scale, solver, ue, T = imh.run(nb=800, M=16, helmholtz_k=k)
     print(k, err, scale, T)
     assert err / scale < 1e-11
+
+
+def test_multiply_connected_modified_helmholtz():
+    """One outer boundary + two holes (exterior-type embedded boundaries), the flow of
+    the reference's examples/multi_modified_helmholtz_update_to_sparse.py."""
+    import multi_modified_helmholtz as mmh
+    err, scale, T = mmh.run(nb=400, M=16, helmholtz_k=2.0)
+    print(err, scale, T)
+    assert err / scale < 1e-10
