@@ -74,6 +74,12 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="kernel geometry variant (tuning)")
     args = ap.parse_args()
 
+    # RCCL writes a version banner to stdout when the communicator is created:
+    # keep fd 1 clean for the single JSON line by pointing it at stderr meanwhile
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -83,7 +89,10 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run the process group is always created (also for a
+    # single rank), so the collective path can be exercised on a one-GPU box
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ipde_amd.device import get_context
@@ -105,7 +114,7 @@ def main():
     out = torch.empty(dt.N, dtype=torch.float64, device=dev)
 
     def step():
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, sig_shard)
             dens = gathered
         else:
@@ -118,7 +127,7 @@ def main():
     kernel_ms = []
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -139,7 +148,7 @@ def main():
     kernel_ms_avg = float(np.mean(kms))
     ctx.enable_timing(False)
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -203,11 +212,14 @@ def main():
             result["cpu_baseline"] = cpu_baseline(c, trg, sigma)
         else:
             result["cpu_baseline"] = None
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
