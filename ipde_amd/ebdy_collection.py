@@ -144,6 +144,14 @@ class EmbeddedBoundaryCollection(object):
     def v2l(self, v):
         return np.split(np.asarray(v), self.splitter)
 
+    def v2l2(self, v):
+        """long stacked vector (per boundary [x; y] blocks) -> list (reference :553-554)"""
+        return np.split(np.asarray(v), [2 * i for i in self.splitter])
+
+    def v2l_vector(self, v):
+        """(2, sum N) -> list of (2, N_i)  (reference :555-559)"""
+        return np.split(np.asarray(v), self.splitter, axis=1)
+
     def v2r(self, v):
         return [w.reshape(e.radial_shape) for w, e in zip(np.split(np.asarray(v), self.rsplitter), self)]
 

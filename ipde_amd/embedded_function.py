@@ -119,6 +119,10 @@ class EmbeddedFunction(np.ndarray):
         g = self.get_grid_value()
         return g, g * self._ebdyc_test().grid_step, self.get_radial_value_list()
 
+    def integrate(self):
+        """volume integral over the physical domain (reference :214-218)"""
+        return self._ebdyc_test().volume_integral(self)
+
     def copy(self):
         return EmbeddedFunction(self._ebdyc_test(), array=np.array(self.view(np.ndarray), copy=True))
 

@@ -93,6 +93,43 @@ def fourier_resample(f, new_N):
     return res if np.iscomplexobj(f) else res.real
 
 
+def arc_length_parameterize(x, y, tol=1e-14):
+    """Resample a closed curve at equal arclength (the role of
+    personal_utilities.arc_length_reparametrization in the reference's scripts,
+    examples/multi_stokes.py:40-43).  The arclength s(t) is the spectral antiderivative of
+    the speed; s(t_j) = j L / N is solved by Newton and the curve's Fourier series is
+    evaluated at the new parameters.  Returns (x, y)."""
+    c = np.asarray(x, dtype=float) + 1j * np.asarray(y, dtype=float)
+    N = c.shape[0]
+    k = np.fft.fftfreq(N, 1.0 / N)
+    ch = np.fft.fft(c) / N
+    dk = 1j * k
+    if N % 2 == 0:
+        dk[N // 2] = 0.0
+    speed = np.abs(np.fft.ifft(dk * ch * N))
+    sh = np.fft.fft(speed) / N
+    L = 2 * np.pi * sh[0].real
+    ah = np.zeros_like(sh)
+    nz = k != 0
+    ah[nz] = sh[nz] / (1j * k[nz])
+    if N % 2 == 0:
+        ah[N // 2] = 0.0
+    target = np.arange(N) * (L / N)
+    t = np.arange(N) * (2 * np.pi / N)
+    E0 = np.exp(1j * np.outer(np.zeros(1), k))
+    s0 = (E0 @ ah).real[0]
+    for _ in range(50):
+        E = np.exp(1j * np.outer(t, k))
+        s = sh[0].real * t + (E @ ah).real - s0
+        sp = (E @ sh).real
+        dtn = (s - target) / sp
+        t = t - dtn
+        if np.abs(dtn).max() < tol:
+            break
+    cn = np.exp(1j * np.outer(t, k)) @ ch
+    return cn.real, cn.imag
+
+
 class Grid(object):
     def __init__(self, x_bounds, Nx, y_bounds, Ny, mask=None, x_endpoints=(True, True),
                  y_endpoints=(True, True)):
@@ -264,3 +301,88 @@ def Modified_Helmholtz_Layer_Singular_Form(bdy, k=1.0, ifcharge=False, ifdipole=
         np.fill_diagonal(D2, -bdy.curvature / (4 * np.pi))
         out += (D1 * R + D2 * bdy.dt) * bdy.speed[None, :]
     return out
+
+
+# ---------------------------------------------------------------------------
+# Stokes (mu = 1): kernels of ipde_amd.layer_potentials.stokes_apply.  Vector densities are
+# stacked [x-components; y-components]; the matrices are 2x2 blocks [[xx, xy], [yx, yy]].
+def _stack_blocks(Bxx, Bxy, Byy):
+    return np.block([[Bxx, Bxy], [Bxy, Byy]])
+
+
+def Stokes_Layer_Form(source, target=None, ifforce=False, ifdipole=False):
+    """Dense off-surface matrix (2 Nt x 2 Ns; weights included) of
+       stokeslet  (1/4pi) [ -log r  I + d d^T / r^2 ]      and / or
+       stresslet  (1/pi) (d.n) d d^T / r^4,     d = target - source, n = source normal
+    (pybie2d.kernels.high_level.stokes call shape; reference examples/multi_stokes.py:131-133)."""
+    if target is None:
+        target = source
+    dx = target.x[:, None] - source.x[None, :]
+    dy = target.y[:, None] - source.y[None, :]
+    d2 = dx * dx + dy * dy
+    id2 = 1.0 / d2
+    w = source.weights[None, :]
+    Bxx = np.zeros_like(d2)
+    Bxy = np.zeros_like(d2)
+    Byy = np.zeros_like(d2)
+    if ifforce:
+        c = 0.25 / np.pi
+        lg = -0.5 * np.log(d2)
+        Bxx += c * (lg + dx * dx * id2) * w
+        Bxy += c * (dx * dy * id2) * w
+        Byy += c * (lg + dy * dy * id2) * w
+    if ifdipole:
+        q = (dx * source.normal_x[None, :] + dy * source.normal_y[None, :]) * id2 * id2 * w / np.pi
+        Bxx += q * dx * dx
+        Bxy += q * dx * dy
+        Byy += q * dy * dy
+    return _stack_blocks(Bxx, Bxy, Byy)
+
+
+def Stokes_Layer_Singular_Form(bdy, ifforce=False, ifdipole=False):
+    """On-surface Nystrom matrices (2N x 2N).  Stokeslet: the -log r part is half the
+    Laplace single layer (Kress split), d d^T / r^2 is smooth with diagonal limit t t^T.
+    Stresslet: smooth, diagonal limit -curvature/(2 pi) t t^T; principal value, the
+    interior limit is D - I/2 (reference examples/multi_stokes.py:134-138)."""
+    N = bdy.N
+    dx = bdy.x[:, None] - bdy.x[None, :]
+    dy = bdy.y[:, None] - bdy.y[None, :]
+    d2 = dx * dx + dy * dy
+    np.fill_diagonal(d2, 1.0)
+    id2 = 1.0 / d2
+    w = bdy.weights[None, :]
+    txx = bdy.tangent_x * bdy.tangent_x
+    txy = bdy.tangent_x * bdy.tangent_y
+    tyy = bdy.tangent_y * bdy.tangent_y
+    Bxx = np.zeros((N, N))
+    Bxy = np.zeros((N, N))
+    Byy = np.zeros((N, N))
+    if ifforce:
+        c = 0.25 / np.pi
+        half_slp = 0.5 * Laplace_Layer_Singular_Form(bdy, ifcharge=True)
+        Rxx, Rxy, Ryy = dx * dx * id2, dx * dy * id2, dy * dy * id2
+        np.fill_diagonal(Rxx, txx)
+        np.fill_diagonal(Rxy, txy)
+        np.fill_diagonal(Ryy, tyy)
+        Bxx += half_slp + c * Rxx * w
+        Bxy += c * Rxy * w
+        Byy += half_slp + c * Ryy * w
+    if ifdipole:
+        q = (dx * bdy.normal_x[None, :] + dy * bdy.normal_y[None, :]) * id2 * id2 / np.pi
+        Dxx, Dxy, Dyy = q * dx * dx, q * dx * dy, q * dy * dy
+        lim = -bdy.curvature / (2 * np.pi)
+        np.fill_diagonal(Dxx, lim * txx)
+        np.fill_diagonal(Dxy, lim * txy)
+        np.fill_diagonal(Dyy, lim * tyy)
+        Bxx += Dxx * w
+        Bxy += Dxy * w
+        Byy += Dyy * w
+    return _stack_blocks(Bxx, Bxy, Byy)
+
+
+def Stokes_Pressure_Fix(source, target):
+    """n_trg (x) n_src w_src / |source curve| — the rank-one completion the reference's
+    scripts add to the interior double-layer block (examples/multi_stokes.py:122-128)."""
+    nt = np.concatenate([target.normal_x, target.normal_y])
+    ns = np.concatenate([source.normal_x * source.weights, source.normal_y * source.weights])
+    return np.outer(nt, ns) / np.sum(source.weights)

@@ -24,7 +24,8 @@ import scipy.linalg
 
 from .pybie2d_compat import (Global_Smooth_Boundary, Laplace_Layer_Form,
                              Laplace_Layer_Singular_Form, Modified_Helmholtz_Layer_Form,
-                             Modified_Helmholtz_Layer_Singular_Form)
+                             Modified_Helmholtz_Layer_Singular_Form, Stokes_Layer_Form,
+                             Stokes_Layer_Singular_Form, Stokes_Pressure_Fix)
 
 
 class QFS_Boundary(object):
@@ -51,6 +52,8 @@ class _QFS(object):
     """qfs([sigma, tau]) -> mu on qfs.source;  qfs.u2s(u) -> mu reproducing boundary
     values u.  Subclasses provide the off-surface and on-surface forms."""
 
+    DEVICE_SOLVE = True
+
     def __init__(self, bdy, interior, slp, dlp, qfs_boundary=None, eps=1e-12):
         self.bdy = bdy
         self.interior = interior
@@ -58,10 +61,13 @@ class _QFS(object):
         self.source = q.interior_source_bdy if interior else q.exterior_source_bdy
         self.slp, self.dlp = slp, dlp
         A = self._s2b(self.source, bdy)                              # (N, Ns)
+        self._nrow = A.shape[0]
         jump = -0.5 if interior else 0.5
         S = self._singular(bdy, True, False) if slp else None
-        D = (self._singular(bdy, False, True) + jump * np.eye(bdy.N)) if dlp else None
-        self._dev = _device()
+        D = self._singular(bdy, False, True) if dlp else None
+        if dlp:
+            D = D + jump * np.eye(D.shape[0])
+        self._dev = _device() if self.DEVICE_SOLVE else None
         if self._dev is not None and A.shape[0] == A.shape[1]:
             # factor and solve on the GPU (rocSOLVER through torch): the per-solve cost of
             # three 4096^2 host LU back-substitutions was the largest single item of a
@@ -99,9 +105,9 @@ class _QFS(object):
             import torch
             densities = [torch.as_tensor(np.ascontiguousarray(d, dtype=float), device=self._dev)
                          for d in densities]
-            u = torch.zeros(self.bdy.N, dtype=torch.float64, device=self._dev)
+            u = torch.zeros(self._nrow, dtype=torch.float64, device=self._dev)
         else:
-            u = np.zeros(self.bdy.N)
+            u = np.zeros(self._nrow)
         i = 0
         if self.slp:
             u = u + self._S @ densities[i]
@@ -168,6 +174,99 @@ class Modified_Helmholtz_QFS(_QFS):
 
     def _singular(self, bdy, c, d):
         return Modified_Helmholtz_Layer_Singular_Form(bdy, k=self.k, ifcharge=c, ifdipole=d)
+
+
+class Stokes_QFS(_QFS):
+    """Vector QFS (reference ipde/solvers/internals/stokes.py:21-24,
+    examples/multi_stokes.py:166-171): densities and results are stacked [x; y] vectors of
+    length 2N.  The stokeslet collocation matrix from a closed source curve has a
+    one-dimensional null space on both sides — the source normal n_s produces no flow
+    (only a constant pressure), and every single-layer field has zero flux through the
+    curve — so the rank-one term  n_trg (x) n_src w_src / L  is added: for flux-free data
+    (all the solver produces) it leaves the velocity untouched and selects the density
+    with  int mu.n = 0, which also pins the pressure constant."""
+
+    MAX_ALPHA = 5.4
+    # host LAPACK: at condition 1e15 the GPU triangular solves (even with refinement) lose
+    # four digits against dgetrs (potential error 1e-8 vs 3e-13, measured at N = 2000)
+    DEVICE_SOLVE = False
+
+    def __init__(self, bdy, interior, slp=True, dlp=True, qfs_boundary=None, eps=1e-12):
+        # Per Fourier mode k the stokeslet block from a curve at distance d is
+        # e^{-|k|d}/(4|k|) (I + |k|d N) with N nilpotent: its small singular value carries an
+        # extra 1/(2|k|d) compared with the Laplace single layer.  At the scalar solvers'
+        # alpha = 6.1 (eps 1e-14) the 2N x 2N matrix is numerically singular (smallest
+        # singular values 1e-16, measured at N = 2000); alpha <= 5.4 keeps the condition
+        # number where the Laplace one is (~1e13) at a quadrature error e^{-2 pi alpha} = 2e-15.
+        if qfs_boundary is None or qfs_boundary.alpha > self.MAX_ALPHA:
+            up = None if qfs_boundary is None else qfs_boundary.upsample
+            qfs_boundary = QFS_Boundary(bdy, eps=eps, forced_source_upsampling_factor=up,
+                                        alpha=min(self.MAX_ALPHA,
+                                                  max(4.0, -np.log(eps) / (2 * np.pi) + 1.0)))
+        super().__init__(bdy, interior, slp, dlp, qfs_boundary, eps)
+        if interior:
+            self._pressure_calibration()
+
+    def _s2b(self, src, trg):
+        return Stokes_Layer_Form(src, trg, ifforce=True) + Stokes_Pressure_Fix(src, trg)
+
+    def _singular(self, bdy, c, d):
+        return Stokes_Layer_Singular_Form(bdy, ifforce=c, ifdipole=d)
+
+    def _pressure_calibration(self):
+        """Inside the curve the density n_src adds a constant pressure and no velocity, so
+        the collocation leaves the pressure level open.  It is pinned at one point deep
+        inside (where the plain trapezoid rule on the curve itself is spectrally accurate):
+        row vectors giving the pressure there of the boundary layers and of the sources."""
+        b, s = self.bdy, self.source
+        x0, y0 = _deep_interior_point(b)
+        self._p_point = (x0, y0)
+
+        def rows(c, force, dipole):
+            dx, dy = x0 - c.x, y0 - c.y
+            ir2 = 1.0 / (dx * dx + dy * dy)
+            out = []
+            if force:
+                out.append(np.concatenate([dx, dy]) * np.tile(ir2 * c.weights, 2) * (0.5 / np.pi))
+            if dipole:
+                dn = dx * c.normal_x + dy * c.normal_y
+                q = 2.0 * dn * ir2 * ir2
+                out.append(np.concatenate([(-c.normal_x * ir2 + q * dx), (-c.normal_y * ir2 + q * dy)])
+                           * np.tile(c.weights, 2) / np.pi)
+            return out
+        self._p_rows = rows(b, self.slp, self.dlp)
+        self._p_src = rows(s, True, False)[0]
+        self._n_src = np.concatenate([s.normal_x, s.normal_y])
+        self._p_null = float(self._p_src @ self._n_src)      # pressure of the null density (-1)
+
+    def __call__(self, densities):
+        densities = list(densities)
+        want = int(self.slp) + int(self.dlp)
+        # the reference's interior double-layer call passes [tau, tau] (one entry feeds its
+        # pressure-fix block, which vanishes for flux-free tau): keep the last `want`
+        densities = densities[max(0, len(densities) - want):]
+        # ... and its combined-layer call on a hole passes one tau for both layers (:171)
+        densities = densities + [densities[-1]] * (want - len(densities))
+        mu = super().__call__(densities)
+        if self.interior:
+            p_true = sum(r @ np.asarray(d, dtype=float) for r, d in zip(self._p_rows, densities))
+            mu = mu + (p_true - self._p_src @ mu) / self._p_null * self._n_src
+        return mu
+
+
+def _deep_interior_point(b, ngrid=48):
+    """A point inside the closed curve far from it (largest distance to the nodes among a
+    coarse lattice of candidates)."""
+    from .near import points_inside_curve
+    xs = np.linspace(b.x.min(), b.x.max(), ngrid + 2)[1:-1]
+    ys = np.linspace(b.y.min(), b.y.max(), ngrid + 2)[1:-1]
+    X, Y = np.meshgrid(xs, ys, indexing='ij')
+    X, Y = X.ravel(), Y.ravel()
+    inside = points_inside_curve(b, X, Y)
+    X, Y = X[inside], Y[inside]
+    d2 = ((X[:, None] - b.x[None, :]) ** 2 + (Y[:, None] - b.y[None, :]) ** 2).min(axis=1)
+    i = int(np.argmax(d2))
+    return float(X[i]), float(Y[i])
 
 
 class QFS_Evaluator(object):

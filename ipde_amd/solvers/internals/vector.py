@@ -1,0 +1,142 @@
+"""VectorHelper — per-boundary helper of the vector (Stokes) solver, mirrors
+ipde/solvers/internals/vector.py:7-162: owns the annular solver, the interface QFS pair
+(single + double layer of the traction / velocity jumps) and the `Layer_Apply` closure
+returning (u, v, p) — the plug point of the GPU Stokes kernel."""
+import numpy as np
+
+from ...annular.annular import ApproximateAnnularGeometry
+from ...annular.annular_full import RealAnnularGeometry
+
+
+def v2f(x):
+    return x.reshape(2, x.size // 2)
+
+
+class VectorHelper(object):
+    def __init__(self, ebdy, annular_solver=None, **kwargs):
+        self.ebdy = ebdy
+        self.interior = self.ebdy.interior
+        self._extract_extra_kwargs(**kwargs)
+        if annular_solver is None:
+            self.AAG = ApproximateAnnularGeometry(self.ebdy.bdy.N, self.ebdy.M,
+                                                  self.ebdy.radial_width, self.ebdy.approximate_radius)
+            self._define_annular_solver()
+        else:
+            self.annular_solver = annular_solver
+            self.AAG = self.annular_solver.AAG
+        self._set_boundary_estimators()
+        self._get_RAG()
+        self._get_qfs()
+        self._define_layer_apply()
+        from ...layer_potentials import DeviceTargets
+        self._interface_dev = DeviceTargets(self.ebdy.interface)
+        self._radial_dev = DeviceTargets(self.ebdy.radial_targ)
+
+    def _extract_extra_kwargs(self, **kwargs):
+        pass
+
+    def _define_annular_solver(self):
+        raise NotImplementedError
+
+    def _get_qfs(self):
+        raise NotImplementedError
+
+    def _define_layer_apply(self):
+        raise NotImplementedError
+
+    def _get_RAG(self):
+        bb = self.ebdy.bdy if self.interior else self.ebdy.interface
+        self.RAG = RealAnnularGeometry(bb.speed, bb.curvature, self.annular_solver.AAG)
+
+    def _set_boundary_estimators(self):
+        CO = self.AAG.CO
+        if self.interior:
+            self._bv_estimator, self._bn_estimator = CO.obc_dirichlet[0], CO.obc_neumann[0]
+            self._iv_estimator, self._in_estimator = CO.ibc_dirichlet[0], CO.ibc_neumann[0]
+        else:
+            self._bv_estimator, self._bn_estimator = CO.ibc_dirichlet[0], CO.ibc_neumann[0]
+            self._iv_estimator, self._in_estimator = CO.obc_dirichlet[0], CO.obc_neumann[0]
+
+    def get_boundary_values(self, fr):
+        return self._bv_estimator.dot(fr)
+
+    def get_interface_values(self, fr):
+        return self._iv_estimator.dot(fr)
+
+    # -- tractions T(U) n on the boundary / interface (reference :65-112) -------------
+    def get_boundary_traction_uvp(self, u, v, p):
+        return self._get_traction_uvp(u, v, p, self._bv_estimator)
+
+    def get_boundary_traction_rtp(self, Ur, Ut, p):
+        return self._get_traction_rtp(Ur, Ut, p, self._bv_estimator)
+
+    def get_interface_traction_uvp(self, u, v, p):
+        return self._get_traction_uvp(u, v, p, self._iv_estimator)
+
+    def get_interface_traction_rtp(self, Ur, Ut, p):
+        return self._get_traction_rtp(Ur, Ut, p, self._iv_estimator)
+
+    def _get_traction_uvp(self, u, v, p, estimator):
+        Ur, Ut = self.ebdy.convert_uv_to_rt(u, v)
+        Tr, Tt = self._get_traction_rtp(Ur, Ut, p, estimator)
+        return self.ebdy.convert_rt_to_uv(Tr, Tt)
+
+    def _get_traction_rtp(self, Ur, Ut, p, estimator):
+        ebdy = self.ebdy
+        Urr = ebdy._radial_grid_r_derivative(Ur)
+        Urt = ebdy._radial_grid_tau_derivative(Ur)
+        Utr = ebdy.radial_speed * ebdy._radial_grid_r_derivative(Ut * ebdy.inverse_radial_speed)
+        Tr = 2 * estimator.dot(Urr) - estimator.dot(p)
+        Tt = estimator.dot(Utr) + estimator.dot(Urt)
+        return Tr, Tt
+
+    def __call__(self, fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs):
+        """Annular solve with homogeneous data, traction / velocity jumps against the grid
+        solution, QFS densities for both sides (reference :113-144)."""
+        ebdy = self.ebdy
+        btx = btxx * ebdy.interface.normal_x + btxy * ebdy.interface.normal_y
+        bty = btxy * ebdy.interface.normal_x + btyy * ebdy.interface.normal_y
+        fr, ft = ebdy.convert_uv_to_rt(fur, fvr)
+        zer = np.zeros(ebdy.bdy.N)
+        rr, tr, pr = self.annular_solver.solve(self.RAG, fr, ft, zer, zer, zer, zer, **kwargs)
+        self.iterations_last_call = self.annular_solver.iterations_last_call
+        rr, tr, pr = np.asarray(rr), np.asarray(tr), np.asarray(pr)
+        ur, vr = ebdy.convert_rt_to_uv(rr, tr)
+        rtx, rty = self.get_interface_traction_uvp(ur, vr, pr)
+        taus = np.concatenate([rtx - btx, rty - bty])
+        taud = np.concatenate([bu, bv])
+        if not self.interior:
+            taus *= -1.0
+            taud *= -1.0
+        sigma_g = v2f(self.interface_qfs_g([taus, taud]))
+        sigma_r = v2f(self.interface_qfs_r([taus, taud]))
+        self.ur, self.vr, self.pr = ur, vr, pr
+        self.sigma_r = sigma_r
+        self.sigma_g = sigma_g
+        return sigma_g
+
+    def correct(self, ub, vb, pb, single_ebdy):
+        """Effect of every OTHER boundary's grid sources on this annulus (reference
+        :145-162).  The reference leaves the pressure of that part undetermined (its
+        comment at :150); here the constant is fixed by matching the mean pressure on the
+        interface, which is all a velocity-matching density leaves open."""
+        if single_ebdy:
+            sigma_r_tot = self.sigma_r
+            p_shift = 0.0
+        else:
+            to_np = lambda a: a.cpu().numpy()
+            src = self.interface_qfs_g.source
+            w = [to_np(a) for a in self.Layer_Apply(src, self._interface_dev, self.sigma_g)]
+            Ub = np.concatenate([ub - w[0], vb - w[1]])
+            sigma_r_adj = v2f(self.interface_qfs_r.u2s(Ub))
+            p_adj = to_np(self.Layer_Apply(self.interface_qfs_r.source, self._interface_dev,
+                                           sigma_r_adj)[2])
+            wi = self.ebdy.interface.weights
+            p_shift = np.sum((pb - w[2] - p_adj) * wi) / np.sum(wi)
+            sigma_r_tot = sigma_r_adj + self.sigma_r
+        src = self.interface_qfs_r.source
+        rslp = [a.cpu().numpy() for a in self.Layer_Apply(src, self._radial_dev, sigma_r_tot)]
+        self.ur = self.ur + rslp[0].reshape(self.ur.shape)
+        self.vr = self.vr + rslp[1].reshape(self.ur.shape)
+        self.pr = self.pr + rslp[2].reshape(self.pr.shape) + p_shift
+        return self.ur, self.vr, self.pr

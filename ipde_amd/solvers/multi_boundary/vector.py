@@ -1,0 +1,148 @@
+"""VectorSolver — the coupled grid + annuli driver for vector (Stokes) problems, mirrors
+ipde/solvers/multi_boundary/vector.py:6-114 step for step:
+  FFT grid solve -> velocity and stress on the interfaces -> per-boundary annular
+  solves and QFS densities -> dense GPU stokeslet sum onto grid_pnai -> correct() ->
+  radial->grid.
+As in the scalar driver the grid-sized arrays stay in HBM for the whole solve.
+"""
+import numpy as np
+import torch
+
+from ...derivatives import fd_x_4, fd_y_4
+from ...embedded_function import EmbeddedFunction
+from ...interp import periodic_interp2d, chebyshev_fourier_eval
+from ...layer_potentials import DeviceTargets
+from ...pybie2d_compat import BoundaryCollection
+from ...spectral import get_plan
+
+
+class VectorSolver(object):
+    def __init__(self, ebdyc, solver_type='spectral', helpers=None, **kwargs):
+        self.ebdyc = ebdyc
+        self.solver_type = solver_type
+        if helpers is None:
+            helpers = [None, ] * self.ebdyc.N
+        self._extract_extra_kwargs(**kwargs)
+        self.helpers = [self._get_helper(ebdy, helper) for ebdy, helper in zip(self.ebdyc, helpers)]
+        self.AS_list = [helper.annular_solver for helper in self.helpers]
+        self.grid = self.ebdyc.grid
+        self.kx, self.ky = self.ebdyc.kx, self.ebdyc.ky
+        self.ikx, self.iky = self.ebdyc.ikx, self.ebdyc.iky
+        self.lap = -self.kx * self.kx - self.ky * self.ky
+        self.plan = get_plan(self.grid.Nx, self.grid.Ny, self.grid.xh, self.grid.yh)
+        self._get_specific_operators()
+        self._set_derivative_method()
+        self.interpolation_order = 3 if self.solver_type == 'fourth' else np.inf
+        self.grid_step = self.ebdyc.grid_step
+        self._define_layer_apply()
+        self._collect_grid_sources()
+        self._make_device_state()
+
+    def _collect_grid_sources(self):
+        self.grid_sources = BoundaryCollection()
+        for helper in self.helpers:
+            self.grid_sources.add(helper.interface_qfs_g.source, 'i' if helper.interior else 'e')
+        self.grid_sources.amass_information()
+
+    def _make_device_state(self):
+        e = self.ebdyc
+        dev = self.plan.ctx.torch_device()
+        self._dev = dev
+        flat = lambda mask: torch.as_tensor(np.flatnonzero(mask.ravel()), device=dev)
+        self._phys_idx = flat(e.phys)
+        self._pna_idx = flat(e.phys_not_in_annulus)
+        self._grid_step_d = torch.as_tensor(np.ascontiguousarray(e.grid_step), device=dev)
+        self._phys_d = torch.as_tensor(e.phys.astype(float), device=dev)
+        self._ikx_d = torch.as_tensor(np.ascontiguousarray(self.ikx), device=dev)
+        self._iky_d = torch.as_tensor(np.ascontiguousarray(self.iky), device=dev)
+        self._ifx_d = torch.as_tensor(e.interfaces_x_transf, device=dev)
+        self._ify_d = torch.as_tensor(e.interfaces_y_transf, device=dev)
+        self._ia = []
+        for ebdy in e:
+            idx = torch.as_tensor(ebdy.grid_ia_xind * self.grid.Ny + ebdy.grid_ia_yind, device=dev)
+            self._ia.append((idx, torch.as_tensor(ebdy.grid_ia_xi, device=dev),
+                             torch.as_tensor(ebdy.grid_ia_t, device=dev)))
+        self._grid_pnai_dev = DeviceTargets(e.grid_pnai)
+        self._pin_in = torch.empty((2, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
+        self._pin_out = torch.empty((3, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
+
+    def _extract_extra_kwargs(self, **kwargs):
+        pass
+
+    def _get_helper(self, ebdy, helper):
+        raise NotImplementedError
+
+    def _grid_solve(self, fuc, fvc):
+        raise NotImplementedError
+
+    def _get_specific_operators(self):
+        pass
+
+    def _set_derivative_method(self):
+        if self.solver_type == 'spectral':
+            self.dx = lambda x: self.plan.dx(x)
+            self.dy = lambda x: self.plan.dy(x)
+        else:
+            self.dx = lambda x: fd_x_4(x, self.ebdyc.grid.xh)
+            self.dy = lambda x: fd_y_4(x, self.ebdyc.grid.yh)
+
+    def get_boundary_values(self, frs):
+        return np.concatenate([helper.get_boundary_values(fr) for fr, helper in zip(frs, self.helpers)])
+
+    def get_boundary_tractions(self, urs, vrs, prs):
+        return np.concatenate([np.concatenate(helper.get_boundary_traction_uvp(ur, vr, pr))
+                               for ur, vr, pr, helper in zip(urs, vrs, prs, self.helpers)])
+
+    def __call__(self, fu, fv, **kwargs):
+        """fu, fv: EmbeddedFunctions -> (u, v, p) EmbeddedFunctions (reference :57-112)."""
+        e = self.ebdyc
+        Nx, Ny = self.grid.shape
+        fur_list = fu.get_radial_value_list()
+        fvr_list = fv.get_radial_value_list()
+        pin = self._pin_in.numpy()
+        pin[0] = fu['grid']
+        pin[1] = fv['grid']
+        fg = torch.zeros((2, Nx * Ny), dtype=torch.float64, device=self._dev)
+        fg[:, self._phys_idx] = self._pin_in.to(self._dev, non_blocking=True)
+        fc = fg.view(2, Nx, Ny) * self._grid_step_d
+        uc, vc, pc = (a.contiguous() for a in self._grid_solve(fc[0], fc[1]))
+        # velocity and stress of the grid solution on every interface node (:66-82)
+        if self.interpolation_order == np.inf:
+            uh, vh, ph = torch.fft.fft2(uc), torch.fft.fft2(vc), torch.fft.fft2(pc)
+            stack = torch.stack([uh, vh, 2 * self._ikx_d * uh - ph,
+                                 self._iky_d * uh + self._ikx_d * vh, 2 * self._iky_d * vh - ph])
+        else:
+            ucx, ucy, vcx, vcy = self.dx(uc), self.dy(uc), self.dx(vc), self.dy(vc)
+            stack = torch.stack([torch.fft.fft2(g) for g in
+                                 (uc, vc, 2 * ucx - pc, ucy + vcx, 2 * vcy - pc)])
+        bvals = periodic_interp2d(stack, self._ifx_d, self._ify_d).real.cpu().numpy()
+        bul, bvl, btxxl, btxyl, btyyl = (e.v2l(b) for b in bvals)
+        sigmag_list = []
+        for helper, fur, fvr, bu, bv, btxx, btxy, btyy in zip(self.helpers, fur_list, fvr_list,
+                                                              bul, bvl, btxxl, btxyl, btyyl):
+            sigmag_list.append(helper(fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs))
+        self.iteration_counts = [helper.iterations_last_call for helper in self.helpers]
+        sigmag = np.column_stack(sigmag_list)
+        out = self.Layer_Apply(self.grid_sources, self._grid_pnai_dev, sigmag)   # device (u, v, p)
+        n_pna = e.grid_pna.N
+        fields = (uc.view(-1), vc.view(-1), pc.view(-1))
+        for f, o in zip(fields, out):
+            f[self._pna_idx] += o[:n_pna]
+        bus, bvs, bps = (e.v2l(o[n_pna:].cpu().numpy()) for o in out)
+        single_ebdy = len(e) == 1
+        urs, vrs, prs = zip(*[helper.correct(bu, bv, bp, single_ebdy)
+                              for helper, bu, bv, bp in zip(self.helpers, bus, bvs, bps)])
+        for k, (f, rs) in enumerate(zip(fields, (urs, vrs, prs))):
+            for r, (idx, xi, t) in zip(rs, self._ia):
+                f[idx] = chebyshev_fourier_eval(r, xi, t)
+            f *= self._phys_d.view(-1)
+            self._pin_out[k].copy_(f[self._phys_idx], non_blocking=False)
+        res = []
+        for k, rs in enumerate((urs, vrs, prs)):
+            g = EmbeddedFunction(e)
+            g.load_data(self._pin_out[k].numpy().copy(), list(rs))
+            res.append(g)
+        return tuple(res)
+
+    def _define_layer_apply(self):
+        self.Layer_Apply = self.helpers[0].Layer_Apply

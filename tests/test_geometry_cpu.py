@@ -125,3 +125,79 @@ def test_qfs_reproduces_layer_potentials_on_both_sides():
         A = Laplace_Layer_Form(Q.source, b, ifcharge=True)
         ub = A @ mu
         assert np.max(np.abs(A @ Q.u2s(ub) - ub)) < 1e-11 * np.max(np.abs(ub))
+
+
+def test_arc_length_parameterize_equalises_speed():
+    from ipde_amd.pybie2d_compat import arc_length_parameterize
+    b = GSB(c=star(400, a=0.3, f=3))
+    x, y = arc_length_parameterize(b.x, b.y)
+    b2 = GSB(x=x, y=y)
+    assert np.ptp(b2.speed) / b2.speed.mean() < 1e-8
+    assert abs(b2.weights.sum() - b.weights.sum()) < 1e-12
+    th = np.arctan2(y, x)
+    assert np.abs(np.hypot(x, y) - (1 + 0.3 * np.cos(3 * th))).max() < 1e-13
+
+
+def _exterior_stokeslet(c, x0=1.9, y0=1.4, f0=(1.0, -0.5)):
+    """velocity and traction on the curve c of a stokeslet placed outside it"""
+    import oracle.layer_potentials as ol
+    f0 = np.asarray(f0)
+    u, v, p = ol.stokes_layer_apply(np.array([x0]), np.array([y0]), c.x, c.y, force=f0.reshape(2, 1))
+    dx, dy = c.x - x0, c.y - y0
+    r2 = dx * dx + dy * dy
+    q = -(dx * f0[0] + dy * f0[1]) * (dx * c.normal_x + dy * c.normal_y) / (np.pi * r2 * r2)
+    return (u, v, p), (q * dx, q * dy)
+
+
+def test_stokes_singular_forms_solve_interior_dirichlet():
+    """D - I/2 (+ n n^T completion) and the Kress-split S reproduce an exterior
+    stokeslet's field inside the curve (reference examples/multi_stokes.py:134-138)."""
+    import oracle.layer_potentials as ol
+    from ipde_amd.pybie2d_compat import (Stokes_Layer_Singular_Form, Stokes_Layer_Form,
+                                         Stokes_Pressure_Fix, PointSet)
+    b = GSB(c=star(300, a=0.2, f=5))
+    (ub, vb, _), _ = _exterior_stokeslet(b)
+    rhs = np.concatenate([ub, vb])
+    xt, yt = np.array([0.1, -0.3, 0.5]), np.array([0.2, 0.4, -0.1])
+    P = type('P', (), dict(x=xt, y=yt, normal_x=0 * xt, normal_y=0 * xt))()
+    (ue, ve, _), _ = _exterior_stokeslet(P)
+    A = Stokes_Layer_Singular_Form(b, ifdipole=True) - 0.5 * np.eye(2 * b.N) + Stokes_Pressure_Fix(b, b)
+    tau = np.linalg.solve(A, rhs)
+    u, v, _ = ol.stokes_layer_apply(b.x, b.y, xt, yt, dipstr=tau.reshape(2, -1), weights=b.weights,
+                                    nx=b.normal_x, ny=b.normal_y)
+    assert max(np.abs(u - ue).max(), np.abs(v - ve).max()) < 1e-13
+    S = Stokes_Layer_Singular_Form(b, ifforce=True) + Stokes_Pressure_Fix(b, b)
+    sig = np.linalg.solve(S, rhs)
+    u, v, _ = ol.stokes_layer_apply(b.x, b.y, xt, yt, force=sig.reshape(2, -1), weights=b.weights)
+    assert max(np.abs(u - ue).max(), np.abs(v - ve).max()) < 1e-13
+    # dense form == kernel sum
+    M = Stokes_Layer_Form(b, PointSet(x=xt, y=yt), ifforce=True, ifdipole=True)
+    u, v, _ = ol.stokes_layer_apply(b.x, b.y, xt, yt, force=tau.reshape(2, -1), dipstr=tau.reshape(2, -1),
+                                    weights=b.weights, nx=b.normal_x, ny=b.normal_y)
+    assert np.abs(M @ tau - np.concatenate([u, v])).max() < 1e-13
+
+
+def test_stokes_qfs_green_representation():
+    """Green's representation u = S[t] - D[u] (inside; 0 outside) of an exterior
+    stokeslet through Stokes_QFS: velocity and (calibrated) pressure right up to the curve."""
+    import oracle.layer_potentials as ol
+    from ipde_amd.qfs import Stokes_QFS
+    b = GSB(c=star(400, a=0.2, f=5))
+    (ub, vb, _), (tx, ty) = _exterior_stokeslet(b)
+    taus, taud = np.concatenate([tx, ty]), -np.concatenate([ub, vb])
+    fine = b.generate_resampled_boundary(3200)
+    h = b.dt * b.speed.min()
+    for interior in (True, False):
+        q = Stokes_QFS(b, interior, True, True)
+        mu = q([taus, taud])
+        c = fine.c + (-1 if interior else 1) * 0.5 * h * fine.normal_c
+        xt, yt = c.real[3::41].copy(), c.imag[3::41].copy()
+        got = ol.stokes_layer_apply(q.source.x, q.source.y, xt, yt, force=mu.reshape(2, -1),
+                                    weights=q.source.weights)
+        if interior:
+            P = type('P', (), dict(x=xt, y=yt, normal_x=0 * xt, normal_y=0 * xt))()
+            (ue, ve, pe), _ = _exterior_stokeslet(P)
+        else:
+            ue = ve = pe = 0 * xt
+        assert max(np.abs(got[0] - ue).max(), np.abs(got[1] - ve).max()) < 1e-11
+        assert np.abs(got[2] - pe).max() < 1e-8

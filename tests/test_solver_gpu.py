@@ -50,3 +50,24 @@ def test_multiply_connected_modified_helmholtz():
     err, scale, T = mmh.run(nb=400, M=16, helmholtz_k=2.0)
     print(err, scale, T)
     assert err / scale < 1e-10
+
+
+def test_stokes_interior_manufactured_solution():
+    """StokesSolver (reference solvers/multi_boundary/stokes.py) + double-layer boundary
+    correction on one 5-arm star: stream-function solution of examples/multi_stokes.py."""
+    import multi_stokes
+    ue, ve, pe, scale, T = multi_stokes.run(nb=400, M=12, simple=True)
+    print(ue, ve, pe, scale, T)
+    assert max(ue, ve) / scale < 2e-8
+    assert pe < 2e-5
+    assert max(T['gmres_iterations']) < 60
+
+
+def test_stokes_multiply_connected():
+    """BASELINE config 5 (reference examples/multi_stokes.py): outer boundary + two
+    holes, arclength-parameterised, block boundary-integral correction."""
+    import multi_stokes
+    ue, ve, pe, scale, T = multi_stokes.run(nb=600, M=14)
+    print(ue, ve, pe, scale, T)
+    assert max(ue, ve) / scale < 5e-6
+    assert pe < 5e-3
