@@ -97,3 +97,47 @@ class ShardedLayerApply:
         self.dist.all_gather(out, pad, group=self.group)
         full = torch.cat([o[:s] for o, s in zip(out, sizes)])
         return full if isinstance(local, torch.Tensor) else full.cpu().numpy()
+
+
+def _all_gather_padded(t, sizes, dist, group=None):
+    """all_gather of ragged 1-D shards of a torch tensor (device tensors over RCCL; with
+    the gloo backend, which the CPU / one-GPU rehearsals use, through host memory)."""
+    import torch
+    m = max(sizes)
+    backend = dist.get_backend(group)
+    via_host = t.is_cuda and backend == "gloo"
+    src = t.cpu() if via_host else t
+    pad = torch.zeros(m, dtype=src.dtype, device=src.device)
+    pad[:src.shape[0]] = src
+    out = [torch.empty_like(pad) for _ in sizes]
+    dist.all_gather(out, pad, group=group)
+    full = torch.cat([o[:s] for o, s in zip(out, sizes)])
+    return full.to(t.device) if via_host else full
+
+
+def make_pnai_evaluator(layer_apply, sources, targets, wrap_targets, dist=None, group=None):
+    """The solvers' `Grid_Evaluator(density)` onto a fixed target set (grid_pnai).
+
+    Single process: one dense sum onto the resident target set.  Under
+    torch.distributed (one process per GPU, every rank holding the replicated solver
+    state and hence the full density) each rank evaluates its contiguous slice of the
+    targets and the slices are all-gathered — the only collective of a solve
+    (BASELINE configs 4 and 5).  `layer_apply(src, trg, density)` returns a device
+    tensor or a tuple of them (Stokes u, v, p)."""
+    if dist is None:
+        import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        resident = wrap_targets(targets.x, targets.y)
+        return lambda density: layer_apply(sources, resident, density)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    nt = int(len(targets.x))
+    sl = target_slice(nt, rank, world)
+    local = wrap_targets(targets.x[sl], targets.y[sl])
+    sizes = shard_sizes(nt, world)
+
+    def evaluator(density):
+        out = layer_apply(sources, local, density)
+        if isinstance(out, tuple):
+            return tuple(_all_gather_padded(o, sizes, dist, group) for o in out)
+        return _all_gather_padded(out, sizes, dist, group)
+    return evaluator

@@ -65,7 +65,5 @@ class ModifiedHelmholtzSolver(ScalarSolver):
             self.Grid_Evaluator = evaluator
             self.split_grid_evaluation = True
         else:
-            def evaluator(ch):
-                return self.Layer_Apply(self.grid_sources, self._grid_pnai_dev, ch)
-            self.Grid_Evaluator = evaluator
+            self.Grid_Evaluator = self._pnai_evaluator()
             self.split_grid_evaluation = False

@@ -46,7 +46,5 @@ class PoissonSolver(ScalarSolver):
         else:
             # the reference's default branch (:57-62): one dense sum onto grid_pnai,
             # here with the target set resident on the device
-            def evaluator(ch):
-                return self.Layer_Apply(self.grid_sources, self._grid_pnai_dev, ch)
-            self.Grid_Evaluator = evaluator
+            self.Grid_Evaluator = self._pnai_evaluator()
             self.split_grid_evaluation = False

@@ -16,6 +16,7 @@ from ...embedded_function import EmbeddedFunction, BoundaryFunction
 from ...interp import periodic_interp2d, chebyshev_fourier_eval
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
+from ...sharding import make_pnai_evaluator
 from ...spectral import get_plan
 
 
@@ -67,10 +68,17 @@ class ScalarSolver(object):
             idx = torch.as_tensor(ebdy.grid_ia_xind * self.grid.Ny + ebdy.grid_ia_yind, device=dev)
             self._ia.append((idx, torch.as_tensor(ebdy.grid_ia_xi, device=dev),
                              torch.as_tensor(ebdy.grid_ia_t, device=dev)))
-        # the solver evaluates onto the same target set in every solve: keep it in HBM
-        self._grid_pnai_dev = DeviceTargets(e.grid_pnai)
         self._pin_in = torch.empty(e.grid_phys.N, dtype=torch.float64, pin_memory=True)
         self._pin_out = torch.empty(e.grid_phys.N, dtype=torch.float64, pin_memory=True)
+
+    def _pnai_evaluator(self):
+        """density -> potential on grid_pnai.  The solver evaluates onto the same target
+        set in every solve: it stays in HBM; under torch.distributed the targets are
+        sharded over the ranks (ipde_amd.sharding.make_pnai_evaluator)."""
+        from ...pybie2d_compat import PointSet
+        return make_pnai_evaluator(lambda src, trg, ch: self.Layer_Apply(src, trg, ch),
+                                   self.grid_sources, self.ebdyc.grid_pnai,
+                                   lambda x, y: DeviceTargets(PointSet(x=x, y=y)))
 
     def _get_helper(self, ebdy, helper):
         raise NotImplementedError

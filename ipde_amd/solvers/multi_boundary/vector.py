@@ -13,6 +13,7 @@ from ...embedded_function import EmbeddedFunction
 from ...interp import periodic_interp2d, chebyshev_fourier_eval
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
+from ...sharding import make_pnai_evaluator
 from ...spectral import get_plan
 
 
@@ -62,7 +63,10 @@ class VectorSolver(object):
             idx = torch.as_tensor(ebdy.grid_ia_xind * self.grid.Ny + ebdy.grid_ia_yind, device=dev)
             self._ia.append((idx, torch.as_tensor(ebdy.grid_ia_xi, device=dev),
                              torch.as_tensor(ebdy.grid_ia_t, device=dev)))
-        self._grid_pnai_dev = DeviceTargets(e.grid_pnai)
+        from ...pybie2d_compat import PointSet
+        self.Grid_Evaluator = make_pnai_evaluator(
+            lambda src, trg, f: self.Layer_Apply(src, trg, f), self.grid_sources, e.grid_pnai,
+            lambda x, y: DeviceTargets(PointSet(x=x, y=y)))
         self._pin_in = torch.empty((2, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
         self._pin_out = torch.empty((3, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
 
@@ -123,7 +127,7 @@ class VectorSolver(object):
             sigmag_list.append(helper(fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs))
         self.iteration_counts = [helper.iterations_last_call for helper in self.helpers]
         sigmag = np.column_stack(sigmag_list)
-        out = self.Layer_Apply(self.grid_sources, self._grid_pnai_dev, sigmag)   # device (u, v, p)
+        out = self.Grid_Evaluator(sigmag)                          # device (u, v, p) on grid_pnai
         n_pna = e.grid_pna.N
         fields = (uc.view(-1), vc.view(-1), pc.view(-1))
         for f, o in zip(fields, out):

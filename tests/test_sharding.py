@@ -94,3 +94,54 @@ def test_sharded_apply_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(r, True) for r in range(world)], results
+
+
+def _worker_pnai(rank, world, port, q):
+    """make_pnai_evaluator: the solvers' sharded Grid_Evaluator (replicated density,
+    sharded targets, all-gathered result), scalar and Stokes-style tuple results."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import layer_potentials as olp
+        from util import Curve, Points
+        from ipde_amd.sharding import make_pnai_evaluator
+        c = Curve(64, a=0.2, f=5)
+        rng = np.random.default_rng(0)
+        trg = Points(rng.uniform(-0.5, 0.5, 1001), rng.uniform(-0.5, 0.5, 1001))
+        sigma = rng.standard_normal(c.N)
+        f = rng.standard_normal((2, c.N))
+        wrap = lambda x, y: Points(x, y)
+
+        def la(src, t, d):
+            return torch.as_tensor(olp.laplace_layer_apply(src.x, src.y, t.x, t.y, charge=d,
+                                                           weights=src.weights))
+
+        def la3(src, t, d):
+            return tuple(torch.as_tensor(a) for a in
+                         olp.stokes_layer_apply(src.x, src.y, t.x, t.y, force=d, weights=src.weights))
+        got = make_pnai_evaluator(la, c, trg, wrap)(sigma).numpy()
+        ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=sigma, weights=c.weights)
+        ok = got.shape == ref.shape and np.allclose(got, ref, rtol=0, atol=1e-13)
+        got3 = make_pnai_evaluator(la3, c, trg, wrap)(f)
+        ref3 = olp.stokes_layer_apply(c.x, c.y, trg.x, trg.y, force=f, weights=c.weights)
+        ok = ok and all(np.allclose(g.numpy(), r, rtol=0, atol=1e-13) for g, r in zip(got3, ref3))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bool(ok)))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pnai_evaluator_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pnai, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, True) for r in range(world)], results

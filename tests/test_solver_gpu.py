@@ -71,3 +71,21 @@ def test_stokes_multiply_connected():
     print(ue, ve, pe, scale, T)
     assert max(ue, ve) / scale < 5e-6
     assert pe < 5e-3
+
+
+def test_target_sharded_poisson_solve_two_ranks():
+    """The N > 1 solver path on real kernels: two ranks share the one GPU of the test box
+    (collectives over gloo), each evaluates half of grid_pnai, the halves are
+    all-gathered — the result must be the single-process one."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "tools", "run_sharded_solve.py"), "--backend", "gloo", "--share-gpu",
+           "--problem", "poisson", "--nb", "600", "--M", "16"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    print(res)
+    assert res["world"] == 2 and res["error"] < 1e-10

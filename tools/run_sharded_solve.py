@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""One rank of a target-sharded solve: every rank holds the replicated solver state and
+evaluates its slice of grid_pnai; the slices are all-gathered (ipde_amd/sharding.py).
+
+On an 8-GPU node:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        tools/run_sharded_solve.py --problem poisson --nb 4096 --M 20
+On a one-GPU box (rehearsal: all ranks share cuda:0, collectives over gloo):
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 \
+        tools/run_sharded_solve.py --backend gloo --share-gpu --problem poisson --nb 400
+Prints one JSON line from rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--problem", choices=["poisson", "modhelm", "stokes"], default="poisson")
+    ap.add_argument("--nb", type=int, default=400)
+    ap.add_argument("--M", type=int, default=16)
+    ap.add_argument("--k", type=float, default=10.0)
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (one-GPU rehearsal)")
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        kw = {} if a.backend == "gloo" else {"device_id": torch.device("cuda", local)}
+        dist.init_process_group(a.backend, **kw)
+    from ipde_amd.device import get_context
+    get_context(local)
+    t0 = time.perf_counter()
+    if a.problem == "poisson":
+        import interior_poisson
+        err, scale, solver, ue, T = interior_poisson.run(nb=a.nb, M=a.M)
+        res = {"error": err / scale}
+    elif a.problem == "modhelm":
+        import interior_modified_helmholtz as imh
+        err, scale, solver, ue, T = imh.run(nb=a.nb, M=a.M, helmholtz_k=a.k)
+        res = {"error": err / scale}
+    else:
+        import multi_stokes
+        ue, ve, pe, scale, T = multi_stokes.run(nb=a.nb, M=a.M)
+        res = {"error": max(ue, ve) / scale, "p_error": pe}
+    res.update({"problem": a.problem, "world": world, "wall_s": time.perf_counter() - t0,
+                "timings": {k: v for k, v in T.items() if isinstance(v, (int, float, list))}})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
