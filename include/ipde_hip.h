@@ -190,6 +190,34 @@ int ipde_fourier_multiply(ipde_fft_plan* plan, int loc, const double* f,
 int ipde_fd4(ipde_ctx* ctx, int loc, int64_t nx, int64_t ny, double h,
              int axis, int periodic_fix, const double* f, double* out);
 
+/* ------------------------------------------------------------------------- */
+/* Ewald-type grid evaluator, first half                       */
+/*
+ * ScalarGridBackend.ewald_local_freespace / ewald_local_periodic
+ * (ipde/grid_evaluators/scalar_grid_evaluator.py:131-178,189-229): for every source
+ * accumulate  q chi(r) G(r)  into `u_loc` and  q rho(r),
+ * rho = 2 chi' G' + (chi'' + chi'/r) G  (= L[(1-chi) G]),  into `op` on the
+ * (2 sw + 3)^2 grid points around it (r <= sw h).  kind 0: G = -log(r)/(2 pi)
+ * (laplace_grid_evaluator.py:8-12); kind 1: G = K0(k r)/(2 pi)
+ * (modified_helmholtz_grid_evaluator.py:8-9).  The second half of the evaluator,
+ * the grid convolution of `op`, is ipde_fourier_multiply with the truncated-kernel
+ * spectrum (scalar_grid_evaluator.py:283-307).
+ * mol_tab (HOST): chi, d chi/dr, d2 chi/dr2 as [3][ni][deg+1] monomial coefficients in
+ * the local variable t in [-1,1] of interval i of x = 1 - 2 r/(sw h) in [-1,1].
+ */
+typedef struct ipde_ewald ipde_ewald;
+int ipde_ewald_create(ipde_ctx* ctx, int kind, double k, double h, int sw,
+                      const double* mol_tab, int ni, int deg, ipde_ewald** out);
+int ipde_ewald_destroy(ipde_ewald* e);
+/* Grid point (ix, iy) = (x0 + ix h, y0 + iy h) is stored at
+ * [(ix + offx) * nby + (iy + offy)]; periodic != 0 wraps the indices modulo (nbx, nby),
+ * otherwise a stencil that leaves the array is an IPDE_ERR_INVALID.  `loc` describes
+ * sx, sy, q; u_loc and op are DEVICE arrays (nbx, nby) that are accumulated into (the
+ * caller zeroes them).  A grid point coinciding with a source is skipped. */
+int ipde_ewald_spread(ipde_ewald* e, int loc, int64_t ns, const double* sx, const double* sy,
+                      const double* q, double x0, double y0, int64_t nbx, int64_t nby,
+                      int64_t offx, int64_t offy, int periodic, double* u_loc, double* op);
+
 /* batched 1-D complex FFT along the last axis of a (batch, n) array:
    ipde.utilities.fft / ifft (ipde/utilities.py:5-12). direction -1 / +1 (scaled). */
 int ipde_fft1_c2c(ipde_ctx* ctx, int loc, int64_t batch, int64_t n, int direction,

@@ -28,6 +28,7 @@ SOURCES = [
     "layer_stokes.hip",
     "spectral.hip",
     "annular.hip",
+    "ewald.hip",
 ]
 
 CXXFLAGS = [

@@ -22,65 +22,12 @@
 //             (+2 for the DLP's a.d), 3 int32 ops, 5 ds_read_b128 (80-byte entry).
 // Roofline: fp64 VALU / LDS-read co-bound; algorithmic HBM traffic 24 B per target.
 #include "layer_pack.h"
-#include "bessel_coeffs.h"
+#include "bessel_device.h"
 #include <cmath>
 
 namespace {
 
 constexpr int MODE_SLP = 1, MODE_DLP = 2;
-
-// ---------------------------------------------------------------------------
-// reference-grade evaluation (no table): series for x <= 2, Chebyshev for x > 2
-__device__ __constant__ double c_i0s[IPDE_K_I0S_N];
-__device__ __constant__ double c_b0[IPDE_K_B0_N];
-__device__ __constant__ double c_j1[IPDE_K_J1_N];
-__device__ __constant__ double c_c1[IPDE_K_C1_N];
-__device__ __constant__ double c_g0[IPDE_K_G0_N];
-__device__ __constant__ double c_g1[IPDE_K_G1_N];
-
-template <int N>
-__device__ __forceinline__ double horner(const double* c, double y) {
-    double p = c[N - 1];
-#pragma unroll
-    for (int i = N - 2; i >= 0; --i) p = fma(p, y, c[i]);
-    return p;
-}
-
-template <int N>
-__device__ __forceinline__ double clenshaw(const double* c, double t) {
-    double b1 = 0.0, b2 = 0.0;
-    const double t2 = 2.0 * t;
-#pragma unroll
-    for (int i = N - 1; i >= 1; --i) {
-        double b0 = fma(t2, b1, c[i]) - b2;
-        b2 = b1;
-        b1 = b0;
-    }
-    return fma(t, b1, c[0]) - b2;
-}
-
-// K0(x) and K1(x)/x for y = x^2 > 0:
-//   x <= 2:  K0 = -log(x) I0s(y) + B0(y),  K1/x = [1 + y (log(x) J1(y) + C1(y))]/y
-//   x  > 2:  K0 = exp(-x)/sqrt(x) G0(t),   K1/x = exp(-x)/sqrt(x) G1(t)/x,  t = 4/x - 1
-template <int MODE>
-__device__ __forceinline__ void bessel_k01(double y, double& k0, double& k1x) {
-    if (y <= IPDE_BESSEL_XS * IPDE_BESSEL_XS) {
-        double lx = 0.5 * log(y);
-        if (MODE & MODE_SLP)
-            k0 = fma(-lx, horner<IPDE_K_I0S_N>(c_i0s, y), horner<IPDE_K_B0_N>(c_b0, y));
-        if (MODE & MODE_DLP) {
-            double in = fma(lx, horner<IPDE_K_J1_N>(c_j1, y), horner<IPDE_K_C1_N>(c_c1, y));
-            k1x = fma(y, in, 1.0) / y;
-        }
-    } else {
-        double x = sqrt(y);
-        double rx = 1.0 / x;
-        double t = fma(2.0 * IPDE_BESSEL_XS, rx, -1.0);
-        double ef = exp(-x) * sqrt(rx);
-        if (MODE & MODE_SLP) k0 = ef * clenshaw<IPDE_K_G0_N>(c_g0, t);
-        if (MODE & MODE_DLP) k1x = ef * clenshaw<IPDE_K_G1_N>(c_g1, t) * rx;
-    }
-}
 
 template <int MODE, bool SKIP, int R>
 __device__ __forceinline__ void modhelm_generic_loop(const double* __restrict__ rec, int j0, int j1,
@@ -331,12 +278,7 @@ void fit_interval(long double c, long double a, F f, double* coef /*8*/) {
 }  // namespace
 
 int ipde_build_k_table(ipde_ctx* ctx) {
-    IPDE_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_i0s), ipde_k_i0s, sizeof(ipde_k_i0s)));
-    IPDE_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_b0), ipde_k_b0, sizeof(ipde_k_b0)));
-    IPDE_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_j1), ipde_k_j1, sizeof(ipde_k_j1)));
-    IPDE_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_c1), ipde_k_c1, sizeof(ipde_k_c1)));
-    IPDE_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_g0), ipde_k_g0, sizeof(ipde_k_g0)));
-    IPDE_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_g1), ipde_k_g1, sizeof(ipde_k_g1)));
+    IPDE_HIP_CHECK(ctx, ipde_bessel_upload());
     // piecewise tables of F0(y) = K0(sqrt y), F1(y) = K1(sqrt y)/sqrt y
     std::vector<double> h((size_t)2 * KT_NKEYS * KT_ENTRY, 0.0);
     const uint64_t key_lo = (uint64_t)((1023 + KT_EXP_LO) << KT_B);

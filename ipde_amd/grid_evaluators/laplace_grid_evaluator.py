@@ -14,8 +14,8 @@ def gf(r):
 
 
 class LaplaceGridBackend(ScalarGridBackend):
-    def __init__(self, h, spread_width, funcgen_tol=1e-10, inline_core=True):
-        super().__init__(h, spread_width, {}, funcgen_tol, inline_core)
+    def __init__(self, h, spread_width, funcgen_tol=1e-10, inline_core=True, method='dense'):
+        super().__init__(h, spread_width, {}, funcgen_tol, inline_core, method)
 
 
 class LaplaceFreespaceGridEvaluator(ScalarFreespaceGridEvaluator):

@@ -7,14 +7,16 @@ from ..layer_potentials import modified_helmholtz_apply
 
 
 class ModifiedHelmholtzGridBackend(ScalarGridBackend):
-    def __init__(self, h, spread_width, helmholtz_k, funcgen_tol=1e-10, inline_core=True):
-        super().__init__(h, spread_width, {'helmholtz_k': helmholtz_k}, funcgen_tol, inline_core)
+    def __init__(self, h, spread_width, helmholtz_k, funcgen_tol=1e-10, inline_core=True,
+                 method='dense'):
+        super().__init__(h, spread_width, {'helmholtz_k': helmholtz_k}, funcgen_tol, inline_core,
+                         method)
 
 
 class ModifiedHelmholtzFreespaceGridEvaluator(ScalarFreespaceGridEvaluator):
     def __init__(self, backend, xv, yv):
-        super().__init__(backend, xv, yv)
         self.k = backend.kernel_kwargs['helmholtz_k']
+        super().__init__(backend, xv, yv)
 
     def _apply(self, sx, sy, ch):
         return modified_helmholtz_apply(sx, sy, self.targets.x, self.targets.y, self.k, w_sigma=ch)

@@ -61,7 +61,7 @@ class ModifiedHelmholtzSolver(ScalarSolver):
 
             def evaluator(ch):
                 return self.ewald_evaluator(self.grid_sources.get_stacked_boundary(),
-                                            ch * self.grid_sources.weights)
+                                            ch * self.grid_sources.weights, device_result=True)
             self.Grid_Evaluator = evaluator
             self.split_grid_evaluation = True
         else:

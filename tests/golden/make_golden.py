@@ -270,6 +270,40 @@ def golden_slepian():
     print("slepian_values.npz", len(out))
 
 
+def golden_grid_evaluator_kernels():
+    """gf / fs / ifs / trunc_sgf of the two kernel modules (laplace_grid_evaluator.py:8-33,
+    modified_helmholtz_grid_evaluator.py:8-17): pure numpy/scipy functions; the modules
+    import once `function_generator` (used only inside the backend constructor) has a
+    stand-in."""
+    fg = types.ModuleType("function_generator")
+    fg.FunctionGenerator = type("FunctionGenerator", (), {})
+    sys.modules.setdefault("function_generator", fg)
+    import ipde.grid_evaluators.laplace_grid_evaluator as L
+    import ipde.grid_evaluators.modified_helmholtz_grid_evaluator as M
+    rng = np.random.default_rng(11)
+    r = np.concatenate([10.0 ** rng.uniform(-6, 1, 200), [1e-3, 1.0, 7.5]])
+    kv = np.fft.fftfreq(24, 0.05 / (2 * np.pi))
+    kx, ky = np.meshgrid(kv, kv, indexing='ij')
+    kk = np.hypot(kx, ky)
+    out = {"r": r, "kx": kx, "ky": ky}
+    out["laplace_gf"] = np.array([L.gf(x) for x in r])
+    out["laplace_fs"] = L.fs(kx, ky)
+    out["laplace_ifs"] = L.ifs(kx.copy(), ky.copy())
+    for i, Lt in enumerate((1.0, 7.5, 0.3)):
+        out["L_%d" % i] = np.array(Lt)
+        out["laplace_tsgf_%d" % i] = L.trunc_sgf(kk, Lt)
+        out["laplace_tsgf_scalar_%d" % i] = np.array([L.trunc_sgf(0.0, Lt), L.trunc_sgf(2.5, Lt)])
+    for j, hk in enumerate((1.0, 10.0)):
+        out["hk_%d" % j] = np.array(hk)
+        out["modhelm_gf_%d" % j] = M.gf(r, helmholtz_k=hk)
+        out["modhelm_fs_%d" % j] = M.fs(kx, ky, helmholtz_k=hk)
+        # M.ifs cannot be called: it drops helmholtz_k (`1.0/fs(kx, ky)`, :12-13) -> TypeError
+        for i, Lt in enumerate((1.0, 7.5, 0.3)):
+            out["modhelm_tsgf_%d_%d" % (j, i)] = M.trunc_sgf(kk, Lt, helmholtz_k=hk)
+    np.savez(os.path.join(OUT, "grid_evaluator_kernels.npz"), **out)
+    print("grid_evaluator_kernels.npz", len(out))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be regenerated where it is")
@@ -279,3 +313,4 @@ if __name__ == "__main__":
     golden_annular_scalar()
     golden_annular_stokes()
     golden_slepian()
+    golden_grid_evaluator_kernels()
