@@ -28,7 +28,8 @@ from ipde_amd.qfs import QFS_Evaluator  # noqa: E402
 from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver  # noqa: E402
 
 
-def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False, timings=None):
+def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False, timings=None,
+        grid_backend=None):
     T = {} if timings is None else timings
     t0 = time.perf_counter()
     MOL = SlepianMollifier(1.5 * M)
@@ -47,7 +48,7 @@ def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False
     ua.define_via_function(solution_func)
     bc = BoundaryFunction(ebdyc)
     bc.define_via_function(solution_func)
-    solver = ModifiedHelmholtzSolver(ebdyc, k=helmholtz_k)
+    solver = ModifiedHelmholtzSolver(ebdyc, k=helmholtz_k, grid_backend=grid_backend)
     T['setup_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     ue = solver(f, tol=solver_tol, verbose=verbose, maxiter=100, restart=20)

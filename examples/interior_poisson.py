@@ -39,7 +39,7 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
     ebdy = EmbeddedBoundary(bdy, True, M, bh / grid_upsample, pad_zone=0, heaviside=MOL.step,
                             qfs_tolerance=1e-14, coordinate_tolerance=1e-14)
     ebdyc = EmbeddedBoundaryCollection([ebdy, ])
-    grid = ebdyc.generate_grid(bh / grid_upsample, Ns=Ns, force_square=grid_backend == 'ewald')
+    grid = ebdyc.generate_grid(bh / grid_upsample, Ns=Ns)
     ebdyc.ready_bump(MOL.bump, (grid.x_bounds[1] - ebdy.radial_width, grid.y_bounds[1] - ebdy.radial_width),
                      ebdyc[0].radial_width)
     if problem == 'easy':
@@ -57,10 +57,7 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
     ua.define_via_function(solution_func)
     bc = BoundaryFunction(ebdyc)
     bc.define_via_function(solution_func)
-    if grid_backend == 'ewald':
-        # the reference's Ewald-split grid evaluator (needs a square grid) instead of the dense sum
-        from ipde_amd.grid_evaluators.laplace_grid_evaluator import LaplaceGridBackend
-        grid_backend = LaplaceGridBackend(grid.xh, 24, method='ewald')
+    # grid_backend='ewald': the Ewald-split grid evaluator instead of the dense sum
     solver = PoissonSolver(ebdyc, solver_type=solver_type, grid_backend=grid_backend)
     T['setup_s'] = time.perf_counter() - t0
 

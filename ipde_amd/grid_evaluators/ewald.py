@@ -78,14 +78,17 @@ def fast_fft_size(n):
         m += 2
 
 
-def _trunc_sgf_quadrant(kq, L, helmholtz_k):
-    """Truncated spectral Green's function on the quadrant kq x kq of wavenumbers (host
-    scipy J0/J1 — torch.special.bessel_j0/j1 are only good to 4e-7 — on the i <= j
-    octant, mirrored)."""
+def _trunc_sgf_quadrant(kqx, kqy, L, helmholtz_k):
+    """Truncated spectral Green's function on the quadrant kqx x kqy of wavenumbers (host
+    scipy J0/J1 — torch.special.bessel_j0/j1 are only good to 4e-7; for a square grid only
+    the i <= j octant is evaluated and mirrored)."""
     from scipy.special import j0, j1
-    m = kq.shape[0]
-    iu, ju = np.triu_indices(m)
-    kk = np.hypot(kq[iu], kq[ju])
+    square = kqx.shape == kqy.shape and np.array_equal(kqx, kqy)
+    if square:
+        iu, ju = np.triu_indices(kqx.shape[0])
+        kk = np.hypot(kqx[iu], kqy[ju])
+    else:
+        kk = np.hypot(kqx[:, None], kqy[None, :]).ravel()
     if helmholtz_k is None:
         ks = np.where(kk == 0, 1.0, kk)
         ts = (1.0 - j0(L * kk)) / ks ** 2 - L * np.log(L) * j1(L * kk) / ks
@@ -94,33 +97,36 @@ def _trunc_sgf_quadrant(kq, L, helmholtz_k):
         kap = float(helmholtz_k)
         ts = (1.0 + L * kk * j1(L * kk) * k0(L * kap) - L * kap * j0(L * kk) * k1(L * kap)) \
             / (kk ** 2 + kap ** 2)
-    out = np.empty((m, m))
+    if not square:
+        return ts.reshape(kqx.shape[0], kqy.shape[0])
+    out = np.empty((kqx.shape[0], kqx.shape[0]))
     out[iu, ju] = ts
     out[ju, iu] = ts
     return out
 
 
-def truncated_operator(n_big, h, L, helmholtz_k, device):
-    """TH (n_big, n_big) complex, kernel origin at index (0,0): ifft2(fft2(f) TH) is the
+def truncated_operator(nbx, nby, h, L, helmholtz_k, device):
+    """TH (nbx, nby) complex, kernel origin at index (0,0): ifft2(fft2(f) TH) is the
     free-space convolution with G for f supported in half the box.  Truncated spectral
     Green's functions of laplace_grid_evaluator.py:21-33 /
     modified_helmholtz_grid_evaluator.py:14-17 sampled on the 2x finer spectral grid,
-    transformed, cropped to the n_big samples nearest the origin (reference :283-293)."""
+    transformed, cropped to the samples nearest the origin (reference :283-293)."""
     import torch
-    N = 2 * n_big
-    # one quadrant (0..N/2)^2 of |k| is enough: the function is even in both indices
-    kq = np.abs(np.fft.fftfreq(N, h / (2 * np.pi))[:N // 2 + 1])
-    ts = torch.as_tensor(_trunc_sgf_quadrant(kq, L, helmholtz_k), device=device)
-    full = torch.empty((N, N), dtype=torch.float64, device=device)
-    full[:N // 2 + 1, :N // 2 + 1] = ts
-    full[N // 2 + 1:, :N // 2 + 1] = torch.flip(ts[1:N // 2, :], dims=(0,))
-    full[:, N // 2 + 1:] = torch.flip(full[:, 1:N // 2], dims=(1,))
+    Nx, Ny = 2 * nbx, 2 * nby
+    # one quadrant of |k| is enough: the function is even in both indices
+    kqx = np.abs(np.fft.fftfreq(Nx, h / (2 * np.pi))[:Nx // 2 + 1])
+    kqy = np.abs(np.fft.fftfreq(Ny, h / (2 * np.pi))[:Ny // 2 + 1])
+    ts = torch.as_tensor(_trunc_sgf_quadrant(kqx, kqy, L, helmholtz_k), device=device)
+    full = torch.empty((Nx, Ny), dtype=torch.float64, device=device)
+    full[:Nx // 2 + 1, :Ny // 2 + 1] = ts
+    full[Nx // 2 + 1:, :Ny // 2 + 1] = torch.flip(ts[1:Nx // 2, :], dims=(0,))
+    full[:, Ny // 2 + 1:] = torch.flip(full[:, 1:Ny // 2], dims=(1,))
     del ts
     T = torch.fft.ifft2(full).real          # kernel samples * h^2, origin at (0,0)
     del full
-    idx = torch.cat([torch.arange(0, n_big // 2, device=device),
-                     torch.arange(N - n_big // 2, N, device=device)])
-    Tc = T[idx][:, idx].contiguous()
+    ix = torch.cat([torch.arange(0, nbx // 2, device=device), torch.arange(Nx - nbx // 2, Nx, device=device)])
+    iy = torch.cat([torch.arange(0, nby // 2, device=device), torch.arange(Ny - nby // 2, Ny, device=device)])
+    Tc = T[ix][:, iy].contiguous()
     del T
     return torch.fft.fft2(Tc)
 
@@ -160,32 +166,35 @@ class EwaldCore(object):
 
 
 class FreespaceEwald(object):
-    """(n, n) grid of sum_j q_j G(|x - s_j|): spread, one padded convolution, crop."""
+    """(nx, ny) grid of sum_j q_j G(|x - s_j|): spread, one padded convolution, crop.
+    (The reference's class insists on a square grid, :234-237; nothing here needs it.)"""
 
     def __init__(self, core, xv, yv):
         import torch
         from ..spectral import get_plan
         self.core = core
-        self.n = int(len(xv))
+        self.nx, self.ny = int(len(xv)), int(len(yv))
         self.x0, self.y0 = float(xv[0]), float(yv[0])
         h, sw = core.h, core.sw
-        self.expand_n = self.n + 2 * sw
-        self.big_n = fast_fft_size(2 * self.expand_n)
+        self.expand_n = max(self.nx, self.ny) + 2 * sw
+        self.big_nx = fast_fft_size(2 * (self.nx + 2 * sw))
+        self.big_ny = fast_fft_size(2 * (self.ny + 2 * sw))
+        self.big_n = max(self.big_nx, self.big_ny)
         self.off = sw
         dev = core.ctx.torch_device()
-        drange = self.n * h
-        self.TH = truncated_operator(self.big_n, h, 2.5 * drange, core.helmholtz_k, dev)
-        self.plan = get_plan(self.big_n, self.big_n, h, h)
-        self.big_op = torch.zeros((self.big_n, self.big_n), dtype=torch.float64, device=dev)
-        self.big_u = torch.zeros((self.big_n, self.big_n), dtype=torch.float64, device=dev)
+        drange = max(self.nx, self.ny) * h
+        self.TH = truncated_operator(self.big_nx, self.big_ny, h, 2.5 * drange, core.helmholtz_k, dev)
+        self.plan = get_plan(self.big_nx, self.big_ny, h, h)
+        self.big_op = torch.zeros((self.big_nx, self.big_ny), dtype=torch.float64, device=dev)
+        self.big_u = torch.zeros((self.big_nx, self.big_ny), dtype=torch.float64, device=dev)
 
     def __call__(self, sx, sy, q):
         self.big_op.zero_()
         self.big_u.zero_()
         self.core.spread(sx, sy, q, self.x0, self.y0, self.big_u, self.big_op, self.off, self.off, False)
         far = self.plan.fourier_multiply(self.big_op, self.TH)
-        o, n = self.off, self.n
-        return (self.big_u[o:o + n, o:o + n] + far[o:o + n, o:o + n]).contiguous()
+        o, nx, ny = self.off, self.nx, self.ny
+        return (self.big_u[o:o + nx, o:o + ny] + far[o:o + nx, o:o + ny]).contiguous()
 
 
 class PeriodicEwald(object):

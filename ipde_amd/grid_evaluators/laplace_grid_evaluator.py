@@ -19,8 +19,8 @@ class LaplaceGridBackend(ScalarGridBackend):
 
 
 class LaplaceFreespaceGridEvaluator(ScalarFreespaceGridEvaluator):
-    def __init__(self, backend, xv, yv):
-        super().__init__(backend, xv, yv)
+    def __init__(self, backend, xv, yv, allow_rectangular=False):
+        super().__init__(backend, xv, yv, allow_rectangular)
 
     def _apply(self, sx, sy, ch):
         return laplace_apply(sx, sy, self.targets.x, self.targets.y, w_sigma=ch)

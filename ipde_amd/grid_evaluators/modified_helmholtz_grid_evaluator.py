@@ -14,9 +14,9 @@ class ModifiedHelmholtzGridBackend(ScalarGridBackend):
 
 
 class ModifiedHelmholtzFreespaceGridEvaluator(ScalarFreespaceGridEvaluator):
-    def __init__(self, backend, xv, yv):
+    def __init__(self, backend, xv, yv, allow_rectangular=False):
         self.k = backend.kernel_kwargs['helmholtz_k']
-        super().__init__(backend, xv, yv)
+        super().__init__(backend, xv, yv, allow_rectangular)
 
     def _apply(self, sx, sy, ch):
         return modified_helmholtz_apply(sx, sy, self.targets.x, self.targets.y, self.k, w_sigma=ch)

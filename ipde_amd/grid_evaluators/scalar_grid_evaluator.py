@@ -69,11 +69,14 @@ class ScalarFreespaceGridEvaluator(object):
     weight-multiplied (reference :299-307; callers pass ch*weights,
     multi_boundary/poisson.py:44-47)."""
 
-    def __init__(self, backend, xv, yv):
+    def __init__(self, backend, xv, yv, allow_rectangular=False):
         self.backend = backend
         self.xv = np.asarray(xv, dtype=float)
         self.yv = np.asarray(yv, dtype=float)
-        self.backend.check_freespace(self.xv, self.yv)
+        if self.backend.method == 'ewald' and allow_rectangular:
+            self.backend.check_either(self.xv, self.yv)
+        else:
+            self.backend.check_freespace(self.xv, self.yv)
         self.backend.initialize_freespace()
         self.h = self.backend.h
         self.n = self.xv.size
@@ -97,7 +100,7 @@ class ScalarFreespaceGridEvaluator(object):
         if self._ewald is not None:
             out = self._ewald(src[0], src[1], ch)
         else:
-            out = self._apply(src[0], src[1], ch).view(self.n, self.n)
+            out = self._apply(src[0], src[1], ch).view(self.xv.size, self.yv.size)
         return out if device_result else out.cpu().numpy()
 
 

@@ -51,11 +51,14 @@ class ModifiedHelmholtzSolver(ScalarSolver):
         self.ihelm = 1.0 / self.helm
 
     def _define_grid_evaluator(self):
+        if self.grid_backend == 'ewald':
+            self.grid_backend = ModifiedHelmholtzGridBackend(self.grid.xh, 24, self.k, method='ewald')
         if type(self.grid_backend) in [ModifiedHelmholtzGridBackend,
                                        ModifiedHelmholtzFreespaceGridEvaluator]:
             if type(self.grid_backend) == ModifiedHelmholtzGridBackend:
                 self.ewald_evaluator = ModifiedHelmholtzFreespaceGridEvaluator(
-                    self.grid_backend, self.grid.xv, self.grid.yv)
+                    self.grid_backend, self.grid.xv, self.grid.yv,
+                    allow_rectangular=self.grid_backend.method == 'ewald')
             else:
                 self.ewald_evaluator = self.grid_backend
 

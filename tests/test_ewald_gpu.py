@@ -98,3 +98,34 @@ def test_poisson_solver_with_ewald_backend():
     err, scale, solver, ue, T = interior_poisson.run(nb=600, M=16, grid_backend='ewald')
     assert solver.split_grid_evaluation
     assert err / scale < 1e-10
+
+
+def test_modhelm_solver_with_ewald_backend_rectangular_grid():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import interior_modified_helmholtz as imh
+    err, scale, solver, ue, T = imh.run(nb=800, M=16, helmholtz_k=10.0, grid_backend='ewald')
+    assert solver.split_grid_evaluation
+    err_d, scale, solver_d, ue_d, T = imh.run(nb=800, M=16, helmholtz_k=10.0)
+    assert not solver_d.split_grid_evaluation
+    assert np.abs(np.asarray(ue) - np.asarray(ue_d)).max() < 1e-11 * scale
+    assert err / scale < 1e-11
+
+
+def test_rectangular_freespace_ewald_matches_dense():
+    from ipde_amd.grid_evaluators.laplace_grid_evaluator import (LaplaceGridBackend,
+                                                                 LaplaceFreespaceGridEvaluator)
+    from ipde_amd.layer_potentials import laplace_apply
+    nx, ny, sw = 200, 312, 24
+    h = 0.01
+    xv, yv = -1.0 + h * np.arange(nx), -1.5 + h * np.arange(ny)
+    rng = np.random.default_rng(4)
+    sx, sy, q = rng.uniform(-0.9, 0.9, 50), rng.uniform(-1.4, 1.4, 50), rng.standard_normal(50)
+    ev = LaplaceFreespaceGridEvaluator(LaplaceGridBackend(h, sw, method='ewald'), xv, yv,
+                                       allow_rectangular=True)
+    got = ev(np.vstack([sx, sy]), q)
+    X, Y = np.meshgrid(xv, yv, indexing='ij')
+    ref = laplace_apply(sx, sy, X.ravel(), Y.ravel(), w_sigma=q, generic_math=True).reshape(nx, ny)
+    assert got.shape == (nx, ny)
+    assert np.abs(got - ref).max() < 2e-13 * np.abs(ref).max()
