@@ -22,7 +22,7 @@ from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
 from ipde_amd.layer_potentials import Laplace_Layer_Apply, DeviceTargets  # noqa: E402
 from ipde_amd.pybie2d_compat import (star, Global_Smooth_Boundary as GSB,  # noqa: E402
                                      Laplace_Layer_Singular_Form, Laplace_Layer_Form)
-from ipde_amd.qfs import QFS_Evaluator  # noqa: E402
+from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.poisson import PoissonSolver  # noqa: E402
 
 Singular_DLP = lambda src, _: Laplace_Layer_Singular_Form(src, ifdipole=True) - 0.5 * np.eye(src.N)
@@ -67,16 +67,15 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
 
     # homogeneous correction: double-layer density on the boundary, evaluated through QFS
     t0 = time.perf_counter()
-    A = Laplace_Layer_Singular_Form(bdy, ifdipole=True) - 0.5 * np.eye(bdy.N)
-    qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [Singular_DLP, ], Naive_SLP, on_surface=True, form_b2c=False)
-    import scipy.linalg
-    Alu = scipy.linalg.lu_factor(A)
+    A = Singular_DLP(bdy, bdy)
+    qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [lambda src, trg: A, ], Naive_SLP, on_surface=True, form_b2c=False)
+    Alu = DenseSolver(A)
     targets = DeviceTargets(ebdyc.grid_and_radial_pts)
     T['homogeneous_form_s'] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     bv = solver.get_boundary_values(ue.get_radial_value_list())
-    tau = scipy.linalg.lu_solve(Alu, np.concatenate((bc - bv).bdy_value_list))
+    tau = Alu.solve(np.concatenate((bc - bv).bdy_value_list))
     sigma = qfs([tau, ])
     out = Laplace_Layer_Apply(ebdyc.bdy_inward_sources, targets, charge=sigma).cpu().numpy()
     gslp, rslpl = ebdyc.divide_grid_and_radial(out)

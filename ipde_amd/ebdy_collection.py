@@ -8,6 +8,7 @@ interpolations and derivatives evaluate on the device.
 """
 import numpy as np
 
+from .device import prewarm
 from .embedded_function import EmbeddedFunction
 from .near import grid_inside_curve
 from .pybie2d_compat import Grid, PointSet
@@ -76,6 +77,7 @@ class EmbeddedBoundaryCollection(object):
     # -- registration (reference :352-526) ------------------------------------------
     def register_grid(self, grid, danger_zone_distance=None, verbose=False):
         self.grid = grid
+        prewarm(grid.shape, (grid.xh, grid.yh))   # rocFFT plans compile while the host classifies points
         phys = np.zeros(grid.shape, dtype=bool) if self.ebdys[0].interior \
             else np.ones(grid.shape, dtype=bool)
         for ebdy in self:
@@ -184,7 +186,10 @@ class EmbeddedBoundaryCollection(object):
                 raise Exception('if ebdyc has no bump_location, need to give bump_loc')
             bump_loc = self.bump_location
         grr = np.hypot(self.grid.xg - bump_loc[0], self.grid.yg - bump_loc[1])
-        bumpy = bump(affine_transformation(grr, 0, bump_width, 0, 1))
+        # the bump is supported in grr < bump_width: evaluate its series only there
+        near = grr < bump_width
+        bumpy = np.zeros(self.grid.shape)
+        bumpy[near] = bump(affine_transformation(grr[near], 0, bump_width, 0, 1))
         self.bumpy = bumpy / self.grid_integral(bumpy)
         self.bumpy_readied = True
 

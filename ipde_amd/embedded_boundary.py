@@ -8,8 +8,9 @@ radial -> grid interpolation evaluates on the device (ipde_amd.interp).
 """
 import numpy as np
 
+from .device import prewarm
 from .heavisides import SlepianMollifier
-from .near import local_coordinates
+from .near import local_coordinates, band_mask
 from .pybie2d_compat import Global_Smooth_Boundary as GSB, PointSet
 from .qfs import QFS_Boundary
 from .utilities import affine_transformation, get_chebyshev_nodes
@@ -21,6 +22,7 @@ def setit(n, dictionary, default):
 
 class EmbeddedBoundary(object):
     def __init__(self, bdy, interior, M, h, **kwargs):
+        prewarm()       # library loads overlap the host geometry set-up
         """bdy: Global_Smooth_Boundary; interior: bool; M: radial modes; h: radial grid
         spacing (radial_width = M*h).  kwargs as the reference (:106-112): pad_zone,
         heaviside, qfs_tolerance, coordinate_tolerance, ... (unknown ones are kept)."""
@@ -107,12 +109,10 @@ class EmbeddedBoundary(object):
         cut-off functions.  Returns (r, t, found) on the whole grid for the collection's
         inside/outside classification."""
         self.grid = grid
-        # candidates: bounding box of the curve +/- width
-        pad = 1.6 * self.radial_width + 3 * max(grid.xh, grid.yh)
-        ix = np.where((grid.xv >= self.bdy.x.min() - pad) & (grid.xv <= self.bdy.x.max() + pad))[0]
-        iy = np.where((grid.yv >= self.bdy.y.min() - pad) & (grid.yv <= self.bdy.y.max() + pad))[0]
-        IX, IY = np.meshgrid(ix, iy, indexing='ij')
-        IX, IY = IX.ravel(), IY.ravel()
+        # candidates: the band of grid points within reach of the curve (local_coordinates
+        # keeps those within 1.5 width + 2 max_h of it)
+        reach = 1.5 * self.radial_width + 2 * self.bdy.max_h + max(grid.xh, grid.yh)
+        IX, IY = np.nonzero(band_mask(self.bdy, grid, reach))
         r, t, found = local_coordinates(self.bdy, grid.xv[IX], grid.yv[IY], self.radial_width,
                                         tol=self.coordinate_tolerance)
         self._near = (IX[found], IY[found], r[found], t[found])

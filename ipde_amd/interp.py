@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from .device import get_context
+from .spectral import fft1
 
 
 def _dev(a, ctx, dtype):
@@ -62,7 +63,9 @@ def chebyshev_fourier_eval(fr, xi, t, ctx=None, chunk=16384):
     xc = np.polynomial.chebyshev.chebgauss(M)[0][::-1].copy()
     VI = np.linalg.inv(np.polynomial.chebyshev.chebvander(xc, M - 1))
     c = _dev(VI, ctx, torch.float64) @ fr                         # (M, N)
-    ch = torch.fft.fft(c, dim=1) / N                              # (M, N) complex
+    # the library's batched 1-D plan (shared with the annular solver: same length, no
+    # second run-time kernel compilation as a first torch.fft call would cost)
+    ch = fft1(c, -1, ctx) / N                                     # (M, N) complex
     k = torch.fft.fftfreq(N, 1.0 / N, dtype=torch.float64, device=fr.device)
     P = t.shape[0]
     out = torch.empty(P, dtype=torch.float64, device=fr.device)

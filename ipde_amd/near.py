@@ -63,7 +63,7 @@ class CurveEvaluator(object):
         return out[0], out[1], out[2]
 
 
-def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30):
+def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30, on_device=False):
     """(r, t, found) of the points (px, py); found = within ~1.5*width of the curve and
     Newton converged.  r is the signed distance along the outward normal."""
     px = np.asarray(px, dtype=float)
@@ -79,6 +79,15 @@ def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30):
         return r, t, found
     p = px[found] + 1j * py[found]
     tt = j[found] * ev.hf
+    # on_device: the same iteration with torch on the GPU.  Off by default: during set-up
+    # the GPU runtime is busy loading libraries in the prewarm threads (device.prewarm) and
+    # first-use kernel loads serialise behind them; ~3e5 points take 0.7 s in numpy.
+    dev = _torch_device() if on_device else None
+    if dev is not None:
+        rr, tf = _newton_device(ev, p, tt, width, tol, maxiter, dev)
+        r[found] = rr
+        t[found] = tf
+        return r, t, found
     for _ in range(maxiter):
         X, Xp, Xpp = ev(tt)
         d = p - X
@@ -99,6 +108,78 @@ def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30):
     r[found] = d.real * nx + d.imag * ny
     t[found] = np.mod(tt, 2 * np.pi)
     return r, t, found
+
+
+def _torch_device():
+    try:
+        import torch
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    except Exception:
+        return None
+
+
+def _newton_device(ev, p, tt, width, tol, maxiter, dev):
+    """The Newton iteration of `local_coordinates` with the arrays on the GPU (torch,
+    fp64): same stencil interpolation, same guards; ~3e5 points x ~6 iterations."""
+    import torch
+    f = torch.as_tensor(ev.f, device=dev)                       # (3, Nf) complex
+    w = torch.as_tensor(ev.w, device=dev)
+    ar = torch.arange(_NL, device=dev)
+    arf = ar.to(torch.float64)
+    p = torch.as_tensor(p, device=dev)
+    tt = torch.as_tensor(tt, device=dev)
+
+    def curve(t):
+        s = t / ev.hf
+        i0 = torch.floor(s).to(torch.int64) - (_NL // 2 - 1)
+        u = s - i0.to(torch.float64)
+        idx = torch.remainder(i0[:, None] + ar[None, :], ev.Nf)
+        d = u[:, None] - arf[None, :]
+        exact = d.abs() < 1e-14
+        d = torch.where(exact, torch.ones_like(d), d)
+        wt = w[None, :] / d
+        hit = exact.any(dim=1)
+        wt = torch.where(hit[:, None], exact.to(torch.float64), wt)
+        wt = wt / wt.sum(dim=1, keepdim=True)
+        vals = f[:, idx]                                        # (3, P, _NL)
+        out = (vals * wt[None].to(vals.dtype)).sum(dim=2)
+        return out[0], out[1], out[2]
+
+    for _ in range(maxiter):
+        X, Xp, Xpp = curve(tt)
+        d = p - X
+        sp2 = Xp.real ** 2 + Xp.imag ** 2
+        g = d.real * Xp.real + d.imag * Xp.imag
+        gp = -sp2 + d.real * Xpp.real + d.imag * Xpp.imag
+        gp = torch.where(gp < -1e-300, gp, -sp2)
+        dt = -g / gp
+        lim = 0.25 * width / torch.sqrt(sp2) + ev.hf
+        dt = torch.maximum(torch.minimum(dt, lim), -lim)
+        tt = tt + dt
+        if float(dt.abs().max()) < tol:
+            break
+    X, Xp, _ = curve(tt)
+    sp = Xp.abs()
+    nx, ny = Xp.imag / sp, -Xp.real / sp
+    d = p - X
+    r = d.real * nx + d.imag * ny
+    return r.cpu().numpy(), torch.remainder(tt, 2 * np.pi).cpu().numpy()
+
+
+def band_mask(bdy, grid, reach):
+    """Boolean grid mask of the points within `reach` (+ one node spacing) of the curve:
+    squares painted around every boundary node.  O(N (reach/h)^2) slice assignments —
+    the pre-filter that keeps the k-d tree query and the Newton iteration off the bulk
+    of the grid."""
+    mask = np.zeros(grid.shape, dtype=bool)
+    rad = reach + bdy.max_h
+    mx, my = int(np.ceil(rad / grid.xh)) + 1, int(np.ceil(rad / grid.yh)) + 1
+    cx = np.floor((bdy.x - grid.xv[0]) / grid.xh).astype(int)
+    cy = np.floor((bdy.y - grid.yv[0]) / grid.yh).astype(int)
+    Nx, Ny = grid.shape
+    for a, b in zip(cx, cy):
+        mask[max(a - mx, 0):max(min(a + mx + 2, Nx), 0), max(b - my, 0):max(min(b + my + 2, Ny), 0)] = True
+    return mask
 
 
 def points_inside_curve(bdy, px, py, r=None, found=None):

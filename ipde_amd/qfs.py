@@ -63,8 +63,8 @@ class _QFS(object):
         A = self._s2b(self.source, bdy)                              # (N, Ns)
         self._nrow = A.shape[0]
         jump = -0.5 if interior else 0.5
-        S = self._singular(bdy, True, False) if slp else None
-        D = self._singular(bdy, False, True) if dlp else None
+        S = self._cached_singular(bdy, True, False) if slp else None
+        D = self._cached_singular(bdy, False, True) if dlp else None
         if dlp:
             D = D + jump * np.eye(D.shape[0])
         self._dev = _device() if self.DEVICE_SOLVE else None
@@ -88,6 +88,15 @@ class _QFS(object):
                 keep = sv > sv[0] * 1e-14
                 self._pinv = (Vt[keep].T / sv[keep]) @ U[:, keep].T
                 self._solve_host = lambda u: self._pinv @ u
+
+    def _cached_singular(self, bdy, c, d):
+        """the on-surface forms depend on the curve only: the two QFS objects of an
+        interface (grid side / radial side) share them"""
+        cache = bdy.__dict__.setdefault('_singular_forms', {})
+        key = (type(self).__name__, getattr(self, 'k', None), c, d)
+        if key not in cache:
+            cache[key] = self._singular(bdy, c, d)
+        return cache[key]
 
     def _solve(self, u):
         if self._dev is None:
@@ -135,6 +144,28 @@ def _refined_lu_solve(A, LU, piv, b, steps=2):
         r = b - A @ x
         x = x + torch.linalg.lu_solve(LU, piv, r[:, None])[:, 0]
     return x
+
+
+class DenseSolver(object):
+    """LU of a well-conditioned dense system (the second-kind boundary integral
+    equations of the example scripts) — on the GPU through torch with one refinement
+    step, host LAPACK without a GPU.  solve(b) -> numpy."""
+
+    def __init__(self, A):
+        self._dev = _device()
+        if self._dev is not None:
+            import torch
+            self._A = torch.as_tensor(np.ascontiguousarray(A), device=self._dev)
+            self._LU, self._piv = torch.linalg.lu_factor(self._A)
+        else:
+            self._lu = scipy.linalg.lu_factor(A)
+
+    def solve(self, b):
+        if self._dev is None:
+            return scipy.linalg.lu_solve(self._lu, np.asarray(b, dtype=float))
+        import torch
+        bd = torch.as_tensor(np.ascontiguousarray(b, dtype=float), device=self._dev)
+        return _refined_lu_solve(self._A, self._LU, self._piv, bd, steps=1).cpu().numpy()
 
 
 def _device():

@@ -116,14 +116,18 @@ class GridPlan:
         return out
 
 
+_plan_lock = __import__('threading').RLock()
+
+
 def get_plan(nx, ny, hx, hy, ctx=None):
     """Cached GridPlan (rocFFT plan creation is expensive; shapes repeat)."""
     ctx = ctx or get_context()
     key = (int(nx), int(ny), float(hx), float(hy))
-    p = ctx._plans.get(key)
-    if p is None or not p.handle:
-        p = GridPlan(nx, ny, hx, hy, ctx)
-        ctx._plans[key] = p
+    with _plan_lock:        # device.prewarm() may be creating the same plan in its thread
+        p = ctx._plans.get(key)
+        if p is None or not p.handle:
+            p = GridPlan(nx, ny, hx, hy, ctx)
+            ctx._plans[key] = p
     return p
 
 
