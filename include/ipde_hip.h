@@ -191,6 +191,17 @@ int ipde_fd4(ipde_ctx* ctx, int loc, int64_t nx, int64_t ny, double h,
              int axis, int periodic_fix, const double* f, double* out);
 
 /* ------------------------------------------------------------------------- */
+/* dense LU substitution (QFS collocation systems)         */
+/*
+ * x = U^-1 L^-1 P b for row-major packed LU factors (unit lower L below the diagonal,
+ * as LAPACK getrf / torch.linalg.lu_factor return them) and the row permutation
+ * perm (int32, (P b)[i] = b[perm[i]]).  Replaces the host `lu_solve` of the reference's
+ * third-party qfs package.  All pointers are DEVICE memory; b and x may not alias.
+ */
+int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, const int* perm,
+                        const double* b, double* x);
+
+/* ------------------------------------------------------------------------- */
 /* Ewald-type grid evaluator, first half                       */
 /*
  * ScalarGridBackend.ewald_local_freespace / ewald_local_periodic
@@ -222,6 +233,9 @@ int ipde_ewald_spread(ipde_ewald* e, int loc, int64_t ns, const double* sx, cons
    ipde.utilities.fft / ifft (ipde/utilities.py:5-12). direction -1 / +1 (scaled). */
 int ipde_fft1_c2c(ipde_ctx* ctx, int loc, int64_t batch, int64_t n, int direction,
                   const double* in_c, double* out_c);
+/* create the plan of that transform ahead of time (rocFFT compiles its kernels at plan
+   creation); thread safe, so a host warm-up thread may call it during set-up */
+int ipde_fft1_prepare(ipde_ctx* ctx, int64_t batch, int64_t n);
 
 /* ------------------------------------------------------------------------- */
 /* annular solvers                                        */

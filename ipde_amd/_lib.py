@@ -72,11 +72,13 @@ SIGNATURES = {
     "ipde_stokes_grid_solve": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "ipde_fourier_deriv": (_int, [_vp, _int, _vp, _int, _vp]),
     "ipde_fourier_multiply": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "ipde_dense_lu_solve": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ipde_ewald_create": (_int, [_vp, _int, _dbl, _dbl, _int, _vp, _int, _int, _c_void_pp]),
     "ipde_ewald_destroy": (_int, [_vp]),
     "ipde_ewald_spread": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _dbl, _dbl, _i64, _i64, _i64, _i64,
                                  _int, _vp, _vp]),
     "ipde_fd4": (_int, [_vp, _int, _i64, _i64, _dbl, _int, _int, _vp, _vp]),
+    "ipde_fft1_prepare": (_int, [_vp, _i64, _i64]),
     "ipde_fft1_c2c": (_int, [_vp, _int, _i64, _i64, _int, _vp, _vp]),
     "ipde_annular_scalar_create": (_int, [_vp, _int, _int, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _c_void_pp]),

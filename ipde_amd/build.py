@@ -29,6 +29,7 @@ SOURCES = [
     "spectral.hip",
     "annular.hip",
     "ewald.hip",
+    "dense.hip",
 ]
 
 CXXFLAGS = [

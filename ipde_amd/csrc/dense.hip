@@ -1,0 +1,99 @@
+// Dense LU substitution on the GPU for the QFS collocation systems (SURVEY §8f rank 2;
+// the reference's third-party `qfs` package solves them with host LAPACK).
+//
+// The factors come from rocSOLVER (torch.linalg.lu_factor) and are fine; the library
+// triangular solve that follows (rocBLAS TRSM with inverted diagonal blocks) is not
+// backward stable on these matrices (cond ~1e12: residual 1.3e-9, against 4e-14 for
+// plain substitution with the SAME factors — measured), and a single right-hand side
+// makes it latency bound (3.2 ms at n = 4096).  Here: blocked plain substitution,
+// 64-row blocks.  Step k is one launch: every workgroup re-solves the 64x64 diagonal
+// block k (LDS, one wave, 64 shuffle steps — redundant but free) and subtracts its own
+// off-diagonal block times x_k from the running right-hand side; workgroup 0 stores
+// x_k.  No inter-workgroup waiting inside a kernel; 2 n/64 launches per solve.
+#include "ipde_common.h"
+
+namespace {
+
+constexpr int DB = 64;        // block size
+constexpr int DT = 256;       // threads per workgroup
+
+// LOWER: unit lower triangle (forward), else upper triangle with diagonal (backward).
+// grid.x = number of block rows touched in this step (first = the diagonal block itself)
+template <bool LOWER>
+__global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ LU, int n, int k,
+                                                    double* __restrict__ v, double* __restrict__ x) {
+    __shared__ double blk[DB][DB + 1];
+    __shared__ double xs[DB];
+    const int tid = threadIdx.x;
+    const int r0 = k * DB;
+    // diagonal block (identity outside the matrix) and the block's right-hand side
+    for (int e = tid; e < DB * DB; e += DT) {
+        int r = e / DB, c = e - r * DB;
+        int gr = r0 + r, gc = r0 + c;
+        double a = (gr < n && gc < n) ? LU[(size_t)gr * n + gc] : (r == c ? 1.0 : 0.0);
+        blk[r][c] = a;
+    }
+    __syncthreads();
+    if (tid < DB) {
+        const int lane = tid;
+        double val = (r0 + lane < n) ? v[r0 + lane] : 0.0;
+        if (LOWER) {
+            for (int j = 0; j < DB; ++j) {
+                double xj = __shfl(val, j);
+                if (lane > j) val = fma(-blk[lane][j], xj, val);
+            }
+        } else {
+            for (int j = DB - 1; j >= 0; --j) {
+                if (lane == j) val /= blk[j][j];
+                double xj = __shfl(val, j);
+                if (lane < j) val = fma(-blk[lane][j], xj, val);
+            }
+        }
+        xs[lane] = val;
+        if (blockIdx.x == 0 && r0 + lane < n) x[r0 + lane] = val;
+    }
+    if (blockIdx.x == 0) return;
+    __syncthreads();
+    const int i = LOWER ? k + (int)blockIdx.x : k - (int)blockIdx.x;   // block row to update
+    const int row = tid >> 2, part = tid & 3;
+    const int gr = i * DB + row;
+    double s = 0.0;
+    if (gr < n) {
+        const double* a = LU + (size_t)gr * n + r0 + part * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            int gc = r0 + part * 16 + c;
+            if (gc < n) s = fma(a[c], xs[part * 16 + c], s);
+        }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (part == 0 && gr < n) v[gr] -= s;
+}
+
+__global__ void permute_kernel(const double* __restrict__ b, const int* __restrict__ perm, int n,
+                               double* __restrict__ v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = b[perm[i]];
+}
+
+}  // namespace
+
+extern "C" int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, const int* perm,
+                                   const double* b, double* x) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, n > 0 && n < (1 << 24) && lu && perm && b && x);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, 2 * (size_t)n * sizeof(double)));
+    double* v = (double*)ctx->partial.p;
+    double* y = v + n;
+    const int nb = (int)((n + DB - 1) / DB);
+    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b,
+                       perm, (int)n, v);
+    for (int k = 0; k < nb; ++k)
+        hipLaunchKernelGGL(lu_subst_step<true>, dim3(nb - k), dim3(DT), 0, ctx->stream, lu, (int)n, k, v, y);
+    for (int k = nb - 1; k >= 0; --k)
+        hipLaunchKernelGGL(lu_subst_step<false>, dim3(k + 1), dim3(DT), 0, ctx->stream, lu, (int)n, k, y, x);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 #include "../../include/ipde_hip.h"
 
 // A growable device buffer owned by the context (never freed between calls so
@@ -47,6 +48,7 @@ struct ipde_ctx {
     double last_kernel_ms = 0.0;
     // 1-D batched fft plan cache: key (batch, n)
     std::map<std::pair<int64_t, int64_t>, void*> fft1_plans;
+    std::mutex fft1_mutex;   // plan creation may run in a host warm-up thread (ipde_fft1_prepare)
     int num_cu = 256;
     // tuning knobs (ipde_ctx_set_option)
     int opt_laplace_variant = 1;

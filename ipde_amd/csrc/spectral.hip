@@ -551,6 +551,7 @@ struct Fft1Plan {
 
 int ipde_fft1_get(ipde_ctx* ctx, int64_t batch, int64_t n, Fft1Plan** out) {
     rocfft_setup_once();
+    std::lock_guard<std::mutex> guard(ctx->fft1_mutex);
     auto key = std::make_pair(batch, n);
     auto it = ctx->fft1_plans.find(key);
     if (it != ctx->fft1_plans.end()) {
@@ -589,6 +590,16 @@ int ipde_fft1_exec(ipde_ctx* ctx, int64_t batch, int64_t n, int direction, const
     void* ob[1] = {out};
     IPDE_FFT_CHECK(ctx, rocfft_execute(direction < 0 ? fp->fwd : fp->bwd, ib, ob, fp->info));
     return IPDE_OK;
+}
+
+// Create (and run-time compile) the plan of a batched 1-D transform ahead of its first use;
+// thread safe, touches no staging buffers, launches nothing.
+extern "C" int ipde_fft1_prepare(ipde_ctx* ctx, int64_t batch, int64_t n) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, batch >= 1 && n >= 1);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Fft1Plan* fp;
+    return ipde_fft1_get(ctx, batch, n, &fp);
 }
 
 void ipde_fft1_plans_destroy(ipde_ctx* ctx) {

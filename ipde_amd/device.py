@@ -83,12 +83,13 @@ def get_context(device=None):
 _warm = {}
 
 
-def prewarm(grid_shape=None, h=None, wait=False):
+def prewarm(grid_shape=None, h=None, wait=False, fft1=()):
     """Pay the one-time library costs of a first solve in background threads while the
     host does geometry set-up: rocBLAS/Tensile load (first complex128 GEMM, ~5 s on a
     fresh process), hipFFT load (first torch.fft call, ~1 s), rocSOLVER load (first LU),
     and — if the grid is given — the rocFFT plans of the grid solve (~1.6 s of run-time
-    kernel compilation at 2048^2).  No-op without a GPU.  `wait=True` joins."""
+    kernel compilation at 2048^2); `fft1` lists (batch, n) of batched 1-D transforms
+    (annular solver, radial interpolation) whose kernels are compiled the same way.  No-op without a GPU.  `wait=True` joins."""
     import threading
     if not torch.cuda.is_available():
         return
@@ -116,9 +117,18 @@ def prewarm(grid_shape=None, h=None, wait=False):
             get_plan(grid_shape[0], grid_shape[1], h[0], h[1], get_context(dev))
         except Exception:
             pass
+    def fft1_plans():
+        try:
+            ctx = get_context(dev)
+            for batch, n in fft1:
+                ctx.lib.ipde_fft1_prepare(ctx.handle, int(batch), int(n))
+        except Exception:
+            pass
     jobs = [("libs", libs)]
     if grid_shape is not None:
         jobs.append((("plan", tuple(grid_shape)), plans))
+    if fft1:
+        jobs.append((("fft1", tuple(fft1)), fft1_plans))
     started = []
     for key, fn in jobs:
         with _lock:

@@ -22,7 +22,9 @@ def setit(n, dictionary, default):
 
 class EmbeddedBoundary(object):
     def __init__(self, bdy, interior, M, h, **kwargs):
-        prewarm()       # library loads overlap the host geometry set-up
+        # library loads and the length-N 1-D FFT kernels (annular solver, radial
+        # interpolation) compile while the host does the geometry set-up
+        prewarm(fft1=((M, bdy.N),))
         """bdy: Global_Smooth_Boundary; interior: bool; M: radial modes; h: radial grid
         spacing (radial_width = M*h).  kwargs as the reference (:106-112): pad_zone,
         heaviside, qfs_tolerance, coordinate_tolerance, ... (unknown ones are kept)."""

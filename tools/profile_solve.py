@@ -1,13 +1,27 @@
-import sys, os, time, cProfile, pstats
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples'))
-import numpy as np
-import interior_poisson
-err, scale, solver, ue, T = interior_poisson.run(nb=4096, M=20, Ns=[2048,2048], solver_tol=1e-12)
-from ipde_amd.embedded_function import EmbeddedFunction
+#!/usr/bin/env python3
+"""Warm full Poisson solves (2048^2 grid, 4096 nodes) in a loop — the target of
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_solve -- python3 tools/profile_solve.py
+(the cold solve is included once; 10 warm solves dominate the kernel statistics)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'examples'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import interior_poisson  # noqa: E402
+from ipde_amd.embedded_function import EmbeddedFunction  # noqa: E402
+
+err, scale, solver, ue, T = interior_poisson.run(nb=4096, M=20, Ns=[2048, 2048], solver_tol=1e-12)
 f = EmbeddedFunction(solver.ebdyc)
-f.define_via_function(lambda x, y: np.sin(x)*np.cos(y))
+f.define_via_function(lambda x, y: np.sin(x) * np.cos(y))
 solver(f, tol=1e-12, maxiter=100, restart=20)
-pr = cProfile.Profile(); pr.enable()
-for _ in range(3): solver(f, tol=1e-12, maxiter=100, restart=20)
-pr.disable()
-pstats.Stats(pr).sort_stats('cumtime').print_stats(35)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 10
+for _ in range(n):
+    solver(f, tol=1e-12, maxiter=100, restart=20)
+torch.cuda.synchronize()
+print("warm solve %.2f ms" % ((time.perf_counter() - t0) / n * 1e3))
