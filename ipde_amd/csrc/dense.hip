@@ -17,6 +17,12 @@ namespace {
 constexpr int DB = 64;        // block size
 constexpr int DT = 256;       // threads per workgroup
 
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // LOWER: unit lower triangle (forward), else upper triangle with diagonal (backward).
 // grid.x = number of block rows touched in this step (first = the diagonal block itself)
 template <bool LOWER>
@@ -37,15 +43,21 @@ __global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ L
     if (tid < DB) {
         const int lane = tid;
         double val = (r0 + lane < n) ? v[r0 + lane] : 0.0;
+        // x_j is broadcast with v_readlane (compile-time lane index under full unrolling):
+        // the 64-step dependency chain costs a few cycles per step instead of a
+        // ds_bpermute round trip
         if (LOWER) {
+#pragma unroll
             for (int j = 0; j < DB; ++j) {
-                double xj = __shfl(val, j);
+                double xj = readlane_f64(val, j);
                 if (lane > j) val = fma(-blk[lane][j], xj, val);
             }
         } else {
+            const double dinv = 1.0 / blk[lane][lane];
+#pragma unroll
             for (int j = DB - 1; j >= 0; --j) {
-                if (lane == j) val /= blk[j][j];
-                double xj = __shfl(val, j);
+                if (lane == j) val *= dinv;
+                double xj = readlane_f64(val, j);
                 if (lane < j) val = fma(-blk[lane][j], xj, val);
             }
         }

@@ -161,7 +161,9 @@ class _DeviceLU(object):
                                                         ptr(self.perm), ptr(b), ptr(x)))
         return x
 
-    def solve(self, A, b, steps=1):
+    def solve(self, A, b, steps=0):
+        """substitution (+ `steps` of iterative refinement; the plain substitution already
+        has LAPACK's residual, so the QFS solves use none)"""
         x = self._subst(b)
         for _ in range(steps):
             x = x + self._subst(b - A @ x)
@@ -200,7 +202,7 @@ class DenseSolver(object):
             return scipy.linalg.lu_solve(self._lu, np.asarray(b, dtype=float))
         import torch
         bd = torch.as_tensor(np.ascontiguousarray(b, dtype=float), device=self._dev)
-        return self._fact.solve(self._A, bd).cpu().numpy()
+        return self._fact.solve(self._A, bd, steps=1).cpu().numpy()
 
 
 def _device():
