@@ -10,6 +10,12 @@
 // block k (LDS, one wave, 64 shuffle steps — redundant but free) and subtracts its own
 // off-diagonal block times x_k from the running right-hand side; workgroup 0 stores
 // x_k.  No inter-workgroup waiting inside a kernel; 2 n/64 launches per solve.
+//
+// Layout: the factors are handed over TILED — 64x64 tiles stored contiguously (32 KB),
+// tile (I, K) at ((I nb + K) 4096) doubles, padded with identity to a multiple of 64 —
+// because a step reads one tile per block row: in the row-major matrix that is a 512-byte
+// piece every n*8 bytes (one DRAM page / TLB entry per row; 13.5 us per step measured at
+// n = 4096), tiled it is one contiguous 32 KB read per workgroup.
 #include "ipde_common.h"
 
 namespace {
@@ -26,19 +32,16 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // LOWER: unit lower triangle (forward), else upper triangle with diagonal (backward).
 // grid.x = number of block rows touched in this step (first = the diagonal block itself)
 template <bool LOWER>
-__global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ LU, int n, int k,
-                                                    double* __restrict__ v, double* __restrict__ x) {
+__global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ LU, int n, int nb,
+                                                    int k, double* __restrict__ v,
+                                                    double* __restrict__ x) {
     __shared__ double blk[DB][DB + 1];
     __shared__ double xs[DB];
     const int tid = threadIdx.x;
     const int r0 = k * DB;
-    // diagonal block (identity outside the matrix) and the block's right-hand side
-    for (int e = tid; e < DB * DB; e += DT) {
-        int r = e / DB, c = e - r * DB;
-        int gr = r0 + r, gc = r0 + c;
-        double a = (gr < n && gc < n) ? LU[(size_t)gr * n + gc] : (r == c ? 1.0 : 0.0);
-        blk[r][c] = a;
-    }
+    // diagonal tile and the block's right-hand side
+    const double* dt = LU + ((size_t)k * nb + k) * (DB * DB);
+    for (int e = tid; e < DB * DB; e += DT) blk[e / DB][e % DB] = dt[e];
     __syncthreads();
     if (tid < DB) {
         const int lane = tid;
@@ -70,13 +73,10 @@ __global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ L
     const int row = tid >> 2, part = tid & 3;
     const int gr = i * DB + row;
     double s = 0.0;
-    if (gr < n) {
-        const double* a = LU + (size_t)gr * n + r0 + part * 16;
+    {
+        const double* a = LU + ((size_t)i * nb + k) * (DB * DB) + row * DB + part * 16;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            int gc = r0 + part * 16 + c;
-            if (gc < n) s = fma(a[c], xs[part * 16 + c], s);
-        }
+        for (int c = 0; c < 16; ++c) s = fma(a[c], xs[part * 16 + c], s);
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
@@ -103,9 +103,9 @@ extern "C" int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, c
     hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b,
                        perm, (int)n, v);
     for (int k = 0; k < nb; ++k)
-        hipLaunchKernelGGL(lu_subst_step<true>, dim3(nb - k), dim3(DT), 0, ctx->stream, lu, (int)n, k, v, y);
+        hipLaunchKernelGGL(lu_subst_step<true>, dim3(nb - k), dim3(DT), 0, ctx->stream, lu, (int)n, nb, k, v, y);
     for (int k = nb - 1; k >= 0; --k)
-        hipLaunchKernelGGL(lu_subst_step<false>, dim3(k + 1), dim3(DT), 0, ctx->stream, lu, (int)n, k, y, x);
+        hipLaunchKernelGGL(lu_subst_step<false>, dim3(k + 1), dim3(DT), 0, ctx->stream, lu, (int)n, nb, k, y, x);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }

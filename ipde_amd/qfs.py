@@ -144,8 +144,12 @@ class _DeviceLU(object):
         import torch
         from .device import get_context
         self.ctx = get_context(LU.device.index)
-        self.LU = LU.contiguous()
-        self.n = int(LU.shape[0])
+        self.n = n = int(LU.shape[0])
+        nb = (n + 63) // 64
+        # 64x64 tiles stored contiguously, identity padding (layout of ipde_dense_lu_solve)
+        pad = torch.eye(nb * 64, dtype=torch.float64, device=LU.device)
+        pad[:n, :n] = LU
+        self.LU = pad.view(nb, 64, nb, 64).permute(0, 2, 1, 3).contiguous()
         p = np.arange(self.n)
         for i, q in enumerate(piv.cpu().numpy() - 1):      # LAPACK ipiv -> permutation vector
             if q != i:
