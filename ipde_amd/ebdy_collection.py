@@ -170,7 +170,7 @@ class EmbeddedBoundaryCollection(object):
         """Spectral interpolation of a periodic grid function to all interface nodes."""
         from .interp import periodic_interp2d
         fh = np.fft.fft2(f)
-        return periodic_interp2d(fh, self.interfaces_x_transf, self.interfaces_y_transf).real.cpu().numpy()
+        return periodic_interp2d(fh, self.interfaces_x_transf, self.interfaces_y_transf, real_part=True).cpu().numpy()
 
     def interpolate_radial_to_grid1(self, fr_list, f):
         for fr, ebdy in zip(fr_list, self):

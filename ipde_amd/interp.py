@@ -22,11 +22,14 @@ def _dev(a, ctx, dtype):
     return torch.as_tensor(np.ascontiguousarray(a), device=ctx.torch_device()).to(dtype)
 
 
-def periodic_interp2d(fh, x, y, ctx=None, chunk=16384):
+def periodic_interp2d(fh, x, y, ctx=None, chunk=16384, real_part=False):
     """Evaluate the Fourier series with fft2-ordered coefficients fh (K, Nx, Ny) (or
     (Nx, Ny)) at the points (x, y) given in [0, 2 pi) units of the periodic box.
     Returns a (K, P) (or (P,)) complex torch tensor on the device:
-        out[k, p] = (1/(Nx Ny)) sum fh[k, a, b] exp(i (kx_a x_p + ky_b y_p))"""
+        out[k, p] = (1/(Nx Ny)) sum fh[k, a, b] exp(i (kx_a x_p + ky_b y_p))
+    real_part=True returns only its real part (a real tensor) at half the cost: the
+    spectrum is Hermitian-symmetrised, (F(k) + conj F(-k))/2 — which leaves the real part
+    of the sum unchanged — and only the ky >= 0 half enters the GEMM."""
     ctx = ctx or get_context()
     fh = _dev(fh, ctx, torch.complex128)
     squeeze = fh.dim() == 2
@@ -35,6 +38,9 @@ def periodic_interp2d(fh, x, y, ctx=None, chunk=16384):
     K, Nx, Ny = fh.shape
     x = _dev(x, ctx, torch.float64)
     y = _dev(y, ctx, torch.float64)
+    if real_part:
+        out = _interp2d_real(fh, x, y, chunk)
+        return out[0] if squeeze else out
     kx = torch.fft.fftfreq(Nx, 1.0 / Nx, dtype=torch.float64, device=fh.device)
     ky = torch.fft.fftfreq(Ny, 1.0 / Ny, dtype=torch.float64, device=fh.device)
     P = x.shape[0]
@@ -48,6 +54,44 @@ def periodic_interp2d(fh, x, y, ctx=None, chunk=16384):
         out[:, a:b] = (A * Ex[None]).sum(dim=1)
     out /= float(Nx * Ny)
     return out[0] if squeeze else out
+
+
+def _interp2d_real(fh, x, y, chunk):
+    """Re sum_k F(k) e^{i k.x} with the fft-ordered wavenumbers (the Nyquist index carries
+    -N/2), through the ky >= 0 half of the spectrum.  Modes pair up with their negatives,
+    Re(F(k) e^{ik.x} + F(-k) e^{-ik.x}) = Re((F(k) + conj F(-k)) e^{ik.x}), except on the
+    Nyquist row / column, where index negation does not conjugate the phase: the column
+    ky = -Ny/2 enters unsymmetrised with weight 1, the row kx = -Nx/2 is summed separately
+    over all ky (a rank-one correction)."""
+    K, Nx, Ny = fh.shape
+    dev = fh.device
+    fm = torch.roll(torch.flip(fh, dims=(1, 2)), shifts=(1, 1), dims=(1, 2))   # F(-k)
+    nyh = Ny // 2 + 1
+    fe = fh[:, :, :nyh] + fm[:, :, :nyh].conj()          # 2 F_eff : weight 2 of 0 < ky < Ny/2
+    fe[:, :, 0] *= 0.5
+    if Ny % 2 == 0:
+        fe[:, :, nyh - 1] = fh[:, :, nyh - 1]
+    if Nx % 2 == 0:
+        fe[:, Nx // 2, :] = 0.0
+    f2 = fe.permute(1, 0, 2).reshape(Nx, K * nyh)                 # (Nx, K nyh)
+    kx = torch.fft.fftfreq(Nx, 1.0 / Nx, dtype=torch.float64, device=dev)
+    kyf = torch.fft.fftfreq(Ny, 1.0 / Ny, dtype=torch.float64, device=dev)
+    ky = kyf[:nyh]
+    P = x.shape[0]
+    out = torch.empty((K, P), dtype=torch.float64, device=dev)
+    for a in range(0, P, chunk):
+        b = min(P, a + chunk)
+        Ex = torch.exp(1j * x[a:b, None] * kx[None, :])          # (p, Nx)
+        A = (Ex @ f2).reshape(b - a, K, nyh)                      # GEMM over kx, half of ky
+        Ey = torch.exp(1j * y[a:b, None] * ky[None, :])          # (p, nyh)
+        val = (A * Ey[:, None, :]).sum(dim=2)                     # (p, K)
+        if Nx % 2 == 0:
+            Eyf = torch.exp(1j * y[a:b, None] * kyf[None, :])    # (p, Ny)
+            row = Eyf @ fh[:, Nx // 2, :].transpose(0, 1)         # (p, K)
+            val = val + row * torch.exp(-0.5j * Nx * x[a:b])[:, None]
+        out[:, a:b] = val.real.transpose(0, 1)
+    out /= float(Nx * Ny)
+    return out
 
 
 _UP_T = 16     # oversampling of the periodic direction before local interpolation

@@ -134,10 +134,10 @@ class ScalarSolver(object):
             # values and gradient on all interface nodes from the spectrum (:80-88); the
             # three fields share one set of exponential matrices
             stack = torch.stack([uch, self._ikx_d * uch, self._iky_d * uch])
-            all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d).real.cpu().numpy()
+            all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         else:
             stack = torch.stack([torch.fft.fft2(g) for g in (uc, self.dx(uc), self.dy(uc))])
-            all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d).real.cpu().numpy()
+            all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         bvl, bxl, byl = e.v2l(all_bvs[0]), e.v2l(all_bvs[1]), e.v2l(all_bvs[2])
         sigmag_list = []
         for helper, fr, bv, bx, by in zip(self.helpers, fr_list, bvl, bxl, byl):

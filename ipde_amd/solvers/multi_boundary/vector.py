@@ -119,7 +119,7 @@ class VectorSolver(object):
             ucx, ucy, vcx, vcy = self.dx(uc), self.dy(uc), self.dx(vc), self.dy(vc)
             stack = torch.stack([torch.fft.fft2(g) for g in
                                  (uc, vc, 2 * ucx - pc, ucy + vcx, 2 * vcy - pc)])
-        bvals = periodic_interp2d(stack, self._ifx_d, self._ify_d).real.cpu().numpy()
+        bvals = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         bul, bvl, btxxl, btxyl, btyyl = (e.v2l(b) for b in bvals)
         sigmag_list = []
         for helper, fur, fvr, bu, bv, btxx, btxy, btyy in zip(self.helpers, fur_list, fvr_list,

@@ -70,3 +70,25 @@ def test_chebyshev_fourier_eval_is_exact_for_full_band_data(M, N):
     got = chebyshev_fourier_eval(fr, xi, t).cpu().numpy()
     ref = np.einsum('pm,mp->p', np.polynomial.chebyshev.chebvander(xi, M - 1), rows(t))
     assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("Nx,Ny", [(16, 16), (24, 17), (15, 32)])
+def test_periodic_interp2d_real_part_path(Nx, Ny):
+    """half-spectrum evaluation == real part of the full complex sum, also for spectra
+    that are not Hermitian (ik * fhat with the Nyquist row kept, as the solver passes)"""
+    import torch
+    from ipde_amd.interp import periodic_interp2d
+    rng = np.random.default_rng(Nx * Ny)
+    f = rng.standard_normal((Nx, Ny))
+    fh = np.fft.fft2(f)
+    kx = np.fft.fftfreq(Nx, 1.0 / Nx)[:, None]
+    stack = np.stack([fh, 1j * kx * fh, rng.standard_normal((Nx, Ny)) + 1j * rng.standard_normal((Nx, Ny))])
+    x, y = rng.uniform(0, 2 * np.pi, 40), rng.uniform(0, 2 * np.pi, 40)
+    full = periodic_interp2d(stack, x, y).cpu().numpy()
+    half = periodic_interp2d(stack, x, y, real_part=True).cpu().numpy()
+    assert half.shape == full.shape and half.dtype == np.float64
+    assert np.abs(half - full.real).max() < 1e-12 * np.abs(full).max()
+    kxv, kyv = np.fft.fftfreq(Nx, 1.0 / Nx), np.fft.fftfreq(Ny, 1.0 / Ny)
+    ref = np.array([(stack[0] * np.exp(1j * (kxv[:, None] * a + kyv[None, :] * b))).sum() / (Nx * Ny)
+                    for a, b in zip(x, y)])
+    assert np.abs(full[0] - ref).max() < 1e-12 * np.abs(ref).max()
