@@ -53,6 +53,7 @@ class _QFS(object):
     values u.  Subclasses provide the off-surface and on-surface forms."""
 
     DEVICE_SOLVE = True
+    REFINE_STEPS = 0
 
     def __init__(self, bdy, interior, slp, dlp, qfs_boundary=None, eps=1e-12):
         self.bdy = bdy
@@ -105,7 +106,7 @@ class _QFS(object):
         import torch
         ud = u if isinstance(u, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(u, dtype=float),
                                                                   device=self._dev)
-        x = self._fact.solve(self._A, ud)
+        x = self._fact.solve(self._A, ud, steps=self.REFINE_STEPS)
         return x if isinstance(u, torch.Tensor) else x.cpu().numpy()
 
     def boundary_limit(self, densities):
@@ -259,9 +260,11 @@ class Stokes_QFS(_QFS):
     with  int mu.n = 0, which also pins the pressure constant."""
 
     MAX_ALPHA = 5.4
-    # host LAPACK: at condition 1e15 the GPU triangular solves (even with refinement) lose
-    # four digits against dgetrs (potential error 1e-8 vs 3e-13, measured at N = 2000)
-    DEVICE_SOLVE = False
+    # factor with rocSOLVER, substitute with csrc/dense.hip (with the library TRSM the
+    # potentials lost four digits at condition 1e15 — 1e-8 vs 3e-13 — which is why this
+    # class first ran on host LAPACK; plain substitution has LAPACK's residual)
+    DEVICE_SOLVE = True
+    REFINE_STEPS = 1
 
     def __init__(self, bdy, interior, slp=True, dlp=True, qfs_boundary=None, eps=1e-12):
         # Per Fourier mode k the stokeslet block from a curve at distance d is
