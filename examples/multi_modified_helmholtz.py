@@ -27,7 +27,7 @@ from ipde_amd.layer_potentials import Modified_Helmholtz_Layer_Apply, DeviceTarg
 from ipde_amd.pybie2d_compat import (star, squish, Grid, Global_Smooth_Boundary as GSB,  # noqa: E402
                                      Modified_Helmholtz_Layer_Form as MH_Layer_Form,
                                      Modified_Helmholtz_Layer_Singular_Form as MH_Self)
-from ipde_amd.qfs import QFS_Evaluator  # noqa: E402
+from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver  # noqa: E402
 
 
@@ -80,7 +80,7 @@ def run(nb=400, M=16, helmholtz_k=2.0, verbose=False):
             else:
                 blk[:] = d_only(bj, bi) if j == 0 else c_and_d(bj, bi)
     bvs = np.concatenate(solver.get_boundary_values(ue.get_radial_value_list()).bdy_value_list)
-    tau = np.linalg.solve(MAT, bcs2v - bvs)
+    tau = DenseSolver(MAT).solve(bcs2v - bvs)
     taul = ebdyc.v2l(tau)
     Naive_SLP = lambda src, trg: MH_Layer_Form(src, trg, k=k, ifcharge=True)
     sigmal = []

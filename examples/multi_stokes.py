@@ -27,7 +27,7 @@ from ipde_amd.pybie2d_compat import (star, squish, Grid, Global_Smooth_Boundary 
                                      BoundaryCollection, arc_length_parameterize,
                                      Stokes_Layer_Form, Stokes_Layer_Singular_Form,
                                      Stokes_Pressure_Fix)
-from ipde_amd.qfs import Stokes_QFS  # noqa: E402
+from ipde_amd.qfs import Stokes_QFS, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.stokes import StokesSolver  # noqa: E402
 
 
@@ -118,7 +118,7 @@ def run(nb=300, M=12, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes
     bu_adj = ebdyc.v2l(bdy_u - bu)
     bv_adj = ebdyc.v2l(bdy_v - bv)
     bc_adj = np.concatenate([np.concatenate([p, q]) for p, q in zip(bu_adj, bv_adj)])
-    tau = np.linalg.solve(MAT, bc_adj)
+    tau = DenseSolver(MAT).solve(bc_adj)
     taul = ebdyc.v2l2(tau)
     sigmal, sources = [], BoundaryCollection()
     for ebdy, t in zip(ebdys, taul):
