@@ -239,21 +239,45 @@ def Laplace_Layer_Singular_Form(bdy, ifcharge=False, ifdipole=False):
 
 # ---------------------------------------------------------------------------
 # modified Helmholtz (k^2 - Lap): kernels of ipde_amd.layer_potentials
+def _row_blocks(fn, nrows, out):
+    """out[a:b] = fn(a, b) over row blocks in a thread pool (numpy / scipy.special ufuncs
+    release the GIL; the 8192^2 Bessel evaluations of one modified-Helmholtz form take
+    ~15 s on one core)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, min(16, os.cpu_count() or 1))
+    step = max(64, -(-nrows // (4 * nthreads)))
+    blocks = [(a, min(nrows, a + step)) for a in range(0, nrows, step)]
+
+    def work(ab):
+        out[ab[0]:ab[1]] = fn(*ab)
+    if nthreads == 1 or len(blocks) == 1:
+        for ab in blocks:
+            work(ab)
+    else:
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(work, blocks))
+    return out
+
+
 def Modified_Helmholtz_Layer_Form(source, target=None, k=1.0, ifcharge=False, ifdipole=False):
     """Dense off-surface matrix: (1/2pi) K0(k r) w  and/or  (k/2pi) K1(k r) (n.d)/r w."""
     from scipy.special import k0, k1
     if target is None:
         target = source
-    dx = target.x[:, None] - source.x[None, :]
-    dy = target.y[:, None] - source.y[None, :]
-    r = np.hypot(dx, dy)
-    out = np.zeros_like(r)
-    if ifcharge:
-        out += (0.5 / np.pi) * k0(k * r) * source.weights[None, :]
-    if ifdipole:
-        nd = dx * source.normal_x[None, :] + dy * source.normal_y[None, :]
-        out += (0.5 * k / np.pi) * k1(k * r) * nd / r * source.weights[None, :]
-    return out
+
+    def rows(a, b):
+        dx = target.x[a:b, None] - source.x[None, :]
+        dy = target.y[a:b, None] - source.y[None, :]
+        r = np.hypot(dx, dy)
+        blk = np.zeros_like(r)
+        if ifcharge:
+            blk += (0.5 / np.pi) * k0(k * r) * source.weights[None, :]
+        if ifdipole:
+            nd = dx * source.normal_x[None, :] + dy * source.normal_y[None, :]
+            blk += (0.5 * k / np.pi) * k1(k * r) * nd / r * source.weights[None, :]
+        return blk
+    return _row_blocks(rows, target.x.shape[0], np.empty((target.x.shape[0], source.x.shape[0])))
 
 
 def Modified_Helmholtz_Layer_Singular_Form(bdy, k=1.0, ifcharge=False, ifdipole=False):
@@ -267,40 +291,53 @@ def Modified_Helmholtz_Layer_Singular_Form(bdy, k=1.0, ifcharge=False, ifdipole=
     smooth, the coefficient stays below I0(6) ~ 67, and beyond the cut-off the plain
     trapezoid rule acts on the smooth kernel.  Diagonal limits:
     -(log(k speed/2) + gamma)/(2 pi) for the SLP remainder, -curvature/(4 pi) for the DLP
-    remainder.  The DLP is the principal value (interior limit D - I/2)."""
+    remainder.  The DLP is the principal value (interior limit D - I/2).
+    Row blocks are built in a thread pool; the cut-off and I0/I1 are evaluated only
+    where psi is neither 0 nor 1 / not 0."""
     from scipy.special import k0, k1, i0, i1
     from .heavisides import SlepianMollifier
     N = bdy.N
-    dx = bdy.x[:, None] - bdy.x[None, :]
-    dy = bdy.y[:, None] - bdy.y[None, :]
-    r = np.hypot(dx, dy)
-    np.fill_diagonal(r, 1.0)
-    dt = bdy.t[:, None] - bdy.t[None, :]
-    L = 4 * np.sin(dt / 2) ** 2
-    np.fill_diagonal(L, 1.0)
-    L = np.log(L)
-    R = _kress_log_weights(N)[np.abs(np.arange(N)[:, None] - np.arange(N)[None, :])]
+    j = np.arange(N)
+    lt = 4 * np.sin(0.5 * bdy.dt * j) ** 2            # L and R depend on |i - j| only
+    lt[0] = 1.0
+    lt = np.log(lt)
+    Rt = _kress_log_weights(N)
     r1 = 2.0 / k
     r2 = max(6.0 / k, r1 + 24 * bdy.max_h)
-    psi = 1.0 - SlepianMollifier(30).step(2.0 * (r - r1) / (r2 - r1) - 1.0)
-    np.fill_diagonal(psi, 1.0)
-    near = psi > 0.0
-    kr = np.where(near, k * r, 0.0)          # keeps I0/I1 from overflowing far away
-    out = np.zeros((N, N))
-    if ifcharge:
-        S1 = -(0.25 / np.pi) * i0(kr) * psi
-        S2 = (0.5 / np.pi) * k0(k * r) - S1 * L
-        np.fill_diagonal(S1, -(0.25 / np.pi))
-        np.fill_diagonal(S2, -(0.5 / np.pi) * (np.log(0.5 * k * bdy.speed) + np.euler_gamma))
-        out += (S1 * R + S2 * bdy.dt) * bdy.speed[None, :]
-    if ifdipole:
-        nd = dx * bdy.normal_x[None, :] + dy * bdy.normal_y[None, :]
-        D1 = (0.25 * k / np.pi) * i1(kr) * psi * nd / r
-        D2 = (0.5 * k / np.pi) * k1(k * r) * nd / r - D1 * L
-        np.fill_diagonal(D1, 0.0)
-        np.fill_diagonal(D2, -bdy.curvature / (4 * np.pi))
-        out += (D1 * R + D2 * bdy.dt) * bdy.speed[None, :]
-    return out
+    mol = SlepianMollifier(30)
+
+    def rows(a, b):
+        ii = np.arange(a, b)
+        dx = bdy.x[a:b, None] - bdy.x[None, :]
+        dy = bdy.y[a:b, None] - bdy.y[None, :]
+        r = np.hypot(dx, dy)
+        diag = (ii - a, ii)
+        r[diag] = 1.0
+        sep = np.abs(ii[:, None] - j[None, :])
+        L, R = lt[sep], Rt[sep]
+        psi = (r <= r1).astype(float)
+        band = (r > r1) & (r < r2)
+        psi[band] = 1.0 - mol.step(2.0 * (r[band] - r1) / (r2 - r1) - 1.0)
+        psi[diag] = 1.0
+        near = psi > 0.0
+        blk = np.zeros((b - a, N))
+        if ifcharge:
+            S1 = np.zeros_like(r)
+            S1[near] = -(0.25 / np.pi) * i0(k * r[near]) * psi[near]
+            S2 = (0.5 / np.pi) * k0(k * r) - S1 * L
+            S1[diag] = -(0.25 / np.pi)
+            S2[diag] = -(0.5 / np.pi) * (np.log(0.5 * k * bdy.speed[a:b]) + np.euler_gamma)
+            blk += (S1 * R + S2 * bdy.dt) * bdy.speed[None, :]
+        if ifdipole:
+            nd = dx * bdy.normal_x[None, :] + dy * bdy.normal_y[None, :]
+            D1 = np.zeros_like(r)
+            D1[near] = (0.25 * k / np.pi) * i1(k * r[near]) * psi[near] * nd[near] / r[near]
+            D2 = (0.5 * k / np.pi) * k1(k * r) * nd / r - D1 * L
+            D1[diag] = 0.0
+            D2[diag] = -bdy.curvature[a:b] / (4 * np.pi)
+            blk += (D1 * R + D2 * bdy.dt) * bdy.speed[None, :]
+        return blk
+    return _row_blocks(rows, N, np.empty((N, N)))
 
 
 # ---------------------------------------------------------------------------

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--nb", type=int, default=400)
     ap.add_argument("--M", type=int, default=16)
     ap.add_argument("--k", type=float, default=10.0)
+    ap.add_argument("--ng", type=int, default=None, help="force an ng x ng grid (scalar problems)")
+    ap.add_argument("--grid-backend", default=None, help="'ewald' for the split grid evaluator")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (one-GPU rehearsal)")
     a = ap.parse_args()
@@ -41,20 +43,33 @@ def main():
         dist.init_process_group(a.backend, **kw)
     from ipde_amd.device import get_context
     get_context(local)
+    Ns = None if a.ng is None else [a.ng, a.ng]
     t0 = time.perf_counter()
     if a.problem == "poisson":
         import interior_poisson
-        err, scale, solver, ue, T = interior_poisson.run(nb=a.nb, M=a.M)
+        err, scale, solver, ue, T = interior_poisson.run(nb=a.nb, M=a.M, Ns=Ns, grid_backend=a.grid_backend)
         res = {"error": err / scale}
     elif a.problem == "modhelm":
         import interior_modified_helmholtz as imh
-        err, scale, solver, ue, T = imh.run(nb=a.nb, M=a.M, helmholtz_k=a.k)
+        err, scale, solver, ue, T = imh.run(nb=a.nb, M=a.M, helmholtz_k=a.k, Ns=Ns, grid_backend=a.grid_backend)
         res = {"error": err / scale}
     else:
         import multi_stokes
         ue, ve, pe, scale, T = multi_stokes.run(nb=a.nb, M=a.M)
         res = {"error": max(ue, ve) / scale, "p_error": pe}
-    res.update({"problem": a.problem, "world": world, "wall_s": time.perf_counter() - t0,
+    if a.problem != "stokes":
+        # a second, warm solve of the same problem
+        import numpy as np
+        from ipde_amd.embedded_function import EmbeddedFunction
+        f = EmbeddedFunction(solver.ebdyc)
+        f.define_via_function(lambda x, y: np.sin(x) * np.cos(y))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        solver(f, tol=1e-12, maxiter=100, restart=20)
+        torch.cuda.synchronize()
+        res["warm_inhomogeneous_solve_s"] = time.perf_counter() - t1
+    res.update({"problem": a.problem, "world": world, "nb": a.nb, "M": a.M,
+                "grid_backend": a.grid_backend, "wall_s": time.perf_counter() - t0,
                 "timings": {k: v for k, v in T.items() if isinstance(v, (int, float, list))}})
     if world > 1:
         dist.barrier()
