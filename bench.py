@@ -28,7 +28,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 NGRID = 2048
 NBDY = 4096
 FLOPS_PER_PAIR_ALGO = 8        # SURVEY §8d counting convention (5 geometry + log + fma)
-FP64_INSTR_PER_PAIR = 11       # what the table kernel issues: 4 + 1 + 5 + 1
+VALU_INSTR_PER_PAIR = 11.5     # ISA count of the row-run table kernel: 8.5 fp64 (2.5 geometry with
+                               # (x-sx)^2 shared by a lane's 4 targets, y, 4 fma log1p + T, accumulate)
+                               # + 3 int32 (v_bfe, v_lshl_add, min3/max3 range tracking); every VALU
+                               # instruction, fp64 or int32, occupies the SIMD for one quad-cycle here
+PEAK_VALU_LANE_INSTR = 256 * 4 * 16 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz
 PEAK_FP64_VECTOR_TFLOPS = 78.6  # MI355X fp64 vector (= 256 CU*4 SIMD*32 flop/clk*2.4 GHz)
 PEAK_HBM_GBS = 8000.0
 ALGO_BYTES_PER_TARGET = 24     # read x, y; write u
@@ -194,9 +198,8 @@ def main():
                 "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": kpairs * FLOPS_PER_PAIR_ALGO / 1e12 / PEAK_FP64_VECTOR_TFLOPS,
                 "flops_per_pair_algorithmic": FLOPS_PER_PAIR_ALGO,
-                "frac_of_fp64_issue_rate": kpairs * FP64_INSTR_PER_PAIR /
-                                           (PEAK_FP64_VECTOR_TFLOPS * 1e12 / 2.0),
-                "fp64_instr_per_pair": FP64_INSTR_PER_PAIR,
+                "frac_of_valu_issue_rate": kpairs * VALU_INSTR_PER_PAIR / PEAK_VALU_LANE_INSTR,
+                "valu_instr_per_pair": VALU_INSTR_PER_PAIR,
                 "kernel_ms": kernel_ms_avg,
                 "kernel_pairs_per_s": kpairs,
                 "hbm": {

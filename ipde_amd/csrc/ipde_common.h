@@ -51,7 +51,7 @@ struct ipde_ctx {
     std::mutex fft1_mutex;   // plan creation may run in a host warm-up thread (ipde_fft1_prepare)
     int num_cu = 256;
     // tuning knobs (ipde_ctx_set_option)
-    int opt_laplace_variant = 1;
+    int opt_laplace_variant = 9;   // row-run single layer (variant 1 for the other modes)
     int opt_stokes_variant = 0;
 };
 

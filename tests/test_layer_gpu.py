@@ -281,3 +281,33 @@ def test_grid_evaluator_class_api():
         LaplaceFreespaceGridEvaluator(LaplaceGridBackend(h * 1.01, 20), xv, xv)
     with pytest.raises(Exception):
         LaplaceFreespaceGridEvaluator(LaplaceGridBackend(h, 20), xv, xv[:-1])
+
+
+@pytest.mark.parametrize("variant", [9, 10, 11])
+def test_laplace_rowrun_variant_is_bitwise_the_strided_kernel(variant):
+    """The row-run single-layer kernel (a lane owns R consecutive targets and shares
+    (x - sx)^2 among them when they sit in one grid row) performs the same arithmetic per
+    pair as the strided table kernel: bitwise equal results on grid-ordered lists with
+    ragged rows, on unstructured lists, and on lengths that are not multiples of R."""
+    import torch
+    from ipde_amd.device import get_context
+    from ipde_amd import layer_potentials as lp
+    ctx = get_context()
+    c = Curve(384, a=0.2, f=5)
+    rng = np.random.default_rng(variant)
+    q = rng.standard_normal(c.N) * c.weights
+    trg, h = grid_targets(c, 301, clearance=3.0)           # rows of unequal length
+    sets = [(trg.x, trg.y),
+            (rng.uniform(-1.5, 1.5, 10007), rng.uniform(-1.5, 1.5, 10007)),
+            (trg.x[:4099], trg.y[:4099])]
+    try:
+        for tx, ty in sets:
+            res = {}
+            for v in (1, variant):
+                ctx.set_option("laplace_variant", v)
+                res[v] = lp.laplace_apply(c.x, c.y, tx, ty, w_sigma=q)
+            assert np.array_equal(res[1], res[variant])
+            ref = lp.laplace_apply(c.x, c.y, tx, ty, w_sigma=q, generic_math=True)
+            assert np.abs(res[variant] - ref).max() < 1e-13 * np.abs(ref).max()
+    finally:
+        ctx.set_option("laplace_variant", 9)
