@@ -24,9 +24,7 @@ from ipde_amd.embedded_function import EmbeddedFunction  # noqa: E402
 from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
 from ipde_amd.layer_potentials import Stokes_Layer_Apply, DeviceTargets  # noqa: E402
 from ipde_amd.pybie2d_compat import (star, squish, Grid, Global_Smooth_Boundary as GSB,  # noqa: E402
-                                     BoundaryCollection, arc_length_parameterize,
-                                     Stokes_Layer_Form, Stokes_Layer_Singular_Form,
-                                     Stokes_Pressure_Fix)
+                                     BoundaryCollection, arc_length_parameterize)
 from ipde_amd.qfs import Stokes_QFS, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.stokes import StokesSolver  # noqa: E402
 
@@ -95,24 +93,31 @@ def run(nb=300, M=12, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes
 
     # block boundary-integral system for the homogeneous correction (reference :104-159)
     t0 = time.perf_counter()
-    d_only = lambda src, trg: Stokes_Layer_Form(src, trg, ifdipole=True)
-    c_and_d = lambda src, trg: Stokes_Layer_Form(src, trg, ifforce=True, ifdipole=True)
-    d_singular = lambda src: Stokes_Layer_Singular_Form(src, ifdipole=True)
-    cd_singular = lambda src: Stokes_Layer_Singular_Form(src, ifforce=True, ifdipole=True)
-    half_eye = lambda src: np.eye(2 * src.N) * 0.5
+    # (assembled on the GPU: the numpy forms of the same names in pybie2d_compat are the
+    # host reference; at 18 600 boundary nodes the matrix is 37 200^2)
+    import torch
+    from ipde_amd import dense_forms as df
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_only = lambda src, trg: df.stokes_form(src, trg, dev, ifdipole=True)
+    c_and_d = lambda src, trg: df.stokes_form(src, trg, dev, ifforce=True, ifdipole=True)
+    d_singular = lambda src: df.stokes_singular_form(src, dev, ifdipole=True)
+    cd_singular = lambda src: df.stokes_singular_form(src, dev, ifforce=True, ifdipole=True)
+    fix = lambda src, trg: df.stokes_pressure_fix(src, trg, dev)
+    half_eye = lambda src: torch.eye(2 * src.N, dtype=torch.float64, device=dev) * 0.5
     Ns = [bd.N for bd in bdys]
     off = 2 * np.concatenate([[0], np.cumsum(Ns)])
-    MAT = np.zeros((off[-1], off[-1]))
+    MAT = torch.zeros((int(off[-1]), int(off[-1])), dtype=torch.float64, device=dev)
     for i, bi in enumerate(bdys):          # target boundary
         for j, bj in enumerate(bdys):      # source boundary
-            blk = MAT[off[i]:off[i + 1], off[j]:off[j + 1]]
             if i == j:
-                blk[:] = (d_singular(bi) - half_eye(bi) + Stokes_Pressure_Fix(bi, bi)) if i == 0 \
+                blk = (d_singular(bi) - half_eye(bi) + fix(bi, bi)) if i == 0 \
                     else (cd_singular(bi) + half_eye(bi))
             elif j == 0:
-                blk[:] = d_only(bj, bi) + Stokes_Pressure_Fix(bj, bi)
+                blk = d_only(bj, bi) + fix(bj, bi)
             else:
-                blk[:] = c_and_d(bj, bi)
+                blk = c_and_d(bj, bi)
+            MAT[off[i]:off[i + 1], off[j]:off[j + 1]] = blk
+            del blk
     bu = solver.get_boundary_values(uc.get_radial_value_list())
     bv = solver.get_boundary_values(vc.get_radial_value_list())
     bu_adj = ebdyc.v2l(bdy_u - bu)

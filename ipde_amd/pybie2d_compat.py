@@ -93,7 +93,7 @@ def fourier_resample(f, new_N):
     return res if np.iscomplexobj(f) else res.real
 
 
-def arc_length_parameterize(x, y, tol=1e-14):
+def arc_length_parameterize(x, y, tol=1e-13):
     """Resample a closed curve at equal arclength (the role of
     personal_utilities.arc_length_reparametrization in the reference's scripts,
     examples/multi_stokes.py:40-43).  The arclength s(t) is the spectral antiderivative of
@@ -116,17 +116,35 @@ def arc_length_parameterize(x, y, tol=1e-14):
         ah[N // 2] = 0.0
     target = np.arange(N) * (L / N)
     t = np.arange(N) * (2 * np.pi / N)
-    E0 = np.exp(1j * np.outer(np.zeros(1), k))
-    s0 = (E0 @ ah).real[0]
+    # trigonometric sums at the N current parameters: dense N x N exponentials, on the GPU
+    # when there is one (N = 12 400 costs seconds per Newton step in numpy)
+    try:
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    except Exception:
+        dev = None
+    if dev is not None:
+        kd = torch.as_tensor(k, device=dev)
+        coef = torch.as_tensor(np.stack([ah, sh, ch], axis=1), device=dev)       # (N, 3)
+
+        def sums(tt):
+            E = torch.exp(1j * torch.as_tensor(tt, device=dev)[:, None] * kd[None, :])
+            r = (E @ coef).cpu().numpy()
+            return r[:, 0], r[:, 1], r[:, 2]
+    else:
+        def sums(tt):
+            E = np.exp(1j * np.outer(tt, k))
+            return E @ ah, E @ sh, E @ ch
+    s0 = float(np.sum(ah).real)                  # periodic part of s at t = 0
     for _ in range(50):
-        E = np.exp(1j * np.outer(t, k))
-        s = sh[0].real * t + (E @ ah).real - s0
-        sp = (E @ sh).real
-        dtn = (s - target) / sp
+        a, b, _c = sums(t)
+        dtn = (sh[0].real * t + a.real - s0 - target) / b.real
         t = t - dtn
+        nit = _ + 1
         if np.abs(dtn).max() < tol:
             break
-    cn = np.exp(1j * np.outer(t, k)) @ ch
+    arc_length_parameterize.last_iterations = nit
+    cn = sums(t)[2]
     return cn.real, cn.imag
 
 

@@ -61,26 +61,35 @@ class _QFS(object):
         q = qfs_boundary if qfs_boundary is not None else QFS_Boundary(bdy, eps=eps)
         self.source = q.interior_source_bdy if interior else q.exterior_source_bdy
         self.slp, self.dlp = slp, dlp
-        A = self._s2b(self.source, bdy)                              # (N, Ns)
+        self._dev = _device() if self.DEVICE_SOLVE else None
+        on_dev = self._dev is not None and hasattr(self, '_s2b_dev')
+        # (N, Ns) collocation matrix and the one-sided on-surface forms; built on the GPU
+        # when the kernel has torch builders (ipde_amd.dense_forms), else on the host
+        A = self._s2b_dev(self.source, bdy, self._dev) if on_dev else self._s2b(self.source, bdy)
         self._nrow = A.shape[0]
         jump = -0.5 if interior else 0.5
-        S = self._cached_singular(bdy, True, False) if slp else None
-        D = self._cached_singular(bdy, False, True) if dlp else None
-        if dlp:
-            D = D + jump * np.eye(D.shape[0])
-        self._dev = _device() if self.DEVICE_SOLVE else None
+        S = self._cached_singular(bdy, True, False, on_dev) if slp else None
+        D = self._cached_singular(bdy, False, True, on_dev) if dlp else None
         if self._dev is not None and A.shape[0] == A.shape[1]:
-            # factor and solve on the GPU (rocSOLVER through torch): the per-solve cost of
-            # three 4096^2 host LU back-substitutions was the largest single item of a
-            # warm 2048^2 Poisson solve
+            # factor with rocSOLVER, substitute with the library's blocked kernels (the
+            # per-solve cost of three 4096^2 host LU back-substitutions was the largest
+            # single item of a warm 2048^2 Poisson solve)
             import torch
-            self._A = torch.as_tensor(A, device=self._dev)
-            self._LU, self._piv = torch.linalg.lu_factor(self._A)
-            self._fact = _DeviceLU(self._LU, self._piv)
-            self._S = None if S is None else torch.as_tensor(S, device=self._dev)
-            self._D = None if D is None else torch.as_tensor(D, device=self._dev)
+            as_dev = lambda M: M if isinstance(M, torch.Tensor) else torch.as_tensor(M, device=self._dev)
+            self._A = as_dev(A)
+            self._fact = _DeviceLU(*_factor(self._A))
+            self._S = None if S is None else as_dev(S)
+            if D is not None:
+                D = as_dev(D)
+                self._D = D + jump * torch.eye(D.shape[0], dtype=torch.float64, device=self._dev)
+            else:
+                self._D = None
         else:
             self._dev = None
+            to_np = lambda M: M.cpu().numpy() if hasattr(M, 'cpu') else M
+            A, S, D = to_np(A), (None if S is None else to_np(S)), (None if D is None else to_np(D))
+            if D is not None:
+                D = D + jump * np.eye(D.shape[0])
             self._S, self._D = S, D
             if A.shape[0] == A.shape[1]:
                 self._lu = scipy.linalg.lu_factor(A)
@@ -91,13 +100,13 @@ class _QFS(object):
                 self._pinv = (Vt[keep].T / sv[keep]) @ U[:, keep].T
                 self._solve_host = lambda u: self._pinv @ u
 
-    def _cached_singular(self, bdy, c, d):
+    def _cached_singular(self, bdy, c, d, on_dev=False):
         """the on-surface forms depend on the curve only: the two QFS objects of an
         interface (grid side / radial side) share them"""
         cache = bdy.__dict__.setdefault('_singular_forms', {})
-        key = (type(self).__name__, getattr(self, 'k', None), c, d)
+        key = (type(self).__name__, getattr(self, 'k', None), c, d, on_dev)
         if key not in cache:
-            cache[key] = self._singular(bdy, c, d)
+            cache[key] = self._singular_dev(bdy, c, d, self._dev) if on_dev else self._singular(bdy, c, d)
         return cache[key]
 
     def _solve(self, u):
@@ -135,13 +144,21 @@ class _QFS(object):
         return self._solve(np.asarray(u, dtype=float))
 
 
+def _factor(A):
+    """(LU, piv) of rocSOLVER (0.04 s at n = 4096, 0.27 s at 16 384 once the library is
+    loaded; a blocked variant built from its panel factorisation + GEMM updates was not
+    faster — measured)"""
+    import torch
+    return torch.linalg.lu_factor(A)
+
+
 class _DeviceLU(object):
     """Substitution with rocSOLVER's factors through the library's own blocked kernels
     (csrc/dense.hip): plain substitution is backward stable where the library TRSM is
     not (residual 4e-14 vs 1.3e-9 on a cond-1e12 collocation matrix) and an order of
     magnitude faster for one right-hand side; one refinement step on top."""
 
-    def __init__(self, LU, piv):
+    def __init__(self, LU, piv=None, perm=None):
         import torch
         from .device import get_context
         self.ctx = get_context(LU.device.index)
@@ -151,11 +168,13 @@ class _DeviceLU(object):
         pad = torch.eye(nb * 64, dtype=torch.float64, device=LU.device)
         pad[:n, :n] = LU
         self.LU = pad.view(nb, 64, nb, 64).permute(0, 2, 1, 3).contiguous()
-        p = np.arange(self.n)
-        for i, q in enumerate(piv.cpu().numpy() - 1):      # LAPACK ipiv -> permutation vector
-            if q != i:
-                p[i], p[q] = p[q], p[i]
-        self.perm = torch.as_tensor(p.astype(np.int32), device=LU.device)
+        if perm is None:
+            p = np.arange(self.n)
+            for i, q in enumerate(piv.cpu().numpy() - 1):  # LAPACK ipiv -> permutation vector
+                if q != i:
+                    p[i], p[q] = p[q], p[i]
+            perm = torch.as_tensor(p, device=LU.device)
+        self.perm = perm.to(torch.int32).contiguous()
 
     def _subst(self, b):
         import torch
@@ -197,8 +216,9 @@ class DenseSolver(object):
         self._dev = _device()
         if self._dev is not None:
             import torch
-            self._A = torch.as_tensor(np.ascontiguousarray(A), device=self._dev)
-            self._fact = _DeviceLU(*torch.linalg.lu_factor(self._A))
+            self._A = A.to(self._dev) if isinstance(A, torch.Tensor) \
+                else torch.as_tensor(np.ascontiguousarray(A), device=self._dev)
+            self._fact = _DeviceLU(*_factor(self._A))
         else:
             self._lu = scipy.linalg.lu_factor(A)
 
@@ -229,6 +249,14 @@ class Laplace_QFS(_QFS):
 
     def _singular(self, bdy, c, d):
         return Laplace_Layer_Singular_Form(bdy, ifcharge=c, ifdipole=d)
+
+    def _s2b_dev(self, src, trg, dev):
+        from . import dense_forms as df
+        return df.laplace_form(src, trg, dev, ifcharge=True)
+
+    def _singular_dev(self, bdy, c, d, dev):
+        from . import dense_forms as df
+        return df.laplace_singular_form(bdy, dev, ifcharge=c, ifdipole=d)
 
 
 class Modified_Helmholtz_QFS(_QFS):
@@ -287,6 +315,14 @@ class Stokes_QFS(_QFS):
 
     def _singular(self, bdy, c, d):
         return Stokes_Layer_Singular_Form(bdy, ifforce=c, ifdipole=d)
+
+    def _s2b_dev(self, src, trg, dev):
+        from . import dense_forms as df
+        return df.stokes_form(src, trg, dev, ifforce=True) + df.stokes_pressure_fix(src, trg, dev)
+
+    def _singular_dev(self, bdy, c, d, dev):
+        from . import dense_forms as df
+        return df.stokes_singular_form(bdy, dev, ifforce=c, ifdipole=d)
 
     def _pressure_calibration(self):
         """Inside the curve the density n_src adds a constant pressure and no velocity, so
@@ -363,7 +399,7 @@ class QFS_Evaluator(object):
         if self._dev is not None:
             import torch
             self._A = torch.as_tensor(A, device=self._dev)
-            self._fact = _DeviceLU(*torch.linalg.lu_factor(self._A))
+            self._fact = _DeviceLU(*_factor(self._A))
             self.b2c_mats = [torch.as_tensor(B, device=self._dev) for B in self.b2c_mats]
         else:
             self._lu = scipy.linalg.lu_factor(A)

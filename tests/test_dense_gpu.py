@@ -92,3 +92,23 @@ def test_periodic_interp2d_real_part_path(Nx, Ny):
     ref = np.array([(stack[0] * np.exp(1j * (kxv[:, None] * a + kyv[None, :] * b))).sum() / (Nx * Ny)
                     for a, b in zip(x, y)])
     assert np.abs(full[0] - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+def test_device_form_builders_match_host_forms():
+    """ipde_amd.dense_forms (torch, GPU) against the numpy forms of pybie2d_compat"""
+    import torch
+    from ipde_amd import dense_forms as df
+    from ipde_amd import pybie2d_compat as pc
+    dev = torch.device("cuda")
+    b = pc.Global_Smooth_Boundary(c=pc.star(300, a=0.2, f=5))
+    s = pc.Global_Smooth_Boundary(c=b.c * 1.1)
+
+    def same(a, ref):
+        assert np.abs(a.cpu().numpy() - ref).max() < 1e-13 * np.abs(ref).max()
+    same(df.laplace_form(s, b, dev, ifcharge=True, ifdipole=True), pc.Laplace_Layer_Form(s, b, ifcharge=True, ifdipole=True))
+    same(df.laplace_singular_form(b, dev, ifcharge=True), pc.Laplace_Layer_Singular_Form(b, ifcharge=True))
+    same(df.laplace_singular_form(b, dev, ifdipole=True), pc.Laplace_Layer_Singular_Form(b, ifdipole=True))
+    same(df.stokes_form(s, b, dev, ifforce=True, ifdipole=True), pc.Stokes_Layer_Form(s, b, ifforce=True, ifdipole=True))
+    same(df.stokes_singular_form(b, dev, ifforce=True), pc.Stokes_Layer_Singular_Form(b, ifforce=True))
+    same(df.stokes_singular_form(b, dev, ifdipole=True), pc.Stokes_Layer_Singular_Form(b, ifdipole=True))
+    same(df.stokes_pressure_fix(s, b, dev), pc.Stokes_Pressure_Fix(s, b))
