@@ -34,7 +34,7 @@ def v2f(x):
 
 
 def run(nb=300, M=12, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes=True,
-        return_fields=False, simple=False, warm=False):
+        return_fields=False, simple=False, warm=False, grid_backend=None):
     T = {}
     t0 = time.perf_counter()
     MOL = SlepianMollifier(1.5 * M)
@@ -81,7 +81,7 @@ def run(nb=300, M=12, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes
     bdy_u = u_function(all_b.x, all_b.y)
     bdy_v = v_function(all_b.x, all_b.y)
 
-    solver = StokesSolver(ebdyc, solver_type=solver_type)
+    solver = StokesSolver(ebdyc, solver_type=solver_type, grid_backend=grid_backend)
     T['setup_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     uc, vc, pc = solver(fu, fv, tol=1e-12, verbose=verbose, maxiter=200, restart=100)
@@ -160,10 +160,12 @@ if __name__ == "__main__":
     ap.add_argument("--a", type=float, default=4.0)
     ap.add_argument("--b", type=float, default=3.0)
     ap.add_argument("--single", action="store_true", help="outer boundary only")
+    ap.add_argument("--ewald", action="store_true", help="Ewald-split grid evaluator instead of the dense sum")
     ap.add_argument("--warm", action="store_true", help="time a second (warm) inhomogeneous solve")
     ap.add_argument("--simple", action="store_true", help="one 5-arm star of radius 1 in [-1.5, 1.5]^2")
     a_ = ap.parse_args()
-    ue, ve, pe, scale, T = run(a_.nb, a_.M, a_.a, a_.b, verbose=True, holes=not a_.single, simple=a_.simple, warm=a_.warm)
+    ue, ve, pe, scale, T = run(a_.nb, a_.M, a_.a, a_.b, verbose=True, holes=not a_.single, simple=a_.simple, warm=a_.warm,
+                               grid_backend='ewald' if a_.ewald else None)
     print('Error, u {:0.2e}'.format(ue))
     print('Error, v {:0.2e}'.format(ve))
     print('Error, p {:0.2e} (mean removed)'.format(pe), ' (|u|max %.3f)' % scale)

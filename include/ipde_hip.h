@@ -231,6 +231,20 @@ int ipde_ewald_spread(ipde_ewald* e, int loc, int64_t ns, const double* sx, cons
                       const double* q, double x0, double y0, int64_t nbx, int64_t nby,
                       int64_t offx, int64_t offy, int periodic, double* u_loc, double* op);
 
+/* Stokeslet sum with pressure through the same split (kind-0 handle): the near part is
+ * accumulated complete into loc3 = (u, v, p) planes, six Laplace densities
+ * rho * {f_x, f_y, y_x f_x, y_x f_y, y_y f_x, y_y f_y} (y relative to (cx, cy)) into the
+ * op6 planes; the caller finishes with
+ *   u_i = loc_i + T*[op_i + d_j op_{2+2i+j}]/2 - (x_i - c_i) B/2,  p = loc_p - B,
+ *   B = T*[d_x op_0 + d_y op_1]
+ * (the Laplace reduction of the stokeslet; reference Layer_Apply of
+ * ipde/solvers/internals/stokes.py:25-35 evaluated on a grid).  loc3 / op6: DEVICE
+ * arrays of 3 / 6 contiguous (nbx, nby) planes, accumulated into. */
+int ipde_ewald_spread_stokes(ipde_ewald* e, int loc, int64_t ns, const double* sx,
+                             const double* sy, const double* fx, const double* fy, double x0,
+                             double y0, double cx, double cy, int64_t nbx, int64_t nby,
+                             int64_t offx, int64_t offy, double* loc3, double* op6);
+
 /* batched 1-D complex FFT along the last axis of a (batch, n) array:
    ipde.utilities.fft / ifft (ipde/utilities.py:5-12). direction -1 / +1 (scaled). */
 int ipde_fft1_c2c(ipde_ctx* ctx, int loc, int64_t batch, int64_t n, int direction,

@@ -77,6 +77,8 @@ SIGNATURES = {
     "ipde_ewald_destroy": (_int, [_vp]),
     "ipde_ewald_spread": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _dbl, _dbl, _i64, _i64, _i64, _i64,
                                  _int, _vp, _vp]),
+    "ipde_ewald_spread_stokes": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl,
+                                        _i64, _i64, _i64, _i64, _vp, _vp]),
     "ipde_fd4": (_int, [_vp, _int, _i64, _i64, _dbl, _int, _int, _vp, _vp]),
     "ipde_fft1_prepare": (_int, [_vp, _i64, _i64]),
     "ipde_fft1_c2c": (_int, [_vp, _int, _i64, _i64, _int, _vp, _vp]),

@@ -99,10 +99,79 @@ __global__ __launch_bounds__(EW_NT) void ewald_spread_kernel(
             Gp = -inv2pi * k * k * r * k1x;
         }
         const double loc = chi * G;
-        const double rho = fma(2.0 * chi_r, Gp, (chi_rr + chi_r / r) * G);
+        // rho -> 0 as r -> 0, but chi' is only ~1e-16 there (the Kaiser-Bessel bump ends on
+        // 1/I0(beta), not on 0): closer than 1e-6 R the 1/r factors would turn that into O(1)
+        const double rho = (r > 1e-6 * R) ? fma(2.0 * chi_r, Gp, (chi_rr + chi_r / r) * G) : 0.0;
         const int64_t idx = gx * nby + gy;
         unsafeAtomicAdd(&u_loc[idx], qs * loc);
         unsafeAtomicAdd(&op[idx], qs * rho);
+    }
+}
+
+// Stokeslet (with pressure) through the Laplace split — see oracle/ewald.py and
+// ipde_amd/grid_evaluators/ewald.py:StokesFreespaceEwald for the identity.  Per pair the
+// near part is complete here,
+//   u_i += (chi G f_i - (chi G)' r_i (r.f)/r) / 2,    p -= (chi G)' (r.f)/r,
+// and six densities rho q, q in {f_x, f_y, y_x f_x, y_x f_y, y_y f_x, y_y f_y} (y relative
+// to the grid centre), are spread for the far field.
+__global__ __launch_bounds__(EW_NT) void ewald_spread_stokes_kernel(
+    const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ fx,
+    const double* __restrict__ fy, int64_t ns, double x0, double y0, double h, int sw, double R,
+    const double* __restrict__ gtab, int ni, int deg, int64_t nbx, int64_t nby, int64_t offx,
+    int64_t offy, double cx, double cy, double* __restrict__ loc3, double* __restrict__ op6,
+    int* __restrict__ flag) {
+    extern __shared__ double tab[];
+    const int ntab = 3 * ni * (deg + 1);
+    for (int i = threadIdx.x; i < ntab; i += EW_NT) tab[i] = gtab[i];
+    __syncthreads();
+    const int64_t j = blockIdx.x;
+    if (j >= ns) return;
+    const double xs = sx[j], ys = sy[j], fxs = fx[j], fys = fy[j];
+    const double yx = xs - cx, yy = ys - cy;
+    const int64_t ccx = (int64_t)floor((xs - x0) / h), ccy = (int64_t)floor((ys - y0) / h);
+    const int W = 2 * sw + 3;
+    const double R2 = R * R, iR2 = 2.0 / R, inv2pi = 0.15915494309189535;
+    const int stride = deg + 1;
+    const size_t plane = (size_t)nbx * nby;
+    for (int p = threadIdx.x; p < W * W; p += EW_NT) {
+        const int a = p / W, b = p - a * W;
+        const int64_t ix = ccx - sw - 1 + a, iy = ccy - sw - 1 + b;
+        const double rx = fma((double)ix, h, x0) - xs, ry = fma((double)iy, h, y0) - ys;
+        const double d2 = fma(rx, rx, ry * ry);
+        if (d2 > R2 || d2 == 0.0) continue;
+        const int64_t gx = ix + offx, gy = iy + offy;
+        if (gx < 0 || gy < 0 || gx >= nbx || gy >= nby) {
+            atomicOr(flag, 1);
+            continue;
+        }
+        const double r = sqrt(d2);
+        double fi = (1.0 - 0.5 * iR2 * r) * (double)ni;
+        int i = (int)fi;
+        i = i < 0 ? 0 : (i >= ni ? ni - 1 : i);
+        const double t = 2.0 * (fi - (double)i) - 1.0;
+        const double* c0 = tab + (size_t)i * stride;
+        const double* c1 = c0 + (size_t)ni * stride;
+        const double* c2 = c1 + (size_t)ni * stride;
+        double chi = c0[deg], chi_r = c1[deg], chi_rr = c2[deg];
+        for (int m = deg - 1; m >= 0; --m) {
+            chi = fma(chi, t, c0[m]);
+            chi_r = fma(chi_r, t, c1[m]);
+            chi_rr = fma(chi_rr, t, c2[m]);
+        }
+        const double G = -0.5 * inv2pi * log(d2), Gp = -inv2pi / r;
+        const double lg = chi * G, dlg = fma(chi_r, G, chi * Gp);
+        const double rho = (r > 1e-6 * R) ? fma(2.0 * chi_r, Gp, (chi_rr + chi_r / r) * G) : 0.0;
+        const double rf = (rx * fxs + ry * fys) / r;
+        const size_t idx = (size_t)gx * nby + gy;
+        unsafeAtomicAdd(&loc3[idx], 0.5 * (lg * fxs - dlg * rx * rf));
+        unsafeAtomicAdd(&loc3[plane + idx], 0.5 * (lg * fys - dlg * ry * rf));
+        unsafeAtomicAdd(&loc3[2 * plane + idx], -dlg * rf);
+        unsafeAtomicAdd(&op6[idx], rho * fxs);
+        unsafeAtomicAdd(&op6[plane + idx], rho * fys);
+        unsafeAtomicAdd(&op6[2 * plane + idx], rho * yx * fxs);
+        unsafeAtomicAdd(&op6[3 * plane + idx], rho * yx * fys);
+        unsafeAtomicAdd(&op6[4 * plane + idx], rho * yy * fxs);
+        unsafeAtomicAdd(&op6[5 * plane + idx], rho * yy * fys);
     }
 }
 
@@ -184,6 +253,40 @@ extern "C" int ipde_ewald_spread(ipde_ewald* e, int loc, int64_t ns, const doubl
             IPDE_SET_ERR(ctx, "ipde_ewald_spread: a source's stencil leaves the padded grid");
             return IPDE_ERR_INVALID;
         }
+    }
+    return IPDE_OK;
+}
+
+extern "C" int ipde_ewald_spread_stokes(ipde_ewald* e, int loc, int64_t ns, const double* sx,
+                                        const double* sy, const double* fx, const double* fy,
+                                        double x0, double y0, double cx, double cy, int64_t nbx,
+                                        int64_t nby, int64_t offx, int64_t offy, double* loc3,
+                                        double* op6) {
+    if (!e) return IPDE_ERR_INVALID;
+    ipde_ctx* ctx = e->ctx;
+    IPDE_CHECK_ARG(ctx, e->kind == 0);   // built on the Laplace cut-off tables
+    IPDE_CHECK_ARG(ctx, loc == IPDE_HOST || loc == IPDE_DEVICE);
+    IPDE_CHECK_ARG(ctx, ns >= 0 && nbx > 0 && nby > 0 && loc3 && op6);
+    if (ns == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, sx && sy && fx && fy);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const double *d_sx, *d_sy, *d_fx, *d_fy;
+    IPDE_TRY(ipde_stage_in(ctx, loc, 0, sx, ns, &d_sx));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 1, sy, ns, &d_sy));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 2, fx, ns, &d_fx));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 3, fy, ns, &d_fy));
+    const size_t lds = (size_t)3 * e->ni * (e->deg + 1) * sizeof(double);
+    hipLaunchKernelGGL(ewald_spread_stokes_kernel, dim3((unsigned)ns), dim3(EW_NT), lds, ctx->stream,
+                       d_sx, d_sy, d_fx, d_fy, ns, x0, y0, e->h, e->sw, e->R, e->d_tab, e->ni, e->deg,
+                       nbx, nby, offx, offy, cx, cy, loc3, op6, e->d_flag);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    int flag = 0;
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(&flag, e->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) {
+        IPDE_HIP_CHECK(ctx, hipMemsetAsync(e->d_flag, 0, sizeof(int), ctx->stream));
+        IPDE_SET_ERR(ctx, "ipde_ewald_spread_stokes: a source's stencil leaves the padded grid");
+        return IPDE_ERR_INVALID;
     }
     return IPDE_OK;
 }

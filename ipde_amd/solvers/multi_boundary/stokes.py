@@ -7,10 +7,10 @@ from ..internals.stokes import StokesHelper
 
 
 class StokesSolver(VectorSolver):
-    def __init__(self, ebdyc, solver_type='spectral', helpers=None):
+    def __init__(self, ebdyc, solver_type='spectral', helpers=None, grid_backend=None):
         if not ebdyc.bumpy_readied:
             raise Exception('Stokes solver requires embedded boundary collection with a bump function.')
-        super().__init__(ebdyc, solver_type, helpers)
+        super().__init__(ebdyc, solver_type, helpers, grid_backend=grid_backend)
 
     def _get_helper_compatability(self, ebdy, helper):
         """0: helper is of no use; 1: its annular solver can be reused; 2: reuse as is

@@ -18,9 +18,10 @@ from ...spectral import get_plan
 
 
 class VectorSolver(object):
-    def __init__(self, ebdyc, solver_type='spectral', helpers=None, **kwargs):
+    def __init__(self, ebdyc, solver_type='spectral', helpers=None, grid_backend=None, **kwargs):
         self.ebdyc = ebdyc
         self.solver_type = solver_type
+        self.grid_backend = grid_backend
         if helpers is None:
             helpers = [None, ] * self.ebdyc.N
         self._extract_extra_kwargs(**kwargs)
@@ -64,9 +65,29 @@ class VectorSolver(object):
             self._ia.append((idx, torch.as_tensor(ebdy.grid_ia_xi, device=dev),
                              torch.as_tensor(ebdy.grid_ia_t, device=dev)))
         from ...pybie2d_compat import PointSet
-        self.Grid_Evaluator = make_pnai_evaluator(
-            lambda src, trg, f: self.Layer_Apply(src, trg, f), self.grid_sources, e.grid_pnai,
-            lambda x, y: DeviceTargets(PointSet(x=x, y=y)))
+        if self.grid_backend == 'ewald':
+            # whole-grid evaluation through the Laplace-split (grid_evaluators/ewald.py) +
+            # the interface nodes by the dense kernel (the scalar solvers'
+            # split_grid_evaluation branch, reference multi_boundary/scalar.py:63-71)
+            from ...grid_evaluators.stokes_grid_evaluator import (StokesGridBackend,
+                                                                  StokesFreespaceGridEvaluator)
+            ev = StokesFreespaceGridEvaluator(StokesGridBackend(self.grid.xh, 24), self.grid.xv,
+                                              self.grid.yv)
+            iv = DeviceTargets(e.all_iv)
+            src = self.grid_sources
+
+            def evaluator(f):
+                fw = np.asarray(f, dtype=float).reshape(2, -1) * src.weights
+                g = ev(src.get_stacked_boundary(), fw, device_result=True)
+                b = self.Layer_Apply(src, iv, f)
+                return tuple(torch.cat([gg.reshape(-1)[self._pna_idx], bb]) for gg, bb in zip(g, b))
+            self.Grid_Evaluator = evaluator
+            self.split_grid_evaluation = True
+        else:
+            self.Grid_Evaluator = make_pnai_evaluator(
+                lambda src, trg, f: self.Layer_Apply(src, trg, f), self.grid_sources, e.grid_pnai,
+                lambda x, y: DeviceTargets(PointSet(x=x, y=y)))
+            self.split_grid_evaluation = False
         self._pin_in = torch.empty((2, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
         self._pin_out = torch.empty((3, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
 

@@ -97,7 +97,9 @@ def radial_parts(mol, r, R, helmholtz_k=None):
         G, Gp = -np.log(r) / (2 * np.pi), -1.0 / (2 * np.pi * r)
     else:
         G, Gp = k0(helmholtz_k * r) / (2 * np.pi), -helmholtz_k * k1(helmholtz_k * r) / (2 * np.pi)
-    return chi * G, 2 * c1 * Gp + (c2 + c1 / r) * G
+    # (rho is zero to rounding near r = 0; chi' is ~1e-16 rather than 0 there, so the 1/r
+    # factors are cut off below 1e-6 R)
+    return chi * G, np.where(r > 1e-6 * R, 2 * c1 * Gp + (c2 + c1 / r) * G, 0.0)
 
 
 def spread(mol, sx, sy, q, x0, y0, h, sw, nbx, nby, offx, offy, periodic, helmholtz_k=None):
@@ -157,3 +159,63 @@ def periodic_eval(sx, sy, q, xv, yv, sw, beta=None, helmholtz_k=None):
                          indexing='ij')
     isym = -laplace_ifs(kx, ky) if helmholtz_k is None else -modhelm_ifs(kx, ky, helmholtz_k)
     return ul + np.fft.ifft2(np.fft.fft2(op) * isym).real
+
+
+# -- Stokes (stokeslet with pressure) through Laplace potentials ---------------
+def stokes_freespace_eval(sx, sy, fx, fy, xv, yv, sw, beta=None):
+    """(u, v, p) of sum_s stokeslet(x - y_s) f_s on the grid through the Laplace split.
+    With G = -log r / (2 pi) and G[q] = sum_s G(x - y_s) q_s:
+        u_i = G[f_i]/2 - x_i d_j G[f_j]/2 + d_j G[y_i f_j]/2,      p = -d_j G[f_j]
+    (r_i r_j / r^2 f_j = (x_i - y_i) d_j(log r) f_j; the classical reduction of the Stokes
+    FMM to Laplace FMMs).  Near part: chi G and its radial derivative directly, with
+    (x_i - y_i) formed exactly; far part: six spread densities rho q, one padded
+    convolution each, the derivative as i k in Fourier space; coordinates are centred on
+    the grid to keep the far-field combination x_i B - C_i well conditioned."""
+    n = len(xv)
+    h = xv[1] - xv[0]
+    R = sw * h
+    mol = KaiserBesselStep(1.6 * sw if beta is None else beta)
+    E = n + 2 * sw
+    big = 2 * E
+    off = sw
+    cx, cy = 0.5 * (xv[0] + xv[-1]), 0.5 * (yv[0] + yv[-1])
+    loc = np.zeros((3, big, big))
+    op = np.zeros((6, big, big))
+    for j in range(len(sx)):
+        ix, iy = int(np.floor((sx[j] - xv[0]) / h)), int(np.floor((sy[j] - yv[0]) / h))
+        I = np.arange(ix - sw - 1, ix + sw + 2)
+        J = np.arange(iy - sw - 1, iy + sw + 2)
+        X, Y = np.meshgrid(xv[0] + I * h, yv[0] + J * h, indexing='ij')
+        rx, ry = X - sx[j], Y - sy[j]
+        d = np.hypot(rx, ry)
+        m = (d <= R) & (d > 0)
+        dd = np.where(m, d, 0.5 * R)
+        chi, c1, c2 = mol.chi(dd, R)
+        G, Gp = -np.log(dd) / (2 * np.pi), -1.0 / (2 * np.pi * dd)
+        lg, dlg = chi * G, c1 * G + chi * Gp
+        rho = np.where(dd > 1e-6 * R, 2 * c1 * Gp + (c2 + c1 / dd) * G, 0.0)
+        rf = (rx * fx[j] + ry * fy[j]) / dd
+        sl = np.ix_(I + off, J + off)
+        loc[0][sl] += np.where(m, 0.5 * (lg * fx[j] - dlg * rx * rf), 0.0)
+        loc[1][sl] += np.where(m, 0.5 * (lg * fy[j] - dlg * ry * rf), 0.0)
+        loc[2][sl] += np.where(m, -dlg * rf, 0.0)
+        yx, yy = sx[j] - cx, sy[j] - cy
+        for k, q in enumerate((fx[j], fy[j], yx * fx[j], yx * fy[j], yy * fx[j], yy * fy[j])):
+            op[k][sl] += np.where(m, rho * q, 0.0)
+    drange = xv[-1] - xv[0] + h
+    TH = truncated_operator(big, h, 2.5 * drange, None)
+    kv = np.fft.fftfreq(big, h / (2 * np.pi))
+    if big % 2 == 0:
+        kv[big // 2] = 0.0
+    ikx, iky = 1j * kv[:, None], 1j * kv[None, :]
+    F = np.fft.fft2(op, axes=(1, 2))
+    B = np.fft.ifft2(TH * (ikx * F[0] + iky * F[1])).real
+    ux = np.fft.ifft2(TH * 0.5 * (F[0] + ikx * F[2] + iky * F[3])).real
+    uy = np.fft.ifft2(TH * 0.5 * (F[1] + ikx * F[4] + iky * F[5])).real
+    xb = xv[0] + h * (np.arange(big) - off) - cx
+    yb = yv[0] + h * (np.arange(big) - off) - cy
+    u = loc[0] + ux - 0.5 * xb[:, None] * B
+    v = loc[1] + uy - 0.5 * yb[None, :] * B
+    p = loc[2] - B
+    s = slice(off, off + n)
+    return u[s, s], v[s, s], p[s, s]

@@ -129,3 +129,34 @@ def test_rectangular_freespace_ewald_matches_dense():
     ref = laplace_apply(sx, sy, X.ravel(), Y.ravel(), w_sigma=q, generic_math=True).reshape(nx, ny)
     assert got.shape == (nx, ny)
     assert np.abs(got - ref).max() < 2e-13 * np.abs(ref).max()
+
+
+def test_stokes_ewald_matches_dense_kernel():
+    from ipde_amd.grid_evaluators.stokes_grid_evaluator import (StokesGridBackend,
+                                                                StokesFreespaceGridEvaluator)
+    from ipde_amd.layer_potentials import stokes_apply
+    nx, ny, sw = 384, 320, 24
+    h = 3.0 / 384
+    xv, yv = -1.5 + h * np.arange(nx), -1.25 + h * np.arange(ny)
+    c = Curve(500, a=0.2, f=5)      # its node at theta = pi/2 sits 6e-17 from a grid point
+    rng = np.random.default_rng(3)
+    f = rng.standard_normal((2, c.N)) * c.weights
+    ev = StokesFreespaceGridEvaluator(StokesGridBackend(h, sw), xv, yv)
+    u, v, p = ev(np.vstack([c.x, c.y]), f)
+    X, Y = np.meshgrid(xv, yv, indexing='ij')
+    ur, vr, pr = stokes_apply(c.x, c.y, X.ravel(), Y.ravel(), wfx=f[0], wfy=f[1], generic_math=True)
+    near = np.hypot(X.ravel()[:, None] - c.x[None, ::1], Y.ravel()[:, None] - c.y[None, ::1]).min(axis=1) < 1e-9
+    for a, b in ((u, ur), (v, vr), (p, pr)):
+        assert a.shape == (nx, ny)
+        assert np.abs(a.ravel() - b)[~near].max() < 3e-12 * np.abs(b[~near]).max()
+
+
+def test_stokes_solver_with_ewald_backend():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import multi_stokes
+    ue, ve, pe, scale, T = multi_stokes.run(nb=400, M=12, simple=True, grid_backend='ewald')
+    ud, vd, pd, scale, T = multi_stokes.run(nb=400, M=12, simple=True)
+    assert max(ue, ve) / scale < 2e-8
+    assert abs(ue - ud) < 1e-9 and abs(pe - pd) < 1e-6
