@@ -17,7 +17,9 @@ lets the dense GPU kernel (`Layer_Apply`) serve near and far targets alike.  The
 collocation matrix is ill-conditioned (e^{pi alpha}) but the solve is backward stable
 and the data are resolved, so the potential keeps ~1e-14 accuracy (measured on the
 5-arm star: alpha = 5 reproduces S+D to 4e-15 down to one node spacing from G).
-Host LAPACK: set-up (LU) once, O(N^2) per call.
+The matrices are built (ipde_amd.dense_forms) and factored (rocSOLVER) on the GPU; the
+per-call solve is the library's blocked substitution (csrc/dense.hip).  Host LAPACK
+without a GPU (CPU tests).
 """
 import numpy as np
 import scipy.linalg
@@ -192,19 +194,6 @@ class _DeviceLU(object):
         for _ in range(steps):
             x = x + self._subst(b - A @ x)
         return x
-
-
-def _refined_lu_solve(A, LU, piv, b, steps=2):
-    """GPU LU solve + iterative refinement.  The library triangular solves (rocBLAS TRSM
-    with inverted diagonal blocks) are not backward stable on these collocation matrices
-    (cond ~1e12: residual 1.5e-9 vs 6e-15 for host LAPACK, measured); two refinement
-    steps with the fp64 residual bring it to 2e-15."""
-    import torch
-    x = torch.linalg.lu_solve(LU, piv, b[:, None])[:, 0]
-    for _ in range(steps):
-        r = b - A @ x
-        x = x + torch.linalg.lu_solve(LU, piv, r[:, None])[:, 0]
-    return x
 
 
 class DenseSolver(object):
