@@ -29,6 +29,15 @@ def timeit(fn, sync, reps=5, warm=2):
     return (time.perf_counter() - t0) / reps
 
 
+def _rel_diff(got, ref):
+    """max |got - ref| / max |ref| over the grid points that are not (numerically) ON a
+    source — the 4096-node star has a node 6e-17 from a grid point, where the kernels
+    legitimately return ~1e2 or inf"""
+    import torch
+    ok = torch.isfinite(ref) & (ref.abs() <= 20.0 * ref.abs().median())
+    return float((got - ref)[ok].abs().max() / ref[ok].abs().max())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -109,12 +118,30 @@ def main():
             "wall_ms": t_e * 1e3, "dense_full_grid_ms": t_d * 1e3, "setup_s": t_setup,
             "spread_ms": t_spread * 1e3, "padded_fft_convolution_ms": t_fft * 1e3,
             "padded_grid": [e.big_nx, e.big_ny], "spread_width": 24,
-            "max_rel_diff_vs_dense": float((got - ref).abs().max() / ref.abs().max()),
+            "max_rel_diff_vs_dense": _rel_diff(got, ref),
             "equivalent_pairs_per_s": float(nb) * ng * ng / t_e,
             "fft_algorithmic_GBps": (8.0 + 8.0 + 16.0) * npad / t_fft / 1e9,
         }
         del ev, evd, ref, got, e
         torch.cuda.empty_cache()
+
+    # Stokes through the Laplace split against the dense Stokes kernel on the full grid
+    from ipde_amd.grid_evaluators.stokes_grid_evaluator import (StokesGridBackend,
+                                                                StokesFreespaceGridEvaluator)
+    fw = f2 * c.weights
+    evs = StokesFreespaceGridEvaluator(StokesGridBackend(hg, 24), xv, xv)
+    got = evs(src, fw, device_result=True)
+    t_e = timeit(lambda: evs(src, fw, device_result=True), sync, reps=5)
+    Xg, Yg = np.meshgrid(xv, xv, indexing='ij')
+    full = lp.DeviceTargets(Xg.ravel(), Yg.ravel())
+    ref = lp.Stokes_Layer_Apply(c, full, forces=f2)
+    t_d = timeit(lambda: lp.Stokes_Layer_Apply(c, full, forces=f2), sync, reps=3)
+    out["ewald_stokes"] = {
+        "wall_ms": t_e * 1e3, "dense_full_grid_ms": t_d * 1e3, "spread_width": 24,
+        "max_rel_diff_vs_dense": [_rel_diff(g.reshape(-1), r) for g, r in zip(got, ref)],
+    }
+    del evs, got, ref, full
+    torch.cuda.empty_cache()
 
     # spectral
     n = ng
