@@ -35,33 +35,45 @@ template <bool LOWER>
 __global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ LU, int n, int nb,
                                                     int k, double* __restrict__ v,
                                                     double* __restrict__ x) {
-    __shared__ double blk[DB][DB + 1];
     __shared__ double xs[DB];
     const int tid = threadIdx.x;
     const int r0 = k * DB;
-    // diagonal tile and the block's right-hand side
-    const double* dt = LU + ((size_t)k * nb + k) * (DB * DB);
-    for (int e = tid; e < DB * DB; e += DT) blk[e / DB][e % DB] = dt[e];
-    __syncthreads();
+    // this workgroup's off-diagonal tile goes into registers first: the loads are in flight
+    // while wave 0 runs the 64-step dependency chain of the diagonal solve
+    const int i = LOWER ? k + (int)blockIdx.x : k - (int)blockIdx.x;   // block row to update
+    const int row = tid >> 2, part = tid & 3;
+    double a[16];
+    if (blockIdx.x != 0) {
+        const double* ap = LU + ((size_t)i * nb + k) * (DB * DB) + row * DB + part * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = ap[c];
+    }
     if (tid < DB) {
         const int lane = tid;
+        // row `lane` of the diagonal tile straight into registers (512 contiguous bytes)
+        const double* dt = LU + ((size_t)k * nb + k) * (DB * DB) + lane * DB;
+        double lrow[DB];
+#pragma unroll
+        for (int c = 0; c < DB; ++c) lrow[c] = dt[c];
         double val = (r0 + lane < n) ? v[r0 + lane] : 0.0;
         // x_j is broadcast with v_readlane (compile-time lane index under full unrolling):
-        // the 64-step dependency chain costs a few cycles per step instead of a
-        // ds_bpermute round trip
+        // a few cycles per step instead of a ds_bpermute round trip
         if (LOWER) {
 #pragma unroll
             for (int j = 0; j < DB; ++j) {
                 double xj = readlane_f64(val, j);
-                if (lane > j) val = fma(-blk[lane][j], xj, val);
+                if (lane > j) val = fma(-lrow[j], xj, val);
             }
         } else {
-            const double dinv = 1.0 / blk[lane][lane];
+            double dinv = 1.0;
+#pragma unroll
+            for (int c = 0; c < DB; ++c) dinv = (c == lane) ? lrow[c] : dinv;
+            dinv = 1.0 / dinv;
 #pragma unroll
             for (int j = DB - 1; j >= 0; --j) {
                 if (lane == j) val *= dinv;
                 double xj = readlane_f64(val, j);
-                if (lane < j) val = fma(-blk[lane][j], xj, val);
+                if (lane < j) val = fma(-lrow[j], xj, val);
             }
         }
         xs[lane] = val;
@@ -69,15 +81,10 @@ __global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ L
     }
     if (blockIdx.x == 0) return;
     __syncthreads();
-    const int i = LOWER ? k + (int)blockIdx.x : k - (int)blockIdx.x;   // block row to update
-    const int row = tid >> 2, part = tid & 3;
     const int gr = i * DB + row;
     double s = 0.0;
-    {
-        const double* a = LU + ((size_t)i * nb + k) * (DB * DB) + row * DB + part * 16;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) s = fma(a[c], xs[part * 16 + c], s);
-    }
+    for (int c = 0; c < 16; ++c) s = fma(a[c], xs[part * 16 + c], s);
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     if (part == 0 && gr < n) v[gr] -= s;

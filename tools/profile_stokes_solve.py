@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Warm 3-body Stokes solves (examples/multi_stokes.py set-up, nb = 800) in a loop — for
+    rocprofv3 --kernel-trace --stats -- python3 tools/profile_stokes_solve.py"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'examples'))
+import torch  # noqa: E402
+import multi_stokes as ms  # noqa: E402
+
+state = {}
+orig = ms.StokesSolver.__call__
+
+
+def wrapped(self, fu, fv, **kw):
+    out = orig(self, fu, fv, **kw)
+    if 'done' not in state:
+        state['done'] = True
+        orig(self, fu, fv, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            orig(self, fu, fv, **kw)
+        torch.cuda.synchronize()
+        print("warm stokes solve %.2f ms" % ((time.perf_counter() - t0) / n * 1e3))
+    return out
+
+
+ms.StokesSolver.__call__ = wrapped
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 800
+ms.run(nb, 14)
