@@ -201,3 +201,15 @@ def test_stokes_qfs_green_representation():
             ue = ve = pe = 0 * xt
         assert max(np.abs(got[0] - ue).max(), np.abs(got[1] - ve).max()) < 1e-11
         assert np.abs(got[2] - pe).max() < 1e-8
+
+
+def test_kress_single_layer_for_odd_and_even_node_counts():
+    """the log-singular quadrature has no Nyquist term for odd N"""
+    for N in (300, 301):
+        b = GSB(c=star(N, a=0.2, f=5))
+        xs, ys, one = np.array([2.0]), np.array([1.5]), np.array([1.0])
+        ub = olp.laplace_layer_apply(xs, ys, b.x, b.y, charge=one)
+        sig = np.linalg.solve(Laplace_Layer_Singular_Form(b, ifcharge=True), ub)
+        xt, yt = np.array([0.1, -0.3]), np.array([0.2, 0.4])
+        u = olp.laplace_layer_apply(b.x, b.y, xt, yt, charge=sig, weights=b.weights)
+        assert np.abs(u - olp.laplace_layer_apply(xs, ys, xt, yt, charge=one)).max() < 1e-13
