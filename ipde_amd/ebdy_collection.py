@@ -177,6 +177,60 @@ class EmbeddedBoundaryCollection(object):
             ebdy.interpolate_radial_to_grid1(fr, f)
         return f
 
+    # -- derivatives of EmbeddedFunctions (reference :709-792) -----------------------------
+    def _grid_values(self, ff, derivative_type):
+        f = ff.get_grid_value()
+        if derivative_type == 'spectral':
+            fc = f * self.grid_step
+            fc[self.ext] = 0.0
+            return fc
+        return f
+
+    def gradient(self, ff, derivative_type='spectral'):
+        """(fx, fy) EmbeddedFunctions.  Grid part: `spectral` = Fourier derivative of the
+        cut-off function (rocFFT, ipde_fourier_deriv), `fourth` = 4th-order centred
+        differences of the raw values (ipde_fd4); radial part: Chebyshev x Fourier
+        differentiation on each annulus, which also overwrites the grid points under it."""
+        from .derivatives import fd_x_4, fd_y_4
+        from .spectral import get_plan
+        fr_list = ff.get_radial_value_list()
+        f = self._grid_values(ff, derivative_type)
+        if derivative_type == 'spectral':
+            plan = get_plan(self.grid.Nx, self.grid.Ny, self.grid.xh, self.grid.yh)
+            fx, fy = np.array(plan.dx(f)), np.array(plan.dy(f))
+        else:
+            fx, fy = np.array(fd_x_4(f, self.grid.xh)), np.array(fd_y_4(f, self.grid.yh))
+        fxrs, fyrs = [], []
+        for ebdy, fr in zip(self, fr_list):
+            fxr, fyr = ebdy.gradient(fx, fy, fr)
+            fxrs.append(fxr)
+            fyrs.append(fyr)
+        fx *= self.phys
+        fy *= self.phys
+        ffx, ffy = EmbeddedFunction(self), EmbeddedFunction(self)
+        ffx.load_data(fx[self.phys], fxrs)
+        ffy.load_data(fy[self.phys], fyrs)
+        return ffx, ffy
+
+    def laplacian(self, ff, derivative_type='spectral'):
+        """(reference :755-792; its `fourth` branch never forms lapf — here it is
+        fxx + fyy of the centred differences, which is what the branch sets out to do)"""
+        from .derivatives import fd_x_4, fd_y_4
+        from .spectral import get_plan
+        fr_list = ff.get_radial_value_list()
+        f = self._grid_values(ff, derivative_type)
+        if derivative_type == 'spectral':
+            plan = get_plan(self.grid.Nx, self.grid.Ny, self.grid.xh, self.grid.yh)
+            lapf = np.array(plan.fourier_multiply(f, self.lap))
+        else:
+            xh, yh = self.grid.xh, self.grid.yh
+            lapf = np.array(fd_x_4(fd_x_4(f, xh), xh)) + np.array(fd_y_4(fd_y_4(f, yh), yh))
+        lapfrs = [ebdy.laplacian(lapf, fr) for ebdy, fr in zip(self, fr_list)]
+        lapf *= self.phys
+        out = EmbeddedFunction(self)
+        out.load_data(lapf[self.phys], lapfrs)
+        return out
+
     # -- demeaning (reference :795-812) ----------------------------------------------------
     def ready_bump(self, bump, bump_loc=None, bump_width=None):
         if bump_width is None:

@@ -179,6 +179,27 @@ class EmbeddedBoundary(object):
         fr = self._radial_grid_r_derivative(f)
         return fr * bdy.normal_x + ft * bdy.tangent_x, fr * bdy.normal_y + ft * bdy.tangent_y
 
+    def radial_grid_laplacian(self, f):
+        """(reference :493-498: the gradient applied twice)"""
+        fx, fy = self.radial_grid_derivatives(f)
+        fxx, _ = self.radial_grid_derivatives(fx)
+        _, fyy = self.radial_grid_derivatives(fy)
+        return fxx + fyy
+
+    def gradient(self, fx, fy, fr):
+        """Gradient on the radial grid; its values replace fx, fy on the grid points under
+        this annulus (reference :499-508)."""
+        fxr, fyr = self.radial_grid_derivatives(fr)
+        self.interpolate_radial_to_grid1(fxr, fx)
+        self.interpolate_radial_to_grid1(fyr, fy)
+        return fxr, fyr
+
+    def laplacian(self, lapf, fr):
+        """(reference :509-517)"""
+        lapfr = self.radial_grid_laplacian(fr)
+        self.interpolate_radial_to_grid1(lapfr, lapf)
+        return lapfr
+
     def convert_uv_to_rt(self, fu, fv):
         bdy = self.bdy
         return fu * bdy.normal_x + fv * bdy.normal_y, fu * bdy.tangent_x + fv * bdy.tangent_y
