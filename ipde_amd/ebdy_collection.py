@@ -172,6 +172,34 @@ class EmbeddedBoundaryCollection(object):
         fh = np.fft.fft2(f)
         return periodic_interp2d(fh, self.interfaces_x_transf, self.interfaces_y_transf, real_part=True).cpu().numpy()
 
+    def interpolate_radial_to_boundary(self, f):
+        """BoundaryFunction of the radial values extrapolated to each boundary (reference :567-571)"""
+        from .embedded_function import BoundaryFunction
+        out = BoundaryFunction(self)
+        out.load_data([ebdy.interpolate_radial_to_boundary(fr) for ebdy, fr in zip(self, f)])
+        return out
+
+    def interpolate_radial_to_boundary_normal_derivative(self, f):
+        """(what reference :572-577 sets out to do; there the methods are never called)"""
+        from .embedded_function import BoundaryFunction
+        out = BoundaryFunction(self)
+        out.load_data([ebdy.interpolate_radial_to_boundary_normal_derivative(fr) for ebdy, fr in zip(self, f)])
+        return out
+
+    def interpolate_grid_to_radial(self, f, order=np.inf):
+        """Values of a periodic grid function at the radial nodes of every boundary — only
+        meaningful for functions smooth across the whole box (reference :630-647 uses a
+        local polynomial interpolant; here the exact trigonometric one, through the same
+        dense Fourier evaluation as grid -> interface)."""
+        from .interp import periodic_interp2d
+        fh = np.fft.fft2(np.asarray(f, dtype=float))
+        out = []
+        for ebdy in self:
+            xt = affine_transformation(ebdy.radial_x.ravel(), self.grid.x_bounds[0], self.grid.x_bounds[1], 0.0, 2 * np.pi)
+            yt = affine_transformation(ebdy.radial_y.ravel(), self.grid.y_bounds[0], self.grid.y_bounds[1], 0.0, 2 * np.pi)
+            out.append(periodic_interp2d(fh, xt, yt, real_part=True).cpu().numpy().reshape(ebdy.radial_shape))
+        return out
+
     def interpolate_radial_to_grid1(self, fr_list, f):
         for fr, ebdy in zip(fr_list, self):
             ebdy.interpolate_radial_to_grid1(fr, f)

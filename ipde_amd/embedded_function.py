@@ -123,6 +123,46 @@ class EmbeddedFunction(np.ndarray):
         """volume integral over the physical domain (reference :214-218)"""
         return self._ebdyc_test().volume_integral(self)
 
+    def gradient(self, derivative_type='spectral'):
+        """(reference :219-220)"""
+        return self._ebdyc_test().gradient(self, derivative_type)
+
+    def get_ebdyc(self):
+        return self._ebdyc_test()
+
+    def get_rdata(self):
+        """all radial values, flattened (reference :82-83)"""
+        return np.ndarray.__getitem__(self, slice(self._ebdyc_test().grid_phys.N, None)).view(np.ndarray)
+
+    def asarray(self):
+        return np.array(self)
+
+    def min(self):
+        return float(np.min(self.view(np.ndarray)))
+
+    def max(self):
+        return float(np.max(self.view(np.ndarray)))
+
+    def define_via_functions(self, f_grid, f_radial_list):
+        """grid values from f_grid(x, y), radial values of boundary i from f_radial_list[i]"""
+        ebdyc = self._ebdyc_test()
+        self.get_gdata()[:] = f_grid(ebdyc.grid_phys.x, ebdyc.grid_phys.y)
+        for arg, (ebdy, fr) in enumerate(zip(ebdyc, f_radial_list)):
+            self[int(arg)] = fr(ebdy.radial_x, ebdy.radial_y)
+
+    def load_full_grid(self, grid_value):
+        """Load from values given on the WHOLE grid; the radial values are interpolated from
+        them, which is only meaningful for a function smooth across the whole box
+        (reference :114-121)."""
+        ebdyc = self._ebdyc_test()
+        self.load_data(grid_value, ebdyc.interpolate_grid_to_radial(grid_value))
+
+    def extract_pnar(self):
+        """[values on phys-not-in-annulus grid points | all radial values] (reference :223-229)"""
+        ebdyc = self._ebdyc_test()
+        gv = self.get_grid_value()
+        return np.concatenate([gv[ebdyc.phys_not_in_annulus], self.get_rdata()])
+
     def copy(self):
         return EmbeddedFunction(self._ebdyc_test(), array=np.array(self.view(np.ndarray), copy=True))
 
@@ -185,6 +225,23 @@ class BoundaryFunction(np.ndarray):
     def load_data(self, value_list):
         for sl, v in zip(self.slices, value_list):
             np.ndarray.__setitem__(self, sl, v)
+
+    def define_via_functions(self, f_list):
+        """(reference :302-307)"""
+        for sl, ebdy, f in zip(self.slices, self.ebdyc(), f_list):
+            np.ndarray.__setitem__(self, sl, f(ebdy.bdy.x, ebdy.bdy.y))
+
+    def asarray(self):
+        return np.array(self)
+
+    def min(self):
+        return float(np.min(self.view(np.ndarray)))
+
+    def max(self):
+        return float(np.max(self.view(np.ndarray)))
+
+    def zero(self):
+        np.ndarray.__setitem__(self, slice(None, None), 0.0)
 
     def define_via_function(self, f):
         for sl, ebdy in zip(self.slices, self.ebdyc()):

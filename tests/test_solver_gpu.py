@@ -127,3 +127,31 @@ def test_embedded_function_gradient_and_laplacian():
     # resolved (the Poisson solve divides that error by k^2, a derivative multiplies it by k)
     assert errs[0] < 1e-4 and errs[1] < 1e-4 and errs[2] < 1e-1
     assert errs[3] < 1e-6 and errs[4] < 1e-3
+
+
+def test_embedded_function_convenience_methods():
+    from ipde_amd.ebdy_collection import EmbeddedBoundaryCollection
+    from ipde_amd.embedded_boundary import EmbeddedBoundary
+    from ipde_amd.embedded_function import EmbeddedFunction, BoundaryFunction
+    from ipde_amd.heavisides import SlepianMollifier
+    from ipde_amd.pybie2d_compat import star, Global_Smooth_Boundary as GSB
+    nb, M = 400, 12
+    bdy = GSB(c=star(nb, a=0.1, f=3))
+    bh = bdy.dt * bdy.speed.min()
+    ebdy = EmbeddedBoundary(bdy, True, M, bh, pad_zone=0, heaviside=SlepianMollifier(1.5 * M).step)
+    ebdyc = EmbeddedBoundaryCollection([ebdy])
+    grid = ebdyc.generate_grid(bh)
+    g = lambda x, y: np.exp(np.sin(2 * np.pi * (x - grid.x_bounds[0]) / (grid.x_bounds[1] - grid.x_bounds[0]))) \
+        * np.cos(2 * np.pi * (y - grid.y_bounds[0]) / (grid.y_bounds[1] - grid.y_bounds[0]))   # box-periodic
+    f = EmbeddedFunction(ebdyc, function=g)
+    assert f.min() <= f.max() and f.asarray().shape == f.shape
+    assert f.get_rdata().size == ebdy.radial_x.size
+    assert f.extract_pnar().size == ebdyc.grid_pna.N + ebdy.radial_x.size
+    f2 = EmbeddedFunction(ebdyc)
+    f2.load_full_grid(g(grid.xg, grid.yg))
+    assert np.abs(np.asarray(f2) - np.asarray(f)).max() < 1e-11
+    fb = ebdyc.interpolate_radial_to_boundary(f)
+    assert isinstance(fb, BoundaryFunction)
+    assert np.abs(fb[0] - g(bdy.x, bdy.y)).max() < 1e-9
+    fx, fy = f.gradient()
+    assert np.asarray(fx).shape == np.asarray(f).shape
