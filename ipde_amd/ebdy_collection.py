@@ -10,7 +10,7 @@ import numpy as np
 
 from .device import prewarm
 from .embedded_function import EmbeddedFunction
-from .near import grid_inside_curve
+from .near import grid_inside_curve, local_coordinates, points_inside_curve
 from .pybie2d_compat import Grid, PointSet
 from .utilities import affine_transformation
 
@@ -30,6 +30,7 @@ class EmbeddedBoundaryCollection(object):
         self.N = len(self.ebdys)
         self.bumpy_readied = False
         self.bump_location = None
+        self.registered_partitions = []
         self.grid = None
 
     def __iter__(self):
@@ -204,6 +205,54 @@ class EmbeddedBoundaryCollection(object):
         for fr, ebdy in zip(fr_list, self):
             ebdy.interpolate_radial_to_grid1(fr, f)
         return f
+
+    # -- interpolation to arbitrary points (reference :650-708) -----------------------------
+    def register_points(self, x, y):
+        """Classify points once: zone 1 = physical and outside every annulus (grid
+        interpolation), zone 2 = inside the annulus of boundary i (radial interpolation),
+        zone 3 = outside the physical domain.  Returns a key for interpolate_to_points."""
+        x = np.asarray(x, dtype=float).ravel()
+        y = np.asarray(y, dtype=float).ravel()
+        for k, p in enumerate(self.registered_partitions):
+            if p['x'].shape == x.shape and np.array_equal(p['x'], x) and np.array_equal(p['y'], y):
+                return k
+        phys = np.ones(x.shape, dtype=bool)
+        zone2 = []
+        taken = np.zeros(x.shape, dtype=bool)
+        for ebdy in self:
+            r, t, found = local_coordinates(ebdy.bdy, x, y, ebdy.radial_width)
+            inside = points_inside_curve(ebdy.bdy, x, y, r, found)
+            phys &= inside if ebdy.interior else ~inside
+            ia = np.zeros(x.shape, dtype=bool)
+            ia[found] = ebdy.check_if_r_in_annulus(r[found])[0]
+            ia &= ~taken
+            taken |= ia
+            lb = -ebdy.radial_width if ebdy.interior else 0.0
+            ub = 0.0 if ebdy.interior else ebdy.radial_width
+            zone2.append((np.flatnonzero(ia), affine_transformation(r[ia], lb, ub, -1.0, 1.0), t[ia]))
+        zone1 = np.flatnonzero(phys & ~taken)
+        zone3 = np.flatnonzero(~phys & ~taken)
+        tr = lambda v, b: affine_transformation(v, b[0], b[1], 0.0, 2 * np.pi)
+        self.registered_partitions.append({
+            'x': x.copy(), 'y': y.copy(), 'zone1': zone1, 'zone2': zone2, 'zone3': zone3,
+            'x_transf': tr(x[zone1], self.grid.x_bounds), 'y_transf': tr(y[zone1], self.grid.y_bounds)})
+        return len(self.registered_partitions) - 1
+
+    def interpolate_to_points(self, ff, x, y):
+        """Values of an EmbeddedFunction at arbitrary points: trigonometric interpolation
+        of the cut-off grid function where the cut-off is 1, Chebyshev x Fourier
+        interpolation in the annuli, nan outside the domain (reference :666-708)."""
+        from .interp import periodic_interp2d
+        p = self.registered_partitions[self.register_points(x, y)]
+        out = np.empty(p['x'].shape)
+        if p['zone1'].size:
+            fh = np.fft.fft2(ff.get_smoothed_grid_value())
+            out[p['zone1']] = periodic_interp2d(fh, p['x_transf'], p['y_transf'], real_part=True).cpu().numpy()
+        for ebdy, fr, (idx, xi, t) in zip(self, ff.get_radial_value_list(), p['zone2']):
+            if idx.size:
+                out[idx] = ebdy.interpolate_radial_to_points(fr, xi, t).cpu().numpy()
+        out[p['zone3']] = np.nan
+        return out.reshape(np.shape(x))
 
     # -- derivatives of EmbeddedFunctions (reference :709-792) -----------------------------
     def _grid_values(self, ff, derivative_type):

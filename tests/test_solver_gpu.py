@@ -155,3 +155,39 @@ def test_embedded_function_convenience_methods():
     assert np.abs(fb[0] - g(bdy.x, bdy.y)).max() < 1e-9
     fx, fy = f.gradient()
     assert np.asarray(fx).shape == np.asarray(f).shape
+
+
+def test_interpolate_to_points():
+    """EmbeddedBoundaryCollection.interpolate_to_points (reference :666-708): grid zone,
+    annulus zone and exterior points of a two-boundary domain"""
+    from ipde_amd.ebdy_collection import EmbeddedBoundaryCollection
+    from ipde_amd.embedded_boundary import EmbeddedBoundary
+    from ipde_amd.embedded_function import EmbeddedFunction
+    from ipde_amd.heavisides import SlepianMollifier
+    from ipde_amd.pybie2d_compat import star, Grid, Global_Smooth_Boundary as GSB
+    nb, M = 600, 16
+    b1 = GSB(c=star(nb, a=0.1, f=3))
+    b2 = GSB(c=star(200, x=0.1, y=-0.05, r=0.25, a=0.0, f=3))
+    bh = min(b.dt * b.speed.min() for b in (b1, b2))
+    mol = SlepianMollifier(1.5 * M)
+    ebdyc = EmbeddedBoundaryCollection([EmbeddedBoundary(b1, True, M, bh, pad_zone=0, heaviside=mol.step),
+                                        EmbeddedBoundary(b2, False, M, bh, pad_zone=0, heaviside=mol.step)])
+    ng = 2 * int(0.5 * 3.0 // bh)
+    ebdyc.register_grid(Grid([-1.5, 1.5], ng, [-1.5, 1.5], ng, x_endpoints=[True, False],
+                             y_endpoints=[True, False]))
+    g = lambda x, y: np.exp(np.sin(x)) * np.cos(2 * y)
+    f = EmbeddedFunction(ebdyc, function=g)
+    rng = np.random.default_rng(0)
+    x, y = rng.uniform(-1.3, 1.3, 4000), rng.uniform(-1.3, 1.3, 4000)
+    out = ebdyc.interpolate_to_points(f, x, y)
+    rad = np.hypot(x, y)
+    th = np.arctan2(y, x)
+    inside1 = rad < 1 + 0.1 * np.cos(3 * th)
+    inhole = np.hypot(x - 0.1, y + 0.05) < 0.25
+    phys = inside1 & ~inhole
+    assert np.all(np.isnan(out[~phys])) and not np.any(np.isnan(out[phys]))
+    assert np.abs(out[phys] - g(x[phys], y[phys])).max() < 1e-8
+    # second call reuses the registered partition
+    assert len(ebdyc.registered_partitions) == 1
+    ebdyc.interpolate_to_points(f, x, y)
+    assert len(ebdyc.registered_partitions) == 1
