@@ -73,6 +73,25 @@ def test_stokes_multiply_connected():
     assert pe < 5e-3
 
 
+def _run_sharded(problem, extra, port):
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tools", "run_sharded_solve.py"), "--backend", "gloo", "--share-gpu",
+           "--problem", problem] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_target_sharded_stokes_solve_two_ranks():
+    """the vector solver's Grid_Evaluator (tuples u, v, p) sharded over two ranks"""
+    res = _run_sharded("stokes", ["--nb", "600", "--M", "14"], 29541)
+    print(res)
+    assert res["world"] == 2 and res["error"] < 5e-6
+
+
 def test_target_sharded_poisson_solve_two_ranks():
     """The N > 1 solver path on real kernels: two ranks share the one GPU of the test box
     (collectives over gloo), each evaluates half of grid_pnai, the halves are
