@@ -63,6 +63,15 @@ class EmbeddedBoundary(object):
         self.radial_shape = (self.M, N)
         self.radial_k = np.fft.fftfreq(N, bdy.dt / (2 * np.pi))
         self.radial_speed = bdy.speed * (1.0 + bdy.curvature * self.radial_r)
+        # the boundary-fitted coordinates need 1 + curvature * r > 0 across the annulus; near 0
+        # they fold (the reference does not check: the solvers then return garbage silently)
+        jac = float(np.min(1.0 + bdy.curvature * (lb if self.interior else ub)))
+        self.min_radial_jacobian = jac
+        if jac <= 0.25:
+            import warnings
+            warnings.warn("EmbeddedBoundary: the annulus (width %.3g = M*h) is %s for this curve: "
+                          "min(1 + curvature*r) = %.2f; use more boundary nodes or a smaller M"
+                          % (self.radial_width, "folded" if jac <= 0 else "nearly folded", jac))
         self.inverse_radial_speed = 1.0 / self.radial_speed
         V0 = np.polynomial.chebyshev.chebvander(rc, self.M - 1)
         VI0 = np.linalg.inv(V0)

@@ -48,3 +48,18 @@ def test_stokes_blocks_match_reference():
     aag = AAG_nyq_dropped(int(n), int(M), width, radius)
     assert aag.ns == aag.n - 1 and np.array_equal(aag.ks, g["ks"])
     assert close(stokes_inverse_blocks(aag, 1.0), g["kinv"], 1e-10)
+
+
+def test_embedded_boundary_warns_when_the_annulus_folds():
+    import warnings
+    from ipde_amd.embedded_boundary import EmbeddedBoundary
+    from ipde_amd.heavisides import SlepianMollifier
+    from ipde_amd.pybie2d_compat import star, Global_Smooth_Boundary as GSB
+    for nb, expect in ((400, True), (800, False)):
+        b = GSB(c=star(nb, a=0.2, f=5))
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            e = EmbeddedBoundary(b, True, 16, b.dt * b.speed.min(), pad_zone=0,
+                                 heaviside=SlepianMollifier(24).step)
+        assert (len(w) > 0) == expect
+        assert (e.min_radial_jacobian < 0.25) == expect
