@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NT) void laplace_table_kernel(
     }
 }
 
-// Row-run variant of the single-layer table kernel: every lane owns R CONSECUTIVE entries
+// Row-run variant of the table kernel (all three modes): every lane owns R CONSECUTIVE entries
 // of the target list.  The solver's target lists are grid points in C order, so the R
 // targets of a lane normally sit in one grid row and share x: then (x - sx)^2 is formed
 // once per source and lane and a pair costs dy, d2 = fma(dy, dy, dx2) — 2 fp64
@@ -186,27 +186,33 @@ __global__ __launch_bounds__(NT) void laplace_table_kernel(
 // all lanes of a wave have that property is decided once per wave (a row boundary or an
 // unstructured list takes the general body); results are bitwise those of the strided
 // kernel's arithmetic (same dx, dy, d2 values).
-template <int R, bool SHARED>
-__device__ __forceinline__ void laplace_slp_rowrun_loop(const double* __restrict__ rec, int j0, int j1,
-                                                        const double2* ltab, TabAddr& ta,
-                                                        const double (&x)[R], const double (&y)[R],
-                                                        double (&acc)[R]) {
+template <int MODE, int R, bool SHARED>
+__device__ __forceinline__ void laplace_rowrun_loop(const double* __restrict__ rec, int j0, int j1,
+                                                    const double2* ltab, TabAddr& ta,
+                                                    const double (&x)[R], const double (&y)[R],
+                                                    double (&acc)[R]) {
     for (int b = j0 / IPDE_SRC_PAD; b < j1 / IPDE_SRC_PAD; ++b) {
-        SrcRow sx, sy, sq;
+        SrcRow sx, sy, sq, sax, say;
         sx.load(rec, b, 0);
         sy.load(rec, b, 1);
-        sq.load(rec, b, 2);
+        if (MODE & MODE_SLP) sq.load(rec, b, 2);
+        if (MODE & MODE_DLP) {
+            sax.load(rec, b, 3);
+            say.load(rec, b, 4);
+        }
 #pragma unroll
         for (int u = 0; u < IPDE_SRC_PAD; ++u) {
-            double d2[R], z[R], p[R];
+            double d2[R], z[R], ad[R];
             double2 e[R];
             if (SHARED) {
                 const double dx = x[0] - sx.v[u];
                 const double dx2 = dx * dx;
+                const double axdx = (MODE & MODE_DLP) ? sax.v[u] * dx : 0.0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const double dy = y[r] - sy.v[u];
                     d2[r] = fma(dy, dy, dx2);
+                    if (MODE & MODE_DLP) ad[r] = fma(say.v[u], dy, axdx);
                     e[r] = ta.lookup(ltab, d2[r]);
                 }
             } else {
@@ -215,26 +221,35 @@ __device__ __forceinline__ void laplace_slp_rowrun_loop(const double* __restrict
                     const double dx = x[r] - sx.v[u];
                     const double dy = y[r] - sy.v[u];
                     d2[r] = fma(dy, dy, dx * dx);
+                    if (MODE & MODE_DLP) ad[r] = fma(say.v[u], dy, sax.v[u] * dx);
                     e[r] = ta.lookup(ltab, d2[r]);
                 }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) z[r] = tab_y(d2[r], e[r].x);
+            if (MODE & MODE_SLP) {
+                double p[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) p[r] = fma(z[r], -4.0, IPDE_LOG_K3);
+                for (int r = 0; r < R; ++r) p[r] = fma(z[r], -4.0, IPDE_LOG_K3);
 #pragma unroll
-            for (int r = 0; r < R; ++r) p[r] = fma(z[r], p[r], -2.0);
+                for (int r = 0; r < R; ++r) p[r] = fma(z[r], p[r], -2.0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) p[r] = fma(z[r], p[r], IPDE_LOG_K1);
+                for (int r = 0; r < R; ++r) p[r] = fma(z[r], p[r], IPDE_LOG_K1);
 #pragma unroll
-            for (int r = 0; r < R; ++r) p[r] = fma(z[r], p[r], e[r].y);
+                for (int r = 0; r < R; ++r) p[r] = fma(z[r], p[r], e[r].y);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fma(sq.v[u], p[r], acc[r]);
+                for (int r = 0; r < R; ++r) acc[r] = fma(sq.v[u], p[r], acc[r]);
+            }
+            if (MODE & MODE_DLP) {
+                // 1/d2 from the same table entry in 6 instructions (3.5e-15, layer_common.h)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = fma(ad[r], rcp_from_y_fast(e[r].x, z[r]), acc[r]);
+            }
         }
     }
 }
 
-template <int R, int NT>
+template <int MODE, int R, int NT>
 __global__ __launch_bounds__(NT) void laplace_rowrun_kernel(
     const double* __restrict__ rec, int ns_pad, int chunk, const double* __restrict__ tx,
     const double* __restrict__ ty, int64_t nt, double* __restrict__ out,
@@ -259,13 +274,13 @@ __global__ __launch_bounds__(NT) void laplace_rowrun_kernel(
         same = same && (x[r] == x[0]);
     }
     if (__all(same))
-        laplace_slp_rowrun_loop<R, true>(rec, j0, j1, ltab, ta, x, y, acc);
+        laplace_rowrun_loop<MODE, R, true>(rec, j0, j1, ltab, ta, x, y, acc);
     else
-        laplace_slp_rowrun_loop<R, false>(rec, j0, j1, ltab, ta, x, y, acc);
+        laplace_rowrun_loop<MODE, R, false>(rec, j0, j1, ltab, ta, x, y, acc);
     if (!ta.all_inside(key_lo)) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.0;
-        laplace_generic_loop<MODE_SLP, false, R>(rec, j0, j1, x, y, acc);
+        laplace_generic_loop<MODE, false, R>(rec, j0, j1, x, y, acc);
     }
     const double corr = (blockIdx.y == 0) ? prm->corr : 0.0;
     double* o = out + (size_t)blockIdx.y * nt;
@@ -276,15 +291,15 @@ __global__ __launch_bounds__(NT) void laplace_rowrun_kernel(
     }
 }
 
-template <int R, int NT>
+template <int MODE, int R, int NT>
 int launch_rowrun_variant(ipde_ctx* ctx, dim3 grid, const double* rec, const LayerGeom& g,
                           const double* tx, const double* ty, int64_t nt, double* dst,
                           const ApplyParams* prm) {
     const LogTable& lt = ctx->logtab;
     size_t lds = (size_t)lt.nkeys * sizeof(double2);
-    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_rowrun_kernel<R, NT>,
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_rowrun_kernel<MODE, R, NT>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((laplace_rowrun_kernel<R, NT>), grid, dim3(NT), lds, ctx->stream, rec, g.ns_pad,
+    hipLaunchKernelGGL((laplace_rowrun_kernel<MODE, R, NT>), grid, dim3(NT), lds, ctx->stream, rec, g.ns_pad,
                        g.chunk, tx, ty, nt, dst, prm, (const double2*)lt.d_tab, (unsigned)lt.key_lo,
                        (unsigned)lt.nkeys, 20 - lt.mant_bits);
     return IPDE_OK;
@@ -310,10 +325,6 @@ int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
     const bool generic = (flags & (IPDE_FLAG_GENERIC_MATH | IPDE_FLAG_SKIP_COINCIDENT)) != 0;
     const bool skip = (flags & IPDE_FLAG_SKIP_COINCIDENT) != 0;
     int variant = generic ? -1 : ctx->opt_laplace_variant;
-    if (MODE != MODE_SLP) {   // the row-run variants exist for the single layer only
-        if (variant == 9 || variant == 11) variant = 1;
-        if (variant == 10) variant = 2;
-    }
     int NTv = 256, Rv = 2;
     switch (variant) {
         case 0: NTv = 512; Rv = 4; break;
@@ -325,7 +336,7 @@ int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
         case 6: NTv = 1024; Rv = 4; break;
         case 7: NTv = 1024; Rv = 2; break;
         case 8: NTv = 1024; Rv = 3; break;
-        case 9: NTv = 1024; Rv = 4; break;   // row-run (SLP only; other modes: variant 1)
+        case 9: NTv = 1024; Rv = 4; break;   // row-run
         case 10: NTv = 512; Rv = 8; break;   // row-run, 8 per lane
         case 11: NTv = 1024; Rv = 6; break;  // row-run, 6 per lane
         default: break;
@@ -356,18 +367,9 @@ int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
             case 6: st = launch_table_variant<MODE, 4, 1024, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
             case 7: st = launch_table_variant<MODE, 2, 1024, 4>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
             case 8: st = launch_table_variant<MODE, 3, 1024, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
-            case 9:
-                st = (MODE == MODE_SLP) ? launch_rowrun_variant<4, 1024>(ctx, grid, rec, g, tx, ty, nt, dst, prm)
-                                        : launch_table_variant<MODE, 4, 1024, 1>(ctx, grid, rec, g, tx, ty, nt, dst, prm);
-                break;
-            case 10:
-                st = (MODE == MODE_SLP) ? launch_rowrun_variant<8, 512>(ctx, grid, rec, g, tx, ty, nt, dst, prm)
-                                        : launch_table_variant<MODE, 8, 512, 1>(ctx, grid, rec, g, tx, ty, nt, dst, prm);
-                break;
-            case 11:
-                st = (MODE == MODE_SLP) ? launch_rowrun_variant<6, 1024>(ctx, grid, rec, g, tx, ty, nt, dst, prm)
-                                        : launch_table_variant<MODE, 4, 1024, 1>(ctx, grid, rec, g, tx, ty, nt, dst, prm);
-                break;
+            case 9: st = launch_rowrun_variant<MODE, 4, 1024>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 10: st = launch_rowrun_variant<MODE, 8, 512>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 11: st = launch_rowrun_variant<MODE, 6, 1024>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
             default: st = launch_table_variant<MODE, 4, 512, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
         }
         IPDE_TRY(st);

@@ -192,39 +192,57 @@ __global__ __launch_bounds__(NT) void stokes_table_kernel(
     stokes_store<R, NT>(acc, base, nt, prm, s1, ou, ov, op);
 }
 
-// Row-run variant of the stokeslet (+ pressure) table kernel, as in layer_laplace.hip:
+// Row-run variant of the table kernel (stokeslet, stresslet or both, with pressure), as in
+// layer_laplace.hip:
 // a lane owns R consecutive targets; when they share x (grid rows; decided per wave)
 // dx, dx^2 and f_x dx are formed once per source and lane.  With the 6-instruction
 // reciprocal: 24 VALU instructions per pair instead of 27.25.
-template <int R, bool SHARED>
-__device__ __forceinline__ void stokes_slp_rowrun_loop(const double* __restrict__ rec, int j0, int j1,
-                                                       const double2* ltab, TabAddr& ta,
-                                                       const double (&x)[R], const double (&y)[R],
-                                                       StokesAcc (&acc)[R]) {
+template <int MODE, int R, bool SHARED>
+__device__ __forceinline__ void stokes_rowrun_loop(const double* __restrict__ rec, int j0, int j1,
+                                                   const double2* ltab, TabAddr& ta,
+                                                   const double (&x)[R], const double (&y)[R],
+                                                   StokesAcc (&acc)[R]) {
     for (int hb = j0 / 4; hb < j1 / 4; ++hb) {
         const double* row = rec + ((size_t)(hb >> 1) * IPDE_SRC_NCH) * IPDE_SRC_PAD + 4 * (hb & 1);
-        double sx[4], sy[4], fx[4], fy[4];
+        double sx[4], sy[4];
+        StokesSrc s[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             sx[u] = row[u];
             sy[u] = row[IPDE_SRC_PAD + u];
-            fx[u] = row[2 * IPDE_SRC_PAD + u];
-            fy[u] = row[3 * IPDE_SRC_PAD + u];
+            s[u] = StokesSrc{};
+            if (MODE & MODE_SLP) {
+                s[u].fx = row[2 * IPDE_SRC_PAD + u];
+                s[u].fy = row[3 * IPDE_SRC_PAD + u];
+            }
+            if (MODE & MODE_DLP) {
+                s[u].gx = row[4 * IPDE_SRC_PAD + u];
+                s[u].gy = row[5 * IPDE_SRC_PAD + u];
+                s[u].nx = row[6 * IPDE_SRC_PAD + u];
+                s[u].ny = row[7 * IPDE_SRC_PAD + u];
+                s[u].ng = row[8 * IPDE_SRC_PAD + u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            double dx[R], dy[R], d2[R], fd[R];
+            double dx[R], dy[R], d2[R], fd[R], dn[R], dg[R];
             double2 e[R];
             if (SHARED) {
                 const double dxs = x[0] - sx[u];
                 const double dx2 = dxs * dxs;
-                const double fxdx = fx[u] * dxs;
+                const double fxdx = (MODE & MODE_SLP) ? s[u].fx * dxs : 0.0;
+                const double nxdx = (MODE & MODE_DLP) ? s[u].nx * dxs : 0.0;
+                const double gxdx = (MODE & MODE_DLP) ? s[u].gx * dxs : 0.0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     dx[r] = dxs;
                     dy[r] = y[r] - sy[u];
                     d2[r] = fma(dy[r], dy[r], dx2);
-                    fd[r] = fma(fy[u], dy[r], fxdx);
+                    if (MODE & MODE_SLP) fd[r] = fma(s[u].fy, dy[r], fxdx);
+                    if (MODE & MODE_DLP) {
+                        dn[r] = fma(s[u].ny, dy[r], nxdx);
+                        dg[r] = fma(s[u].gy, dy[r], gxdx);
+                    }
                     e[r] = ta.lookup(ltab, d2[r]);
                 }
             } else {
@@ -233,27 +251,40 @@ __device__ __forceinline__ void stokes_slp_rowrun_loop(const double* __restrict_
                     dx[r] = x[r] - sx[u];
                     dy[r] = y[r] - sy[u];
                     d2[r] = fma(dy[r], dy[r], dx[r] * dx[r]);
-                    fd[r] = fma(fy[u], dy[r], fx[u] * dx[r]);
+                    if (MODE & MODE_SLP) fd[r] = fma(s[u].fy, dy[r], s[u].fx * dx[r]);
+                    if (MODE & MODE_DLP) {
+                        dn[r] = fma(s[u].ny, dy[r], s[u].nx * dx[r]);
+                        dg[r] = fma(s[u].gy, dy[r], s[u].gx * dx[r]);
+                    }
                     e[r] = ta.lookup(ltab, d2[r]);
                 }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const double yy = tab_y(d2[r], e[r].x);
-                const double t = fd[r] * rcp_from_y_fast(e[r].x, yy);
-                const double L = log_from_y(yy, e[r].y);
-                acc[r].uL = fma(fx[u], L, acc[r].uL);
-                acc[r].vL = fma(fy[u], L, acc[r].vL);
-                acc[r].u = fma(t, dx[r], acc[r].u);
-                acc[r].v = fma(t, dy[r], acc[r].v);
-                acc[r].p += t;
+                const double rinv = rcp_from_y_fast(e[r].x, yy);
+                if (MODE & MODE_SLP) {
+                    const double t = fd[r] * rinv;
+                    const double L = log_from_y(yy, e[r].y);
+                    acc[r].uL = fma(s[u].fx, L, acc[r].uL);
+                    acc[r].vL = fma(s[u].fy, L, acc[r].vL);
+                    acc[r].u = fma(t, dx[r], acc[r].u);
+                    acc[r].v = fma(t, dy[r], acc[r].v);
+                    acc[r].p += t;
+                }
+                if (MODE & MODE_DLP) {
+                    const double w = dn[r] * dg[r] * rinv * rinv;
+                    acc[r].u = fma(w, dx[r], acc[r].u);
+                    acc[r].v = fma(w, dy[r], acc[r].v);
+                    acc[r].p += fma(-0.5 * s[u].ng, rinv, w);
+                }
             }
         }
     }
 }
 
-template <int R, int NT>
-__global__ __launch_bounds__(NT) void stokes_slp_rowrun_kernel(
+template <int MODE, int R, int NT>
+__global__ __launch_bounds__(NT) void stokes_rowrun_kernel(
     const double* __restrict__ rec, int ns_pad, int chunk, const double* __restrict__ tx,
     const double* __restrict__ ty, int64_t nt, double* __restrict__ ou, double* __restrict__ ov,
     double* __restrict__ op, const ApplyParams* __restrict__ prm,
@@ -278,13 +309,13 @@ __global__ __launch_bounds__(NT) void stokes_slp_rowrun_kernel(
         same = same && (x[r] == x[0]);
     }
     if (__all(same))
-        stokes_slp_rowrun_loop<R, true>(rec, j0, j1, ltab, ta, x, y, acc);
+        stokes_rowrun_loop<MODE, R, true>(rec, j0, j1, ltab, ta, x, y, acc);
     else
-        stokes_slp_rowrun_loop<R, false>(rec, j0, j1, ltab, ta, x, y, acc);
+        stokes_rowrun_loop<MODE, R, false>(rec, j0, j1, ltab, ta, x, y, acc);
     if (!ta.all_inside(key_lo)) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = StokesAcc{0, 0, 0, 0, 0};
-        stokes_generic_loop<MODE_SLP, false, R>(rec, j0, j1, x, y, acc);
+        stokes_generic_loop<MODE, false, R>(rec, j0, j1, x, y, acc);
     }
     // consecutive targets per lane: the store helper's strided indexing does not apply
     const bool first = blockIdx.y == 0;
@@ -309,7 +340,7 @@ int launch_stokes(ipde_ctx* ctx, const double* rec, int64_t ns, const double* tx
     const bool generic = (flags & (IPDE_FLAG_GENERIC_MATH | IPDE_FLAG_SKIP_COINCIDENT)) != 0;
     const bool skip = (flags & IPDE_FLAG_SKIP_COINCIDENT) != 0;
     constexpr int NT_TAB = 512, R_TAB = 2, U_TAB = 2;
-    const bool rowrun = (MODE == MODE_SLP) && !generic && ctx->opt_stokes_variant == 1;
+    const bool rowrun = !generic && ctx->opt_stokes_variant == 1;
     constexpr int NT_RR = 512, R_RR = 4;
     constexpr int NT_GEN = 256, R_GEN = 2;
     const LayerGeom g = ipde_layer_geom(
@@ -334,9 +365,9 @@ int launch_stokes(ipde_ctx* ctx, const double* rec, int64_t ns, const double* tx
     } else if (rowrun) {
         const LogTable& lt = ctx->logtab;
         size_t lds = (size_t)lt.nkeys * sizeof(double2);
-        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stokes_slp_rowrun_kernel<R_RR, NT_RR>,
+        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stokes_rowrun_kernel<MODE, R_RR, NT_RR>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((stokes_slp_rowrun_kernel<R_RR, NT_RR>), grid, dim3(NT_RR), lds, ctx->stream,
+        hipLaunchKernelGGL((stokes_rowrun_kernel<MODE, R_RR, NT_RR>), grid, dim3(NT_RR), lds, ctx->stream,
                            rec, g.ns_pad, g.chunk, tx, ty, nt, du, dv, dp, prm,
                            (const double2*)lt.d_tab, (unsigned)lt.key_lo, (unsigned)lt.nkeys,
                            20 - lt.mant_bits);

@@ -309,6 +309,13 @@ def test_laplace_rowrun_variant_is_bitwise_the_strided_kernel(variant):
             assert np.array_equal(res[1], res[variant])
             ref = lp.laplace_apply(c.x, c.y, tx, ty, w_sigma=q, generic_math=True)
             assert np.abs(res[variant] - ref).max() < 1e-13 * np.abs(ref).max()
+            # double layer and the fused sum: same structure, 6-instruction reciprocal (3.5e-15)
+            for kw in (dict(w_tau=q), dict(w_sigma=q, w_tau=0.5 * q)):
+                ctx.set_option("laplace_variant", variant)
+                got = lp.laplace_apply(c.x, c.y, tx, ty, nx=c.normal_x, ny=c.normal_y, **kw)
+                ref = lp.laplace_apply(c.x, c.y, tx, ty, nx=c.normal_x, ny=c.normal_y,
+                                       generic_math=True, **kw)
+                assert np.abs(got - ref).max() < 1e-13 * np.abs(ref).max()
     finally:
         ctx.set_option("laplace_variant", 9)
 
@@ -336,5 +343,13 @@ def test_stokes_rowrun_variant_matches_strided_kernel():
             for a, b, r in zip(res[0], res[1], ref):
                 assert np.abs(a - b).max() < 1e-13 * np.abs(r).max()
                 assert np.abs(b - r).max() < 1e-12 * np.abs(r).max()
+            # stresslet and the combined sum
+            for kw in (dict(wdx=f[1], wdy=f[0]), dict(wfx=f[0], wfy=f[1], wdx=f[1], wdy=f[0])):
+                ctx.set_option("stokes_variant", 1)
+                got = lp.stokes_apply(c.x, c.y, tx, ty, nx=c.normal_x, ny=c.normal_y, **kw)
+                ref = lp.stokes_apply(c.x, c.y, tx, ty, nx=c.normal_x, ny=c.normal_y,
+                                      generic_math=True, **kw)
+                for b, r in zip(got, ref):
+                    assert np.abs(b - r).max() < 1e-12 * np.abs(r).max()
     finally:
         ctx.set_option("stokes_variant", 1)
