@@ -117,8 +117,33 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _Library(lib)
+    return _lib
+
+
+def _uses_fft(name):
+    """entry points that may create or run rocFFT plans"""
+    return name.startswith(("ipde_fft", "ipde_fourier", "ipde_annular")) or name.endswith("_grid_solve")
+
+
+class _Library(object):
+    """The loaded library.  Entry points that can reach rocFFT first join the warm-up thread
+    (ipde_amd.device.prewarm_wait): rocFFT plan creation / run-time compilation must not be
+    entered from two threads at once."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if _uses_fft(name):
+            def guarded(*args, _fn=fn):
+                from .device import prewarm_wait
+                prewarm_wait()
+                return _fn(*args)
+            fn = guarded
+        self.__dict__[name] = fn
+        return fn
 
 
 def check(status, ctx_handle=None, allow=()):

@@ -28,7 +28,7 @@ __host__ __device__ __forceinline__ size_t ipde_rec_index(int64_t j, int ch) {
 // Per-call parameters produced on the device by the pack kernel (no host sync).
 struct ApplyParams {
     int sh;        // coordinates are scaled by 2^sh so that all d^2 < 2^exp_hi
-    int pad;
+    int pad;       // modified Helmholtz: index of the table window (layer_modhelm.hip), else 0
     double corr;   // constant added to every output (undoes the log scaling)
     double corr2;  // second constant (Stokes v component)
     double inv_s;  // 2^-sh

@@ -9,15 +9,18 @@
 // Record rows: [0] k x [1] k y [2] q' [3] ax' [4] ay'.
 //
 // Table kernel (the fast path).  F0(y) = K0(sqrt y) and F1(y) = K1(sqrt y)/sqrt y are
-// smooth on log-spaced intervals (the only singularity is y = 0), so each of the
-// 32 covered binades [2^-21, 2^11) is cut into 2^5 intervals by the top 5 mantissa
-// bits of y; per interval the LDS table holds R ~ 1/centre and the 8 coefficients
-// of a degree-7 polynomial in z = y R - 1 (|z| <= 2^-6), fitted at Chebyshev nodes
-// from long-double std::cyl_bessel_k at context creation.  Degree 7 keeps the
-// ABSOLUTE error below 2e-18 for every k r (the (p+1)-th log-derivative of K0 peaks
-// at k r ~ p+1) and the relative error below 1e-15 for k r <= 45.  y outside the
-// table (k r < 7e-4 or > 45, or r = 0) is detected per lane and that lane's targets
-// are redone with the series / Chebyshev code below (bessel_coeffs.h).
+// smooth on log-spaced intervals (the only singularity is y = 0), so each covered binade
+// is cut into 2^5 intervals by the top 5 mantissa bits of y; per interval the LDS table
+// holds R ~ 1/centre and the 8 coefficients of a degree-7 polynomial in z = y R - 1
+// (|z| <= 2^-6), fitted at Chebyshev nodes from long-double std::cyl_bessel_k at context
+// creation.  A table covers 32 binades; EIGHT windows [2^(-21+2w), 2^(11+2w)) are resident
+// in HBM and the pack kernel picks, from the bounding box, the lowest one whose top covers
+// (k * diameter)^2 — so for any k every pair farther apart than diameter * 2^-16 is a table
+// hit (with the single window [2^-21, 2^11), k r > 45 sent whole lanes to the fallback:
+// 75 ms instead of 10 ms at k = 100 on the 2048^2 x 4096 case).  Pointwise relative
+// accuracy: 1e-15 for k r <= 11, 2e-14 at 20, 9e-14 at 30, 2e-12 at 40, 1e-10 at 45
+// (where the value is 1e-20 of a near-field one); y below the window or r = 0 is detected
+// per lane and that lane's targets are redone with the series / Chebyshev code below.
 //   per pair: 4 (dx,dy,y) + 1 (z) + 7 (Horner) + 1 (accumulate) fp64 ops
 //             (+2 for the DLP's a.d), 3 int32 ops, 5 ds_read_b128 (80-byte entry).
 // Roofline: fp64 VALU / LDS-read co-bound; algorithmic HBM traffic 24 B per target.
@@ -88,18 +91,26 @@ __global__ __launch_bounds__(NT) void modhelm_generic_kernel(
 #define KT_SHIFT (20 - KT_B)
 #define KT_BINADES 32
 #define KT_NKEYS (KT_BINADES << KT_B)    // 1024 entries
+#define KT_NC 8                          // coefficients: degree 7 (degree 6 / 64-byte entries is 3 %
+                                         // faster but only 3.5e-12 RELATIVE at k r = 10, where the
+                                         // functions fall by 27 % across an interval)
 #define KT_ENTRY 10                      // doubles per entry: R, a0..a7, pad  (80 B)
-#define KT_EXP_LO (-21)
+#define KT_EXP_LO (-21)                  // window 0 covers y in [2^-21, 2^11): k r in [7e-4, 45]
+#define KT_NWIN 8                        // window w is shifted up by 2w binades (k r up to 5800)
 
 template <int MODE, int R, int NT, int U>
 __global__ __launch_bounds__(NT) void modhelm_table_kernel(
     const double* __restrict__ rec, int ns_pad, int chunk, const double* __restrict__ tx,
     const double* __restrict__ ty, int64_t nt, double* __restrict__ out,
     const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab, int accumulate) {
-    extern __shared__ double2 ltab[];  // KT_NKEYS * 5 double2
+    extern __shared__ double2 ltab[];  // KT_NKEYS * KT_ENTRY/2 double2
+    // the pack kernel picked the window from the bounding box: (k * diameter)^2 < 2^(11 + 2w),
+    // so every pair farther apart than diameter * 2^-16 is inside the table whatever k is
+    const int win = prm->pad;
+    gtab += (size_t)win * KT_NKEYS * (KT_ENTRY / 2);
     for (unsigned i = threadIdx.x; i < KT_NKEYS * (KT_ENTRY / 2); i += NT) ltab[i] = gtab[i];
     __syncthreads();
-    const unsigned key_lo = (unsigned)((1023 + KT_EXP_LO) << KT_B);
+    const unsigned key_lo = (unsigned)((1023 + KT_EXP_LO + 2 * win) << KT_B);
     unsigned hmin = 0xFFFFFFFFu, hmax = 0u;
 
     const int j0 = blockIdx.y * chunk;
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(NT) void modhelm_table_kernel(
 #pragma unroll
         for (int u0 = 0; u0 < IPDE_SRC_PAD; u0 += U) {
             double dx[U][R], dy[U][R], d2[U][R];
-            double2 e[U][R][5];
+            double2 e[U][R][KT_ENTRY / 2];
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(NT) void modhelm_table_kernel(
                     const double2* ep = (const double2*)((const char*)ltab +
                                                          __umul24(idx, KT_ENTRY * 8u));
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) e[u][r][c] = ep[c];
+                    for (int c = 0; c < KT_ENTRY / 2; ++c) e[u][r][c] = ep[c];
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -215,7 +226,7 @@ int launch_modhelm(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
             hipLaunchKernelGGL((modhelm_generic_kernel<MODE, false, R_G, NT_G>), grid, dim3(NT_G), 0,
                                ctx->stream, rec, g.ns_pad, g.chunk, tx, ty, nt, dst, prm, acc_main);
     } else {
-        const double* tab = ctx->d_ktab + (MODE == MODE_SLP ? 0 : (size_t)KT_NKEYS * KT_ENTRY);
+        const double* tab = ctx->d_ktab + (MODE == MODE_SLP ? 0 : (size_t)KT_NWIN * KT_NKEYS * KT_ENTRY);
         size_t lds = (size_t)KT_NKEYS * KT_ENTRY * sizeof(double);
         IPDE_HIP_CHECK(ctx, hipFuncSetAttribute(
                                 (const void*)modhelm_table_kernel<MODE, R_T, NT_T, U_T>,
@@ -238,10 +249,10 @@ int launch_modhelm(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
 }
 
 // ---- host: table construction ---------------------------------------------
-// degree-7 fit of F on x = c (1 + z), |z| <= a, at 8 Chebyshev nodes
+// degree-(KT_NC-1) fit of F on x = c (1 + z), |z| <= a, at KT_NC Chebyshev nodes
 template <class F>
-void fit_interval(long double c, long double a, F f, double* coef /*8*/) {
-    const int n = 8;
+void fit_interval(long double c, long double a, F f, double* coef /*KT_NC*/) {
+    const int n = KT_NC;
     long double v[n], b[n];
     for (int i = 0; i < n; ++i) {
         long double u = cosl(M_PIl * (i + 0.5L) / n);
@@ -280,30 +291,36 @@ void fit_interval(long double c, long double a, F f, double* coef /*8*/) {
 int ipde_build_k_table(ipde_ctx* ctx) {
     IPDE_HIP_CHECK(ctx, ipde_bessel_upload());
     // piecewise tables of F0(y) = K0(sqrt y), F1(y) = K1(sqrt y)/sqrt y
-    std::vector<double> h((size_t)2 * KT_NKEYS * KT_ENTRY, 0.0);
-    const uint64_t key_lo = (uint64_t)((1023 + KT_EXP_LO) << KT_B);
+    // layout: [kind (K0 | K1/x)][window][key][entry]
+    std::vector<double> h((size_t)2 * KT_NWIN * KT_NKEYS * KT_ENTRY, 0.0);
     auto F0 = [](long double y) { return std::cyl_bessel_kl(0.0L, sqrtl(y)); };
     auto F1 = [](long double y) {
         long double x = sqrtl(y);
         return std::cyl_bessel_kl(1.0L, x) / x;
     };
-    for (int n = 0; n < KT_NKEYS; ++n) {
-        uint64_t key = key_lo + (uint64_t)n;
-        size_t pos = (size_t)(key & (uint64_t)(KT_NKEYS - 1));
-        uint64_t lo_bits = key << (52 - KT_B), hi_bits = (key + 1) << (52 - KT_B);
-        double xlo, xhi;
-        memcpy(&xlo, &lo_bits, 8);
-        memcpy(&xhi, &hi_bits, 8);
-        double R = (double)(2.0L / ((long double)xlo + (long double)xhi));
-        long double c = 1.0L / (long double)R;  // the centre the kernel actually uses
-        long double a = fmaxl(fabsl((long double)xlo / c - 1.0L), fabsl((long double)xhi / c - 1.0L));
-        for (int t = 0; t < 2; ++t) {
-            double* e = &h[((size_t)t * KT_NKEYS + pos) * KT_ENTRY];
-            e[0] = R;
-            if (t == 0)
-                fit_interval(c, a, F0, e + 1);
-            else
-                fit_interval(c, a, F1, e + 1);
+    for (int w = 0; w < KT_NWIN; ++w) {
+        const uint64_t key_lo = (uint64_t)((1023 + KT_EXP_LO + 2 * w) << KT_B);
+        for (int n = 0; n < KT_NKEYS; ++n) {
+            uint64_t key = key_lo + (uint64_t)n;
+            size_t pos = (size_t)(key & (uint64_t)(KT_NKEYS - 1));
+            uint64_t lo_bits = key << (52 - KT_B), hi_bits = (key + 1) << (52 - KT_B);
+            double xlo, xhi;
+            memcpy(&xlo, &lo_bits, 8);
+            memcpy(&xhi, &hi_bits, 8);
+            double R = (double)(2.0L / ((long double)xlo + (long double)xhi));
+            long double c = 1.0L / (long double)R;  // the centre the kernel actually uses
+            long double a =
+                fmaxl(fabsl((long double)xlo / c - 1.0L), fabsl((long double)xhi / c - 1.0L));
+            for (int t = 0; t < 2; ++t) {
+                double* e = &h[(((size_t)t * KT_NWIN + w) * KT_NKEYS + pos) * KT_ENTRY];
+                e[0] = R;
+                // beyond k r ~ 700 the functions underflow even in long double: zero entries
+                if (xlo > 4.9e5) continue;
+                if (t == 0)
+                    fit_interval(c, a, F0, e + 1);
+                else
+                    fit_interval(c, a, F1, e + 1);
+            }
         }
     }
     IPDE_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_ktab, h.size() * sizeof(double)));
@@ -354,7 +371,7 @@ extern "C" int ipde_modhelm_apply(ipde_ctx* ctx, int loc, double k, int64_t ns, 
     pa.mul[2] = 0.5 * k / M_PI;
     pa.corr_ch = -1;
     pa.corr2_ch = -1;
-    pa.use_scale = 0;
+    pa.use_scale = 1;   // bounding box on the device: selects the table window
     pa.fixed_scale = k;
     const double* rec;
     const ApplyParams* prm;

@@ -63,10 +63,10 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
                                                                  double* __restrict__ rec,
                                                                  ApplyParams* __restrict__ prm) {
     __shared__ double red[16][4];
-    __shared__ int s_sh;
+    __shared__ int s_sh, s_win;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    int sh = 0;
+    int sh = 0, win = 0;
     if (a.use_scale) {
         double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
         for (int i = tid; i < nbbox; i += 1024) {
@@ -111,9 +111,20 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
                 if (shv < -400) shv = -400;
             }
             s_sh = shv;
+            // modified-Helmholtz table window (layer_modhelm.hip): smallest window whose top
+            // binade 2^(11 + 2w) covers y_max = (k * diameter)^2
+            int wv = 0;
+            if (a.fixed_scale != 0.0 && D2 > 0.0 && D2 < INFINITY) {
+                int ey = ilogb(D2 * a.fixed_scale * a.fixed_scale) + 1;   // y_max < 2^ey
+                wv = (ey - 11 + 1) / 2;
+                if (ey <= 11) wv = 0;
+                if (wv > 7) wv = 7;
+            }
+            s_win = wv;
         }
         __syncthreads();
-        sh = s_sh;
+        sh = a.fixed_scale != 0.0 ? 0 : s_sh;
+        win = s_win;
         __syncthreads();
     }
     const double s1 = a.fixed_scale != 0.0 ? a.fixed_scale : ldexp(1.0, sh);
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
         }
         const double two_ln2 = 1.3862943611198906188;
         prm->sh = sh;
-        prm->pad = 0;
+        prm->pad = win;   // table window of the modified-Helmholtz kernels, else 0
         prm->corr = -two_ln2 * (double)sh * t1;
         prm->corr2 = -two_ln2 * (double)sh * t2;
         prm->inv_s = ldexp(1.0, -sh);

@@ -80,67 +80,82 @@ def get_context(device=None):
         return ctx
 
 
-_warm = {}
+_warm = {"thread": None, "queue": None, "keys": set()}
+
+
+def _warm_worker():
+    q = _warm["queue"]
+    while True:
+        fn = q.get()
+        try:
+            fn()
+        except Exception:       # best effort; real errors surface in the real calls
+            pass
+        finally:
+            q.task_done()
 
 
 def prewarm(grid_shape=None, h=None, wait=False, fft1=()):
-    """Pay the one-time library costs of a first solve in background threads while the
-    host does geometry set-up: rocBLAS/Tensile load (first complex128 GEMM, ~5 s on a
-    fresh process), hipFFT load (first torch.fft call, ~1 s), rocSOLVER load (first LU),
-    and — if the grid is given — the rocFFT plans of the grid solve (~1.6 s of run-time
-    kernel compilation at 2048^2); `fft1` lists (batch, n) of batched 1-D transforms
-    (annular solver, radial interpolation) whose kernels are compiled the same way.  No-op without a GPU.  `wait=True` joins."""
+    """Pay the one-time library costs of a first solve in ONE background thread while the
+    host does geometry set-up: hipFFT / rocSOLVER loads (first torch.fft call ~1 s), the
+    rocFFT kernels of the batched 1-D transforms `fft1` = ((batch, n), ...) (annular solver,
+    radial interpolation) and, if the grid is given, of the 2-D grid solve (~1.6 s of
+    run-time compilation at 2048^2).  Jobs run strictly one after the other, and every
+    FFT entry point of the package joins the thread first (`prewarm_wait`): rocFFT's plan
+    creation / run-time compilation is never entered from two threads at once (doing so
+    crashed a two-rank rehearsal with SIGSEGV).  No-op without a GPU."""
+    import queue
     import threading
     if not torch.cuda.is_available():
         return
     dev = torch.cuda.current_device()
 
     def libs():
-        try:
-            torch.cuda.set_device(dev)
-            d = get_context(dev).torch_device()
-            a = torch.ones((64, 64), dtype=torch.complex128, device=d)
-            (a @ a).sum().item()
-            b = torch.ones((64, 64), dtype=torch.float64, device=d) + torch.eye(64, dtype=torch.float64, device=d)
-            (b @ b).sum().item()
-            torch.fft.fft(a, dim=1).sum().item()
-            torch.fft.fft2(b).sum().item()
-            LU, piv = torch.linalg.lu_factor(b)
-            torch.linalg.lu_solve(LU, piv, b[:, :1]).sum().item()
-        except Exception:       # best effort; real errors surface in the real calls
-            pass
+        torch.cuda.set_device(dev)
+        d = get_context(dev).torch_device()
+        a = torch.ones((64, 64), dtype=torch.complex128, device=d)
+        (a @ a).sum().item()
+        b = torch.ones((64, 64), dtype=torch.float64, device=d) + torch.eye(64, dtype=torch.float64, device=d)
+        (b @ b).sum().item()
+        torch.fft.fft(a, dim=1).sum().item()
+        torch.fft.fft2(b).sum().item()
+        LU, piv = torch.linalg.lu_factor(b)
+        torch.linalg.lu_solve(LU, piv, b[:, :1]).sum().item()
 
     def plans():
-        try:
-            torch.cuda.set_device(dev)
-            from .spectral import get_plan
-            get_plan(grid_shape[0], grid_shape[1], h[0], h[1], get_context(dev))
-        except Exception:
-            pass
+        torch.cuda.set_device(dev)
+        from .spectral import get_plan
+        get_plan(grid_shape[0], grid_shape[1], h[0], h[1], get_context(dev))
+
     def fft1_plans():
-        try:
-            ctx = get_context(dev)
-            for batch, n in fft1:
-                ctx.lib.ipde_fft1_prepare(ctx.handle, int(batch), int(n))
-        except Exception:
-            pass
+        ctx = get_context(dev)
+        for batch, n in fft1:
+            ctx.lib.ipde_fft1_prepare(ctx.handle, int(batch), int(n))
     jobs = [("libs", libs)]
-    if grid_shape is not None:
-        jobs.append((("plan", tuple(grid_shape)), plans))
     if fft1:
         jobs.append((("fft1", tuple(fft1)), fft1_plans))
-    started = []
-    for key, fn in jobs:
-        with _lock:
-            t = _warm.get(key)
-            if t is None:
-                t = threading.Thread(target=fn, name="ipde-prewarm", daemon=True)
-                _warm[key] = t
-                t.start()
-        started.append(t)
+    if grid_shape is not None:
+        jobs.append((("plan", tuple(grid_shape)), plans))
+    with _lock:
+        if _warm["queue"] is None:
+            _warm["queue"] = queue.Queue()
+            _warm["thread"] = threading.Thread(target=_warm_worker, name="ipde-prewarm", daemon=True)
+            _warm["thread"].start()
+        for key, fn in jobs:
+            if key not in _warm["keys"]:
+                _warm["keys"].add(key)
+                _warm["queue"].put(fn)
     if wait:
-        for t in started:
-            t.join()
+        prewarm_wait()
+
+
+def prewarm_wait():
+    """Block until the warm-up thread is idle (called by every FFT entry point)."""
+    import threading
+    q = _warm["queue"]
+    if q is None or threading.current_thread() is _warm["thread"]:
+        return
+    q.join()
 
 
 # ---------------------------------------------------------------------------

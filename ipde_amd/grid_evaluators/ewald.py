@@ -21,7 +21,7 @@ from numpy.polynomial import chebyshev as C
 from scipy.special import i0e, i1e, k0, k1
 
 from .. import _lib
-from ..device import get_context, location_of, as_f64, ptr
+from ..device import get_context, location_of, as_f64, ptr, prewarm_wait
 
 NI, DEG = 32, 15
 
@@ -112,6 +112,7 @@ def truncated_operator(nbx, nby, h, L, helmholtz_k, device):
     modified_helmholtz_grid_evaluator.py:14-17 sampled on the 2x finer spectral grid,
     transformed, cropped to the samples nearest the origin (reference :283-293)."""
     import torch
+    prewarm_wait()
     Nx, Ny = 2 * nbx, 2 * nby
     # one quadrant of |k| is enough: the function is even in both indices
     kqx = np.abs(np.fft.fftfreq(Nx, h / (2 * np.pi))[:Nx // 2 + 1])
@@ -280,6 +281,7 @@ class StokesFreespaceEwald(object):
         self.op6.zero_()
         loc = location_of(sx, sy, fx, fy)
         sx, sy, fx, fy = (as_f64(a, loc) for a in (sx, sy, fx, fy))
+        prewarm_wait()
         core.ctx.check(core.ctx.lib.ipde_ewald_spread_stokes(
             core.handle, loc, int(sx.shape[0]), ptr(sx), ptr(sy), ptr(fx), ptr(fy), self.x0, self.y0,
             self.cx, self.cy, self.big_nx, self.big_ny, self.off, self.off, ptr(self.loc3), ptr(self.op6)))

@@ -13,6 +13,7 @@ from ...embedded_function import EmbeddedFunction
 from ...interp import periodic_interp2d, chebyshev_fourier_eval
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
+from ...device import prewarm_wait
 from ...sharding import make_pnai_evaluator
 from ...spectral import get_plan
 
@@ -120,6 +121,7 @@ class VectorSolver(object):
 
     def __call__(self, fu, fv, **kwargs):
         """fu, fv: EmbeddedFunctions -> (u, v, p) EmbeddedFunctions (reference :57-112)."""
+        prewarm_wait()      # torch.fft below: never concurrently with the warm-up thread
         e = self.ebdyc
         Nx, Ny = self.grid.shape
         fur_list = fu.get_radial_value_list()

@@ -176,8 +176,11 @@ def test_modhelm_parity(lp, setup, k, mode):
 
 @pytest.mark.parametrize("k", [0.05, 3.0, 200.0])
 def test_modhelm_generic_path_and_table_misses(lp, setup, k):
-    """k*r far below / above the LDS table (k r < 7e-4 or > 45) must fall back to
-    the series / Chebyshev code per lane; generic_math forces that code everywhere."""
+    """k*r below the table window (r < diameter * 2^-16) falls back to the series / Chebyshev
+    code per lane; generic_math forces that code everywhere.  At k = 200 every pair of this
+    set-up has k r >= 31: the whole field is < 1e-14 of a near-field value, and there the
+    polynomial table holds 1e-13..1e-12 of the LOCAL value (1e-15 for k r <= 11; measured in
+    DESIGN section 3) — hence the looser bound for that case."""
     c, trg, sig, tau, _, _ = setup
     ref = olp.modified_helmholtz_layer_apply(c.x, c.y, trg.x, trg.y, k, charge=sig, dipstr=tau,
                                              weights=c.weights, nx=c.normal_x, ny=c.normal_y)
@@ -186,7 +189,7 @@ def test_modhelm_generic_path_and_table_misses(lp, setup, k):
         got = lp.modified_helmholtz_apply(c.x, c.y, trg.x, trg.y, k, w_sigma=sig * w,
                                           nx=c.normal_x, ny=c.normal_y, w_tau=tau * w,
                                           generic_math=generic)
-        assert rel_err(got, ref) < TOL, (k, generic)
+        assert rel_err(got, ref) < (TOL if (generic or k < 100) else 1e-11), (k, generic)
 
 
 def test_modhelm_closure_and_self(lp, setup):
