@@ -339,6 +339,10 @@ int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
         case 9: NTv = 1024; Rv = 4; break;   // row-run
         case 10: NTv = 512; Rv = 8; break;   // row-run, 8 per lane
         case 11: NTv = 1024; Rv = 6; break;  // row-run, 6 per lane
+        case 12: NTv = 512; Rv = 4; break;
+        case 13: NTv = 1024; Rv = 3; break;
+        case 14: NTv = 1024; Rv = 5; break;
+        case 15: NTv = 768; Rv = 4; break;
         default: break;
     }
     const LayerGeom g = ipde_layer_geom(ns, nt, NTv * Rv, ctx->num_cu);
@@ -370,6 +374,10 @@ int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
             case 9: st = launch_rowrun_variant<MODE, 4, 1024>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
             case 10: st = launch_rowrun_variant<MODE, 8, 512>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
             case 11: st = launch_rowrun_variant<MODE, 6, 1024>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 12: st = launch_rowrun_variant<MODE, 4, 512>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 13: st = launch_rowrun_variant<MODE, 3, 1024>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 14: st = launch_rowrun_variant<MODE, 5, 1024>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
+            case 15: st = launch_rowrun_variant<MODE, 4, 768>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
             default: st = launch_table_variant<MODE, 4, 512, 2>(ctx, grid, rec, g, tx, ty, nt, dst, prm); break;
         }
         IPDE_TRY(st);
