@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .device import get_context, location_of, as_f64, ptr, empty_like_loc
+from .device import get_context, location_of, as_f64, ptr, empty_like_loc, prewarm_wait
 
 
 class GridPlan:
@@ -123,7 +123,10 @@ def get_plan(nx, ny, hx, hy, ctx=None):
     """Cached GridPlan (rocFFT plan creation is expensive; shapes repeat)."""
     ctx = ctx or get_context()
     key = (int(nx), int(ny), float(hx), float(hy))
-    with _plan_lock:        # device.prewarm() may be creating the same plan in its thread
+    # join the warm-up thread BEFORE taking the lock: its plan job takes the same lock, and
+    # the plan creation below would otherwise wait for it while holding the lock
+    prewarm_wait()
+    with _plan_lock:
         p = ctx._plans.get(key)
         if p is None or not p.handle:
             p = GridPlan(nx, ny, hx, hy, ctx)
