@@ -6,6 +6,7 @@ memory only — every computation on this path is a kernel of libipde_hip.so.
 """
 import ctypes
 import threading
+import time
 
 import numpy as np
 import torch
@@ -155,7 +156,15 @@ def prewarm_wait():
     q = _warm["queue"]
     if q is None or threading.current_thread() is _warm["thread"]:
         return
-    q.join()
+    # queue.join() without the possibility of waiting forever: the jobs are seconds of
+    # library loading / kernel compilation; after two minutes carry on regardless
+    deadline = time.monotonic() + 120.0
+    with q.all_tasks_done:
+        while q.unfinished_tasks:
+            remaining = deadline - time.monotonic()
+            if remaining <= 0.0:
+                break
+            q.all_tasks_done.wait(remaining)
 
 
 # ---------------------------------------------------------------------------
