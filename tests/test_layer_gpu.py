@@ -356,3 +356,24 @@ def test_stokes_rowrun_variant_matches_strided_kernel():
                     assert np.abs(b - r).max() < 1e-12 * np.abs(r).max()
     finally:
         ctx.set_option("stokes_variant", 1)
+
+
+def test_empty_and_degenerate_inputs_all_kernels(lp):
+    """ns = 0, nt = 0, a single coincident pair with SKIP_COINCIDENT — every kernel family"""
+    z, one = np.zeros(0), np.array([0.3])
+    sx, sy, q = np.array([0.0, 1.0]), np.array([0.0, 0.5]), np.array([1.0, -2.0])
+    assert lp.modified_helmholtz_apply(sx, sy, z, z, 2.0, w_sigma=q).shape == (0,)
+    assert np.array_equal(lp.modified_helmholtz_apply(z, z, one, one, 2.0, w_sigma=z), [0.0])
+    assert all(a.shape == (0,) for a in lp.stokes_apply(sx, sy, z, z, wfx=q, wfy=q))
+    assert all(np.array_equal(a, [0.0]) for a in lp.stokes_apply(z, z, one, one, wfx=z, wfy=z))
+    assert np.array_equal(lp.laplace_apply(z, z, one, one, w_sigma=z), [0.0])
+    two = np.array([2.0])
+    assert np.array_equal(lp.laplace_apply(one, one, one, one, w_sigma=two, skip_coincident=True), [0.0])
+    assert np.array_equal(lp.modified_helmholtz_apply(one, one, one, one, 3.0, w_sigma=two,
+                                                      skip_coincident=True), [0.0])
+    assert all(np.array_equal(a, [0.0]) for a in
+               lp.stokes_apply(one, one, one, one, wfx=two, wfy=two, skip_coincident=True))
+    # far-apart coordinates in large units (power-of-two rescaling of the table kernels)
+    got = lp.laplace_apply(sx * 1e6, sy * 1e6, np.array([5e6]), np.array([3e6]), w_sigma=q)
+    ref = -(np.log(np.hypot(5e6, 3e6)) - 2 * np.log(np.hypot(4e6, 2.5e6))) / (2 * np.pi)
+    assert abs(got[0] - ref) < 1e-13 * abs(ref)
