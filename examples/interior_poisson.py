@@ -30,12 +30,12 @@ Naive_SLP = lambda src, trg: Laplace_Layer_Form(src, trg, ifcharge=True)
 
 
 def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, grid_upsample=1,
-        Ns=None, verbose=False, timings=None, grid_backend=None):
+        Ns=None, verbose=False, timings=None, grid_backend=None, h=None):
     T = {} if timings is None else timings
     t0 = time.perf_counter()
     MOL = SlepianMollifier(1.5 * M)
     bdy = GSB(c=star(nb, a=0.2, f=5))
-    bh = bdy.dt * bdy.speed.min()
+    bh = bdy.dt * bdy.speed.min() if h is None else h      # h: grid spacing override (BASELINE configs[0])
     ebdy = EmbeddedBoundary(bdy, True, M, bh / grid_upsample, pad_zone=0, heaviside=MOL.step,
                             qfs_tolerance=1e-14, coordinate_tolerance=1e-14)
     ebdyc = EmbeddedBoundaryCollection([ebdy, ])

@@ -23,6 +23,17 @@ def test_interior_poisson_manufactured_solution():
     assert max(solver.iteration_counts) < 40
 
 
+def test_baseline_config0_256_grid_512_nodes():
+    """BASELINE.json configs[0]: examples/interior_poisson.py on a 256^2 grid with a 512-node
+    star.  The grid spacing is set by the grid here (h = 3.2/256), not by the boundary; at
+    this resolution the manufactured solution is resolved to ~1e-8."""
+    import interior_poisson
+    err, scale, solver, ue, T = interior_poisson.run(nb=512, M=8, Ns=[256, 256], h=3.2 / 256)
+    assert list(T['grid']) == [256, 256]
+    assert err / scale < 2e-7
+    assert max(solver.iteration_counts) < 40
+
+
 def test_interior_poisson_converges_with_resolution():
     import interior_poisson
     errs = []
