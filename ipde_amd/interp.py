@@ -22,6 +22,21 @@ def _dev(a, ctx, dtype):
     return torch.as_tensor(np.ascontiguousarray(a), device=ctx.torch_device()).to(dtype)
 
 
+def periodic_interp2d_gradient(fh, x, y, ikx, iky, ctx=None, chunk=16384):
+    """(3, P) real tensor: the real Fourier series fh (Nx, Ny) and its x and y derivatives
+    (multipliers ikx (Nx, 1), iky (Ny,) as in ebdy_collection.ikx/iky) at the points
+    (x, y) — what reference multi_boundary/scalar.py:80-88 gets from three type-2 NUFFTs.
+    Two fields go through the kx GEMM (F and ikx F); the y derivative is taken on its
+    product."""
+    ctx = ctx or get_context()
+    fh = _dev(fh, ctx, torch.complex128)
+    ikx = _dev(ikx, ctx, torch.complex128).reshape(-1, 1)
+    iky = _dev(iky, ctx, torch.complex128).reshape(-1)
+    out = _interp2d_real(torch.stack([fh, ikx * fh]), _dev(x, ctx, torch.float64),
+                         _dev(y, ctx, torch.float64), chunk, iky0=iky)
+    return out
+
+
 def periodic_interp2d(fh, x, y, ctx=None, chunk=16384, real_part=False):
     """Evaluate the Fourier series with fft2-ordered coefficients fh (K, Nx, Ny) (or
     (Nx, Ny)) at the points (x, y) given in [0, 2 pi) units of the periodic box.
@@ -56,13 +71,15 @@ def periodic_interp2d(fh, x, y, ctx=None, chunk=16384, real_part=False):
     return out[0] if squeeze else out
 
 
-def _interp2d_real(fh, x, y, chunk):
+def _interp2d_real(fh, x, y, chunk, iky0=None):
     """Re sum_k F(k) e^{i k.x} with the fft-ordered wavenumbers (the Nyquist index carries
     -N/2), through the ky >= 0 half of the spectrum.  Modes pair up with their negatives,
     Re(F(k) e^{ik.x} + F(-k) e^{-ik.x}) = Re((F(k) + conj F(-k)) e^{ik.x}), except on the
     Nyquist row / column, where index negation does not conjugate the phase: the column
     ky = -Ny/2 enters unsymmetrised with weight 1, the row kx = -Nx/2 is summed separately
-    over all ky (a rank-one correction)."""
+    over all ky (a rank-one correction).
+    iky0 (Ny,) complex: append one more output row, the field 0 multiplied by iky0 (its y
+    derivative) — the multiplier commutes with the kx GEMM, so it costs no GEMM of its own."""
     K, Nx, Ny = fh.shape
     dev = fh.device
     fm = torch.roll(torch.flip(fh, dims=(1, 2)), shifts=(1, 1), dims=(1, 2))   # F(-k)
@@ -78,16 +95,23 @@ def _interp2d_real(fh, x, y, chunk):
     kyf = torch.fft.fftfreq(Ny, 1.0 / Ny, dtype=torch.float64, device=dev)
     ky = kyf[:nyh]
     P = x.shape[0]
-    out = torch.empty((K, P), dtype=torch.float64, device=dev)
+    Ko = K + (iky0 is not None)
+    out = torch.empty((Ko, P), dtype=torch.float64, device=dev)
+    nyq = fh[:, Nx // 2, :]
+    if iky0 is not None:
+        nyq = torch.cat([nyq, (iky0 * fh[0, Nx // 2, :])[None]], dim=0)
     for a in range(0, P, chunk):
         b = min(P, a + chunk)
         Ex = torch.exp(1j * x[a:b, None] * kx[None, :])          # (p, Nx)
         A = (Ex @ f2).reshape(b - a, K, nyh)                      # GEMM over kx, half of ky
         Ey = torch.exp(1j * y[a:b, None] * ky[None, :])          # (p, nyh)
         val = (A * Ey[:, None, :]).sum(dim=2)                     # (p, K)
+        if iky0 is not None:
+            vdy = (A[:, 0, :] * (Ey * iky0[None, :nyh])).sum(dim=1)
+            val = torch.cat([val, vdy[:, None]], dim=1)           # (p, Ko)
         if Nx % 2 == 0:
             Eyf = torch.exp(1j * y[a:b, None] * kyf[None, :])    # (p, Ny)
-            row = Eyf @ fh[:, Nx // 2, :].transpose(0, 1)         # (p, K)
+            row = Eyf @ nyq.transpose(0, 1)                       # (p, Ko)
             val = val + row * torch.exp(-0.5j * Nx * x[a:b])[:, None]
         out[:, a:b] = val.real.transpose(0, 1)
     out /= float(Nx * Ny)

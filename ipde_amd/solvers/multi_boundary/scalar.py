@@ -13,7 +13,7 @@ import torch
 
 from ...derivatives import fd_x_4, fd_y_4
 from ...embedded_function import EmbeddedFunction, BoundaryFunction
-from ...interp import periodic_interp2d, chebyshev_fourier_eval
+from ...interp import periodic_interp2d, periodic_interp2d_gradient, chebyshev_fourier_eval
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...device import prewarm_wait
@@ -135,8 +135,8 @@ class ScalarSolver(object):
         if self.interpolation_order == np.inf:
             # values and gradient on all interface nodes from the spectrum (:80-88); the
             # three fields share one set of exponential matrices
-            stack = torch.stack([uch, self._ikx_d * uch, self._iky_d * uch])
-            all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
+            all_bvs = periodic_interp2d_gradient(uch, self._ifx_d, self._ify_d, self._ikx_d,
+                                                  self._iky_d).cpu().numpy()
         else:
             stack = torch.stack([torch.fft.fft2(g) for g in (uc, self.dx(uc), self.dy(uc))])
             all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()

@@ -94,6 +94,23 @@ def test_periodic_interp2d_real_part_path(Nx, Ny):
     assert np.abs(full[0] - ref).max() < 1e-12 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("Nx,Ny", [(16, 16), (24, 17), (15, 32)])
+def test_periodic_interp2d_gradient_equals_three_field_stack(Nx, Ny):
+    """value + gradient through two GEMM fields == the three separately interpolated
+    fields [F, ikx F, iky F] (multipliers in physical units, Nyquist entries kept)"""
+    from ipde_amd.interp import periodic_interp2d, periodic_interp2d_gradient
+    rng = np.random.default_rng(7 * Nx + Ny)
+    fh = np.fft.fft2(rng.standard_normal((Nx, Ny)))
+    ikx = 1j * np.fft.fftfreq(Nx, 0.37 / (2 * np.pi))[:, None]
+    iky = 1j * np.fft.fftfreq(Ny, 0.21 / (2 * np.pi))
+    x, y = rng.uniform(0, 2 * np.pi, 33), rng.uniform(0, 2 * np.pi, 33)
+    ref = periodic_interp2d(np.stack([fh, ikx * fh, iky * fh]), x, y).cpu().numpy().real
+    got = periodic_interp2d_gradient(fh, x, y, ikx, iky).cpu().numpy()
+    assert got.shape == (3, 33)
+    for a, b in zip(got, ref):
+        assert np.abs(a - b).max() < 1e-12 * max(np.abs(b).max(), 1.0)
+
+
 def test_device_form_builders_match_host_forms():
     """ipde_amd.dense_forms (torch, GPU) against the numpy forms of pybie2d_compat"""
     import torch
