@@ -128,7 +128,8 @@ def arc_length_parameterize(x, y, tol=1e-13):
         coef = torch.as_tensor(np.stack([ah, sh, ch], axis=1), device=dev)       # (N, 3)
 
         def sums(tt):
-            E = torch.exp(1j * torch.as_tensor(tt, device=dev)[:, None] * kd[None, :])
+            ang = torch.as_tensor(tt, device=dev)[:, None] * kd[None, :]
+            E = torch.complex(torch.cos(ang), torch.sin(ang))
             r = (E @ coef).cpu().numpy()
             return r[:, 0], r[:, 1], r[:, 2]
     else:
