@@ -20,13 +20,21 @@ from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
 from ipde_amd.embedded_function import EmbeddedFunction, BoundaryFunction  # noqa: E402
 from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
 from ipde_amd.layer_potentials import Laplace_Layer_Apply, DeviceTargets  # noqa: E402
-from ipde_amd.pybie2d_compat import (star, Global_Smooth_Boundary as GSB,  # noqa: E402
-                                     Laplace_Layer_Singular_Form, Laplace_Layer_Form)
+from ipde_amd.pybie2d_compat import star, Global_Smooth_Boundary as GSB  # noqa: E402
 from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.poisson import PoissonSolver  # noqa: E402
 
-Singular_DLP = lambda src, _: Laplace_Layer_Singular_Form(src, ifdipole=True) - 0.5 * np.eye(src.N)
-Naive_SLP = lambda src, trg: Laplace_Layer_Form(src, trg, ifcharge=True)
+
+
+def _forms():
+    """the example's dense matrices (reference :16-20), assembled on the GPU"""
+    import torch
+    from ipde_amd import dense_forms as df
+    dev = torch.device('cuda', torch.cuda.current_device())
+    eye = lambda n: torch.eye(n, dtype=torch.float64, device=dev)
+    singular_dlp = lambda src, _: df.laplace_singular_form(src, dev, ifdipole=True) - 0.5 * eye(src.N)
+    naive_slp = lambda src, trg: df.laplace_form(src, trg, dev, ifcharge=True)
+    return singular_dlp, naive_slp
 
 
 def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, grid_upsample=1,
@@ -67,6 +75,7 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
 
     # homogeneous correction: double-layer density on the boundary, evaluated through QFS
     t0 = time.perf_counter()
+    Singular_DLP, Naive_SLP = _forms()
     A = Singular_DLP(bdy, bdy)
     qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [lambda src, trg: A, ], Naive_SLP, on_surface=True, form_b2c=False)
     Alu = DenseSolver(A)

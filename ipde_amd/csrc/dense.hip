@@ -15,7 +15,13 @@
 // tile (I, K) at ((I nb + K) 4096) doubles, padded with identity to a multiple of 64 —
 // because a step reads one tile per block row: in the row-major matrix that is a 512-byte
 // piece every n*8 bytes (one DRAM page / TLB entry per row; 13.5 us per step measured at
-// n = 4096), tiled it is one contiguous 32 KB read per workgroup.
+// n = 4096), tiled it is one contiguous 32 KB read per workgroup.  Inside a tile the
+// storage is COLUMN-major (element (r, c) at c*64 + r): lane = row, so every load
+// instruction of a wave reads one 512-byte column.
+//
+// A step costs ~4.5 us, the GPU's latency between dependent launches: replaying the 2 nb
+// launches from a hipGraph changed nothing (0.589 vs 0.581 ms at n = 4096 — measured), so
+// they are simply launched one by one.
 #include "ipde_common.h"
 
 namespace {
@@ -36,25 +42,27 @@ __global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ L
                                                     int k, double* __restrict__ v,
                                                     double* __restrict__ x) {
     __shared__ double xs[DB];
+    __shared__ double red[DT / DB][DB];
     const int tid = threadIdx.x;
     const int r0 = k * DB;
     // this workgroup's off-diagonal tile goes into registers first: the loads are in flight
     // while wave 0 runs the 64-step dependency chain of the diagonal solve
     const int i = LOWER ? k + (int)blockIdx.x : k - (int)blockIdx.x;   // block row to update
-    const int row = tid >> 2, part = tid & 3;
+    const int row = tid & (DB - 1), part = tid >> 6;       // part = wave: 16 columns each
     double a[16];
     if (blockIdx.x != 0) {
-        const double* ap = LU + ((size_t)i * nb + k) * (DB * DB) + row * DB + part * 16;
+        const double* ap = LU + ((size_t)i * nb + k) * (DB * DB) + (size_t)part * 16 * DB + row;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = ap[c];
+        for (int c = 0; c < 16; ++c) a[c] = ap[c * DB];
     }
     if (tid < DB) {
         const int lane = tid;
-        // row `lane` of the diagonal tile straight into registers (512 contiguous bytes)
-        const double* dt = LU + ((size_t)k * nb + k) * (DB * DB) + lane * DB;
+        // row `lane` of the diagonal tile straight into registers (one coalesced column
+        // per load instruction)
+        const double* dt = LU + ((size_t)k * nb + k) * (DB * DB) + lane;
         double lrow[DB];
 #pragma unroll
-        for (int c = 0; c < DB; ++c) lrow[c] = dt[c];
+        for (int c = 0; c < DB; ++c) lrow[c] = dt[c * DB];
         double val = (r0 + lane < n) ? v[r0 + lane] : 0.0;
         // x_j is broadcast with v_readlane (compile-time lane index under full unrolling):
         // a few cycles per step instead of a ds_bpermute round trip
@@ -81,13 +89,13 @@ __global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ L
     }
     if (blockIdx.x == 0) return;
     __syncthreads();
-    const int gr = i * DB + row;
     double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) s = fma(a[c], xs[part * 16 + c], s);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (part == 0 && gr < n) v[gr] -= s;
+    for (int c = 0; c < 16; ++c) s = fma(a[c], xs[part * 16 + c], s);      // xs: LDS broadcast
+    red[part][row] = s;
+    __syncthreads();
+    const int gr = i * DB + row;
+    if (part == 0 && gr < n) v[gr] -= (red[0][row] + red[1][row]) + (red[2][row] + red[3][row]);
 }
 
 __global__ void permute_kernel(const double* __restrict__ b, const int* __restrict__ perm, int n,

@@ -1,8 +1,8 @@
 """Grid points near a closed curve: closest-point ("local") coordinates and inside
 tests.  Own replacement for the near_finder calls of the reference
 (`gridpoints_near_curve_update`, `points_inside_curve_update`; reference
-ipde/embedded_boundary.py:185-214, ipde/ebdy_collection.py:376-382).  Host numpy,
-one-time set-up per geometry.
+ipde/embedded_boundary.py:185-214, ipde/ebdy_collection.py:376-382).  One-time set-up
+per geometry: k-d tree on the host, Newton iteration on the GPU when there is one.
 
 For a point p within `width` of the curve X(t) we want (r, t):  p = X(t) + r n(t),
 n the outward unit normal (r < 0 inside a ccw curve).  The curve is trigonometrically
@@ -63,7 +63,7 @@ class CurveEvaluator(object):
         return out[0], out[1], out[2]
 
 
-def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30, on_device=False):
+def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30, on_device=True):
     """(r, t, found) of the points (px, py); found = within ~1.5*width of the curve and
     Newton converged.  r is the signed distance along the outward normal."""
     px = np.asarray(px, dtype=float)
@@ -71,7 +71,8 @@ def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30, on_device=False
     ev = CurveEvaluator(bdy)
     fine = ev.f[0]
     tree = cKDTree(np.column_stack([fine.real, fine.imag]))
-    dist, j = tree.query(np.column_stack([px, py]), distance_upper_bound=1.5 * width + 2 * bdy.max_h)
+    dist, j = tree.query(np.column_stack([px, py]), distance_upper_bound=1.5 * width + 2 * bdy.max_h,
+                         workers=-1)
     found = np.isfinite(dist)
     r = np.full(px.shape, np.nan)
     t = np.full(px.shape, np.nan)
@@ -79,9 +80,8 @@ def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30, on_device=False
         return r, t, found
     p = px[found] + 1j * py[found]
     tt = j[found] * ev.hf
-    # on_device: the same iteration with torch on the GPU.  Off by default: during set-up
-    # the GPU runtime is busy loading libraries in the prewarm threads (device.prewarm) and
-    # first-use kernel loads serialise behind them; ~3e5 points take 0.7 s in numpy.
+    # on_device: the same iteration with torch on the GPU (0.2 s for ~3e5 points, 0.7 s in
+    # numpy); the numpy loop below is what runs on a machine without a GPU.
     dev = _torch_device() if on_device else None
     if dev is not None:
         rr, tf = _newton_device(ev, p, tt, width, tol, maxiter, dev)

@@ -166,10 +166,11 @@ class _DeviceLU(object):
         self.ctx = get_context(LU.device.index)
         self.n = n = int(LU.shape[0])
         nb = (n + 63) // 64
-        # 64x64 tiles stored contiguously, identity padding (layout of ipde_dense_lu_solve)
+        # 64x64 tiles stored contiguously, column-major inside a tile, identity padding
+        # (layout of ipde_dense_lu_solve)
         pad = torch.eye(nb * 64, dtype=torch.float64, device=LU.device)
         pad[:n, :n] = LU
-        self.LU = pad.view(nb, 64, nb, 64).permute(0, 2, 1, 3).contiguous()
+        self.LU = pad.view(nb, 64, nb, 64).permute(0, 2, 3, 1).contiguous()
         if perm is None:
             p = np.arange(self.n)
             for i, q in enumerate(piv.cpu().numpy() - 1):  # LAPACK ipiv -> permutation vector
