@@ -12,7 +12,6 @@ import sys
 import time
 
 import numpy as np
-import scipy.linalg
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -21,10 +20,8 @@ from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
 from ipde_amd.embedded_function import EmbeddedFunction, BoundaryFunction  # noqa: E402
 from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
 from ipde_amd.layer_potentials import Modified_Helmholtz_Layer_Apply, DeviceTargets  # noqa: E402
-from ipde_amd.pybie2d_compat import (star, Global_Smooth_Boundary as GSB,  # noqa: E402
-                                     Modified_Helmholtz_Layer_Form as MH_Layer_Form,
-                                     Modified_Helmholtz_Layer_Singular_Form as MH_Singular_Form)
-from ipde_amd.qfs import QFS_Evaluator  # noqa: E402
+from ipde_amd.pybie2d_compat import star, Global_Smooth_Boundary as GSB  # noqa: E402
+from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver  # noqa: E402
 
 
@@ -55,16 +52,20 @@ def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False
     T['inhomogeneous_solve_s'] = time.perf_counter() - t0
     # homogeneous correction with a double layer on the boundary (interior: D - I/2)
     t0 = time.perf_counter()
-    K = lambda src, _: MH_Singular_Form(src, k=helmholtz_k, ifdipole=True) - 0.5 * np.eye(src.N)
-    Naive_SLP = lambda src, trg: MH_Layer_Form(src, trg, k=helmholtz_k, ifcharge=True)
+    import torch
+    from ipde_amd import dense_forms as df      # the dense matrices are assembled on the GPU
+    dev = torch.device('cuda', torch.cuda.current_device())
+    eye = lambda n: torch.eye(n, dtype=torch.float64, device=dev)
+    K = lambda src, _: df.modhelm_singular_form(src, dev, helmholtz_k, ifdipole=True) - 0.5 * eye(src.N)
+    Naive_SLP = lambda src, trg: df.modhelm_form(src, trg, dev, helmholtz_k, ifcharge=True)
     A = K(bdy, bdy)
-    qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [K, ], Naive_SLP, on_surface=True, form_b2c=False)
-    Alu = scipy.linalg.lu_factor(A)
+    qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [lambda src, trg: A, ], Naive_SLP, on_surface=True, form_b2c=False)
+    Alu = DenseSolver(A)
     targets = DeviceTargets(ebdyc.grid_and_radial_pts)
     T['homogeneous_form_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     bv = solver.get_boundary_values(ue.get_radial_value_list())
-    tau = scipy.linalg.lu_solve(Alu, np.concatenate((bc - bv).bdy_value_list))
+    tau = Alu.solve(np.concatenate((bc - bv).bdy_value_list))
     sigma = qfs([tau, ])
     out = Modified_Helmholtz_Layer_Apply(ebdyc.bdy_inward_sources, targets, k=helmholtz_k,
                                          charge=sigma).cpu().numpy()

@@ -24,9 +24,7 @@ from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
 from ipde_amd.embedded_function import EmbeddedFunction  # noqa: E402
 from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
 from ipde_amd.layer_potentials import Modified_Helmholtz_Layer_Apply, DeviceTargets  # noqa: E402
-from ipde_amd.pybie2d_compat import (star, squish, Grid, Global_Smooth_Boundary as GSB,  # noqa: E402
-                                     Modified_Helmholtz_Layer_Form as MH_Layer_Form,
-                                     Modified_Helmholtz_Layer_Singular_Form as MH_Self)
+from ipde_amd.pybie2d_compat import star, squish, Grid, Global_Smooth_Boundary as GSB  # noqa: E402
 from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver  # noqa: E402
 
@@ -64,14 +62,17 @@ def run(nb=400, M=16, helmholtz_k=2.0, verbose=False):
     # block boundary-integral system (reference :100-120)
     t0 = time.perf_counter()
     k = helmholtz_k
-    d_only = lambda src, trg: MH_Layer_Form(src, trg, k=k, ifdipole=True)
-    c_and_d = lambda src, trg: MH_Layer_Form(src, trg, k=k, ifcharge=True, ifdipole=True)
-    d_singular = lambda src: MH_Self(src, k=k, ifdipole=True)
-    cd_singular = lambda src: MH_Self(src, k=k, ifcharge=True, ifdipole=True)
-    half_eye = lambda src: np.eye(src.N) * 0.5
+    import torch
+    from ipde_amd import dense_forms as df      # the dense matrices are assembled on the GPU
+    dev = torch.device('cuda', torch.cuda.current_device())
+    d_only = lambda src, trg: df.modhelm_form(src, trg, dev, k, ifdipole=True)
+    c_and_d = lambda src, trg: df.modhelm_form(src, trg, dev, k, ifcharge=True, ifdipole=True)
+    d_singular = lambda src: df.modhelm_singular_form(src, dev, k, ifdipole=True)
+    cd_singular = lambda src: df.modhelm_singular_form(src, dev, k, ifcharge=True, ifdipole=True)
+    half_eye = lambda src: torch.eye(src.N, dtype=torch.float64, device=dev) * 0.5
     Ns = [b.N for b in bdys]
     off = np.concatenate([[0], np.cumsum(Ns)])
-    MAT = np.zeros((off[-1], off[-1]))
+    MAT = torch.zeros((int(off[-1]), int(off[-1])), dtype=torch.float64, device=dev)
     for i, bi in enumerate(bdys):          # target boundary
         for j, bj in enumerate(bdys):      # source boundary
             blk = MAT[off[i]:off[i + 1], off[j]:off[j + 1]]
@@ -82,13 +83,13 @@ def run(nb=400, M=16, helmholtz_k=2.0, verbose=False):
     bvs = np.concatenate(solver.get_boundary_values(ue.get_radial_value_list()).bdy_value_list)
     tau = DenseSolver(MAT).solve(bcs2v - bvs)
     taul = ebdyc.v2l(tau)
-    Naive_SLP = lambda src, trg: MH_Layer_Form(src, trg, k=k, ifcharge=True)
+    Naive_SLP = lambda src, trg: df.modhelm_form(src, trg, dev, k, ifcharge=True)
     sigmal = []
     for ebdy, t in zip(ebdys, taul):
         if ebdy.interior:
-            K = lambda src, _: MH_Self(src, k=k, ifdipole=True) - 0.5 * np.eye(src.N)
+            K = lambda src, _: d_singular(src) - half_eye(src)
         else:
-            K = lambda src, _: MH_Self(src, k=k, ifcharge=True, ifdipole=True) + 0.5 * np.eye(src.N)
+            K = lambda src, _: cd_singular(src) + half_eye(src)
         qfs = QFS_Evaluator(ebdy.bdy_qfs, ebdy.interior, [K, ], Naive_SLP, on_surface=True, form_b2c=False)
         sigmal.append(qfs([t, ]))
     sigmav = np.concatenate(sigmal)

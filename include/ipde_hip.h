@@ -204,6 +204,24 @@ int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, const int* p
                         const double* b, double* x);
 
 /* ------------------------------------------------------------------------- */
+/* Closest-point coordinates of points near a closed curve  */
+/*
+ * For every point p = (px[i], py[i]) within ~1.5 width of the curve X(t): the local
+ * coordinates (r, t) with p = X(t) + r n(t), n the outward unit normal (r < 0 inside a
+ * counter-clockwise curve), by Newton's method from the start values t0[i] (parameter of
+ * the nearest sample).  Replaces near_finder.gridpoints_near_curve_update as used by
+ * ipde/embedded_boundary.py:185-214.
+ *   curve_tab : DEVICE, 3*nf complex128 (x + i y): X, X', X'' at t_j = 2 pi j / nf (the
+ *               curve trigonometrically upsampled, >= 16 samples per shortest wavelength)
+ *   bary_w    : HOST, 12 barycentric weights of 12 equispaced nodes
+ *   px, py, t0, r_out, t_out : DEVICE, npts doubles; t_out in [0, 2 pi)
+ */
+int ipde_curve_local_coordinates(ipde_ctx* ctx, int64_t nf, const double* curve_tab,
+                                 const double* bary_w, int64_t npts, const double* px,
+                                 const double* py, const double* t0, double width, double tol,
+                                 int maxiter, double* r_out, double* t_out);
+
+/* ------------------------------------------------------------------------- */
 /* Ewald-type grid evaluator, first half                       */
 /*
  * ScalarGridBackend.ewald_local_freespace / ewald_local_periodic

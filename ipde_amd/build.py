@@ -30,6 +30,7 @@ SOURCES = [
     "annular.hip",
     "ewald.hip",
     "dense.hip",
+    "geometry.hip",
 ]
 
 CXXFLAGS = [

@@ -89,14 +89,32 @@ def _trunc_sgf_quadrant(kqx, kqy, L, helmholtz_k):
         kk = np.hypot(kqx[iu], kqy[ju])
     else:
         kk = np.hypot(kqx[:, None], kqy[None, :]).ravel()
-    if helmholtz_k is None:
-        ks = np.where(kk == 0, 1.0, kk)
-        ts = (1.0 - j0(L * kk)) / ks ** 2 - L * np.log(L) * j1(L * kk) / ks
-        ts[kk == 0] = -L ** 2 * np.log(L) + L ** 2 * (1 + 2 * np.log(L)) / 4
-    else:
+    def symbol(kk):
+        if helmholtz_k is None:
+            ks = np.where(kk == 0, 1.0, kk)
+            ts = (1.0 - j0(L * kk)) / ks ** 2 - L * np.log(L) * j1(L * kk) / ks
+            ts[kk == 0] = -L ** 2 * np.log(L) + L ** 2 * (1 + 2 * np.log(L)) / 4
+            return ts
         kap = float(helmholtz_k)
-        ts = (1.0 + L * kk * j1(L * kk) * k0(L * kap) - L * kap * j0(L * kk) * k1(L * kap)) \
+        return (1.0 + L * kk * j1(L * kk) * k0(L * kap) - L * kap * j0(L * kk) * k1(L * kap)) \
             / (kk ** 2 + kap ** 2)
+    # scipy's Bessel ufuncs release the GIL: chunks in a thread pool (8.6 M evaluations of
+    # J0 and J1 for a 4096^2 grid take 1.9 s on one core)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, min(16, os.cpu_count() or 1))
+    ts = np.empty_like(kk)
+    step = max(65536, -(-kk.shape[0] // (4 * nthreads)))
+    chunks = [(a, min(kk.shape[0], a + step)) for a in range(0, kk.shape[0], step)]
+
+    def work(ab):
+        ts[ab[0]:ab[1]] = symbol(kk[ab[0]:ab[1]])
+    if nthreads == 1 or len(chunks) == 1:
+        for ab in chunks:
+            work(ab)
+    else:
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(work, chunks))
     if not square:
         return ts.reshape(kqx.shape[0], kqy.shape[0])
     out = np.empty((kqx.shape[0], kqx.shape[0]))

@@ -217,19 +217,25 @@ def Laplace_Layer_Form(source, target=None, ifcharge=False, ifdipole=False):
     return out
 
 
+_kress_cache = {}
+
+
 def _kress_log_weights(N):
     """R_j with  int_0^{2pi} log(4 sin^2((t_i-s)/2)) f(s) ds ~ sum_j R_{|i-j|} f(s_j)
     for trigonometric f (Kress' quadrature for the periodic log singularity):
     R_j = -(4 pi/N) [ sum_{m=1}^{M} cos(m t_j)/m  (+ cos(N t_j/2)/N for even N) ],
-    M = N/2 - 1 (even N) or (N-1)/2 (odd N: no Nyquist mode)."""
-    j = np.arange(N)
-    if N % 2 == 0:
-        m = np.arange(1, N // 2)
-        extra = np.cos(np.pi * j) / N
-    else:
-        m = np.arange(1, (N - 1) // 2 + 1)
-        extra = 0.0
-    return -(4 * np.pi / N) * (np.cos(np.outer(j, m) * (2 * np.pi / N)) @ (1.0 / m) + extra)
+    M = N/2 - 1 (even N) or (N-1)/2 (odd N: no Nyquist mode).  The cosine sum is the real
+    part of a length-N FFT of the coefficients 1/m; kept per N."""
+    R = _kress_cache.get(N)
+    if R is None:
+        j = np.arange(N)
+        M = N // 2 - 1 if N % 2 == 0 else (N - 1) // 2
+        a = np.zeros(N)
+        a[1:M + 1] = 1.0 / np.arange(1, M + 1)
+        extra = np.cos(np.pi * j) / N if N % 2 == 0 else 0.0
+        R = -(4 * np.pi / N) * (np.fft.fft(a).real + extra)
+        _kress_cache[N] = R
+    return R
 
 
 def Laplace_Layer_Singular_Form(bdy, ifcharge=False, ifdipole=False):

@@ -266,6 +266,14 @@ class Modified_Helmholtz_QFS(_QFS):
     def _singular(self, bdy, c, d):
         return Modified_Helmholtz_Layer_Singular_Form(bdy, k=self.k, ifcharge=c, ifdipole=d)
 
+    def _s2b_dev(self, src, trg, dev):
+        from . import dense_forms as df
+        return df.modhelm_form(src, trg, dev, self.k, ifcharge=True)
+
+    def _singular_dev(self, bdy, c, d, dev):
+        from . import dense_forms as df
+        return df.modhelm_singular_form(bdy, dev, self.k, ifcharge=c, ifdipole=d)
+
 
 class Stokes_QFS(_QFS):
     """Vector QFS (reference ipde/solvers/internals/stokes.py:21-24,

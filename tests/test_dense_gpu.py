@@ -129,3 +129,35 @@ def test_device_form_builders_match_host_forms():
     same(df.stokes_singular_form(b, dev, ifforce=True), pc.Stokes_Layer_Singular_Form(b, ifforce=True))
     same(df.stokes_singular_form(b, dev, ifdipole=True), pc.Stokes_Layer_Singular_Form(b, ifdipole=True))
     same(df.stokes_pressure_fix(s, b, dev), pc.Stokes_Pressure_Fix(s, b))
+    for k in (1.0, 5.0):            # k = 5: the cut-off band of the Kress split (k r in 2..6) is active
+        same(df.modhelm_form(s, b, dev, k, ifcharge=True, ifdipole=True),
+             pc.Modified_Helmholtz_Layer_Form(s, b, k=k, ifcharge=True, ifdipole=True))
+        same(df.modhelm_singular_form(b, dev, k, ifcharge=True),
+             pc.Modified_Helmholtz_Layer_Singular_Form(b, k=k, ifcharge=True))
+        same(df.modhelm_singular_form(b, dev, k, ifdipole=True),
+             pc.Modified_Helmholtz_Layer_Singular_Form(b, k=k, ifdipole=True))
+
+
+def test_local_coordinates_kernel_matches_host_iteration():
+    """csrc/geometry.hip (closest-point Newton, one thread per point) against the numpy
+    iteration of ipde_amd/near.py on a star: same (r, t) to rounding, and p = X(t) + r n(t)."""
+    from ipde_amd import near
+    from ipde_amd.pybie2d_compat import Global_Smooth_Boundary, star
+    bdy = Global_Smooth_Boundary(c=star(400, a=0.2, f=5))
+    rng = np.random.default_rng(3)
+    width = 12 * bdy.max_h
+    j = rng.integers(0, bdy.N, 20000)
+    rr = rng.uniform(-1.2 * width, 1.2 * width, j.shape[0])
+    px = bdy.x[j] + rr * bdy.normal_x[j] + rng.uniform(-1, 1, j.shape[0]) * bdy.max_h
+    py = bdy.y[j] + rr * bdy.normal_y[j] + rng.uniform(-1, 1, j.shape[0]) * bdy.max_h
+    # a few points exactly on nodes of the upsampled curve and on the curve itself
+    px[:50], py[:50] = bdy.x[:50], bdy.y[:50]
+    r_h, t_h, f_h = near.local_coordinates(bdy, px, py, width, on_device=False)
+    r_d, t_d, f_d = near.local_coordinates(bdy, px, py, width, on_device=True)
+    assert f_h.all() and (f_h == f_d).all()
+    dt = np.abs(np.angle(np.exp(1j * (t_h - t_d))))
+    assert np.abs(r_h - r_d).max() < 1e-13 and dt.max() < 1e-12
+    ev = near.CurveEvaluator(bdy)
+    X, Xp, _ = ev(t_d)
+    n = -1j * Xp / np.abs(Xp)
+    assert np.abs(X + r_d * n - (px + 1j * py)).max() < 1e-12

@@ -9,11 +9,20 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export ROCFFT_RTC_CACHE_PATH="$PWD/gpurun_out/rocfft_gfx950.db"
 rm -f "$ROCFFT_RTC_CACHE_PATH"
+# start from the shipped cache (KEEP=1) or from scratch
+if [ "${KEEP:-1}" = "1" ] && [ -f ipde_amd/kernel_cache/rocfft_gfx950.db.gz ]; then
+    gzip -dc ipde_amd/kernel_cache/rocfft_gfx950.db.gz > "$ROCFFT_RTC_CACHE_PATH"
+fi
 timeout -k 10 900 python -m pytest tests -m gpu -q -x
 timeout -k 10 200 python bench.py --steps 3 --warmup 1 > /dev/null
 timeout -k 10 200 python examples/multi_stokes.py > /dev/null
 timeout -k 10 200 python examples/multi_modified_helmholtz.py > /dev/null
 timeout -k 10 200 python examples/interior_modified_helmholtz.py > /dev/null
+# the Ewald-split grid evaluator's padded transforms at the BASELINE grid sizes
+timeout -k 10 200 python tools/run_sharded_solve.py --problem poisson --nb 4096 --M 20 --ng 2048 --grid-backend ewald > /dev/null
+timeout -k 10 300 python tools/run_sharded_solve.py --problem modhelm --nb 8192 --M 20 --ng 4096 --k 10 --grid-backend ewald > /dev/null
+timeout -k 10 300 python examples/multi_stokes.py --nb 800 --M 14 > /dev/null
+timeout -k 10 300 python examples/multi_stokes.py --nb 3100 --M 14 > /dev/null    # config-5 scale (5312^2 grid)
 # plans of the larger BASELINE configurations (4096^2 grid, 8192-node boundaries) and of
 # the common power-of-two boundary sizes
 timeout -k 10 300 python - <<'PY'
