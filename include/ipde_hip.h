@@ -221,6 +221,17 @@ int ipde_curve_local_coordinates(ipde_ctx* ctx, int64_t nf, const double* curve_
                                  const double* py, const double* t0, double width, double tol,
                                  int maxiter, double* r_out, double* t_out);
 
+/*
+ * Radial -> grid interpolation, gather half (replaces the per-mode type-2 NUFFT of
+ * ipde/embedded_boundary.py:419-443): out[i] = sum_m T_m(xi[i]) c_m(t[i]), the Chebyshev
+ * coefficient rows c_m given oversampled on nf equispaced t (cf: DEVICE, M x nf doubles,
+ * row-major, nf = 16 x the boundary's node count) and read with 16-point barycentric
+ * Lagrange interpolation.  bary_w: HOST, 16 weights; xi, t, out: DEVICE, npts doubles.
+ */
+int ipde_chebfourier_gather(ipde_ctx* ctx, int64_t M, int64_t nf, const double* cf,
+                            const double* bary_w, int64_t npts, const double* xi, const double* t,
+                            double* out);
+
 /* ------------------------------------------------------------------------- */
 /* Ewald-type grid evaluator, first half                       */
 /*

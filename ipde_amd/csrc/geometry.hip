@@ -121,3 +121,97 @@ extern "C" int ipde_curve_local_coordinates(ipde_ctx* ctx, int64_t nf, const dou
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Radial -> grid interpolation, second half (reference
+// ipde/embedded_boundary.py:419-443 uses a type-2 NUFFT per Chebyshev mode): the M
+// Chebyshev-coefficient rows arrive oversampled along t (cf[m][j] = c_m(2 pi j / nf), nf = 16 N,
+// produced by phase-shifted FFTs in ipde_amd/interp.py); a thread evaluates one point
+// (xi, t): 16-point barycentric Lagrange along t for every row, Chebyshev recurrence in xi.
+// The table (M x nf doubles, 10 MB at M = 20, N = 4096) is L2 resident.
+namespace {
+
+constexpr int NLT = 16;   // stencil width along t (interp.py _NL_T)
+
+struct BaryW {
+    double w[NLT];
+};
+
+__global__ __launch_bounds__(256) void chebfourier_gather_kernel(const double* __restrict__ cf, int M, int nf,
+                                                                 BaryW bw, long long n,
+                                                                 const double* __restrict__ xi,
+                                                                 const double* __restrict__ t,
+                                                                 double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double twopi = 6.283185307179586476925286766559;
+    const double hf = twopi / (double)nf;
+    double tm = fmod(t[i], twopi);
+    if (tm < 0.0) tm += twopi;
+    const double s = tm / hf;
+    const long long i0 = (long long)floor(s) - (NLT / 2 - 1);
+    const double u = s - (double)i0;
+    double wt[NLT];
+    double wsum = 0.0;
+    int hit = -1;
+#pragma unroll
+    for (int j = 0; j < NLT; ++j) {
+        const double d = u - (double)j;
+        if (d == 0.0) hit = j;
+        wt[j] = bw.w[j] / (d == 0.0 ? 1.0 : d);
+        wsum += wt[j];
+    }
+    if (hit >= 0) {
+#pragma unroll
+        for (int j = 0; j < NLT; ++j) wt[j] = (j == hit) ? 1.0 : 0.0;
+        wsum = 1.0;
+    }
+    const double inv = 1.0 / wsum;
+    long long base = i0 % nf;
+    if (base < 0) base += nf;
+    int idx[NLT];
+#pragma unroll
+    for (int j = 0; j < NLT; ++j) {
+        int k = (int)(base + j);
+        idx[j] = k >= nf ? k - nf : k;
+        wt[j] *= inv;
+    }
+    const double x = xi[i];
+    double T0 = 1.0, T1 = x, acc = 0.0;
+    for (int m = 0; m < M; ++m) {
+        const double* row = cf + (size_t)m * nf;
+        double b = 0.0;
+#pragma unroll
+        for (int j = 0; j < NLT; ++j) b = fma(row[idx[j]], wt[j], b);
+        double Tm;
+        if (m == 0) {
+            Tm = 1.0;
+        } else if (m == 1) {
+            Tm = x;
+        } else {
+            Tm = 2.0 * x * T1 - T0;
+            T0 = T1;
+            T1 = Tm;
+        }
+        acc = fma(b, Tm, acc);
+    }
+    out[i] = acc;
+}
+
+}  // namespace
+
+extern "C" int ipde_chebfourier_gather(ipde_ctx* ctx, int64_t M, int64_t nf, const double* cf,
+                                       const double* bary_w, int64_t npts, const double* xi, const double* t,
+                                       double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, M > 0 && M < 4096 && nf >= NLT && nf < (1ll << 30) && cf && bary_w && npts >= 0);
+    if (npts == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, xi && t && out);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    BaryW bw;
+    for (int j = 0; j < NLT; ++j) bw.w[j] = bary_w[j];
+    hipLaunchKernelGGL(chebfourier_gather_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream,
+                       cf, (int)M, (int)nf, bw, (long long)npts, xi, t, out);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}

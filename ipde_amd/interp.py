@@ -129,16 +129,32 @@ _NL_T = 16     # Lagrange stencil width
 _bary = {}
 
 
-def _bary_weights(dev):
-    w = _bary.get(dev)
+def _bary_host():
+    """barycentric weights of _NL_T equispaced nodes (scaled to max 1), host array"""
+    w = _bary.get('host')
     if w is None:
         j = np.arange(_NL_T)
         w = np.array([1.0 / np.prod([float(a - b) for b in j if b != a]) for a in j])
-        w = _bary[dev] = torch.as_tensor(w / np.abs(w).max(), device=dev)
+        w = _bary['host'] = np.ascontiguousarray(w / np.abs(w).max())
     return w
 
 
-def chebyshev_fourier_eval(fr, xi, t, ctx=None, chunk=32768):
+_cheb_inv = {}
+_phase = {}
+
+
+def _cheb_inverse(M, ctx):
+    """V^{-1} of the Chebyshev-Gauss nodes (ascending), on the device, kept per M"""
+    key = (M, ctx.device)
+    VI = _cheb_inv.get(key)
+    if VI is None:
+        xc = np.polynomial.chebyshev.chebgauss(M)[0][::-1].copy()
+        VI = np.linalg.inv(np.polynomial.chebyshev.chebvander(xc, M - 1))
+        VI = _cheb_inv[key] = _dev(VI, ctx, torch.float64)
+    return VI
+
+
+def chebyshev_fourier_eval(fr, xi, t, ctx=None):
     """Evaluate a function given on (M Chebyshev-Gauss nodes, lowest first) x
     (N equispaced t) at scattered (xi in [-1, 1], t).  fr: (M, N) real.
     Returns a real (P,) torch tensor on the device.
@@ -154,44 +170,25 @@ def chebyshev_fourier_eval(fr, xi, t, ctx=None, chunk=32768):
     t = _dev(t, ctx, torch.float64)
     dev = fr.device
     # Chebyshev coefficients along r: c = V^{-1} f  (nodes ascending)
-    xc = np.polynomial.chebyshev.chebgauss(M)[0][::-1].copy()
-    VI = np.linalg.inv(np.polynomial.chebyshev.chebvander(xc, M - 1))
-    c = _dev(VI, ctx, torch.float64) @ fr                         # (M, N)
+    c = _cheb_inverse(M, ctx) @ fr                                # (M, N)
     ch = fft1(c, -1, ctx)                                         # (M, N) complex, unscaled
     # 16x finer samples of the M rows as 16 phase-shifted inverse transforms of the SAME
     # length N (row (s, m) holds f_m(t_j + s h/16)): no new FFT length, hence no new
     # run-time kernel compilation in rocFFT, and the batch is still one library call
     Nf = _UP_T * N
-    k = torch.fft.fftfreq(N, 1.0 / N, dtype=torch.float64, device=dev)
-    shift = torch.arange(_UP_T, dtype=torch.float64, device=dev) * (2 * np.pi / Nf)
-    phase = _cis(shift[:, None] * k[None, :])           # (16, N)
+    phase = _phase.get((N, dev))
+    if phase is None:
+        k = torch.fft.fftfreq(N, 1.0 / N, dtype=torch.float64, device=dev)
+        shift = torch.arange(_UP_T, dtype=torch.float64, device=dev) * (2 * np.pi / Nf)
+        phase = _phase[(N, dev)] = _cis(shift[:, None] * k[None, :])           # (16, N)
     fine = fft1((phase[:, None, :] * ch[None, :, :]).reshape(_UP_T * M, N), +1, ctx).real
     cf = fine.reshape(_UP_T, M, N).permute(1, 2, 0).reshape(M, Nf).contiguous()
-    w = _bary_weights(dev)
-    ar = torch.arange(_NL_T, device=dev)
-    hf = 2 * np.pi / Nf
+    # gather half: one HIP kernel, a thread per point (csrc/geometry.hip)
+    from .device import ptr
     P = t.shape[0]
     out = torch.empty(P, dtype=torch.float64, device=dev)
-    for a in range(0, P, chunk):
-        b = min(P, a + chunk)
-        s = torch.remainder(t[a:b], 2 * np.pi) / hf
-        i0 = torch.floor(s).to(torch.int64) - (_NL_T // 2 - 1)
-        d = (s - i0.to(torch.float64))[:, None] - ar[None, :].to(torch.float64)
-        exact = d == 0.0
-        wt = w[None, :] / torch.where(exact, torch.ones_like(d), d)
-        wt = torch.where(exact.any(dim=1, keepdim=True), exact.to(torch.float64), wt)
-        wt = wt / wt.sum(dim=1, keepdim=True)
-        idx = torch.remainder(i0[:, None] + ar[None, :], Nf)      # (p, NL)
-        B = (cf[:, idx] * wt[None]).sum(dim=2)                    # (M, p)
-        # T_m(xi) by the three-term recurrence
-        x = xi[a:b]
-        T0 = torch.ones_like(x)
-        T1 = x.clone()
-        acc = B[0] * T0
-        if M > 1:
-            acc = acc + B[1] * T1
-        for m in range(2, M):
-            T0, T1 = T1, 2 * x * T1 - T0
-            acc = acc + B[m] * T1
-        out[a:b] = acc
+    xi = xi.contiguous()
+    t = t.contiguous()
+    ctx.check(ctx.lib.ipde_chebfourier_gather(ctx.handle, M, Nf, ptr(cf), ptr(_bary_host()), P,
+                                              ptr(xi), ptr(t), ptr(out)))
     return out
