@@ -195,7 +195,7 @@ int ipde_fd4(ipde_ctx* ctx, int loc, int64_t nx, int64_t ny, double h,
 /*
  * x = U^-1 L^-1 P b for packed LU factors (unit lower L below the diagonal, as LAPACK
  * getrf / torch.linalg.lu_factor return them) and the row permutation perm (int32,
- * (P b)[i] = b[perm[i]]).  `lu` is TILED: nb = ceil(n/64), the matrix padded with the
+ * (P b)[i] = b[perm[i]]).  `lu` is TILED: nb = 2 ceil(n/128), the matrix padded with the
  * identity to (64 nb)^2 and stored as nb x nb contiguous 64x64 tiles, tile (I, K) at
  * ((I nb + K) * 4096) doubles, COLUMN-major inside a tile (element (r, c) at c*64 + r).  Replaces the host `lu_solve` of the reference's
  * third-party qfs package.  All pointers are DEVICE memory; b and x may not alias.

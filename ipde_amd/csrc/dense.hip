@@ -19,9 +19,8 @@
 // storage is COLUMN-major (element (r, c) at c*64 + r): lane = row, so every load
 // instruction of a wave reads one 512-byte column.
 //
-// A step costs ~4.5 us, the GPU's latency between dependent launches: replaying the 2 nb
-// launches from a hipGraph changed nothing (0.589 vs 0.581 ms at n = 4096 — measured), so
-// they are simply launched one by one.
+// Replaying the launches of a solve from a hipGraph changed nothing (0.589 vs 0.581 ms at
+// n = 4096 — measured: the host is not the limit), so they are simply launched one by one.
 #include "ipde_common.h"
 
 namespace {
@@ -98,6 +97,128 @@ __global__ __launch_bounds__(DT) void lu_subst_step(const double* __restrict__ L
     if (part == 0 && gr < n) v[gr] -= (red[0][row] + red[1][row]) + (red[2][row] + red[3][row]);
 }
 
+// Two block rows per launch (the default).  Step K owns the 128 rows of block pair
+// (2K, 2K+1): wave 0 solves the first diagonal block, all waves subtract the coupling tile
+// times that solution from the second block's right-hand side, wave 1 (whose registers have
+// held the second diagonal tile since the start of the kernel) solves it, then workgroup j
+// updates its own pair of block rows with its four tiles.  The arithmetic — products,
+// partial sums and their order — is that of two consecutive lu_subst_step launches, so the
+// results are bitwise the same.  Measured: 0.534 vs 0.581 ms at n = 4096 (8.3 us per pair
+// against 2 x 4.5 us): most of a step is not launch latency but the two things that cannot
+// overlap — the tile loads (~2 us from HBM / Infinity Cache) and the 64-step dependency chain
+// (~1 us per diagonal block) — so the pairing only saves the launch gap and the second
+// tile's load latency.
+template <bool LOWER>
+__device__ __forceinline__ double diag_chain(const double (&lrow)[DB], int lane, double val) {
+    if (LOWER) {
+#pragma unroll
+        for (int j = 0; j < DB; ++j) {
+            double xj = readlane_f64(val, j);
+            if (lane > j) val = fma(-lrow[j], xj, val);
+        }
+    } else {
+        double dinv = 1.0;
+#pragma unroll
+        for (int c = 0; c < DB; ++c) dinv = (c == lane) ? lrow[c] : dinv;
+        dinv = 1.0 / dinv;
+#pragma unroll
+        for (int j = DB - 1; j >= 0; --j) {
+            if (lane == j) val *= dinv;
+            double xj = readlane_f64(val, j);
+            if (lane < j) val = fma(-lrow[j], xj, val);
+        }
+    }
+    return val;
+}
+
+template <bool LOWER>
+__global__ __launch_bounds__(DT) void lu_subst_step2(const double* __restrict__ LU, int n, int nb,
+                                                     int K, double* __restrict__ v,
+                                                     double* __restrict__ x) {
+    __shared__ double xs[2 * DB];
+    __shared__ double redc[DT / DB][DB];
+    __shared__ double red[2][2][DT / DB][DB];
+    const int tid = threadIdx.x;
+    const int row = tid & (DB - 1), part = tid >> 6;
+    // the two diagonal blocks in the order they are solved
+    const int first = LOWER ? 2 * K : 2 * K + 1, second = LOWER ? 2 * K + 1 : 2 * K;
+    const int ip = LOWER ? K + (int)blockIdx.x : K - (int)blockIdx.x;   // block pair to update
+    const size_t T = (size_t)DB * DB;
+    const size_t off = (size_t)part * 16 * DB + row;
+    // everything this thread will need is requested before the first dependency chain starts
+    double lrow[DB];
+    if (part < 2) {
+        const int d = part == 0 ? first : second;
+        const double* dt = LU + ((size_t)d * nb + d) * T + row;
+#pragma unroll
+        for (int c = 0; c < DB; ++c) lrow[c] = dt[c * DB];
+    }
+    double cpl[16];
+    {
+        const double* ap = LU + ((size_t)second * nb + first) * T + off;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cpl[c] = ap[c * DB];
+    }
+    double u[2][2][16];
+    if (blockIdx.x != 0) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const double* ap = LU + ((size_t)(2 * ip + rb) * nb + (cb == 0 ? first : second)) * T + off;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) u[rb][cb][c] = ap[c * DB];
+            }
+    }
+    // first diagonal block: wave 0
+    if (part == 0) {
+        const int g = first * DB + row;
+        double val = (g < n) ? v[g] : 0.0;
+        val = diag_chain<LOWER>(lrow, row, val);
+        xs[row] = val;
+        if (blockIdx.x == 0 && g < n) x[g] = val;
+    }
+    __syncthreads();
+    // second block's right-hand side -= coupling tile * x_first
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s = fma(cpl[c], xs[part * 16 + c], s);
+        redc[part][row] = s;
+    }
+    __syncthreads();
+    if (part == 1) {
+        const int g = second * DB + row;
+        double val = (g < n) ? v[g] : 0.0;
+        val -= (redc[0][row] + redc[1][row]) + (redc[2][row] + redc[3][row]);
+        val = diag_chain<LOWER>(lrow, row, val);
+        xs[DB + row] = val;
+        if (blockIdx.x == 0 && g < n) x[g] = val;
+    }
+    if (blockIdx.x == 0) return;
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) s = fma(u[rb][cb][c], xs[cb * DB + part * 16 + c], s);
+            red[rb][cb][part][row] = s;
+        }
+    __syncthreads();
+    if (part < 2) {
+        const int rb = part;
+        const int g = (2 * ip + rb) * DB + row;
+        if (g < n) {
+            double vv = v[g];
+            vv -= (red[rb][0][0][row] + red[rb][0][1][row]) + (red[rb][0][2][row] + red[rb][0][3][row]);
+            vv -= (red[rb][1][0][row] + red[rb][1][1][row]) + (red[rb][1][2][row] + red[rb][1][3][row]);
+            v[g] = vv;
+        }
+    }
+}
+
 __global__ void permute_kernel(const double* __restrict__ b, const int* __restrict__ perm, int n,
                                double* __restrict__ v) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,13 +235,25 @@ extern "C" int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, c
     IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, 2 * (size_t)n * sizeof(double)));
     double* v = (double*)ctx->partial.p;
     double* y = v + n;
-    const int nb = (int)((n + DB - 1) / DB);
+    const int nbp = (int)((n + 2 * DB - 1) / (2 * DB));   // block pairs
+    const int nb = 2 * nbp;                                // 64-row blocks (tiles per row)
     hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b,
                        perm, (int)n, v);
-    for (int k = 0; k < nb; ++k)
-        hipLaunchKernelGGL(lu_subst_step<true>, dim3(nb - k), dim3(DT), 0, ctx->stream, lu, (int)n, nb, k, v, y);
-    for (int k = nb - 1; k >= 0; --k)
-        hipLaunchKernelGGL(lu_subst_step<false>, dim3(k + 1), dim3(DT), 0, ctx->stream, lu, (int)n, nb, k, y, x);
+    if (ctx->opt_dense_pairs) {
+        for (int K = 0; K < nbp; ++K)
+            hipLaunchKernelGGL(lu_subst_step2<true>, dim3(nbp - K), dim3(DT), 0, ctx->stream, lu, (int)n, nb, K,
+                               v, y);
+        for (int K = nbp - 1; K >= 0; --K)
+            hipLaunchKernelGGL(lu_subst_step2<false>, dim3(K + 1), dim3(DT), 0, ctx->stream, lu, (int)n, nb, K, y,
+                               x);
+    } else {
+        for (int k = 0; k < nb; ++k)
+            hipLaunchKernelGGL(lu_subst_step<true>, dim3(nb - k), dim3(DT), 0, ctx->stream, lu, (int)n, nb, k, v,
+                               y);
+        for (int k = nb - 1; k >= 0; --k)
+            hipLaunchKernelGGL(lu_subst_step<false>, dim3(k + 1), dim3(DT), 0, ctx->stream, lu, (int)n, nb, k, y,
+                               x);
+    }
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }

@@ -165,7 +165,7 @@ class _DeviceLU(object):
         from .device import get_context
         self.ctx = get_context(LU.device.index)
         self.n = n = int(LU.shape[0])
-        nb = (n + 63) // 64
+        nb = 2 * ((n + 127) // 128)      # an even number of 64-row blocks: two per launch
         # 64x64 tiles stored contiguously, column-major inside a tile, identity padding
         # (layout of ipde_dense_lu_solve)
         pad = torch.eye(nb * 64, dtype=torch.float64, device=LU.device)
