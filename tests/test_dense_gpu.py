@@ -8,7 +8,7 @@ import scipy.linalg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 300, 1000])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 127, 128, 129, 300, 1000])
 def test_lu_solve_matches_lapack(n):
     import torch
     from ipde_amd.qfs import _DeviceLU
@@ -21,6 +21,13 @@ def test_lu_solve_matches_lapack(n):
     ref = scipy.linalg.solve(A, b)
     assert np.abs(x - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
     assert np.abs(A @ x - b).max() < 1e-12 * n * max(1.0, np.abs(x).max())
+    # one 64-row block per launch instead of two: the same arithmetic, bit for bit
+    f.ctx.set_option("dense_pairs", 0)
+    try:
+        x1 = f._subst(torch.as_tensor(b, device="cuda")).cpu().numpy()
+    finally:
+        f.ctx.set_option("dense_pairs", 1)
+    assert np.array_equal(x, x1)
 
 
 def test_lu_solve_is_backward_stable_on_qfs_matrix():
