@@ -96,8 +96,9 @@ def full_poisson_solve(nb=4096, ng=2048, M=20):
         "homogeneous_correction_s": T["homogeneous_form_s"] + T["homogeneous_apply_s"],
         "end_to_end_s": total, "warm_inhomogeneous_solve_ms": 1e3 * warm,
         "gmres_iterations": T["gmres_iterations"],
-        "note": "end_to_end includes one-time library loads / rocFFT kernel compilation of a "
-                "process that has only run the dense-sum benchmark before",
+        "note": "end_to_end = set-up + first solve + correction in a process that has only run the "
+                "dense-sum benchmark before (one-time library loads included; rocFFT kernels come "
+                "from the shipped cache, tools/cold_solve.py times the same from process start)",
     }
 
 
