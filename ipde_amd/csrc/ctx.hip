@@ -138,7 +138,8 @@ extern "C" int ipde_ctx_create(int device_id, ipde_ctx** out) {
         return IPDE_ERR_ALLOC;
     }
     int s = ipde_build_log_table(ctx);
-    if (s == IPDE_OK) s = ipde_build_k_table(ctx);
+    // (the modified-Helmholtz K0/K1 table — 125 000 long-double Bessel evaluations, 0.1 s —
+    // is built by the first ipde_modhelm_apply)
     if (s != IPDE_OK) {
         fprintf(stderr, "ipde_hip: table construction failed: %s\n", ctx->err.c_str());
         delete ctx;

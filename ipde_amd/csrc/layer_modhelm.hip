@@ -342,6 +342,7 @@ extern "C" int ipde_modhelm_apply(ipde_ctx* ctx, int loc, double k, int64_t ns, 
     if (nt == 0) return IPDE_OK;
     IPDE_CHECK_ARG(ctx, tx && ty && out);
     IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_ktab) IPDE_TRY(ipde_build_k_table(ctx));   // first use on this context
     double* d_out;
     IPDE_TRY(ipde_stage_out(ctx, loc, 7, out, nt, &d_out));
     if (ns == 0) {

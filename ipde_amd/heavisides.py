@@ -10,9 +10,26 @@ partition of unity needs consistency, not a particular window).  Host numpy: eva
 once at set-up on O(annulus) points.
 """
 import numpy as np
-import scipy.signal
-from scipy.interpolate import InterpolatedUnivariateSpline
 from numpy.polynomial import chebyshev as C
+
+
+def _dpss(n, nw):
+    """scipy.signal.windows.dpss(n, nw).  `import scipy.signal` pulls in scipy.stats,
+    .optimize, .interpolate, ... (0.3 s, an eighth of a cold 2048^2 solve); the window
+    functions live in one file that only needs scipy.linalg / special / fft, so that file is
+    loaded on its own when it is where this scipy keeps it."""
+    try:
+        import importlib.util
+        import os
+        import scipy
+        path = os.path.join(os.path.dirname(scipy.__file__), "signal", "windows", "_windows.py")
+        spec = importlib.util.spec_from_file_location("_ipde_scipy_windows", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.dpss(n, nw)
+    except Exception:
+        import scipy.signal
+        return scipy.signal.windows.dpss(n, nw)
 
 _cache = {}
 
@@ -24,10 +41,11 @@ def _build(r, nsamp=1000, deg=200):
     # sample the dpss window at Chebyshev-Lobatto-like points by interpolating the
     # (very smooth) discrete sequence with a high-order fit
     x = np.linspace(-1.0, 1.0, nsamp)
-    w = scipy.signal.windows.dpss(nsamp, 0.25 * float(r))
+    w = _dpss(nsamp, 0.25 * float(r))
     w = 0.5 * (w + w[::-1])  # exact evenness
     # quintic spline through the samples (as the reference's construction), then
     # Chebyshev interpolation at deg+1 Chebyshev points (square, well conditioned)
+    from scipy.interpolate import InterpolatedUnivariateSpline
     spl = InterpolatedUnivariateSpline(x, w, k=5)
     xc = np.cos(np.pi * (np.arange(deg + 1) + 0.5) / (deg + 1))
     bump_c = C.chebfit(xc, spl(xc), deg)
