@@ -28,9 +28,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 NGRID = 2048
 NBDY = 4096
 FLOPS_PER_PAIR_ALGO = 8        # SURVEY §8d counting convention (5 geometry + log + fma)
-VALU_INSTR_PER_PAIR = 11.5     # ISA count of the row-run table kernel: 8.5 fp64 (2.5 geometry with
+VALU_INSTR_PER_PAIR = 11.0     # ISA count of the row-run table kernel: 8.5 fp64 (2.5 geometry with
                                # (x-sx)^2 shared by a lane's 4 targets, y, 4 fma log1p + T, accumulate)
-                               # + 3 int32 (v_bfe, v_lshl_add, min3/max3 range tracking); every VALU
+                               # + 2.5 int32 (v_bfe, v_lshl_add, one v_min3_u32 per two pairs for the
+                               # lower table bound; the upper one is guaranteed by the scaling); every VALU
                                # instruction, fp64 or int32, occupies the SIMD for one quad-cycle here
 PEAK_VALU_LANE_INSTR = 256 * 4 * 16 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz
 PEAK_FP64_VECTOR_TFLOPS = 78.6  # MI355X fp64 vector (= 256 CU*4 SIMD*32 flop/clk*2.4 GHz)

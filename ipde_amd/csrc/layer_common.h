@@ -28,7 +28,9 @@ __host__ __device__ __forceinline__ size_t ipde_rec_index(int64_t j, int ch) {
 // Per-call parameters produced on the device by the pack kernel (no host sync).
 struct ApplyParams {
     int sh;        // coordinates are scaled by 2^sh so that all d^2 < 2^exp_hi
-    int pad;       // modified Helmholtz: index of the table window (layer_modhelm.hip), else 0
+    int pad;       // modified Helmholtz: index of the table window (layer_modhelm.hip);
+                   // Laplace / Stokes: 1 = the scaling could not bring the pairs under the top of
+                   // the table (coordinates beyond 2^400): use the generic kernel body
     double corr;   // constant added to every output (undoes the log scaling)
     double corr2;  // second constant (Stokes v component)
     double inv_s;  // 2^-sh
@@ -106,12 +108,16 @@ __device__ __forceinline__ double rcp_from_y_fast(double Rh, double y) {
 // Table addressing: one v_bfe_u32 + one v_lshl_add_u32, plus min3/max3 tracking of
 // hi32(x) so that the covered range is validated ONCE per lane after the source loop.
 struct TabAddr {
-    unsigned hmin, hmax;
-    __device__ __forceinline__ TabAddr() : hmin(0xFFFFFFFFu), hmax(0u) {}
+    // Only the LOWER end of the table needs watching: the pack kernel scales the coordinates
+    // so that the bounding-box diagonal — hence every pair — stays below the top covered
+    // binade (with a 2^-30 relative margin for the roundings), and flags the launch for the
+    // generic kernel when it cannot (ApplyParams::pad).  Tracking a minimum alone is one
+    // v_min3_u32 per TWO pairs.
+    unsigned hmin;
+    __device__ __forceinline__ TabAddr() : hmin(0xFFFFFFFFu) {}
     __device__ __forceinline__ double2 lookup(const double2* ltab, double x) {
         unsigned hi = (unsigned)__double2hiint(x);
         hmin = min(hmin, hi);
-        hmax = max(hmax, hi);
         // hipcc lowers the C form to v_lshrrev + v_and (+ v_lshl_add for the address);
         // the bit-field extract is one instruction.  Plain VALU op: no wait counters,
         // VALU->VALU dependencies are hardware-interlocked.
@@ -120,10 +126,11 @@ struct TabAddr {
         asm("v_bfe_u32 %0, %1, 12, 13" : "=v"(idx) : "v"(hi));
         return ltab[idx];
     }
-    // every x seen so far was inside the covered binades?
+    // every x seen so far was at or above the lowest covered binade?  (NaN / Inf inputs give
+    // NaN / Inf results through the arithmetic itself; the 13-bit index keeps any read
+    // inside the table)
     __device__ __forceinline__ bool all_inside(unsigned key_lo) const {
-        return (hmin >> IPDE_TAB_SHIFT) >= key_lo &&
-               (hmax >> IPDE_TAB_SHIFT) < key_lo + IPDE_TAB_NKEYS;
+        return (hmin >> IPDE_TAB_SHIFT) >= key_lo;
     }
 };
 

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NT) void laplace_table_kernel(
             }
         }
     }
-    if (!ta.all_inside(key_lo)) {
+    if (!ta.all_inside(key_lo) || prm->pad) {
         // some pair of this lane fell outside the table (d^2 == 0, tiny or huge):
         // redo the lane's targets with the generic math.  Rare by construction.
 #pragma unroll
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NT) void laplace_rowrun_kernel(
         laplace_rowrun_loop<MODE, R, true>(rec, j0, j1, ltab, ta, x, y, acc);
     else
         laplace_rowrun_loop<MODE, R, false>(rec, j0, j1, ltab, ta, x, y, acc);
-    if (!ta.all_inside(key_lo)) {
+    if (!ta.all_inside(key_lo) || prm->pad) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.0;
         laplace_generic_loop<MODE, false, R>(rec, j0, j1, x, y, acc);

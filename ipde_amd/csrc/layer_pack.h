@@ -63,10 +63,10 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
                                                                  double* __restrict__ rec,
                                                                  ApplyParams* __restrict__ prm) {
     __shared__ double red[16][4];
-    __shared__ int s_sh, s_win;
+    __shared__ int s_sh, s_win, s_force;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    int sh = 0, win = 0;
+    int sh = 0, win = 0, force_generic = 0;
     if (a.use_scale) {
         double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
         for (int i = tid; i < nbbox; i += 1024) {
@@ -102,15 +102,23 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
             }
             double ddx = xmax - xmin, ddy = ymax - ymin;
             double D2 = ddx * ddx + ddy * ddy;
-            int shv = 0;
+            int shv = 0, force = 0;
             if (D2 > 0.0 && D2 < INFINITY) {
-                int e = ilogb(D2);           // D2 in [2^e, 2^(e+1))
-                int num = a.exp_hi - 1 - e;  // need 2*sh + e + 1 <= exp_hi
+                // (margin: D2 and every pair's d2 carry a few roundings; the kernels do not
+                // watch the upper end of the table)
+                int e = ilogb(D2 * (1.0 + 0x1p-30));   // D2 in [2^e, 2^(e+1))
+                int num = a.exp_hi - 1 - e;             // need 2*sh + e + 1 <= exp_hi
                 shv = (num >= 0) ? (num / 2) : -((-num + 1) / 2);
-                if (shv > 400) shv = 400;
-                if (shv < -400) shv = -400;
+                if (shv > 400) {
+                    shv = 400;
+                }
+                if (shv < -400) {
+                    shv = -400;
+                    force = 1;     // cannot be scaled under the top of the table
+                }
             }
             s_sh = shv;
+            s_force = force;
             // modified-Helmholtz table window (layer_modhelm.hip): smallest window whose top
             // binade 2^(11 + 2w) covers y_max = (k * diameter)^2
             int wv = 0;
@@ -125,6 +133,7 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
         __syncthreads();
         sh = a.fixed_scale != 0.0 ? 0 : s_sh;
         win = s_win;
+        force_generic = s_force;
         __syncthreads();
     }
     const double s1 = a.fixed_scale != 0.0 ? a.fixed_scale : ldexp(1.0, sh);
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
         }
         const double two_ln2 = 1.3862943611198906188;
         prm->sh = sh;
-        prm->pad = win;   // table window of the modified-Helmholtz kernels, else 0
+        prm->pad = a.fixed_scale != 0.0 ? win : force_generic;   // MH: table window; else: force generic
         prm->corr = -two_ln2 * (double)sh * t1;
         prm->corr2 = -two_ln2 * (double)sh * t2;
         prm->inv_s = ldexp(1.0, -sh);

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NT) void stokes_table_kernel(
                 }
         }
     }
-    if (!ta.all_inside(key_lo)) {
+    if (!ta.all_inside(key_lo) || prm->pad) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = StokesAcc{0, 0, 0, 0, 0};
         stokes_generic_loop<MODE, false, R>(rec, j0, j1, x, y, acc);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NT) void stokes_rowrun_kernel(
         stokes_rowrun_loop<MODE, R, true>(rec, j0, j1, ltab, ta, x, y, acc);
     else
         stokes_rowrun_loop<MODE, R, false>(rec, j0, j1, ltab, ta, x, y, acc);
-    if (!ta.all_inside(key_lo)) {
+    if (!ta.all_inside(key_lo) || prm->pad) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = StokesAcc{0, 0, 0, 0, 0};
         stokes_generic_loop<MODE, false, R>(rec, j0, j1, x, y, acc);
