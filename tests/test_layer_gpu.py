@@ -377,3 +377,26 @@ def test_empty_and_degenerate_inputs_all_kernels(lp):
     got = lp.laplace_apply(sx * 1e6, sy * 1e6, np.array([5e6]), np.array([3e6]), w_sigma=q)
     ref = -(np.log(np.hypot(5e6, 3e6)) - 2 * np.log(np.hypot(4e6, 2.5e6))) / (2 * np.pi)
     assert abs(got[0] - ref) < 1e-13 * abs(ref)
+
+
+@pytest.mark.parametrize("scale", [1e130, 1e-130, 2.0 ** 200, 1.0 + 2.0 ** -40])
+def test_table_kernels_at_extreme_coordinate_scales(lp, scale):
+    """The table kernels watch only the lower table bound; the pack kernel's power-of-two
+    scaling keeps every pair under the upper one, or (beyond 2^400) flags the launch for the
+    generic body.  u(s x) = u(x) - log(s) sum(q) / (2 pi) for the Laplace single layer."""
+    rng = np.random.default_rng(11)
+    ns, nt = 200, 3000
+    sx, sy, q = rng.uniform(-1, 1, ns), rng.uniform(-1, 1, ns), rng.standard_normal(ns)
+    tx, ty = rng.uniform(-2, 2, nt), rng.uniform(-2, 2, nt)
+    # the bounding-box diagonal just below a power of two (rounding margin of the scaling)
+    tx[0], ty[0], tx[1], ty[1] = -2.0, -2.0, 2.0 * (1 - 2.0 ** -52), 2.0 * (1 - 2.0 ** -52)
+    base = lp.laplace_apply(sx, sy, tx, ty, w_sigma=q)
+    got = lp.laplace_apply(sx * scale, sy * scale, tx * scale, ty * scale, w_sigma=q)
+    ref = base - np.log(scale) * q.sum() / (2 * np.pi)
+    assert np.abs(got - ref).max() < 2e-13 * np.abs(ref).max()
+    u0, v0, p0 = lp.stokes_apply(sx, sy, tx, ty, wfx=q, wfy=q[::-1].copy())
+    u1, v1, p1 = lp.stokes_apply(sx * scale, sy * scale, tx * scale, ty * scale, wfx=q, wfy=q[::-1].copy())
+    shift = -np.log(scale) / (4 * np.pi)
+    assert np.abs(u1 - (u0 + shift * q.sum())).max() < 2e-13 * max(np.abs(u1).max(), 1.0)
+    assert np.abs(v1 - (v0 + shift * q.sum())).max() < 2e-13 * max(np.abs(v1).max(), 1.0)
+    assert np.abs(p1 * scale - p0).max() < 1e-12 * np.abs(p0).max()
