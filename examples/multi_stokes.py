@@ -7,7 +7,12 @@ correction (double layer + pressure fix on the outer curve, combined single + do
 layer on the holes; :121-159), Stokes QFS sources per boundary (:164-177), one dense
 stokeslet evaluation onto all grid and radial points (:179-181).
 
-    python examples/multi_stokes.py [--nb 300] [--M 12]
+    python examples/multi_stokes.py [--nb 800] [--M 14]
+
+The outer 11-arm star is strongly curved: its annulus (M nodes wide at the boundary's node
+spacing) only stays a valid coordinate patch for n_b >~ 600 at M = 14 (curvature x width
+< 0.5; EmbeddedBoundary warns otherwise) — the reference's own n_b = 500, M = 10 resolves the
+flow to 1e-6.
 """
 import argparse
 import os
@@ -33,7 +38,7 @@ def v2f(x):
     return x.reshape(2, x.size // 2)
 
 
-def run(nb=300, M=12, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes=True,
+def run(nb=800, M=14, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes=True,
         return_fields=False, simple=False, warm=False, grid_backend=None):
     T = {}
     t0 = time.perf_counter()
@@ -155,8 +160,8 @@ def run(nb=300, M=12, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--nb", type=int, default=300)
-    ap.add_argument("--M", type=int, default=12)
+    ap.add_argument("--nb", type=int, default=800)
+    ap.add_argument("--M", type=int, default=14)
     ap.add_argument("--a", type=float, default=4.0)
     ap.add_argument("--b", type=float, default=3.0)
     ap.add_argument("--single", action="store_true", help="outer boundary only")
