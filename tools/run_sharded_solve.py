@@ -7,7 +7,7 @@ On an 8-GPU node:
         tools/run_sharded_solve.py --problem poisson --nb 4096 --M 20
 On a one-GPU box (rehearsal: all ranks share cuda:0, collectives over gloo):
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 \
-        tools/run_sharded_solve.py --backend gloo --share-gpu --problem poisson --nb 400
+        tools/run_sharded_solve.py --backend gloo --share-gpu --problem poisson --nb 800
 Prints one JSON line from rank 0.
 """
 import argparse
@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "examples"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--problem", choices=["poisson", "modhelm", "stokes"], default="poisson")
-    ap.add_argument("--nb", type=int, default=400)
+    ap.add_argument("--nb", type=int, default=800)
     ap.add_argument("--M", type=int, default=16)
     ap.add_argument("--k", type=float, default=10.0)
     ap.add_argument("--ng", type=int, default=None, help="force an ng x ng grid (scalar problems)")
