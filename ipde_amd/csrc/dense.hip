@@ -131,10 +131,21 @@ __device__ __forceinline__ double diag_chain(const double (&lrow)[DB], int lane,
     return val;
 }
 
+// Up to LU_MAXB independent systems of the same size advance in lock-step, blockIdx.y = system:
+// a step is latency bound, so the second system rides along for free (the two QFS solves of
+// an interface — grid side and annulus side — are issued this way).
+constexpr int LU_MAXB = 4;
+struct LuBatch {
+    const double* lu[LU_MAXB];
+    double* v[LU_MAXB];   // running right-hand side of the pass
+    double* x[LU_MAXB];   // result of the pass
+};
+
 template <bool LOWER>
-__global__ __launch_bounds__(DT) void lu_subst_step2(const double* __restrict__ LU, int n, int nb,
-                                                     int K, double* __restrict__ v,
-                                                     double* __restrict__ x) {
+__global__ __launch_bounds__(DT) void lu_subst_step2(LuBatch B, int n, int nb, int K) {
+    const double* __restrict__ LU = B.lu[blockIdx.y];
+    double* __restrict__ v = B.v[blockIdx.y];
+    double* __restrict__ x = B.x[blockIdx.y];
     __shared__ double xs[2 * DB];
     __shared__ double redc[DT / DB][DB];
     __shared__ double red[2][2][DT / DB][DB];
@@ -227,33 +238,49 @@ __global__ void permute_kernel(const double* __restrict__ b, const int* __restri
 
 }  // namespace
 
-extern "C" int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, const int* perm,
-                                   const double* b, double* x) {
+extern "C" int ipde_dense_lu_solve_batch(ipde_ctx* ctx, int nsys, int64_t n, const double* const* lu,
+                                         const int* const* perm, const double* const* b, double* const* x) {
     if (!ctx) return IPDE_ERR_INVALID;
-    IPDE_CHECK_ARG(ctx, n > 0 && n < (1 << 24) && lu && perm && b && x);
+    IPDE_CHECK_ARG(ctx, nsys >= 1 && nsys <= LU_MAXB && n > 0 && n < (1 << 24) && lu && perm && b && x);
+    for (int s = 0; s < nsys; ++s) IPDE_CHECK_ARG(ctx, lu[s] && perm[s] && b[s] && x[s]);
     IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, 2 * (size_t)n * sizeof(double)));
-    double* v = (double*)ctx->partial.p;
-    double* y = v + n;
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, 2 * (size_t)nsys * n * sizeof(double)));
     const int nbp = (int)((n + 2 * DB - 1) / (2 * DB));   // block pairs
     const int nb = 2 * nbp;                                // 64-row blocks (tiles per row)
-    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b,
-                       perm, (int)n, v);
+    LuBatch fw{}, bw{};
+    for (int s = 0; s < nsys; ++s) {
+        double* v = (double*)ctx->partial.p + (size_t)2 * s * n;
+        double* y = v + n;
+        fw.lu[s] = bw.lu[s] = lu[s];
+        fw.v[s] = v;
+        fw.x[s] = y;
+        bw.v[s] = y;
+        bw.x[s] = x[s];
+        hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b[s],
+                           perm[s], (int)n, v);
+    }
     if (ctx->opt_dense_pairs) {
         for (int K = 0; K < nbp; ++K)
-            hipLaunchKernelGGL(lu_subst_step2<true>, dim3(nbp - K), dim3(DT), 0, ctx->stream, lu, (int)n, nb, K,
-                               v, y);
+            hipLaunchKernelGGL(lu_subst_step2<true>, dim3(nbp - K, nsys), dim3(DT), 0, ctx->stream, fw, (int)n, nb,
+                               K);
         for (int K = nbp - 1; K >= 0; --K)
-            hipLaunchKernelGGL(lu_subst_step2<false>, dim3(K + 1), dim3(DT), 0, ctx->stream, lu, (int)n, nb, K, y,
-                               x);
+            hipLaunchKernelGGL(lu_subst_step2<false>, dim3(K + 1, nsys), dim3(DT), 0, ctx->stream, bw, (int)n, nb,
+                               K);
     } else {
-        for (int k = 0; k < nb; ++k)
-            hipLaunchKernelGGL(lu_subst_step<true>, dim3(nb - k), dim3(DT), 0, ctx->stream, lu, (int)n, nb, k, v,
-                               y);
-        for (int k = nb - 1; k >= 0; --k)
-            hipLaunchKernelGGL(lu_subst_step<false>, dim3(k + 1), dim3(DT), 0, ctx->stream, lu, (int)n, nb, k, y,
-                               x);
+        for (int s = 0; s < nsys; ++s) {
+            for (int k = 0; k < nb; ++k)
+                hipLaunchKernelGGL(lu_subst_step<true>, dim3(nb - k), dim3(DT), 0, ctx->stream, lu[s], (int)n, nb, k,
+                                   fw.v[s], fw.x[s]);
+            for (int k = nb - 1; k >= 0; --k)
+                hipLaunchKernelGGL(lu_subst_step<false>, dim3(k + 1), dim3(DT), 0, ctx->stream, lu[s], (int)n, nb,
+                                   k, bw.v[s], bw.x[s]);
+        }
     }
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
+}
+
+extern "C" int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, const int* perm,
+                                   const double* b, double* x) {
+    return ipde_dense_lu_solve_batch(ctx, 1, n, &lu, &perm, &b, &x);
 }

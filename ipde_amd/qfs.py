@@ -139,11 +139,34 @@ class _QFS(object):
         return u
 
     def __call__(self, densities):
+        densities = self._prepare(densities)
         x = self._solve(self.boundary_limit(densities))
-        return x.cpu().numpy() if self._dev is not None else x
+        return self._post(x.cpu().numpy() if self._dev is not None else x, densities)
+
+    # hooks of the subclasses around the linear solve (Stokes: density bookkeeping, pressure)
+    def _prepare(self, densities):
+        return list(densities)
+
+    def _post(self, mu, densities):
+        return mu
 
     def u2s(self, u):
         return self._solve(np.asarray(u, dtype=float))
+
+
+def call_pair(qa, qb, densities):
+    """(qa(densities), qb(densities)) — the grid-side and the annulus-side QFS of one
+    interface (reference internals/scalar.py:87-88, internals/vector.py:133-134).  With both
+    systems factored on the GPU and of one size, their substitutions (and refinement steps)
+    run in lock-step through one batched launch sequence."""
+    same = (qa._dev is not None and qb._dev is not None and hasattr(qa, '_fact') and hasattr(qb, '_fact')
+            and qa._fact.n == qb._fact.n and qa.REFINE_STEPS == qb.REFINE_STEPS)
+    if not same:
+        return qa(densities), qb(densities)
+    da, db = qa._prepare(densities), qb._prepare(densities)
+    ua, ub = qa.boundary_limit(da), qb.boundary_limit(db)
+    xa, xb = _DeviceLU.solve_batch([qa._fact, qb._fact], [qa._A, qb._A], [ua, ub], steps=qa.REFINE_STEPS)
+    return qa._post(xa.cpu().numpy(), da), qb._post(xb.cpu().numpy(), db)
 
 
 def _factor(A):
@@ -195,6 +218,29 @@ class _DeviceLU(object):
         for _ in range(steps):
             x = x + self._subst(b - A @ x)
         return x
+
+    @staticmethod
+    def _subst_batch(facts, bs):
+        """the substitutions of several systems of ONE size in lock-step
+        (ipde_dense_lu_solve_batch): latency bound, so two cost what one does"""
+        import ctypes
+        import torch
+        ctx, n, k = facts[0].ctx, facts[0].n, len(facts)
+        bs = [b.contiguous() for b in bs]
+        xs = [torch.empty_like(b) for b in bs]
+        arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+        ctx.check(ctx.lib.ipde_dense_lu_solve_batch(ctx.handle, k, n, arr([f.LU for f in facts]),
+                                                    arr([f.perm for f in facts]), arr(bs), arr(xs)))
+        return xs
+
+    @staticmethod
+    def solve_batch(facts, As, bs, steps=0):
+        """solve() for systems of one size together; facts: _DeviceLU objects"""
+        xs = _DeviceLU._subst_batch(facts, bs)
+        for _ in range(steps):
+            ds = _DeviceLU._subst_batch(facts, [b - A @ x for A, b, x in zip(As, bs, xs)])
+            xs = [x + d for x, d in zip(xs, ds)]
+        return xs
 
 
 class DenseSolver(object):
@@ -348,15 +394,16 @@ class Stokes_QFS(_QFS):
         self._n_src = np.concatenate([s.normal_x, s.normal_y])
         self._p_null = float(self._p_src @ self._n_src)      # pressure of the null density (-1)
 
-    def __call__(self, densities):
+    def _prepare(self, densities):
         densities = list(densities)
         want = int(self.slp) + int(self.dlp)
         # the reference's interior double-layer call passes [tau, tau] (one entry feeds its
         # pressure-fix block, which vanishes for flux-free tau): keep the last `want`
         densities = densities[max(0, len(densities) - want):]
         # ... and its combined-layer call on a hole passes one tau for both layers (:171)
-        densities = densities + [densities[-1]] * (want - len(densities))
-        mu = super().__call__(densities)
+        return densities + [densities[-1]] * (want - len(densities))
+
+    def _post(self, mu, densities):
         if self.interior:
             p_true = sum(r @ np.asarray(d, dtype=float) for r, d in zip(self._p_rows, densities))
             mu = mu + (p_true - self._p_src @ mu) / self._p_null * self._n_src

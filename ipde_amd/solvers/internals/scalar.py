@@ -3,6 +3,7 @@ ipde/solvers/internals/scalar.py:5-116: owns the annular solver, the interface Q
 pair and the `Layer_Apply` closure (the plug point of the GPU kernels)."""
 import numpy as np
 
+from ...qfs import call_pair
 from ...annular.annular_full import ApproximateAnnularGeometry, RealAnnularGeometry
 
 
@@ -74,8 +75,7 @@ class ScalarHelper(object):
         if not self.interior:
             slp *= -1.0
             dlp *= -1.0
-        sigma_g = self.interface_qfs_g([slp, dlp])
-        sigma_r = self.interface_qfs_r([slp, dlp])
+        sigma_g, sigma_r = call_pair(self.interface_qfs_g, self.interface_qfs_r, [slp, dlp])
         self.ur = ur
         self.sigma_r = sigma_r
         self.sigma_g = sigma_g

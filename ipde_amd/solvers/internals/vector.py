@@ -4,6 +4,7 @@ ipde/solvers/internals/vector.py:7-162: owns the annular solver, the interface Q
 returning (u, v, p) — the plug point of the GPU Stokes kernel."""
 import numpy as np
 
+from ...qfs import call_pair
 from ...annular.annular import ApproximateAnnularGeometry
 from ...annular.annular_full import RealAnnularGeometry
 
@@ -108,8 +109,8 @@ class VectorHelper(object):
         if not self.interior:
             taus *= -1.0
             taud *= -1.0
-        sigma_g = v2f(self.interface_qfs_g([taus, taud]))
-        sigma_r = v2f(self.interface_qfs_r([taus, taud]))
+        sigma_g, sigma_r = (v2f(m) for m in call_pair(self.interface_qfs_g, self.interface_qfs_r,
+                                                      [taus, taud]))
         self.ur, self.vr, self.pr = ur, vr, pr
         self.sigma_r = sigma_r
         self.sigma_g = sigma_g

@@ -168,3 +168,35 @@ def test_local_coordinates_kernel_matches_host_iteration():
     X, Xp, _ = ev(t_d)
     n = -1j * Xp / np.abs(Xp)
     assert np.abs(X + r_d * n - (px + 1j * py)).max() < 1e-12
+
+
+def test_batched_substitution_equals_separate_solves():
+    """ipde_dense_lu_solve_batch: two systems in lock-step == each one alone, bit for bit,
+    with and without the refinement step"""
+    import torch
+    from ipde_amd.qfs import _DeviceLU
+    rng = np.random.default_rng(5)
+    n = 700
+    As = [torch.as_tensor(rng.standard_normal((n, n)) + 0.1 * n * np.eye(n), device="cuda") for _ in range(3)]
+    bs = [torch.as_tensor(rng.standard_normal(n), device="cuda") for _ in range(3)]
+    fs = [_DeviceLU(*torch.linalg.lu_factor(A)) for A in As]
+    for steps in (0, 1):
+        single = [f.solve(A, b, steps=steps) for f, A, b in zip(fs, As, bs)]
+        batch = _DeviceLU.solve_batch(fs, As, bs, steps=steps)
+        for a, b in zip(single, batch):
+            assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        _DeviceLU._subst_batch(fs * 2, bs * 2)        # more than 4 systems
+
+
+def test_qfs_call_pair_equals_two_calls():
+    from ipde_amd import qfs
+    from ipde_amd.pybie2d_compat import Global_Smooth_Boundary, star
+    bdy = Global_Smooth_Boundary(c=star(300, a=0.2, f=5))
+    rng = np.random.default_rng(9)
+    for cls, dens in ((qfs.Laplace_QFS, [rng.standard_normal(300), rng.standard_normal(300)]),
+                      (qfs.Stokes_QFS, [rng.standard_normal(600), rng.standard_normal(600)])):
+        qa, qb = cls(bdy, True, True, True), cls(bdy, False, True, True)
+        a1, b1 = qa(dens), qb(dens)
+        a2, b2 = qfs.call_pair(qa, qb, dens)
+        assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
