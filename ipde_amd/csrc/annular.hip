@@ -800,6 +800,7 @@ struct ipde_annular_stokes : public LinOp {
     bool have_geom = false;
 
     int apply(const cd* uuh, cd* out) override;
+    int apply_grouped(const cd* uuh, cd* out);
     int precond(const cd* in, cd* out) override {
         // unknown ordering [ur (M,ns); ut (M,ns); p (M-1,ns)] is already the (B, ns)
         // row-major stacking the block matvec wants (stokes.py:200-210 transposes
@@ -850,6 +851,138 @@ __global__ __launch_bounds__(256) void rfield_axpby_kernel(double* __restrict__ 
     if (beta != 0.0) v = fma(beta, y[idx], v);
     y[idx] = v;
 }
+
+// ---- grouped launches of the Stokes operator -------------------------------------------
+// The operator is ~45 small dependent launches on one stream; a launch costs ~4 us of
+// dependency latency whatever it computes (the kernels themselves average 6 us at n = 3200),
+// so mutually independent launches are grouped into one and accumulation chains
+// (out = beta out + alpha P (A (Q in)), five in a row into the same rows) become term lists
+// evaluated by one thread per output entry — IN THE ORDER of the chain, with the chain's
+// roundings: the results are bitwise those of the ungrouped sequence.
+struct MixTerm {
+    const double* A;     // (rows, ca) row-major; nullptr: identity (in must have `rows` rows)
+    const void* in;      // complex rows (real part used) or real rows, leading dimension n
+    const double* Q;     // nullable (ca, n) field on the input rows
+    const double* P;     // nullable (rows, n) field on the output rows
+    double alpha;
+    int ca;
+    int cplx;
+};
+constexpr int MIX_MAXT = 6, MIX_MAXO = 3;
+struct MixOut {
+    double* out;         // (rows, n)
+    int rows;
+    int nterms;
+    MixTerm t[MIX_MAXT];
+};
+struct MixBatch {
+    MixOut o[MIX_MAXO];
+};
+// grid = (ceil(n/256), max rows, outputs)
+__global__ __launch_bounds__(256) void mix_multi_kernel(MixBatch B, int n) {
+    const MixOut& O = B.o[blockIdx.z];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int a = blockIdx.y;
+    if (j >= n || a >= O.rows) return;
+    double acc = 0.0;
+    for (int k = 0; k < O.nterms; ++k) {
+        const MixTerm& T = O.t[k];
+        double s = 0.0;
+        if (T.A) {
+            const double* Ar = T.A + (size_t)a * T.ca;
+            if (T.cplx) {
+                const cd* in = (const cd*)T.in;
+                for (int b = 0; b < T.ca; ++b) {
+                    double v = in[(size_t)b * n + j].x;
+                    if (T.Q) v *= T.Q[(size_t)b * n + j];
+                    s = fma(Ar[b], v, s);
+                }
+            } else {
+                const double* in = (const double*)T.in;
+                for (int b = 0; b < T.ca; ++b) s = fma(Ar[b], in[(size_t)b * n + j], s);
+            }
+            if (T.P) s *= T.P[(size_t)a * n + j];
+            s = T.alpha * s;
+        } else {
+            // identity term with the rounding of rfield_axpby_kernel: (alpha x) F
+            s = T.alpha * ((const double*)T.in)[(size_t)a * n + j];
+            if (T.P) s *= T.P[(size_t)a * n + j];
+        }
+        acc = (k == 0) ? s : fma(1.0, acc, s);
+    }
+    O.out[(size_t)a * n + j] = acc;
+}
+
+// the six splats of the operator's first stage: A rows [ur | ut | p | ik ur | ik ut | ik p]
+__global__ __launch_bounds__(256) void splat6_kernel(cd* __restrict__ out, const cd* __restrict__ urh,
+                                                     const cd* __restrict__ uth, const cd* __restrict__ ph,
+                                                     const cd* __restrict__ iks, int M, int n) {
+    const int m1 = M - 1, rows = 2 * M + m1;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)2 * rows * n) return;
+    int a = (int)(idx / n), j = (int)(idx - (int64_t)a * n);
+    const bool deriv = a >= rows;
+    int r = deriv ? a - rows : a;
+    const cd* src = r < M ? urh : (r < 2 * M ? uth : ph);
+    r = r < M ? r : (r < 2 * M ? r - M : r - 2 * M);
+    const int N2 = n / 2, ns = n - 1;
+    cd v{0.0, 0.0};
+    if (j != N2) {
+        int js = j < N2 ? j : j - 1;
+        v = src[(size_t)r * ns + js];
+        if (deriv) v = cmul(v, iks[js]);
+    }
+    out[idx] = v;
+}
+// desplat followed by splat, in one pass on the (rows, n) layout: zero the Nyquist column,
+// multiply the others by colfac
+__global__ __launch_bounds__(256) void nyquist_mul_kernel(cd* __restrict__ out, const cd* __restrict__ in,
+                                                          int rows, int n, const cd* __restrict__ colfac) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * n) return;
+    int j = (int)(idx % n);
+    const int N2 = n / 2;
+    cd v{0.0, 0.0};
+    if (j != N2) {
+        int js = j < N2 ? j : j - 1;
+        cd w = cmul(in[idx], colfac[js]);
+        v = cd{1.0 * w.x, 1.0 * w.y};
+    }
+    out[idx] = v;
+}
+// the three desplats of the last stage: FH rows [Fr (m2) | Ft (m2) | Fp (m1)] -> the first
+// m2 / m2 / m1 rows of the three (M, ns) blocks of `out` (block stride NU)
+__global__ __launch_bounds__(256) void desplat3_kernel(cd* __restrict__ out, int64_t NU,
+                                                       const cd* __restrict__ in, int M, int n) {
+    const int m1 = M - 1, m2 = M - 2, ns = n - 1, N2 = n / 2;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)(2 * m2 + m1) * ns) return;
+    int a = (int)(idx / ns), js = (int)(idx - (int64_t)a * ns);
+    int j = js < N2 ? js : js + 1;
+    cd v = in[(size_t)a * n + j];
+    int blk = a < m2 ? 0 : (a < 2 * m2 ? 1 : 2);
+    int r = a - (blk == 0 ? 0 : (blk == 1 ? m2 : 2 * m2));
+    out[(size_t)blk * NU + (size_t)r * ns + js] = cd{1.0 * v.x, 1.0 * v.y};
+}
+// the two boundary-condition mixc launches (blockIdx.z = 0: ur, 1: ut)
+__global__ __launch_bounds__(256) void bc2_kernel(cd* __restrict__ out0, cd* __restrict__ out1, int ldo,
+                                                  const double* __restrict__ A, int ca,
+                                                  const cd* __restrict__ in0, const cd* __restrict__ in1,
+                                                  int ldi, int n) {
+    int j = blockIdx.x * 256 + threadIdx.x;
+    int a = blockIdx.y;
+    if (j >= n) return;
+    cd* out = blockIdx.z == 0 ? out0 : out1;
+    const cd* in = blockIdx.z == 0 ? in0 : in1;
+    const double* Ar = A + (size_t)a * ca;
+    double sr = 0.0, si = 0.0;
+    for (int b = 0; b < ca; ++b) {
+        cd v = in[(size_t)b * ldi + j];
+        sr = fma(Ar[b], v.x, sr);
+        si = fma(Ar[b], v.y, si);
+    }
+    out[(size_t)a * ldo + j] = cd{1.0 * sr, 1.0 * si};
+}
 }  // namespace
 
 // _apply_optim_real (ipde/annular/stokes.py:321-385)
@@ -864,6 +997,7 @@ int ipde_annular_stokes::apply(const cd* uuh, cd* out) {
     cd* fth = out + NU;
     cd* fph = out + 2 * NU;
     const size_t Mn = (size_t)M * n;
+    if (ctx->opt_annular_grouped) return apply_grouped(uuh, out);
     // --- inverse transforms: A rows [ur(M) | ut(M) | p(M-1) | dur(M) | dut(M) | dp(M-1)]
     cd* a_ur = A;
     cd* a_ut = A + Mn;
@@ -985,6 +1119,124 @@ int ipde_annular_stokes::apply(const cd* uuh, cd* out) {
                        (const double*)BC, M, uth, ns, ns, (const cd*)nullptr, 1.0, 0.0);
     hipLaunchKernelGGL(pressure_mean_kernel, dim3(1), dim3(64), 0, st, fph, ns, m1,
                        (const double*)VI1, ph, ns);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
+// The same operator with grouped launches (mix_multi_kernel and friends above): 12 launches
+// + 4 transforms instead of ~45 + 4, bitwise the same result.
+int ipde_annular_stokes::apply_grouped(const cd* uuh, cd* out) {
+    hipStream_t st = ctx->stream;
+    const int m1 = M - 1, m2 = M - 2;
+    const dim3 b(256);
+    const cd* urh = uuh;
+    const cd* uth = uuh + NU;
+    const cd* ph = uuh + 2 * NU;
+    const size_t Mn = (size_t)M * n;
+    const int rowsA = 4 * M + 2 * m1;
+    hipLaunchKernelGGL(splat6_kernel, dim3(nb256((int64_t)rowsA * n)), b, 0, st, A, urh, uth, ph, (const cd*)iks,
+                       M, n);
+    IPDE_TRY(ipde_fft1_exec(ctx, rowsA, n, +1, A, Bw));
+    const double in = 1.0 / n;
+    const cd* ur = Bw;
+    const cd* ut = Bw + Mn;
+    const cd* p = Bw + 2 * Mn;
+    const cd* dur = p + (size_t)m1 * n;
+    const cd* dut = dur + Mn;
+    const cd* dp = dut + Mn;
+    double* X = Rw;
+    double* W2 = Rw + (size_t)2 * m1 * n;
+    double* Fr = W2 + (size_t)m1 * n;
+    double* Ft = Fr + (size_t)m2 * n;
+    double* Fp = Ft + (size_t)m2 * n;
+    double* Gr = Fp + (size_t)m1 * n;        // D01 ur * psi1
+    double* Gt = Gr + (size_t)m1 * n;        // D01 ut * psi1
+    auto term = [](const double* Amat, int ca, const void* inp, int cplx, const double* Q, const double* P,
+                   double alpha) {
+        MixTerm t;
+        t.A = Amat;
+        t.in = inp;
+        t.Q = Q;
+        t.P = P;
+        t.alpha = alpha;
+        t.ca = ca;
+        t.cplx = cplx;
+        return t;
+    };
+    {   // X = [(R01 dur) ipsi1 ; (R01 dut) ipsi1],  W2 = R01 dut
+        MixBatch B{};
+        B.o[0].out = X;
+        B.o[1].out = X + (size_t)m1 * n;
+        B.o[2].out = W2;
+        for (int k = 0; k < 3; ++k) {
+            B.o[k].rows = m1;
+            B.o[k].nterms = 1;
+        }
+        B.o[0].t[0] = term(R01, M, dur, 1, nullptr, ipsi1, in);
+        B.o[1].t[0] = term(R01, M, dut, 1, nullptr, ipsi1, in);
+        B.o[2].t[0] = term(R01, M, dut, 1, nullptr, nullptr, in);
+        hipLaunchKernelGGL(mix_multi_kernel, dim3(nb256(n), m1, 3), b, 0, st, B, n);
+    }
+    cd* C1 = A;
+    cd* C2 = A + (size_t)2 * m1 * n;
+    hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, C1, (const double*)X,
+                       (int64_t)2 * m1 * n, 1.0);
+    IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, -1, C1, C2));
+    hipLaunchKernelGGL(nyquist_mul_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, C1, (const cd*)C2, 2 * m1,
+                       n, (const cd*)iks);
+    IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, +1, C1, C2));
+    const cd* urt2 = C2;
+    const cd* utt2 = C2 + (size_t)m1 * n;
+    {   // Gr, Gt and the divergence rows Fp = (D01 (ur psi0)) ipsi1 + W2 ipsi1
+        MixBatch B{};
+        B.o[0].out = Gr;
+        B.o[0].rows = m1;
+        B.o[0].nterms = 1;
+        B.o[0].t[0] = term(D01, M, ur, 1, nullptr, psi1, in);
+        B.o[1].out = Gt;
+        B.o[1].rows = m1;
+        B.o[1].nterms = 1;
+        B.o[1].t[0] = term(D01, M, ut, 1, nullptr, psi1, in);
+        B.o[2].out = Fp;
+        B.o[2].rows = m1;
+        B.o[2].nterms = 2;
+        B.o[2].t[0] = term(D01, M, ur, 1, psi0, ipsi1, in);
+        B.o[2].t[1] = term(nullptr, 0, W2, 0, nullptr, ipsi1, 1.0);
+        hipLaunchKernelGGL(mix_multi_kernel, dim3(nb256(n), m1, 3), b, 0, st, B, n);
+    }
+    {   // Fr = mu (-lap_ur + t1 + t2 + t3) + t4,  Ft = mu (-lap_ut - t1 + t2 - t3) + t4
+        MixBatch B{};
+        B.o[0].out = Fr;
+        B.o[0].rows = m2;
+        B.o[0].nterms = 6;
+        B.o[0].t[0] = term(D12, m1, Gr, 0, nullptr, ipsi2, -mu);
+        B.o[0].t[1] = term(R12, m1, urt2, 1, nullptr, ipsi2, -mu * in);
+        B.o[0].t[2] = term(R02, M, dut, 1, nullptr, combo1, mu * in);
+        B.o[0].t[3] = term(R02, M, ur, 1, nullptr, combo2, mu * in);
+        B.o[0].t[4] = term(R02, M, ut, 1, nullptr, c3, mu * in);
+        B.o[0].t[5] = term(D12, m1, p, 1, nullptr, nullptr, in);
+        B.o[1].out = Ft;
+        B.o[1].rows = m2;
+        B.o[1].nterms = 6;
+        B.o[1].t[0] = term(D12, m1, Gt, 0, nullptr, ipsi2, -mu);
+        B.o[1].t[1] = term(R12, m1, utt2, 1, nullptr, ipsi2, -mu * in);
+        B.o[1].t[2] = term(R02, M, dur, 1, nullptr, combo1, -mu * in);
+        B.o[1].t[3] = term(R02, M, ut, 1, nullptr, combo2, mu * in);
+        B.o[1].t[4] = term(R02, M, ur, 1, nullptr, c4, -mu * in);
+        B.o[1].t[5] = term(R12, m1, dp, 1, nullptr, ipsi2, in);
+        hipLaunchKernelGGL(mix_multi_kernel, dim3(nb256(n), m2, 2), b, 0, st, B, n);
+    }
+    const int rowsF = 2 * m2 + m1;
+    hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256((int64_t)rowsF * n)), b, 0, st, A, (const double*)Fr,
+                       (int64_t)rowsF * n, 1.0);
+    cd* FH = A + (size_t)rowsF * n;
+    IPDE_TRY(ipde_fft1_exec(ctx, rowsF, n, -1, A, FH));
+    hipLaunchKernelGGL(desplat3_kernel, dim3(nb256((int64_t)rowsF * ns)), b, 0, st, out, (int64_t)NU, (const cd*)FH,
+                       M, n);
+    hipLaunchKernelGGL(bc2_kernel, dim3(nb256(ns), 2, 2), b, 0, st, out + (size_t)m2 * ns,
+                       out + NU + (size_t)m2 * ns, ns, (const double*)BC, M, urh, uth, ns, ns);
+    hipLaunchKernelGGL(pressure_mean_kernel, dim3(1), dim3(64), 0, st, out + 2 * NU, ns, m1, (const double*)VI1, ph,
+                       ns);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }

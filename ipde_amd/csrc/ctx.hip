@@ -201,6 +201,8 @@ extern "C" int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value) {
         ctx->opt_stokes_variant = value;
     } else if (!strcmp(name, "dense_pairs")) {
         ctx->opt_dense_pairs = value;
+    } else if (!strcmp(name, "annular_grouped")) {
+        ctx->opt_annular_grouped = value;
     } else {
         IPDE_SET_ERR(ctx, "unknown option '%s'", name);
         return IPDE_ERR_INVALID;

@@ -52,6 +52,7 @@ struct ipde_ctx {
     int num_cu = 256;
     // tuning knobs (ipde_ctx_set_option)
     int opt_laplace_variant = 9;   // row-run single layer (variant 1 for the other modes)
+    int opt_annular_grouped = 1;  // Stokes annular operator with grouped launches (0: one launch per term)
     int opt_dense_pairs = 1;      // substitution: two 64-row blocks per launch (0: one)
     int opt_stokes_variant = 1;   // 1: row-run stokeslet kernel (single layer), 0: strided table kernel
 };

@@ -130,7 +130,16 @@ def test_stokes_solver_matches_oracle_mid_size():
     O = oa.StokesSolver(oaag, 1.0)
     S._set_geometry(rag)
     v = rng.standard_normal(S.NB) + 1j * rng.standard_normal(S.NB)
-    assert rel_err(S._apply_optim_real(v), O.apply(v, orag)) < 1e-12
+    grouped = S._apply_optim_real(v)
+    assert rel_err(grouped, O.apply(v, orag)) < 1e-12
+    # the operator with one launch per term (what the grouped launches replace): same
+    # arithmetic in the same order, bit for bit
+    S.ctx.set_option("annular_grouped", 0)
+    try:
+        single = S._apply_optim_real(v)
+    finally:
+        S.ctx.set_option("annular_grouped", 1)
+    assert np.array_equal(np.asarray(grouped), np.asarray(single))
     assert rel_err(S._preconditioner(v), O.precondition(v)) < 1e-11
     T = t[None, :]
     rv = aag.rv0[:, None]
