@@ -200,3 +200,31 @@ def test_qfs_call_pair_equals_two_calls():
         a1, b1 = qa(dens), qb(dens)
         a2, b2 = qfs.call_pair(qa, qb, dens)
         assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
+
+
+def test_setup_kernels_reject_bad_arguments_and_accept_empty_sets():
+    """ipde_curve_local_coordinates / ipde_chebfourier_gather: status codes, no work for
+    zero points"""
+    import torch
+    from ipde_amd._lib import IpdeHipError
+    from ipde_amd.device import get_context, ptr
+    ctx = get_context(0)
+    tab = torch.zeros(3 * 64, dtype=torch.complex128, device="cuda")
+    w = np.ones(16)
+    z = torch.zeros(0, dtype=torch.float64, device="cuda")
+    one = torch.zeros(1, dtype=torch.float64, device="cuda")
+    # empty point sets are fine
+    ctx.check(ctx.lib.ipde_curve_local_coordinates(ctx.handle, 64, ptr(tab), ptr(w), 0, ptr(z), ptr(z), ptr(z),
+                                                   0.1, 1e-14, 30, ptr(z), ptr(z)))
+    cf = torch.zeros(4 * 64, dtype=torch.float64, device="cuda")
+    ctx.check(ctx.lib.ipde_chebfourier_gather(ctx.handle, 4, 64, ptr(cf), ptr(w), 0, ptr(z), ptr(z), ptr(z)))
+    # too short a table, non-positive width, missing weights
+    for args in ((ctx.handle, 8, ptr(tab), ptr(w), 1, ptr(one), ptr(one), ptr(one), 0.1, 1e-14, 30, ptr(one), ptr(one)),
+                 (ctx.handle, 64, ptr(tab), ptr(w), 1, ptr(one), ptr(one), ptr(one), 0.0, 1e-14, 30, ptr(one), ptr(one)),
+                 (ctx.handle, 64, ptr(tab), None, 1, ptr(one), ptr(one), ptr(one), 0.1, 1e-14, 30, ptr(one), ptr(one))):
+        with pytest.raises(IpdeHipError):
+            ctx.check(ctx.lib.ipde_curve_local_coordinates(*args))
+    with pytest.raises(IpdeHipError):
+        ctx.check(ctx.lib.ipde_chebfourier_gather(ctx.handle, 0, 64, ptr(cf), ptr(w), 1, ptr(one), ptr(one), ptr(one)))
+    with pytest.raises(IpdeHipError):
+        ctx.check(ctx.lib.ipde_chebfourier_gather(ctx.handle, 4, 64, ptr(cf), ptr(w), 1, None, ptr(one), ptr(one)))
