@@ -125,9 +125,11 @@ class VectorHelper(object):
             sigma_r_tot = self.sigma_r
             p_shift = 0.0
         else:
+            import torch
             to_np = lambda a: a.cpu().numpy()
             src = self.interface_qfs_g.source
-            w = [to_np(a) for a in self.Layer_Apply(src, self._interface_dev, self.sigma_g)]
+            # (one device -> host transfer for the three fields, not three synchronisations)
+            w = to_np(torch.stack(list(self.Layer_Apply(src, self._interface_dev, self.sigma_g))))
             Ub = np.concatenate([ub - w[0], vb - w[1]])
             sigma_r_adj = v2f(self.interface_qfs_r.u2s(Ub))
             p_adj = to_np(self.Layer_Apply(self.interface_qfs_r.source, self._interface_dev,
@@ -136,7 +138,8 @@ class VectorHelper(object):
             p_shift = np.sum((pb - w[2] - p_adj) * wi) / np.sum(wi)
             sigma_r_tot = sigma_r_adj + self.sigma_r
         src = self.interface_qfs_r.source
-        rslp = [a.cpu().numpy() for a in self.Layer_Apply(src, self._radial_dev, sigma_r_tot)]
+        import torch
+        rslp = torch.stack(list(self.Layer_Apply(src, self._radial_dev, sigma_r_tot))).cpu().numpy()
         self.ur = self.ur + rslp[0].reshape(self.ur.shape)
         self.vr = self.vr + rslp[1].reshape(self.ur.shape)
         self.pr = self.pr + rslp[2].reshape(self.pr.shape) + p_shift

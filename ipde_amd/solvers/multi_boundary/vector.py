@@ -155,7 +155,7 @@ class VectorSolver(object):
         fields = (uc.view(-1), vc.view(-1), pc.view(-1))
         for f, o in zip(fields, out):
             f[self._pna_idx] += o[:n_pna]
-        bus, bvs, bps = (e.v2l(o[n_pna:].cpu().numpy()) for o in out)
+        bus, bvs, bps = (e.v2l(o) for o in torch.stack([o[n_pna:] for o in out]).cpu().numpy())
         single_ebdy = len(e) == 1
         urs, vrs, prs = zip(*[helper.correct(bu, bv, bp, single_ebdy)
                               for helper, bu, bv, bp in zip(self.helpers, bus, bvs, bps)])
