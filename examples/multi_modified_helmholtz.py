@@ -15,7 +15,6 @@ import sys
 import time
 
 import numpy as np
-import scipy.linalg
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 

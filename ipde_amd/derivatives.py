@@ -1,6 +1,5 @@
 """Drop-in for ipde/derivatives.py (reference :3-28): same names, argument meaning
 and results, computed by HIP kernels / rocFFT."""
-import numpy as np
 
 from .spectral import fd4, get_plan
 

@@ -20,7 +20,6 @@ import numpy as np
 from numpy.polynomial import chebyshev as C
 from scipy.special import i0e, i1e, k0, k1
 
-from .. import _lib
 from ..device import get_context, location_of, as_f64, ptr, prewarm_wait
 
 NI, DEG = 32, 15

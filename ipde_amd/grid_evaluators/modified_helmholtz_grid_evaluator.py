@@ -1,5 +1,4 @@
 """ipde/grid_evaluators/modified_helmholtz_grid_evaluator.py API (reference :19-30)."""
-import numpy as np
 
 from .scalar_grid_evaluator import (ScalarGridBackend, ScalarFreespaceGridEvaluator,
                                     ScalarPeriodicGridEvaluator)

@@ -1,5 +1,4 @@
 """ModifiedHelmholtzSolver — mirrors ipde/solvers/multi_boundary/modified_helmholtz.py:8-67."""
-import numpy as np
 
 from .scalar import ScalarSolver
 from ..internals.modified_helmholtz import ModifiedHelmholtzHelper
