@@ -70,6 +70,13 @@ def cpu_baseline(c, trg, sigma, budget_s=15.0):
     }
 
 
+def f_like(solver, EmbeddedFunction):
+    f = EmbeddedFunction(solver.ebdyc)
+    f.define_via_function(lambda x, y: (2.0 * np.cos(x) + 3.0 * np.cos(x) * np.sin(x) - np.cos(x) ** 3)
+                          * np.exp(np.sin(x)) * np.sin(y))
+    return f
+
+
 def full_poisson_solve(nb=4096, ng=2048, M=20):
     """examples/interior_poisson.py at BASELINE configs[2] (the reference's
     examples/poisson_for_paper.py brackets: set-up / inhomogeneous solve / homogeneous
@@ -81,21 +88,34 @@ def full_poisson_solve(nb=4096, ng=2048, M=20):
     t0 = time.perf_counter()
     err, scale, solver, ue, T = interior_poisson.run(nb=nb, M=M, Ns=[ng, ng], solver_tol=1e-12)
     total = time.perf_counter() - t0
-    f = EmbeddedFunction(solver.ebdyc)
-    f.define_via_function(lambda x, y: (2.0 * np.cos(x) + 3.0 * np.cos(x) * np.sin(x) - np.cos(x) ** 3)
-                          * np.exp(np.sin(x)) * np.sin(y))
+    f = f_like(solver, EmbeddedFunction)
     solver(f, tol=1e-12, maxiter=100, restart=20)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     solver(f, tol=1e-12, maxiter=100, restart=20)
     torch.cuda.synchronize()
     warm = time.perf_counter() - t0
+    # the same solve with the O(N_s sw^2 + n^2 log n) split grid evaluator instead of the
+    # dense sum onto the grid (grid_backend='ewald', 7e-15 from the dense sum)
+    del solver, ue
+    torch.cuda.empty_cache()
+    err_e, scale_e, solver_e, _, _ = interior_poisson.run(nb=nb, M=M, Ns=[ng, ng], solver_tol=1e-12,
+                                                          grid_backend='ewald')
+    solver_e(f_like(solver_e, EmbeddedFunction), tol=1e-12, maxiter=100, restart=20)
+    torch.cuda.synchronize()
+    fe = f_like(solver_e, EmbeddedFunction)
+    t0 = time.perf_counter()
+    solver_e(fe, tol=1e-12, maxiter=100, restart=20)
+    torch.cuda.synchronize()
+    warm_e = time.perf_counter() - t0
     return {
         "workload": "interior Poisson, %d^2 grid, %d-node star boundary, M = %d, %d dof" % (ng, nb, M, T["dof"]),
         "max_rel_err_vs_manufactured_solution": err / scale,
         "setup_s": T["setup_s"], "first_inhomogeneous_solve_s": T["inhomogeneous_solve_s"],
         "homogeneous_correction_s": T["homogeneous_form_s"] + T["homogeneous_apply_s"],
         "end_to_end_s": total, "warm_inhomogeneous_solve_ms": 1e3 * warm,
+        "ewald_grid_backend": {"max_rel_err_vs_manufactured_solution": err_e / scale_e,
+                               "warm_inhomogeneous_solve_ms": 1e3 * warm_e},
         "gmres_iterations": T["gmres_iterations"],
         "note": "end_to_end = set-up + first solve + correction in a process that has only run the "
                 "dense-sum benchmark before (one-time library loads included; rocFFT kernels come "
