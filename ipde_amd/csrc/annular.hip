@@ -274,6 +274,55 @@ __global__ __launch_bounds__(256) void multiaxpy_kernel(cd* __restrict__ w,
     }
     w[k] = acc;
 }
+// The same, and ||w||^2 of the result into *nrm2 (the CGS2 sequence ends with this norm: one
+// launch less per iteration).  Block partial sums, the last block to finish (ticket) adds
+// them in a fixed order — thread t takes partials t, t + 256, ... in order, then a fixed tree.
+__global__ __launch_bounds__(256) void multiaxpy_norm_kernel(cd* __restrict__ w, const cd* __restrict__ V,
+                                                             int64_t ld, const cd* __restrict__ h, int nv,
+                                                             int64_t n, double* __restrict__ partial,
+                                                             unsigned* __restrict__ ticket,
+                                                             cd* __restrict__ nrm2) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double s = 0.0;
+    if (k < n) {
+        cd acc = w[k];
+        for (int i = 0; i < nv; ++i) {
+            cd c = h[i];
+            cd v = V[(size_t)i * ld + k];
+            acc.x -= c.x * v.x - c.y * v.y;
+            acc.y -= c.x * v.y + c.y * v.x;
+        }
+        w[k] = acc;
+        s = fma(acc.x, acc.x, acc.y * acc.y);
+    }
+    __shared__ double red[4];
+    __shared__ bool last;
+    auto block_sum = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    double bs = block_sum(s);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = bs;
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const volatile double* p = partial;
+    double t = 0.0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += p[i];
+    double tot = block_sum(t);
+    if (threadIdx.x == 0) {
+        *nrm2 = cd{tot, 0.0};
+        *ticket = 0u;
+    }
+}
 // y = sum_i c[i] V_i  (c on device)
 __global__ __launch_bounds__(256) void lincomb_kernel(cd* __restrict__ y, const cd* __restrict__ V,
                                                       int64_t ld, const cd* __restrict__ c, int nv,
@@ -317,7 +366,8 @@ struct GmresWork {
     cd* t = nullptr;   // NB
     cd* hdev = nullptr;  // 2*(restart+2)
     cd* mdpart = nullptr;     // (restart+2) * MD_SPLIT partial sums of multidot_kernel
-    unsigned* mdticket = nullptr;  // (restart+2) counters, zero between launches
+    unsigned* mdticket = nullptr;  // (restart+3) counters, zero between launches (last: norm)
+    double* nrmpart = nullptr;     // ceil(NB/256) block sums of multiaxpy_norm_kernel
     int restart_cap = 0;
     int64_t nb_cap = 0;
 };
@@ -339,8 +389,10 @@ int gmres_reserve(ipde_ctx* ctx, GmresWork& g, int64_t NB, int restart) {
     if (g.mdpart) hipFree(g.mdpart);
     if (g.mdticket) hipFree(g.mdticket);
     IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.mdpart, (size_t)(restart + 2) * MD_SPLIT * sizeof(cd)));
-    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.mdticket, (size_t)(restart + 2) * sizeof(unsigned)));
-    IPDE_HIP_CHECK(ctx, hipMemset(g.mdticket, 0, (size_t)(restart + 2) * sizeof(unsigned)));
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.mdticket, (size_t)(restart + 3) * sizeof(unsigned)));
+    IPDE_HIP_CHECK(ctx, hipMemset(g.mdticket, 0, (size_t)(restart + 3) * sizeof(unsigned)));
+    if (g.nrmpart) hipFree(g.nrmpart);
+    IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.nrmpart, (size_t)nb256(NB) * sizeof(double)));
     g.restart_cap = restart;
     g.nb_cap = NB;
     return IPDE_OK;
@@ -353,6 +405,8 @@ void gmres_free(GmresWork& g) {
         }
     if (g.mdticket) hipFree(g.mdticket);
     g.mdticket = nullptr;
+    if (g.nrmpart) hipFree(g.nrmpart);
+    g.nrmpart = nullptr;
 }
 
 struct hc {
@@ -433,10 +487,9 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
                                (const cd*)g.V, NB, (const cd*)h1, j + 1, NB);
             hipLaunchKernelGGL(multidot_kernel, dim3(j + 1, MD_SPLIT), dim3(256), 0, st, (const cd*)g.V, NB,
                                (const cd*)g.w, NB, h2, g.mdpart, g.mdticket);
-            hipLaunchKernelGGL(multiaxpy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.w,
-                               (const cd*)g.V, NB, (const cd*)h2, j + 1, NB);
-            hipLaunchKernelGGL(multidot_kernel, dim3(1, MD_SPLIT), dim3(256), 0, st, (const cd*)g.w, NB,
-                               (const cd*)g.w, NB, h1 + (j + 1), g.mdpart, g.mdticket);
+            hipLaunchKernelGGL(multiaxpy_norm_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.w, (const cd*)g.V, NB,
+                               (const cd*)h2, j + 1, NB, g.nrmpart, g.mdticket + (restart + 2),
+                               h1 + (j + 1));
             IPDE_HIP_CHECK(ctx, hipGetLastError());
             IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, g.hdev, (size_t)(2 * restart + 4) * sizeof(cd),
                                                hipMemcpyDeviceToHost, st));
