@@ -202,10 +202,11 @@ int ipde_fd4(ipde_ctx* ctx, int loc, int64_t nx, int64_t ny, double h,
  */
 int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, const int* perm,
                         const double* b, double* x);
-/* The same for nsys <= 4 independent systems of one size n, advanced in lock-step (the
- * substitution is latency bound: the two QFS solves of an interface cost one).  lu, perm, b,
- * x: HOST arrays of nsys DEVICE pointers. */
-int ipde_dense_lu_solve_batch(ipde_ctx* ctx, int nsys, int64_t n, const double* const* lu,
+/* The same for nsys <= 8 independent systems advanced in lock-step (the substitution is latency
+ * bound: a batch costs the steps of its largest member — the two QFS systems of an interface,
+ * or those of all boundaries of a multiply connected domain, in one sequence of launches).
+ * n: HOST array of nsys sizes; lu, perm, b, x: HOST arrays of nsys DEVICE pointers. */
+int ipde_dense_lu_solve_batch(ipde_ctx* ctx, int nsys, const int64_t* n, const double* const* lu,
                               const int* const* perm, const double* const* b, double* const* x);
 
 /* ------------------------------------------------------------------------- */

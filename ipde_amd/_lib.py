@@ -73,7 +73,7 @@ SIGNATURES = {
     "ipde_fourier_deriv": (_int, [_vp, _int, _vp, _int, _vp]),
     "ipde_fourier_multiply": (_int, [_vp, _int, _vp, _vp, _vp]),
     "ipde_dense_lu_solve": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
-    "ipde_dense_lu_solve_batch": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp]),
+    "ipde_dense_lu_solve_batch": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "ipde_chebfourier_gather": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ipde_curve_local_coordinates": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
     "ipde_ewald_create": (_int, [_vp, _int, _dbl, _dbl, _int, _vp, _int, _int, _c_void_pp]),

@@ -134,15 +134,25 @@ __device__ __forceinline__ double diag_chain(const double (&lrow)[DB], int lane,
 // Up to LU_MAXB independent systems of the same size advance in lock-step, blockIdx.y = system:
 // a step is latency bound, so the second system rides along for free (the two QFS solves of
 // an interface — grid side and annulus side — are issued this way).
-constexpr int LU_MAXB = 4;
+// The systems may differ in size: step K of a pass is step K of every system that still has
+// one (forward: K < its number of block pairs; backward: the pass starts at the largest
+// system's last pair and the smaller ones join when K reaches theirs), so a batch costs the
+// steps of its largest member.
+constexpr int LU_MAXB = 8;
 struct LuBatch {
     const double* lu[LU_MAXB];
     double* v[LU_MAXB];   // running right-hand side of the pass
     double* x[LU_MAXB];   // result of the pass
+    int n[LU_MAXB];
 };
 
 template <bool LOWER>
-__global__ __launch_bounds__(DT) void lu_subst_step2(LuBatch B, int n, int nb, int K) {
+__global__ __launch_bounds__(DT) void lu_subst_step2(LuBatch B, int K) {
+    const int n = B.n[blockIdx.y];
+    const int nbp = (n + 2 * DB - 1) / (2 * DB);
+    const int nb = 2 * nbp;
+    // this system has no step K, or fewer block pairs left to update than the grid is wide
+    if (K >= nbp || (LOWER && (int)blockIdx.x >= nbp - K)) return;
     const double* __restrict__ LU = B.lu[blockIdx.y];
     double* __restrict__ v = B.v[blockIdx.y];
     double* __restrict__ x = B.x[blockIdx.y];
@@ -238,42 +248,48 @@ __global__ void permute_kernel(const double* __restrict__ b, const int* __restri
 
 }  // namespace
 
-extern "C" int ipde_dense_lu_solve_batch(ipde_ctx* ctx, int nsys, int64_t n, const double* const* lu,
+extern "C" int ipde_dense_lu_solve_batch(ipde_ctx* ctx, int nsys, const int64_t* n, const double* const* lu,
                                          const int* const* perm, const double* const* b, double* const* x) {
     if (!ctx) return IPDE_ERR_INVALID;
-    IPDE_CHECK_ARG(ctx, nsys >= 1 && nsys <= LU_MAXB && n > 0 && n < (1 << 24) && lu && perm && b && x);
-    for (int s = 0; s < nsys; ++s) IPDE_CHECK_ARG(ctx, lu[s] && perm[s] && b[s] && x[s]);
-    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, 2 * (size_t)nsys * n * sizeof(double)));
-    const int nbp = (int)((n + 2 * DB - 1) / (2 * DB));   // block pairs
-    const int nb = 2 * nbp;                                // 64-row blocks (tiles per row)
-    LuBatch fw{}, bw{};
+    IPDE_CHECK_ARG(ctx, nsys >= 1 && nsys <= LU_MAXB && n && lu && perm && b && x);
+    size_t total = 0;
+    int nbp_max = 0;
     for (int s = 0; s < nsys; ++s) {
-        double* v = (double*)ctx->partial.p + (size_t)2 * s * n;
-        double* y = v + n;
+        IPDE_CHECK_ARG(ctx, n[s] > 0 && n[s] < (1 << 24) && lu[s] && perm[s] && b[s] && x[s]);
+        total += (size_t)n[s];
+        nbp_max = std::max(nbp_max, (int)((n[s] + 2 * DB - 1) / (2 * DB)));
+    }
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, 2 * total * sizeof(double)));
+    LuBatch fw{}, bw{};
+    double* base = (double*)ctx->partial.p;
+    for (int s = 0; s < nsys; ++s) {
+        double* v = base;
+        double* y = v + n[s];
+        base = y + n[s];
         fw.lu[s] = bw.lu[s] = lu[s];
+        fw.n[s] = bw.n[s] = (int)n[s];
         fw.v[s] = v;
         fw.x[s] = y;
         bw.v[s] = y;
         bw.x[s] = x[s];
-        hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, b[s],
-                           perm[s], (int)n, v);
+        hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n[s] + 255) / 256)), dim3(256), 0, ctx->stream, b[s],
+                           perm[s], (int)n[s], v);
     }
     if (ctx->opt_dense_pairs) {
-        for (int K = 0; K < nbp; ++K)
-            hipLaunchKernelGGL(lu_subst_step2<true>, dim3(nbp - K, nsys), dim3(DT), 0, ctx->stream, fw, (int)n, nb,
-                               K);
-        for (int K = nbp - 1; K >= 0; --K)
-            hipLaunchKernelGGL(lu_subst_step2<false>, dim3(K + 1, nsys), dim3(DT), 0, ctx->stream, bw, (int)n, nb,
-                               K);
+        for (int K = 0; K < nbp_max; ++K)
+            hipLaunchKernelGGL(lu_subst_step2<true>, dim3(nbp_max - K, nsys), dim3(DT), 0, ctx->stream, fw, K);
+        for (int K = nbp_max - 1; K >= 0; --K)
+            hipLaunchKernelGGL(lu_subst_step2<false>, dim3(K + 1, nsys), dim3(DT), 0, ctx->stream, bw, K);
     } else {
         for (int s = 0; s < nsys; ++s) {
+            const int nb = 2 * (int)((n[s] + 2 * DB - 1) / (2 * DB));
             for (int k = 0; k < nb; ++k)
-                hipLaunchKernelGGL(lu_subst_step<true>, dim3(nb - k), dim3(DT), 0, ctx->stream, lu[s], (int)n, nb, k,
-                                   fw.v[s], fw.x[s]);
+                hipLaunchKernelGGL(lu_subst_step<true>, dim3(nb - k), dim3(DT), 0, ctx->stream, lu[s], (int)n[s], nb,
+                                   k, fw.v[s], fw.x[s]);
             for (int k = nb - 1; k >= 0; --k)
-                hipLaunchKernelGGL(lu_subst_step<false>, dim3(k + 1), dim3(DT), 0, ctx->stream, lu[s], (int)n, nb,
-                                   k, bw.v[s], bw.x[s]);
+                hipLaunchKernelGGL(lu_subst_step<false>, dim3(k + 1), dim3(DT), 0, ctx->stream, lu[s], (int)n[s],
+                                   nb, k, bw.v[s], bw.x[s]);
         }
     }
     IPDE_HIP_CHECK(ctx, hipGetLastError());
@@ -282,5 +298,5 @@ extern "C" int ipde_dense_lu_solve_batch(ipde_ctx* ctx, int nsys, int64_t n, con
 
 extern "C" int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, const int* perm,
                                    const double* b, double* x) {
-    return ipde_dense_lu_solve_batch(ctx, 1, n, &lu, &perm, &b, &x);
+    return ipde_dense_lu_solve_batch(ctx, 1, &n, &lu, &perm, &b, &x);
 }

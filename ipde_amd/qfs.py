@@ -154,19 +154,52 @@ class _QFS(object):
         return self._solve(np.asarray(u, dtype=float))
 
 
+def call_many(requests):
+    """[q(densities) for q, densities in requests] — the QFS solves of one stage of a solver:
+    the grid-side and the annulus-side system of every interface (reference
+    internals/scalar.py:87-88, internals/vector.py:133-134).  Systems factored on the GPU are
+    substituted (and refined) in lock-step through batched launch sequences, grouped by their
+    number of refinement steps; the rest are solved one by one."""
+    out = [None] * len(requests)
+    groups = {}
+    for i, (q, d) in enumerate(requests):
+        if q._dev is not None and hasattr(q, '_fact'):
+            groups.setdefault(q.REFINE_STEPS, []).append(i)
+        else:
+            out[i] = q(d)
+    for steps, idx in groups.items():
+        qs = [requests[i][0] for i in idx]
+        ds = [q._prepare(requests[i][1]) for q, i in zip(qs, idx)]
+        us = [q.boundary_limit(d) for q, d in zip(qs, ds)]
+        xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps)
+        for i, q, d, x in zip(idx, qs, ds, xs):
+            out[i] = q._post(x.cpu().numpy(), d)
+    return out
+
+
 def call_pair(qa, qb, densities):
-    """(qa(densities), qb(densities)) — the grid-side and the annulus-side QFS of one
-    interface (reference internals/scalar.py:87-88, internals/vector.py:133-134).  With both
-    systems factored on the GPU and of one size, their substitutions (and refinement steps)
-    run in lock-step through one batched launch sequence."""
-    same = (qa._dev is not None and qb._dev is not None and hasattr(qa, '_fact') and hasattr(qb, '_fact')
-            and qa._fact.n == qb._fact.n and qa.REFINE_STEPS == qb.REFINE_STEPS)
-    if not same:
-        return qa(densities), qb(densities)
-    da, db = qa._prepare(densities), qb._prepare(densities)
-    ua, ub = qa.boundary_limit(da), qb.boundary_limit(db)
-    xa, xb = _DeviceLU.solve_batch([qa._fact, qb._fact], [qa._A, qb._A], [ua, ub], steps=qa.REFINE_STEPS)
-    return qa._post(xa.cpu().numpy(), da), qb._post(xb.cpu().numpy(), db)
+    """(qa(densities), qb(densities)) in one batched substitution (see call_many)"""
+    return tuple(call_many([(qa, densities), (qb, densities)]))
+
+
+def u2s_many(requests):
+    """[q.u2s(u) for q, u in requests], batched like call_many"""
+    import torch
+    out = [None] * len(requests)
+    groups = {}
+    for i, (q, u) in enumerate(requests):
+        if q._dev is not None and hasattr(q, '_fact'):
+            groups.setdefault(q.REFINE_STEPS, []).append(i)
+        else:
+            out[i] = q.u2s(u)
+    for steps, idx in groups.items():
+        qs = [requests[i][0] for i in idx]
+        us = [torch.as_tensor(np.ascontiguousarray(requests[i][1], dtype=float), device=q._dev)
+              for q, i in zip(qs, idx)]
+        xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps)
+        for i, x in zip(idx, xs):
+            out[i] = x.cpu().numpy()
+    return out
 
 
 def _factor(A):
@@ -221,21 +254,26 @@ class _DeviceLU(object):
 
     @staticmethod
     def _subst_batch(facts, bs):
-        """the substitutions of several systems of ONE size in lock-step
-        (ipde_dense_lu_solve_batch): latency bound, so two cost what one does"""
+        """the substitutions of several systems in lock-step (ipde_dense_lu_solve_batch):
+        latency bound, so a batch costs what its largest member does.  Up to 8 systems per
+        call; longer lists go in groups."""
         import ctypes
         import torch
-        ctx, n, k = facts[0].ctx, facts[0].n, len(facts)
+        ctx = facts[0].ctx
         bs = [b.contiguous() for b in bs]
         xs = [torch.empty_like(b) for b in bs]
-        arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
-        ctx.check(ctx.lib.ipde_dense_lu_solve_batch(ctx.handle, k, n, arr([f.LU for f in facts]),
-                                                    arr([f.perm for f in facts]), arr(bs), arr(xs)))
+        for a in range(0, len(facts), 8):
+            fa, ba, xa = facts[a:a + 8], bs[a:a + 8], xs[a:a + 8]
+            k = len(fa)
+            arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+            ns = (ctypes.c_int64 * k)(*[f.n for f in fa])
+            ctx.check(ctx.lib.ipde_dense_lu_solve_batch(ctx.handle, k, ns, arr([f.LU for f in fa]),
+                                                        arr([f.perm for f in fa]), arr(ba), arr(xa)))
         return xs
 
     @staticmethod
     def solve_batch(facts, As, bs, steps=0):
-        """solve() for systems of one size together; facts: _DeviceLU objects"""
+        """solve() for several systems together; facts: _DeviceLU objects"""
         xs = _DeviceLU._subst_batch(facts, bs)
         for _ in range(steps):
             ds = _DeviceLU._subst_batch(facts, [b - A @ x for A, b, x in zip(As, bs, xs)])

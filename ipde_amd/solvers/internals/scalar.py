@@ -3,7 +3,7 @@ ipde/solvers/internals/scalar.py:5-116: owns the annular solver, the interface Q
 pair and the `Layer_Apply` closure (the plug point of the GPU kernels)."""
 import numpy as np
 
-from ...qfs import call_pair
+from ...qfs import call_many, u2s_many
 from ...annular.annular_full import ApproximateAnnularGeometry, RealAnnularGeometry
 
 
@@ -62,8 +62,16 @@ class ScalarHelper(object):
     def get_interface_normal_derivatives(self, ur):
         return self._in_estimator.dot(ur)
 
+    # The reference's __call__ (:68-94) and correct (:95-116) each contain dense QFS solves.
+    # They are split in two around them (start_* returns the solves it needs, finish_* takes
+    # their results) so that the multi-boundary solver can run the solves of ALL boundaries
+    # in one batched substitution (qfs.call_many / u2s_many); __call__ and correct keep the
+    # reference's one-boundary form.
     def __call__(self, fr, bv, bx, by, **kwargs):
         """kwargs go to the annular solver (reference :68-94)."""
+        return self.finish_call(*call_many(self.start_call(fr, bv, bx, by, **kwargs)))
+
+    def start_call(self, fr, bv, bx, by, **kwargs):
         ebdy = self.ebdy
         ucn = bx * ebdy.interface.normal_x + by * ebdy.interface.normal_y
         zer = np.zeros_like(bv)
@@ -75,18 +83,24 @@ class ScalarHelper(object):
         if not self.interior:
             slp *= -1.0
             dlp *= -1.0
-        sigma_g, sigma_r = call_pair(self.interface_qfs_g, self.interface_qfs_r, [slp, dlp])
         self.ur = ur
+        return [(self.interface_qfs_g, [slp, dlp]), (self.interface_qfs_r, [slp, dlp])]
+
+    def finish_call(self, sigma_g, sigma_r):
         self.sigma_r = sigma_r
         self.sigma_g = sigma_g
         return sigma_g
 
     def correct(self, ub):
         """(reference :95-116)"""
+        return self.finish_correct(*u2s_many(self.start_correct(ub)))
+
+    def start_correct(self, ub):
         src = self.interface_qfs_g.source
         w = self.Layer_Apply(src, self._interface_dev, self.sigma_g).cpu().numpy()
-        ub = ub - w
-        sigma_r_adj = self.interface_qfs_r.u2s(ub)
+        return [(self.interface_qfs_r, ub - w)]
+
+    def finish_correct(self, sigma_r_adj):
         sigma_r_tot = sigma_r_adj + self.sigma_r
         src = self.interface_qfs_r.source
         rslp = self.Layer_Apply(src, self._radial_dev, sigma_r_tot).cpu().numpy()

@@ -4,7 +4,7 @@ ipde/solvers/internals/vector.py:7-162: owns the annular solver, the interface Q
 returning (u, v, p) — the plug point of the GPU Stokes kernel."""
 import numpy as np
 
-from ...qfs import call_pair
+from ...qfs import call_many, u2s_many
 from ...annular.annular import ApproximateAnnularGeometry
 from ...annular.annular_full import RealAnnularGeometry
 
@@ -91,9 +91,13 @@ class VectorHelper(object):
         Tt = estimator.dot(Utr) + estimator.dot(Urt)
         return Tr, Tt
 
+    # (start_* / finish_* around the dense QFS solves: see ScalarHelper)
     def __call__(self, fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs):
         """Annular solve with homogeneous data, traction / velocity jumps against the grid
         solution, QFS densities for both sides (reference :113-144)."""
+        return self.finish_call(*call_many(self.start_call(fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs)))
+
+    def start_call(self, fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs):
         ebdy = self.ebdy
         btx = btxx * ebdy.interface.normal_x + btxy * ebdy.interface.normal_y
         bty = btxy * ebdy.interface.normal_x + btyy * ebdy.interface.normal_y
@@ -109,33 +113,42 @@ class VectorHelper(object):
         if not self.interior:
             taus *= -1.0
             taud *= -1.0
-        sigma_g, sigma_r = (v2f(m) for m in call_pair(self.interface_qfs_g, self.interface_qfs_r,
-                                                      [taus, taud]))
         self.ur, self.vr, self.pr = ur, vr, pr
-        self.sigma_r = sigma_r
-        self.sigma_g = sigma_g
-        return sigma_g
+        return [(self.interface_qfs_g, [taus, taud]), (self.interface_qfs_r, [taus, taud])]
+
+    def finish_call(self, mu_g, mu_r):
+        self.sigma_r = v2f(mu_r)
+        self.sigma_g = v2f(mu_g)
+        return self.sigma_g
 
     def correct(self, ub, vb, pb, single_ebdy):
         """Effect of every OTHER boundary's grid sources on this annulus (reference
         :145-162).  The reference leaves the pressure of that part undetermined (its
         comment at :150); here the constant is fixed by matching the mean pressure on the
         interface, which is all a velocity-matching density leaves open."""
+        return self.finish_correct(*u2s_many(self.start_correct(ub, vb, pb, single_ebdy)))
+
+    def start_correct(self, ub, vb, pb, single_ebdy):
+        self._single = single_ebdy
         if single_ebdy:
+            return []
+        import torch
+        src = self.interface_qfs_g.source
+        # (one device -> host transfer for the three fields, not three synchronisations)
+        w = torch.stack(list(self.Layer_Apply(src, self._interface_dev, self.sigma_g))).cpu().numpy()
+        self._pb_rest = pb - w[2]
+        return [(self.interface_qfs_r, np.concatenate([ub - w[0], vb - w[1]]))]
+
+    def finish_correct(self, mu_adj=None):
+        if self._single:
             sigma_r_tot = self.sigma_r
             p_shift = 0.0
         else:
-            import torch
-            to_np = lambda a: a.cpu().numpy()
-            src = self.interface_qfs_g.source
-            # (one device -> host transfer for the three fields, not three synchronisations)
-            w = to_np(torch.stack(list(self.Layer_Apply(src, self._interface_dev, self.sigma_g))))
-            Ub = np.concatenate([ub - w[0], vb - w[1]])
-            sigma_r_adj = v2f(self.interface_qfs_r.u2s(Ub))
-            p_adj = to_np(self.Layer_Apply(self.interface_qfs_r.source, self._interface_dev,
-                                           sigma_r_adj)[2])
+            sigma_r_adj = v2f(mu_adj)
+            p_adj = self.Layer_Apply(self.interface_qfs_r.source, self._interface_dev,
+                                     sigma_r_adj)[2].cpu().numpy()
             wi = self.ebdy.interface.weights
-            p_shift = np.sum((pb - w[2] - p_adj) * wi) / np.sum(wi)
+            p_shift = np.sum((self._pb_rest - p_adj) * wi) / np.sum(wi)
             sigma_r_tot = sigma_r_adj + self.sigma_r
         src = self.interface_qfs_r.source
         import torch

@@ -14,11 +14,23 @@ import torch
 from ...derivatives import fd_x_4, fd_y_4
 from ...embedded_function import EmbeddedFunction, BoundaryFunction
 from ...interp import periodic_interp2d, periodic_interp2d_gradient, chebyshev_fourier_eval
+from ...qfs import call_many, u2s_many
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...device import prewarm_wait
 from ...sharding import make_pnai_evaluator
 from ...spectral import get_plan
+
+
+def _finish_all(helpers, method, reqs, solve_many):
+    """run the QFS solves requested by all helpers together and hand each helper its own"""
+    flat = [r for req in reqs for r in req]
+    res = solve_many(flat) if flat else []
+    out, k = [], 0
+    for helper, req in zip(helpers, reqs):
+        out.append(getattr(helper, method)(*res[k:k + len(req)]))
+        k += len(req)
+    return out
 
 
 class ScalarSolver(object):
@@ -141,9 +153,11 @@ class ScalarSolver(object):
             stack = torch.stack([torch.fft.fft2(g) for g in (uc, self.dx(uc), self.dy(uc))])
             all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         bvl, bxl, byl = e.v2l(all_bvs[0]), e.v2l(all_bvs[1]), e.v2l(all_bvs[2])
-        sigmag_list = []
-        for helper, fr, bv, bx, by in zip(self.helpers, fr_list, bvl, bxl, byl):
-            sigmag_list.append(helper(fr, bv, bx, by, **kwargs))
+        # annular solves boundary by boundary, then the QFS solves of all boundaries in one
+        # batched substitution (qfs.call_many)
+        reqs = [helper.start_call(fr, bv, bx, by, **kwargs)
+                for helper, fr, bv, bx, by in zip(self.helpers, fr_list, bvl, bxl, byl)]
+        sigmag_list = _finish_all(self.helpers, 'finish_call', reqs, call_many)
         self.iteration_counts = [helper.iterations_last_call for helper in self.helpers]
         sigmag = np.concatenate(sigmag_list)
         out = self.evaluate_to_grid_pnai(sigmag)                 # device, len(grid_pnai)
@@ -151,7 +165,8 @@ class ScalarSolver(object):
         ucf = uc.view(-1)
         ucf[self._pna_idx] += out[:n_pna]
         bus = e.v2l(out[n_pna:].cpu().numpy())
-        urs = [helper.correct(bu) for helper, bu in zip(self.helpers, bus)]
+        reqs = [helper.start_correct(bu) for helper, bu in zip(self.helpers, bus)]
+        urs = _finish_all(self.helpers, 'finish_correct', reqs, u2s_many)
         for ur, (idx, xi, t) in zip(urs, self._ia):
             ucf[idx] = chebyshev_fourier_eval(ur, xi, t)
         ucf *= self._phys_d.view(-1)

@@ -13,6 +13,8 @@ from ...embedded_function import EmbeddedFunction
 from ...interp import periodic_interp2d, chebyshev_fourier_eval
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
+from ...qfs import call_many, u2s_many
+from .scalar import _finish_all
 from ...device import prewarm_wait
 from ...sharding import make_pnai_evaluator
 from ...spectral import get_plan
@@ -144,10 +146,12 @@ class VectorSolver(object):
                                  (uc, vc, 2 * ucx - pc, ucy + vcx, 2 * vcy - pc)])
         bvals = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         bul, bvl, btxxl, btxyl, btyyl = (e.v2l(b) for b in bvals)
-        sigmag_list = []
-        for helper, fur, fvr, bu, bv, btxx, btxy, btyy in zip(self.helpers, fur_list, fvr_list,
-                                                              bul, bvl, btxxl, btxyl, btyyl):
-            sigmag_list.append(helper(fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs))
+        # annular solves boundary by boundary, then the QFS solves of all boundaries in one
+        # batched substitution (qfs.call_many)
+        reqs = [helper.start_call(fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs)
+                for helper, fur, fvr, bu, bv, btxx, btxy, btyy in zip(self.helpers, fur_list, fvr_list,
+                                                                      bul, bvl, btxxl, btxyl, btyyl)]
+        sigmag_list = _finish_all(self.helpers, 'finish_call', reqs, call_many)
         self.iteration_counts = [helper.iterations_last_call for helper in self.helpers]
         sigmag = np.column_stack(sigmag_list)
         out = self.Grid_Evaluator(sigmag)                          # device (u, v, p) on grid_pnai
@@ -157,8 +161,9 @@ class VectorSolver(object):
             f[self._pna_idx] += o[:n_pna]
         bus, bvs, bps = (e.v2l(o) for o in torch.stack([o[n_pna:] for o in out]).cpu().numpy())
         single_ebdy = len(e) == 1
-        urs, vrs, prs = zip(*[helper.correct(bu, bv, bp, single_ebdy)
-                              for helper, bu, bv, bp in zip(self.helpers, bus, bvs, bps)])
+        reqs = [helper.start_correct(bu, bv, bp, single_ebdy)
+                for helper, bu, bv, bp in zip(self.helpers, bus, bvs, bps)]
+        urs, vrs, prs = zip(*_finish_all(self.helpers, 'finish_correct', reqs, u2s_many))
         for k, (f, rs) in enumerate(zip(fields, (urs, vrs, prs))):
             for r, (idx, xi, t) in zip(rs, self._ia):
                 f[idx] = chebyshev_fourier_eval(r, xi, t)
