@@ -549,6 +549,12 @@ struct Fft1Plan {
     size_t work_bytes = 0;
 };
 
+// rocFFT plan creation (and its run-time kernel compilation) is entered by one thread at a
+// time, whatever context it is for: contexts of different boundaries are driven from
+// different host threads (concurrent annular solves), and two threads inside plan creation
+// crashed before.
+static std::mutex g_rocfft_plan_mutex;
+
 int ipde_fft1_get(ipde_ctx* ctx, int64_t batch, int64_t n, Fft1Plan** out) {
     rocfft_setup_once();
     std::lock_guard<std::mutex> guard(ctx->fft1_mutex);
@@ -558,6 +564,7 @@ int ipde_fft1_get(ipde_ctx* ctx, int64_t batch, int64_t n, Fft1Plan** out) {
         *out = (Fft1Plan*)it->second;
         return IPDE_OK;
     }
+    std::lock_guard<std::mutex> global(g_rocfft_plan_mutex);
     Fft1Plan* fp = new Fft1Plan();
     size_t len[1] = {(size_t)n};
     IPDE_FFT_CHECK(ctx, rocfft_plan_create(&fp->fwd, rocfft_placement_notinplace,

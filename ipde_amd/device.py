@@ -81,6 +81,13 @@ def get_context(device=None):
         return ctx
 
 
+def private_context(device=None):
+    """A context of its own (own stream, own work buffers and FFT plans) — what an object needs
+    to be driven from a separate host thread concurrently with the others (the annular
+    solvers of a multiply connected domain, solvers/multi_boundary/vector.py)."""
+    return Context(device)
+
+
 _warm = {"thread": None, "queue": None, "keys": set()}
 
 

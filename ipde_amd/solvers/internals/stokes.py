@@ -10,11 +10,19 @@ from ...qfs import Stokes_QFS
 class StokesHelper(VectorHelper):
     """Inhomogeneous Stokes solver on a general domain (per-boundary part)."""
 
-    def __init__(self, ebdy, annular_solver=None):
+    def __init__(self, ebdy, annular_solver=None, private_ctx=False):
+        # private_ctx: give the annular solver a library context of its own (stream, work
+        # buffers, FFT plans), so that the solver of a multiply connected domain can run the
+        # annular solves of its boundaries concurrently from separate host threads
+        self._private_ctx = private_ctx
         super().__init__(ebdy, annular_solver)
 
     def _define_annular_solver(self):
-        self.annular_solver = AnnularStokesSolver(self.AAG, mu=1.0)
+        ctx = None
+        if self._private_ctx:
+            from ...device import private_context
+            ctx = private_context()
+        self.annular_solver = AnnularStokesSolver(self.AAG, mu=1.0, ctx=ctx)
 
     def _get_qfs(self):
         q = self.ebdy.interface_qfs

@@ -26,7 +26,7 @@ class StokesSolver(VectorSolver):
     def _get_helper(self, ebdy, helper):
         c = self._get_helper_compatability(ebdy, helper)
         if c == 0:
-            return StokesHelper(ebdy)
+            return StokesHelper(ebdy, private_ctx=self.ebdyc.N > 1)
         elif c == 1:
             return StokesHelper(ebdy, helper.annular_solver)
         return helper

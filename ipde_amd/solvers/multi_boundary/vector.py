@@ -43,6 +43,20 @@ class VectorSolver(object):
         self._collect_grid_sources()
         self._make_device_state()
 
+    def _concurrent_helpers(self):
+        ok = getattr(self, '_concurrent', None)
+        if ok is None:
+            solvers = [h.annular_solver for h in self.helpers]
+            ctxs = [getattr(a, 'ctx', None) for a in solvers]
+            ok = (len(solvers) > 1 and len({id(a) for a in solvers}) == len(solvers)
+                  and all(c is not None for c in ctxs) and len({id(c) for c in ctxs}) == len(ctxs)
+                  and all(c is not self.plan.ctx for c in ctxs))
+            if ok:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(len(solvers), thread_name_prefix="ipde-annular")
+            self._concurrent = ok
+        return ok
+
     def _collect_grid_sources(self):
         self.grid_sources = BoundaryCollection()
         for helper in self.helpers:
@@ -148,9 +162,15 @@ class VectorSolver(object):
         bul, bvl, btxxl, btxyl, btyyl = (e.v2l(b) for b in bvals)
         # annular solves boundary by boundary, then the QFS solves of all boundaries in one
         # batched substitution (qfs.call_many)
-        reqs = [helper.start_call(fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs)
-                for helper, fur, fvr, bu, bv, btxx, btxy, btyy in zip(self.helpers, fur_list, fvr_list,
-                                                                      bul, bvl, btxxl, btxyl, btyyl)]
+        args = list(zip(self.helpers, fur_list, fvr_list, bul, bvl, btxxl, btxyl, btyyl))
+        start = lambda a: a[0].start_call(*a[1:], **kwargs)
+        if self._concurrent_helpers():
+            # every annular solver has its own library context (stream, buffers, plans): the
+            # latency-bound GMRES solves of the boundaries overlap on the GPU, each driven by
+            # its own host thread (the library call releases the GIL)
+            reqs = list(self._pool.map(start, args))
+        else:
+            reqs = [start(a) for a in args]
         sigmag_list = _finish_all(self.helpers, 'finish_call', reqs, call_many)
         self.iteration_counts = [helper.iterations_last_call for helper in self.helpers]
         sigmag = np.column_stack(sigmag_list)
