@@ -43,7 +43,11 @@ class VectorSolver(object):
         self._collect_grid_sources()
         self._make_device_state()
 
+    CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other
+
     def _concurrent_helpers(self):
+        if not self.CONCURRENT_ANNULAR:
+            return False
         ok = getattr(self, '_concurrent', None)
         if ok is None:
             solvers = [h.annular_solver for h in self.helpers]

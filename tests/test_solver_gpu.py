@@ -84,6 +84,21 @@ def test_stokes_multiply_connected():
     assert pe < 5e-3
 
 
+def test_concurrent_annular_solves_equal_sequential_ones():
+    """3-body Stokes: the annular solves of the boundaries run from one host thread each on
+    library contexts of their own; the result is bitwise that of the sequential order"""
+    import multi_stokes
+    from ipde_amd.solvers.multi_boundary.vector import VectorSolver
+    _, conc, _, _ = multi_stokes.run(nb=600, M=14, return_fields=True)
+    VectorSolver.CONCURRENT_ANNULAR = False
+    try:
+        _, seq, _, _ = multi_stokes.run(nb=600, M=14, return_fields=True)
+    finally:
+        VectorSolver.CONCURRENT_ANNULAR = True
+    for a, b in zip(conc, seq):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def _run_sharded(problem, extra, port):
     import json
     import subprocess
