@@ -9,13 +9,13 @@ class ModifiedHelmholtzHelper(ScalarHelper):
     """Inhomogeneous modified-Helmholtz solver on a general domain (per boundary)."""
 
     def __init__(self, ebdy, annular_solver=None, k=1.0, source_upsample_factor=1.0,
-                 grid_backend='hip'):
+                 grid_backend='hip', private_ctx=False):
         self.k = k
         self.source_upsample_factor = source_upsample_factor
-        super().__init__(ebdy, annular_solver, grid_backend)
+        super().__init__(ebdy, annular_solver, grid_backend, private_ctx)
 
     def _define_annular_solver(self):
-        self.annular_solver = AnnularModifiedHelmholtzSolver(self.AAG, k=self.k)
+        self.annular_solver = AnnularModifiedHelmholtzSolver(self.AAG, k=self.k, ctx=self._annular_ctx())
 
     def _get_qfs(self):
         q = self.ebdy.interface_qfs

@@ -9,11 +9,11 @@ from ...qfs import Laplace_QFS
 class PoissonHelper(ScalarHelper):
     """Inhomogeneous Poisson solver on a general domain (per-boundary part)."""
 
-    def __init__(self, ebdy, annular_solver=None, grid_backend='hip'):
-        super().__init__(ebdy, annular_solver, grid_backend)
+    def __init__(self, ebdy, annular_solver=None, grid_backend='hip', private_ctx=False):
+        super().__init__(ebdy, annular_solver, grid_backend, private_ctx)
 
     def _define_annular_solver(self):
-        self.annular_solver = AnnularPoissonSolver(self.AAG)
+        self.annular_solver = AnnularPoissonSolver(self.AAG, ctx=self._annular_ctx())
 
     def _get_qfs(self):
         q = self.ebdy.interface_qfs

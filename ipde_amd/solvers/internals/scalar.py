@@ -8,8 +8,12 @@ from ...annular.annular_full import ApproximateAnnularGeometry, RealAnnularGeome
 
 
 class ScalarHelper(object):
-    def __init__(self, ebdy, helper=None, grid_backend='hip'):
+    def __init__(self, ebdy, helper=None, grid_backend='hip', private_ctx=False):
+        # private_ctx: a library context of its own for the annular solver (stream, work
+        # buffers, FFT plans) — the multi-boundary solver then runs the annular solves of its
+        # boundaries concurrently from separate host threads
         self.ebdy = ebdy
+        self._private_ctx = private_ctx
         self.grid_backend = grid_backend
         self.interior = self.ebdy.interior
         if helper is None:
@@ -27,6 +31,12 @@ class ScalarHelper(object):
         from ...layer_potentials import DeviceTargets
         self._interface_dev = DeviceTargets(self.ebdy.interface)
         self._radial_dev = DeviceTargets(self.ebdy.radial_targ)
+
+    def _annular_ctx(self):
+        if not self._private_ctx:
+            return None
+        from ...device import private_context
+        return private_context()
 
     def _define_annular_solver(self):
         raise NotImplementedError

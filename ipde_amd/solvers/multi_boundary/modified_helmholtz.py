@@ -32,7 +32,7 @@ class ModifiedHelmholtzSolver(ScalarSolver):
         if c == 0:
             return ModifiedHelmholtzHelper(ebdy, k=self.k,
                                            source_upsample_factor=self.source_upsample_factor,
-                                           grid_backend=self.grid_backend)
+                                           grid_backend=self.grid_backend, private_ctx=self.ebdyc.N > 1)
         elif c == 1:
             return ModifiedHelmholtzHelper(ebdy, helper, k=self.k,
                                            source_upsample_factor=self.source_upsample_factor,

@@ -12,7 +12,8 @@ class PoissonSolver(ScalarSolver):
         super().__init__(ebdyc, solver_type, AS_list, grid_backend)
 
     def _get_helper(self, ebdy, helper):
-        return PoissonHelper(ebdy, helper, grid_backend=self.grid_backend)
+        return PoissonHelper(ebdy, helper, grid_backend=self.grid_backend,
+                             private_ctx=helper is None and self.ebdyc.N > 1)
 
     def _grid_solve(self, fc):
         """fc: device (Nx, Ny).  Demean with the bump (ebdy_collection.py:808-810), then

@@ -33,6 +33,25 @@ def _finish_all(helpers, method, reqs, solve_many):
     return out
 
 
+def _concurrent_helpers(solver):
+    """True (and a thread pool on solver._pool) if the annular solvers of the helpers can be
+    driven concurrently: several of them, all distinct, each on a library context of its own"""
+    if not solver.CONCURRENT_ANNULAR:
+        return False
+    ok = getattr(solver, '_concurrent', None)
+    if ok is None:
+        solvers = [h.annular_solver for h in solver.helpers]
+        ctxs = [getattr(a, 'ctx', None) for a in solvers]
+        ok = (len(solvers) > 1 and len({id(a) for a in solvers}) == len(solvers)
+              and all(c is not None for c in ctxs) and len({id(c) for c in ctxs}) == len(ctxs)
+              and all(c is not solver.plan.ctx for c in ctxs))
+        if ok:
+            from concurrent.futures import ThreadPoolExecutor
+            solver._pool = ThreadPoolExecutor(len(solvers), thread_name_prefix="ipde-annular")
+        solver._concurrent = ok
+    return ok
+
+
 class ScalarSolver(object):
     def __init__(self, ebdyc, solver_type='spectral', helpers=None, grid_backend='hip'):
         self.ebdyc = ebdyc
@@ -55,6 +74,11 @@ class ScalarSolver(object):
         self._collect_grid_sources()
         self._make_device_state()
         self._define_grid_evaluator()
+
+    CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other
+
+    def _concurrent_helpers(self):
+        return _concurrent_helpers(self)
 
     def _collect_grid_sources(self):
         self.grid_sources = BoundaryCollection()
@@ -155,8 +179,13 @@ class ScalarSolver(object):
         bvl, bxl, byl = e.v2l(all_bvs[0]), e.v2l(all_bvs[1]), e.v2l(all_bvs[2])
         # annular solves boundary by boundary, then the QFS solves of all boundaries in one
         # batched substitution (qfs.call_many)
-        reqs = [helper.start_call(fr, bv, bx, by, **kwargs)
-                for helper, fr, bv, bx, by in zip(self.helpers, fr_list, bvl, bxl, byl)]
+        args = list(zip(self.helpers, fr_list, bvl, bxl, byl))
+        start = lambda a: a[0].start_call(*a[1:], **kwargs)
+        if self._concurrent_helpers():
+            # (a library context and a host thread per boundary: see VectorSolver)
+            reqs = list(self._pool.map(start, args))
+        else:
+            reqs = [start(a) for a in args]
         sigmag_list = _finish_all(self.helpers, 'finish_call', reqs, call_many)
         self.iteration_counts = [helper.iterations_last_call for helper in self.helpers]
         sigmag = np.concatenate(sigmag_list)

@@ -14,7 +14,7 @@ from ...interp import periodic_interp2d, chebyshev_fourier_eval
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...qfs import call_many, u2s_many
-from .scalar import _finish_all
+from .scalar import _finish_all, _concurrent_helpers
 from ...device import prewarm_wait
 from ...sharding import make_pnai_evaluator
 from ...spectral import get_plan
@@ -46,20 +46,7 @@ class VectorSolver(object):
     CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other
 
     def _concurrent_helpers(self):
-        if not self.CONCURRENT_ANNULAR:
-            return False
-        ok = getattr(self, '_concurrent', None)
-        if ok is None:
-            solvers = [h.annular_solver for h in self.helpers]
-            ctxs = [getattr(a, 'ctx', None) for a in solvers]
-            ok = (len(solvers) > 1 and len({id(a) for a in solvers}) == len(solvers)
-                  and all(c is not None for c in ctxs) and len({id(c) for c in ctxs}) == len(ctxs)
-                  and all(c is not self.plan.ctx for c in ctxs))
-            if ok:
-                from concurrent.futures import ThreadPoolExecutor
-                self._pool = ThreadPoolExecutor(len(solvers), thread_name_prefix="ipde-annular")
-            self._concurrent = ok
-        return ok
+        return _concurrent_helpers(self)
 
     def _collect_grid_sources(self):
         self.grid_sources = BoundaryCollection()
