@@ -32,6 +32,19 @@ class Context:
         self.handle = h
         self._plans = {}
 
+    _private = False
+
+    def __del__(self):
+        # private contexts (private_context()) go with their owner — the owner holds the only
+        # reference, so its own handles are destroyed first; the process-wide ones live on
+        try:
+            import sys
+            if self._private and self.handle and not sys.is_finalizing():
+                h, self.handle = self.handle, None
+                self.lib.ipde_ctx_destroy(h)
+        except Exception:
+            pass
+
     # -- misc ---------------------------------------------------------------
     def check(self, status, allow=()):
         return _lib.check(status, self.handle, allow)
@@ -85,7 +98,9 @@ def private_context(device=None):
     """A context of its own (own stream, own work buffers and FFT plans) — what an object needs
     to be driven from a separate host thread concurrently with the others (the annular
     solvers of a multiply connected domain, solvers/multi_boundary/vector.py)."""
-    return Context(device)
+    ctx = Context(device)
+    ctx._private = True
+    return ctx
 
 
 _warm = {"thread": None, "queue": None, "keys": set()}
