@@ -55,6 +55,7 @@ SIGNATURES = {
     "ipde_ctx_get_stream": (_vp, [_vp]),
     "ipde_last_error": (ctypes.c_char_p, [_vp]),
     "ipde_ctx_set_option": (_int, [_vp, ctypes.c_char_p, _int]),
+    "ipde_ctx_get_option": (_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_int)]),
     "ipde_ctx_enable_timing": (_int, [_vp, _int]),
     "ipde_ctx_last_kernel_ms": (_int, [_vp, _c_double_p]),
     "ipde_laplace_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,

@@ -193,20 +193,33 @@ extern "C" void* ipde_ctx_get_stream(ipde_ctx* ctx) { return ctx ? (void*)ctx->s
 
 extern "C" const char* ipde_last_error(ipde_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+static int* option_slot(ipde_ctx* ctx, const char* name) {
+    if (!strcmp(name, "laplace_variant")) return &ctx->opt_laplace_variant;
+    if (!strcmp(name, "stokes_variant")) return &ctx->opt_stokes_variant;
+    if (!strcmp(name, "dense_pairs")) return &ctx->opt_dense_pairs;
+    if (!strcmp(name, "annular_grouped")) return &ctx->opt_annular_grouped;
+    return nullptr;
+}
+
 extern "C" int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return IPDE_ERR_INVALID;
-    if (!strcmp(name, "laplace_variant")) {
-        ctx->opt_laplace_variant = value;
-    } else if (!strcmp(name, "stokes_variant")) {
-        ctx->opt_stokes_variant = value;
-    } else if (!strcmp(name, "dense_pairs")) {
-        ctx->opt_dense_pairs = value;
-    } else if (!strcmp(name, "annular_grouped")) {
-        ctx->opt_annular_grouped = value;
-    } else {
+    int* slot = option_slot(ctx, name);
+    if (!slot) {
         IPDE_SET_ERR(ctx, "unknown option '%s'", name);
         return IPDE_ERR_INVALID;
     }
+    *slot = value;
+    return IPDE_OK;
+}
+
+extern "C" int ipde_ctx_get_option(ipde_ctx* ctx, const char* name, int* value) {
+    if (!ctx || !name || !value) return IPDE_ERR_INVALID;
+    int* slot = option_slot(ctx, name);
+    if (!slot) {
+        IPDE_SET_ERR(ctx, "unknown option '%s'", name);
+        return IPDE_ERR_INVALID;
+    }
+    *value = *slot;
     return IPDE_OK;
 }
 

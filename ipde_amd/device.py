@@ -60,6 +60,11 @@ class Context:
     def set_option(self, name, value):
         self.check(self.lib.ipde_ctx_set_option(self.handle, name.encode(), int(value)))
 
+    def get_option(self, name):
+        v = ctypes.c_int()
+        self.check(self.lib.ipde_ctx_get_option(self.handle, name.encode(), ctypes.byref(v)))
+        return v.value
+
     def enable_timing(self, on=True):
         self.check(self.lib.ipde_ctx_enable_timing(self.handle, int(bool(on))))
 

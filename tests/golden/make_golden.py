@@ -18,6 +18,11 @@ What can be imported:
     OPERATOR-level outputs (matrices, apply, preconditioner) are exact goldens;
     the solve outputs are stored with the manufactured solution they must
     reproduce and are compared at solver tolerance.
+  * ipde.solvers.multi_boundary.poisson (Laplace_Eval), ipde.solvers.internals.stokes_save
+    (PSLP / PDLP pressure rows, eval_p1) — plain numpy inside modules that also import
+    pybie2d, pyfmmlib2d, qfs, flexmm, fmm2dpy, near_finder, function_generator: those get
+    EMPTY stand-ins (importable, raise when called) from a meta-path finder; see
+    golden_layer_kernels().
 """
 import os
 import sys
@@ -304,6 +309,134 @@ def golden_grid_evaluator_kernels():
     print("grid_evaluator_kernels.npz", len(out))
 
 
+# ---- layer-potential kernels: what the tree itself can compute -------------------------
+
+_ABSENT = ("pybie2d", "pyfmmlib2d", "qfs", "flexmm", "fmm2dpy", "near_finder",
+           "function_generator", "finufft")
+
+
+class _Stub:
+    """attribute of a stand-in package: importable, raises when called"""
+
+    def __init__(self, name):
+        self._n = name
+
+    def __getattr__(self, a):
+        if a.startswith("__"):
+            raise AttributeError(a)
+        return _Stub(self._n + "." + a)
+
+    def __call__(self, *a, **k):
+        raise RuntimeError("stand-in %s called" % self._n)
+
+
+class _StubModule(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, a):
+        if a.startswith("__"):
+            raise AttributeError(a)
+        return _Stub(self.__name__ + "." + a)
+
+
+def _install_absent_package_finder():
+    """Make `import pybie2d...`, `from qfs.two_d_qfs import X`, ... succeed with empty
+    stand-ins (the packages are not in the image and not under the reference tree), so that
+    the reference modules which ALSO hold plain-numpy kernel arithmetic can be imported:
+    ipde/solvers/multi_boundary/poisson.py (Laplace_Eval, :10-17) and
+    ipde/solvers/internals/stokes_save.py (PSLP / PDLP pressure rows, eval_p1, :29-81)."""
+    import importlib.abc
+    import importlib.machinery
+
+    class Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path, target=None):
+            if name.split(".")[0] in _ABSENT:
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+        def create_module(self, spec):
+            return _StubModule(spec.name)
+
+        def exec_module(self, m):
+            pass
+    sys.meta_path.append(Finder())
+
+
+class _Src:
+    pass
+
+
+def _star_source(n, a, f, scale=1.0, cx=0.0, cy=0.0):
+    t = np.linspace(0.0, 2 * np.pi, n, endpoint=False)
+    r = 1.0 + a * np.cos(f * t)
+    rp = -a * f * np.sin(f * t)
+    s = _Src()
+    s.x = scale * r * np.cos(t) + cx
+    s.y = scale * r * np.sin(t) + cy
+    xp = scale * (rp * np.cos(t) - r * np.sin(t))
+    yp = scale * (rp * np.sin(t) + r * np.cos(t))
+    sp = np.hypot(xp, yp)
+    s.normal_x, s.normal_y = yp / sp, -xp / sp
+    s.weights = sp * 2 * np.pi / n
+    s.N = n
+    return s
+
+
+def golden_layer_kernels():
+    """Layer-potential numbers computed by the reference's own code:
+      * Laplace single layer through `Laplace_Eval` (multi_boundary/poisson.py:10-17) and
+        through `gf` (grid_evaluators/laplace_grid_evaluator.py:8-12);
+      * modified-Helmholtz single layer through `gf`
+        (grid_evaluators/modified_helmholtz_grid_evaluator.py:8-9), k = 0.7, 10, 40;
+      * Stokes single- and double-layer PRESSURE through the last rows of `PSLP` / `PDLP`
+        and through `eval_p1` (solvers/internals/stokes_save.py:29-81).
+    Everything else on the path (Laplace / modified-Helmholtz double layers, Stokes
+    velocities) is computed by pybie2d / pyfmmlib2d, absent here: not in this fixture."""
+    import ipde.solvers.multi_boundary.poisson as RP
+    import ipde.solvers.internals.stokes_save as RS
+    import ipde.grid_evaluators.laplace_grid_evaluator as RL
+    import ipde.grid_evaluators.modified_helmholtz_grid_evaluator as RM
+    assert RP.flexmm_okay
+    # velocity blocks of PSLP / PDLP come from pybie2d (absent): zero them, the pressure
+    # row below them is the reference's own arithmetic
+    RS.Stokes_Layer_Form = lambda src, trg, **kw: np.zeros((2 * trg.N, 2 * src.N))
+    rng = np.random.default_rng(404)
+    src = _star_source(120, 0.2, 5, scale=0.9, cx=0.1, cy=-0.2)
+    nt = 160
+    th = rng.uniform(0, 2 * np.pi, nt)
+    # inside (0.05..0.7 of the local radius) and outside (1.3..2.5), plus four near-curve points
+    fac = np.where(rng.uniform(size=nt) < 0.5, rng.uniform(0.05, 0.7, nt), rng.uniform(1.3, 2.5, nt))
+    fac[:4] = [0.97, 1.03, 0.995, 1.005]
+    rad = 0.9 * (1.0 + 0.2 * np.cos(5 * th)) * fac
+    tx, ty = 0.1 + rad * np.cos(th), -0.2 + rad * np.sin(th)
+    sig = rng.standard_normal(src.N)
+    f = rng.standard_normal((2, src.N))
+    g = rng.standard_normal((2, src.N))
+    out = dict(sx=src.x, sy=src.y, nx=src.normal_x, ny=src.normal_y, w=src.weights,
+               tx=tx, ty=ty, sigma=sig, force=f, dipstr=g)
+    q = sig * src.weights
+    out["laplace_slp_eval"] = np.array(
+        [np.sum(RP.Laplace_Eval(src.x, src.y, tx[i], ty[i]) * q) for i in range(nt)])
+    R = np.hypot(tx[:, None] - src.x[None, :], ty[:, None] - src.y[None, :])
+    out["laplace_slp_gf"] = np.array([np.sum(RL.gf(R[i]) * q) for i in range(nt)])
+    ks = np.array([0.7, 10.0, 40.0])
+    out["modhelm_k"] = ks
+    for j, k in enumerate(ks):
+        out["modhelm_slp_gf_%d" % j] = np.array(
+            [np.sum(RM.gf(R[i], helmholtz_k=k) * q) for i in range(nt)])
+    ps, pd, p1s, p1b = np.zeros(nt), np.zeros(nt), np.zeros(nt), np.zeros(nt)
+    for i in range(nt):
+        trg = _Src()
+        trg.x, trg.y, trg.N = tx[i:i + 1], ty[i:i + 1], 1
+        ps[i] = RS.PSLP(src, trg)[-1].dot(f.ravel())
+        pd[i] = RS.PDLP(src, trg)[-1].dot(g.ravel())
+        p1s[i] = RS.eval_p1(src, tx[i], ty[i], f)
+        p1b[i] = RS.eval_p1(src, tx[i], ty[i], f, g)
+    out["stokes_p_slp_row"], out["stokes_p_dlp_row"] = ps, pd
+    out["stokes_p_slp_eval_p1"], out["stokes_p_both_eval_p1"] = p1s, p1b
+    np.savez(os.path.join(OUT, "layer_kernels.npz"), **out)
+    print("layer_kernels.npz", len(out))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be regenerated where it is")
@@ -314,3 +447,5 @@ if __name__ == "__main__":
     golden_annular_stokes()
     golden_slepian()
     golden_grid_evaluator_kernels()
+    _install_absent_package_finder()
+    golden_layer_kernels()

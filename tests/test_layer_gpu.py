@@ -53,11 +53,13 @@ def test_laplace_kernel_variants_agree(lp, ctx, setup, variant):
     c, trg, sig, tau, _, _ = setup
     ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=sig, dipstr=tau,
                                   weights=c.weights, nx=c.normal_x, ny=c.normal_y)
+    default = ctx.get_option("laplace_variant")
+    assert default == 9          # the row-run kernel bench.py times (csrc/ipde_common.h)
     ctx.set_option("laplace_variant", variant)
     try:
         got = lp.Laplace_Layer_Apply(c, trg, charge=sig, dipstr=tau)
     finally:
-        ctx.set_option("laplace_variant", 1)
+        ctx.set_option("laplace_variant", default)
     assert rel_err(got, ref) < TOL
 
 
@@ -120,6 +122,35 @@ def test_laplace_table_miss_falls_back(lp):
     assert rel_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("mode", ["slp", "dlp", "both"])
+def test_laplace_rowrun_table_miss_on_grid_ordered_ragged_list(lp, ctx, mode):
+    """The DEFAULT (row-run) kernel on the list shape it is built for — grid order, rows of
+    unequal length, a length that is no multiple of the lane's run — with near-coincident
+    targets (1e-9 and 1e-13 off the curve: d^2 far below the LDS table) spliced into the
+    rows: the per-lane table-miss fallback (csrc/layer_laplace.hip) against the C oracle."""
+    assert ctx.get_option("laplace_variant") == 9
+    c = Curve(192, a=0.2, f=5)
+    rng = np.random.default_rng(23)
+    trg, h = grid_targets(c, 157, clearance=2.0)
+    tx, ty = trg.x.copy(), trg.y.copy()
+    pos = np.sort(rng.choice(tx.shape[0], 120, replace=False))
+    j = rng.integers(0, c.N, 120)
+    eps = np.where(np.arange(120) % 2 == 0, 1e-9, 1e-13) * np.where(np.arange(120) % 3 == 0, -1, 1)
+    tx[pos] = c.x[j] + eps * c.normal_x[j]
+    ty[pos] = c.y[j] + eps * c.normal_y[j]
+    tx, ty = tx[:-3], ty[:-3]
+    sig, tau = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    kw = {}
+    if mode in ("slp", "both"):
+        kw["w_sigma"] = sig * c.weights
+    if mode in ("dlp", "both"):
+        kw.update(nx=c.normal_x, ny=c.normal_y, w_tau=tau * c.weights)
+    ref = oracle.c_laplace_apply(c.x, c.y, tx, ty, **kw)
+    got = lp.laplace_apply(c.x, c.y, tx, ty, **kw)
+    # the double layer of a near-coincident pair is O(1/eps): compare target by target
+    assert np.all(np.abs(got - ref) <= TOL * np.maximum(np.abs(ref), np.abs(ref[np.abs(ref) < 1e3]).max()))
+
+
 def test_laplace_self_evaluation_and_edge_sizes(lp):
     c = Curve(200, a=0.2, f=5)
     sig = np.cos(3 * c.t)
@@ -160,6 +191,36 @@ def test_laplace_linearity_full_size(lp):
     ref = oracle.c_laplace_apply(c.x, c.y, trg.x[idx], trg.y[idx], w_sigma=s1 * c.weights)
     got = u1.cpu().numpy()[idx]
     assert np.max(np.abs(got - ref)) < 1e-12 * float(torch.max(torch.abs(u1)))
+
+
+@pytest.mark.parametrize("mode", ["dlp", "both"])
+def test_laplace_dlp_and_fused_full_size(lp, ctx, mode):
+    """BASELINE configs[1], the double-layer half: 2048^2 grid x 4096 nodes, double layer and
+    the fused single+double sum on the default kernel — linearity on the whole list, 4096
+    random targets against the C oracle, and (double layer) the Gauss identity."""
+    import torch
+    assert ctx.get_option("laplace_variant") == 9
+    c = Curve(4096, a=0.2, f=5)
+    trg, h = grid_targets(c, 2048)
+    dt = lp.DeviceTargets(trg)
+    rng = np.random.default_rng(1)
+    s1, s2 = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    t1, t2 = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    ch = (lambda s: s) if mode == "both" else (lambda s: None)
+    u1 = lp.Laplace_Layer_Apply(c, dt, charge=ch(s1), dipstr=t1)
+    u2 = lp.Laplace_Layer_Apply(c, dt, charge=ch(s2), dipstr=t2)
+    u3 = lp.Laplace_Layer_Apply(c, dt, charge=ch(2.0 * s1 - 0.5 * s2), dipstr=2.0 * t1 - 0.5 * t2)
+    scale = float(torch.max(torch.abs(u3)))
+    assert float(torch.max(torch.abs(u3 - (2.0 * u1 - 0.5 * u2)))) < 1e-12 * scale
+    idx = rng.choice(trg.N, 4096, replace=False)
+    ref = oracle.c_laplace_apply(c.x, c.y, trg.x[idx], trg.y[idx],
+                                 w_sigma=None if mode == "dlp" else s1 * c.weights,
+                                 nx=c.normal_x, ny=c.normal_y, w_tau=t1 * c.weights)
+    assert np.max(np.abs(u1.cpu().numpy()[idx] - ref)) < 1e-12 * float(torch.max(torch.abs(u1)))
+    if mode == "dlp":
+        g = lp.Laplace_Layer_Apply(c, dt, dipstr=np.ones(c.N)).cpu().numpy()
+        inside = np.hypot(trg.x, trg.y) < c.radius_at(np.arctan2(trg.y, trg.x))
+        assert np.max(np.abs(g[inside] + 1.0)) < 1e-12 and np.max(np.abs(g[~inside])) < 1e-12
 
 
 @pytest.mark.parametrize("k", [0.5, 10.0, 40.0])
