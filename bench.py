@@ -4,12 +4,14 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One "step" = one Laplace single-layer evaluation of a 4096-node star boundary
-onto a 2048^2 grid (points within 5h of the curve removed, as the solver never
+onto a 2048^2 grid (points within 7.5 h of the curve removed, as the solver never
 evaluates on-surface) through the C ABI (ipde_laplace_apply), inputs
 resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU)
-every rank owns one such grid (weak scaling: targets are independent units, no
-data-path collective) and 1/N of the boundary density, which is all-gathered over
-RCCL each step — the one real exchange of the path.
+the ONE 2048^2 target list is split into N contiguous slices (strong scaling, the
+north_star's "2048^2 grid / 4096-node boundary at 1, 2, 4 and 8 GPUs"); every rank owns
+1/N of the boundary density, which is all-gathered over RCCL each step — the one real
+exchange of the path; results stay sharded (no data-path collective on the targets).
+`--scaling weak` gives every rank a whole 2048^2 grid instead.
 
 Prints ONE JSON line (rank 0).
 """
@@ -123,6 +125,37 @@ def full_poisson_solve(nb=4096, ng=2048, M=20):
     }
 
 
+def fft_block(n=NGRID, reps=40):
+    """The spectral half of the path at the BASELINE grid: `_grid_solve`
+    (Poisson) and `fourier` (d/dx), device resident.  GB/s on the algorithmic 16 B per grid
+    point (read f, write u = 67 MB at 2048^2), GFLOP/s on 2.5 N log2 N per real transform
+    (two per call), fraction of the 8 TB/s HBM peak."""
+    import torch
+    from ipde_amd.spectral import get_plan
+    g = torch.Generator(device="cuda").manual_seed(0)
+    f = torch.randn(n, n, dtype=torch.float64, device="cuda", generator=g)
+    f -= f.mean()
+    plan = get_plan(n, n, 3.0 / n, 3.0 / n)
+    out = {"grid": [n, n], "algorithmic_bytes": 16 * n * n,
+           "flops_convention": "2 x 2.5 N log2 N (one real forward + one real inverse 2-D transform)"}
+    N = float(n) * n
+    flops = 2 * 2.5 * N * np.log2(N)
+    for name, fn in (("poisson_grid_solve", lambda: plan.poisson_solve(f)),
+                     ("fourier_dx", lambda: plan.dx(f))):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        gbs = 16 * N / (ms * 1e-3) / 1e9
+        out[name] = {"ms": ms, "GB/s": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
+                     "GFLOP/s": flops / (ms * 1e-3) / 1e9}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +165,10 @@ def main():
     ap.add_argument("--no-full-solve", action="store_true",
                     help="skip the secondary measurement (full interior Poisson solve, 2048^2 grid)")
     ap.add_argument("--variant", type=int, default=None, help="kernel geometry variant (tuning)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): one 2048^2 target list split over the ranks; "
+                         "weak: one 2048^2 grid per rank")
+    ap.add_argument("--no-fft", action="store_true", help="skip the spectral-path measurement")
     args = ap.parse_args()
 
     # RCCL writes a version banner to stdout when the communicator is created:
@@ -163,7 +200,10 @@ def main():
         ctx.set_option("laplace_variant", args.variant)
     c, trg, sigma = make_workload()
     dev = ctx.torch_device()
-    dt = lp.DeviceTargets(trg, ctx=ctx)
+    from ipde_amd.sharding import target_slice
+    strong = args.scaling == "strong"
+    sl = target_slice(trg.N, rank, world) if strong else slice(0, trg.N)
+    dt = lp.DeviceTargets(trg.x[sl], trg.y[sl], ctx=ctx)
     sx = torch.as_tensor(c.x, device=dev)
     sy = torch.as_tensor(c.y, device=dev)
     w = torch.as_tensor(c.weights, device=dev)
@@ -213,22 +253,37 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    pairs_per_step = float(NBDY) * float(dt.N) * world
+    # strong: the whole job evaluates the one target list once per step
+    pairs_per_step = float(NBDY) * (float(trg.N) if strong else float(dt.N) * world)
+    # cost of the step's exchange alone (density all-gather + the fence's barrier), untimed
+    collective_ms = None
+    if use_dist:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            dist.all_gather_into_tensor(gathered, sig_shard)
+        torch.cuda.synchronize()
+        collective_ms = 1e3 * (time.perf_counter() - t0) / 50
     value = pairs_per_step * args.steps / elapsed
     # parity spot check inside the bench run (not timed): 2048 targets vs the oracle
     result = None
     if rank == 0:
         import oracle
-        idx = np.random.default_rng(1).choice(trg.N, 2048, replace=False)
-        ref = oracle.c_laplace_apply(c.x, c.y, trg.x[idx], trg.y[idx], w_sigma=sigma * c.weights)
+        idx = np.random.default_rng(1).choice(dt.N, 2048, replace=False)
+        ref = oracle.c_laplace_apply(c.x, c.y, trg.x[sl][idx], trg.y[sl][idx], w_sigma=sigma * c.weights)
         got = out.cpu().numpy()[idx]
         parity = float(np.max(np.abs(got - ref)) / float(torch.max(torch.abs(out))))
         kpairs = float(NBDY) * float(dt.N) / (kernel_ms_avg * 1e-3)
-        traffic = None
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside
+        # this process; the number is the rocprofv3 FETCH_SIZE / WRITE_SIZE measurement of this
+        # same command (tools/collect_traffic.py), stamped with the commit it was taken at
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and world == 1:
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = {k: tj.get(k) for k in ("kernel", "measured_at_commit", "measured_on", "command")}
             except Exception:
                 traffic = None
         result = {
@@ -236,16 +291,21 @@ def main():
             "value": value, "unit": "pair-interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "Laplace SLP grid_evaluator, 2048^2 grid x 4096-node star boundary "
-                            "(BASELINE configs[1]); %d targets per GPU after removing points "
-                            "within 5h of the curve" % dt.N,
-                "n_sources": NBDY, "n_targets_per_gpu": int(dt.N),
-                "parallelism": "targets sharded, %d rank(s), density all-gather over RCCL" % world,
+                            "(BASELINE configs[1]); %d targets after removing the grid points within "
+                            "7.5 h of the curve (tests/util.py grid_targets, clearance 5 x 1.5 h)" % trg.N,
+                "n_sources": NBDY, "n_targets_total": int(trg.N if strong else dt.N * world),
+                "n_targets_per_gpu": int(dt.N),
+                "parallelism": ("one target list split into %d contiguous slice(s), " % world if strong
+                                else "one full grid per rank (%d rank(s)), " % world)
+                               + ("density all-gather over RCCL each step" if use_dist
+                                  else "single process, no collective"),
                 "kernel_variant": args.variant,
             },
+            "collective_ms_per_step": collective_ms,
             "parity_max_rel_err_vs_oracle": parity,
             "roofline": {
                 "bound": "fp64 VALU (vector, non-MFMA): the dense sum is compute bound by "
@@ -265,8 +325,11 @@ def main():
                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_TARGET * dt.N,
                 },
                 "traffic": traffic,
+                "traffic_source": traffic_src,
             },
         }
+        if not args.no_fft and world == 1:
+            result["fft"] = fft_block()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(c, trg, sigma)
         else:

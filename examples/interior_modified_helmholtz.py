@@ -19,7 +19,7 @@ from ipde_amd.ebdy_collection import EmbeddedBoundaryCollection  # noqa: E402
 from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
 from ipde_amd.embedded_function import EmbeddedFunction, BoundaryFunction  # noqa: E402
 from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
-from ipde_amd.layer_potentials import Modified_Helmholtz_Layer_Apply, DeviceTargets  # noqa: E402
+from ipde_amd.layer_potentials import Modified_Helmholtz_Layer_Apply, DeviceTargets, ShardedTargets  # noqa: E402
 from ipde_amd.pybie2d_compat import star, Global_Smooth_Boundary as GSB  # noqa: E402
 from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver  # noqa: E402
@@ -61,7 +61,7 @@ def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False
     A = K(bdy, bdy)
     qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [lambda src, trg: A, ], Naive_SLP, on_surface=True, form_b2c=False)
     Alu = DenseSolver(A)
-    targets = DeviceTargets(ebdyc.grid_and_radial_pts)
+    targets = ShardedTargets(ebdyc.grid_and_radial_pts)
     T['homogeneous_form_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     bv = solver.get_boundary_values(ue.get_radial_value_list())

@@ -22,7 +22,7 @@ from ipde_amd.ebdy_collection import EmbeddedBoundaryCollection  # noqa: E402
 from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
 from ipde_amd.embedded_function import EmbeddedFunction  # noqa: E402
 from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
-from ipde_amd.layer_potentials import Modified_Helmholtz_Layer_Apply, DeviceTargets  # noqa: E402
+from ipde_amd.layer_potentials import Modified_Helmholtz_Layer_Apply, DeviceTargets, ShardedTargets  # noqa: E402
 from ipde_amd.pybie2d_compat import star, squish, Grid, Global_Smooth_Boundary as GSB  # noqa: E402
 from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver  # noqa: E402
@@ -92,7 +92,7 @@ def run(nb=400, M=16, helmholtz_k=2.0, verbose=False):
         qfs = QFS_Evaluator(ebdy.bdy_qfs, ebdy.interior, [K, ], Naive_SLP, on_surface=True, form_b2c=False)
         sigmal.append(qfs([t, ]))
     sigmav = np.concatenate(sigmal)
-    out = Modified_Helmholtz_Layer_Apply(ebdyc.bdy_inward_sources, DeviceTargets(ebdyc.grid_and_radial_pts),
+    out = Modified_Helmholtz_Layer_Apply(ebdyc.bdy_inward_sources, ShardedTargets(ebdyc.grid_and_radial_pts),
                                          k=k, charge=sigmav).cpu().numpy()
     gslp, rslpl = ebdyc.divide_grid_and_radial(out)
     for i in range(len(ebdys)):

@@ -27,7 +27,7 @@ from ipde_amd.ebdy_collection import EmbeddedBoundaryCollection  # noqa: E402
 from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
 from ipde_amd.embedded_function import EmbeddedFunction  # noqa: E402
 from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
-from ipde_amd.layer_potentials import Stokes_Layer_Apply, DeviceTargets  # noqa: E402
+from ipde_amd.layer_potentials import Stokes_Layer_Apply, DeviceTargets, ShardedTargets  # noqa: E402
 from ipde_amd.pybie2d_compat import (star, squish, Grid, Global_Smooth_Boundary as GSB,  # noqa: E402
                                      BoundaryCollection, arc_length_parameterize)
 from ipde_amd.qfs import Stokes_QFS, DenseSolver  # noqa: E402
@@ -137,7 +137,7 @@ def run(nb=800, M=14, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes
         sources.add(qfs.source, 'i' if qfs.interior else 'e')
     sources.amass_information()
     sigmav = np.column_stack([v2f(s) for s in sigmal])
-    out = Stokes_Layer_Apply(sources, DeviceTargets(ebdyc.grid_and_radial_pts), forces=sigmav)
+    out = Stokes_Layer_Apply(sources, ShardedTargets(ebdyc.grid_and_radial_pts), forces=sigmav)
     for f, o in zip((uc, vc, pc), out):
         f += o.cpu().numpy()
     T['homogeneous_s'] = time.perf_counter() - t0

@@ -16,6 +16,7 @@
 
 int ipde_fft1_exec(ipde_ctx* ctx, int64_t batch, int64_t n, int direction, const void* in,
                    void* out);
+extern "C" int ipde_fft1_prepare(ipde_ctx* ctx, int64_t batch, int64_t n);
 
 namespace {
 
@@ -425,6 +426,10 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     hipStream_t st = ctx->stream;
     if (restart < 1) restart = 1;
     if (maxiter < 1) maxiter = 1;
+    if (restart > maxiter) restart = maxiter;   // a cycle never runs longer than maxiter
+    // one cycle's Hessenberg column travels through the context's pinned buffer
+    IPDE_CHECK_ARG(ctx, (size_t)(2 * restart + 4) * sizeof(cd) <= ctx->h_pinned_bytes);
+    IPDE_CHECK_ARG(ctx, tol > 0.0);
     IPDE_TRY(gmres_reserve(ctx, g, NB, restart));
     IPDE_HIP_CHECK(ctx, hipMemsetAsync(g.x, 0, NB * sizeof(cd), st));
     cd* hp = (cd*)ctx->h_pinned;  // pinned: [restart+2] entries used per transfer
@@ -714,6 +719,10 @@ extern "C" int ipde_annular_scalar_create(ipde_ctx* ctx, int M, int n, double he
     al((void**)&h->rwork, (size_t)(M + 2) * n * sizeof(double));
     al((void**)&h->hin, (size_t)M * n * sizeof(cd));
     al((void**)&h->hout, (size_t)M * n * sizeof(cd));
+    // the batched 1-D plans of THIS context (a private context has its own plan cache: warm
+    // it here, at construction, instead of inside the first concurrent solves)
+    for (int64_t b : {(int64_t)2 * m1, (int64_t)m2, (int64_t)M})
+        if (st == IPDE_OK) st = ipde_fft1_prepare(ctx, b, n);
     if (st != IPDE_OK) {
         delete h;
         return st;
@@ -1371,6 +1380,10 @@ extern "C" int ipde_annular_stokes_create(ipde_ctx* ctx, int M, int n, double mu
     al((void**)&h->hin, (size_t)h->NB * sizeof(cd));
     al((void**)&h->hout, (size_t)h->NB * sizeof(cd));
     al((void**)&h->rstage, (size_t)(3 * M + 8) * n * 8);
+    // batched 1-D plans of this context, see ipde_annular_scalar_create
+    for (int64_t b : {(int64_t)4 * M + 2 * m1, (int64_t)2 * m1, (int64_t)2 * m2 + m1, (int64_t)2 * M,
+                      (int64_t)2 * M + m1})
+        if (st == IPDE_OK) st = ipde_fft1_prepare(ctx, b, n);
     if (st != IPDE_OK) {
         delete h;
         return st;

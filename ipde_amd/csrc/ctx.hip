@@ -123,26 +123,27 @@ extern "C" int ipde_ctx_create(int device_id, ipde_ctx** out) {
     ipde_ctx* ctx = new ipde_ctx();
     ctx->device = device_id;
     ctx->num_cu = prop.multiProcessorCount;
+    // every failure below goes through ipde_ctx_destroy, which frees whatever exists
     // a BLOCKING stream: it orders itself against the legacy default stream, which is
     // where a host framework (torch) allocates and fills the buffers it hands us
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamDefault) != hipSuccess) {
-        delete ctx;
-        return IPDE_ERR_HIP;
-    }
+    int s = IPDE_OK;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamDefault) != hipSuccess) s = IPDE_ERR_HIP;
     ctx->stream = ctx->own_stream;
-    hipEventCreate(&ctx->ev0);
-    hipEventCreate(&ctx->ev1);
+    if (s == IPDE_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess))
+        s = IPDE_ERR_HIP;
     ctx->h_pinned_bytes = 1 << 16;
-    if (hipHostMalloc((void**)&ctx->h_pinned, ctx->h_pinned_bytes) != hipSuccess) {
-        delete ctx;
-        return IPDE_ERR_ALLOC;
+    if (s == IPDE_OK && hipHostMalloc((void**)&ctx->h_pinned, ctx->h_pinned_bytes) != hipSuccess) {
+        ctx->h_pinned = nullptr;
+        s = IPDE_ERR_ALLOC;
     }
-    int s = ipde_build_log_table(ctx);
-    // (the modified-Helmholtz K0/K1 table — 125 000 long-double Bessel evaluations, 0.1 s —
-    // is built by the first ipde_modhelm_apply)
+    if (s == IPDE_OK) {
+        s = ipde_build_log_table(ctx);
+        // (the modified-Helmholtz K0/K1 table — 125 000 long-double Bessel evaluations, 0.1 s —
+        // is built by the first ipde_modhelm_apply)
+        if (s != IPDE_OK) fprintf(stderr, "ipde_hip: table construction failed: %s\n", ctx->err.c_str());
+    }
     if (s != IPDE_OK) {
-        fprintf(stderr, "ipde_hip: table construction failed: %s\n", ctx->err.c_str());
-        delete ctx;
+        ipde_ctx_destroy(ctx);
         return s;
     }
     *out = ctx;
@@ -154,7 +155,7 @@ void ipde_fft1_plans_destroy(ipde_ctx* ctx);  // spectral.hip
 extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
     if (!ctx) return IPDE_ERR_INVALID;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ipde_fft1_plans_destroy(ctx);
     auto freebuf = [](DevBuf& b) {
         if (b.p) hipFree(b.p);

@@ -20,6 +20,12 @@
         }                                                                                 \
     } while (0)
 
+// rocFFT plan creation (and its run-time kernel compilation) is entered by one thread at a
+// time, whatever context or plan kind it is for: contexts of different boundaries are driven
+// from different host threads (concurrent annular solves), a warm-up thread creates plans
+// during set-up, and a two-rank rehearsal with two threads inside plan creation ended in a
+// SIGSEGV (no backtrace of it was kept; serialising ALL plan creation is the mitigation).
+static std::mutex g_rocfft_plan_mutex;
 static std::once_flag g_rocfft_once;
 static void rocfft_setup_once() {
     std::call_once(g_rocfft_once, []() { rocfft_setup(); });
@@ -226,6 +232,7 @@ __global__ __launch_bounds__(256) void scale_kernel(double* __restrict__ a, int6
 
 int make_plan(ipde_ctx* ctx, rocfft_plan* plan, rocfft_transform_type type, size_t dims,
               const size_t* lengths, size_t batch) {
+    std::lock_guard<std::mutex> global(g_rocfft_plan_mutex);
     IPDE_FFT_CHECK(ctx, rocfft_plan_create(plan, rocfft_placement_notinplace, type,
                                            rocfft_precision_double, dims, lengths, batch, nullptr));
     return IPDE_OK;
@@ -548,12 +555,6 @@ struct Fft1Plan {
     void* work = nullptr;
     size_t work_bytes = 0;
 };
-
-// rocFFT plan creation (and its run-time kernel compilation) is entered by one thread at a
-// time, whatever context it is for: contexts of different boundaries are driven from
-// different host threads (concurrent annular solves), and two threads inside plan creation
-// crashed before.
-static std::mutex g_rocfft_plan_mutex;
 
 int ipde_fft1_get(ipde_ctx* ctx, int64_t batch, int64_t n, Fft1Plan** out) {
     rocfft_setup_once();

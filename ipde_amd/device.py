@@ -109,6 +109,7 @@ def private_context(device=None):
 
 
 _warm = {"thread": None, "queue": None, "keys": set()}
+PREWARM_TIMEOUT_S = 300.0
 
 
 def _warm_worker():
@@ -184,13 +185,16 @@ def prewarm_wait():
     if q is None or threading.current_thread() is _warm["thread"]:
         return
     # queue.join() without the possibility of waiting forever: the jobs are seconds of
-    # library loading / kernel compilation; after two minutes carry on regardless
-    deadline = time.monotonic() + 120.0
+    # library loading / kernel compilation.  Carrying on while the thread is still inside
+    # rocFFT would enter plan creation from two threads (the condition this join exists to
+    # exclude), so a timeout is an error.
+    deadline = time.monotonic() + PREWARM_TIMEOUT_S
     with q.all_tasks_done:
         while q.unfinished_tasks:
             remaining = deadline - time.monotonic()
             if remaining <= 0.0:
-                break
+                raise _lib.IpdeHipError("the library warm-up thread did not finish within %.0f s"
+                                        % PREWARM_TIMEOUT_S)
             q.all_tasks_done.wait(remaining)
 
 

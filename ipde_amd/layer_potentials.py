@@ -21,7 +21,7 @@ from .device import get_context, location_of, as_f64, ptr, empty_like_loc, to_de
 __all__ = [
     "laplace_apply", "modified_helmholtz_apply", "stokes_apply",
     "Laplace_Layer_Apply", "Modified_Helmholtz_Layer_Apply", "Stokes_Layer_Apply",
-    "DeviceTargets", "make_laplace_layer_apply", "make_modified_helmholtz_layer_apply",
+    "DeviceTargets", "ShardedTargets", "make_laplace_layer_apply", "make_modified_helmholtz_layer_apply",
     "make_stokes_layer_apply",
 ]
 
@@ -40,6 +40,40 @@ class DeviceTargets:
         self.y = to_device(np.asarray(y, dtype=np.float64).ravel(), self.ctx) \
             if not isinstance(y, torch.Tensor) else y.to(torch.float64).contiguous().view(-1)
         self.N = int(self.x.shape[0])
+
+
+class ShardedTargets:
+    """A resident target set split over the ranks of a torch.distributed job (one process
+    per GPU): this rank keeps its contiguous slice in HBM, the high-level *_Layer_Apply
+    functions evaluate the slice and all-gather the slices, so the caller sees the full
+    result on every rank exactly as with `DeviceTargets`.  In a single process it IS a
+    `DeviceTargets`.  For the big one-off sums of the example scripts (homogeneous
+    correction onto grid_and_radial_pts, reference examples/interior_poisson.py:84-92)."""
+
+    def __init__(self, x, y=None, ctx=None):
+        from . import sharding
+        if y is None:
+            x, y = x.x, x.y
+        x, y = np.asarray(x, dtype=np.float64).ravel(), np.asarray(y, dtype=np.float64).ravel()
+        self.N = int(x.shape[0])
+        _, rank, world = sharding._dist_state()
+        self.world = world
+        sl = sharding.target_slice(self.N, rank, world)
+        self.local = DeviceTargets(x[sl], y[sl], ctx=ctx)
+        self._gathers = {}
+
+    def evaluate(self, apply_local):
+        """apply_local(DeviceTargets) -> tensor or tuple of tensors on the local slice"""
+        out = apply_local(self.local)
+        if self.world == 1:
+            return out
+        from . import sharding
+        parts = out if isinstance(out, tuple) else (out,)
+        g = self._gathers.get(len(parts))
+        if g is None:
+            g = self._gathers[len(parts)] = sharding.ResultGather(self.N, len(parts))
+        full = g(parts)
+        return full if isinstance(out, tuple) else full[0]
 
 
 def _match(a, loc, ctx):
@@ -124,6 +158,8 @@ def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=N
     """out = SLP[charge] + DLP[dipstr] evaluated at target (pybie2d call shape;
     reference ipde/solvers/internals/poisson.py:35, examples/interior_poisson.py:89).
     target None: source onto itself, the coincident pairs skipped."""
+    if isinstance(target, ShardedTargets):
+        return target.evaluate(lambda t: Laplace_Layer_Apply(source, t, charge=charge, dipstr=dipstr))
     self_eval = target is None
     trg = source if self_eval else target
     tx, ty = _xy(trg)
@@ -140,6 +176,9 @@ def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=N
 def Modified_Helmholtz_Layer_Apply(source, target=None, k=1.0, charge=None, dipstr=None,
                                    backend=None, **kwargs):
     """(reference ipde/solvers/internals/modified_helmholtz.py:37)"""
+    if isinstance(target, ShardedTargets):
+        return target.evaluate(lambda t: Modified_Helmholtz_Layer_Apply(source, t, k=k, charge=charge,
+                                                                        dipstr=dipstr))
     self_eval = target is None
     trg = source if self_eval else target
     tx, ty = _xy(trg)
@@ -156,6 +195,9 @@ def Modified_Helmholtz_Layer_Apply(source, target=None, k=1.0, charge=None, dips
 def Stokes_Layer_Apply(source, target=None, forces=None, dipstr=None, pressure=True, **kwargs):
     """Returns (u, v, p) like the reference's Stokes Layer_Apply closure
     (ipde/solvers/internals/stokes.py:25-35).  forces / dipstr have shape (2, N)."""
+    if isinstance(target, ShardedTargets):
+        return target.evaluate(lambda t: Stokes_Layer_Apply(source, t, forces=forces, dipstr=dipstr,
+                                                            pressure=pressure))
     self_eval = target is None
     trg = source if self_eval else target
     tx, ty = _xy(trg)

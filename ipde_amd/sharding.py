@@ -1,17 +1,28 @@
 """Multi-GPU evaluation of layer potentials: one process per GPU.
 
 The target list shards (targets are independent units): rank r owns the
-contiguous slice `target_slice(nt, r, world)`; every rank holds all sources.  The one
-exchange is the boundary density: each rank owns the densities of "its" boundary
-nodes (the annular solves that produce them run one boundary per GPU) and they are
-all-gathered (RCCL over xGMI; gloo in the CPU tests) before every apply — a few tens
-of KB, latency bound.  Results stay sharded unless `gather_result` is asked for.
+contiguous slice `target_slice(nt, r, world)`; every rank holds all sources.  Exchanges:
+
+  * boundary densities (a few tens of KB): all-gathered before an apply when each rank
+    holds only "its" part (`allgather_density`, bench.py), or — inside the solvers, where the
+    annular solve of boundary i runs on rank i mod world — summed into a zero-filled buffer
+    (`exchange_owned`: x + 0 + ... + 0 is exact, so an all-reduce IS the gather for
+    disjoint owners);
+  * results: every rank's slice into one preallocated buffer with `all_gather_into_tensor`
+    (`ResultGather`; equal-size padded segments, nothing allocated per call).
+
+RCCL over xGMI with the nccl backend; gloo in the CPU tests and in the one-GPU rehearsals
+(device tensors then travel through host memory).
 
 The compute function is injected so that the host logic can be exercised on CPU with
 the gloo backend (tests/test_sharding.py uses the oracle as the compute function;
 production passes `ipde_amd.layer_potentials.laplace_apply` & friends).
 """
 import numpy as np
+
+# sums smaller than this many source-target pairs are evaluated by every rank itself (a
+# collective costs ~50 us; 2.5e8 pairs is ~0.15 ms of kernel time)
+MIN_PAIRS_TO_SHARD = 2.5e8
 
 
 def target_slice(nt, rank, world):
@@ -25,33 +36,100 @@ def shard_sizes(n, world):
     return [target_slice(n, r, world).stop - target_slice(n, r, world).start for r in range(world)]
 
 
+def _dist_state(dist=None, group=None):
+    """(dist module, rank, world) — (dist, 0, 1) when no process group is up"""
+    if dist is None:
+        import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return dist, 0, 1
+    return dist, dist.get_rank(group), dist.get_world_size(group)
+
+
+def is_distributed(dist=None, group=None):
+    return _dist_state(dist, group)[2] > 1
+
+
+class ResultGather:
+    """All-gather of ragged contiguous shards of `ncomp` equally long 1-D results into
+    full-length results on every rank.  Buffers are allocated once per (device, dtype):
+    send (ncomp, m), receive (world, ncomp, m), m = ceil(nt / world); one
+    `all_gather_into_tensor` per call whatever `ncomp` is."""
+
+    def __init__(self, nt, ncomp=1, dist=None, group=None):
+        self.dist, self.rank, self.world = _dist_state(dist, group)
+        self.group = group
+        self.nt, self.ncomp = int(nt), int(ncomp)
+        self.sizes = shard_sizes(self.nt, self.world)
+        self.m = max(self.sizes) if self.sizes else 0
+        self._bufs = {}
+        self._keep = {}
+
+    def _buffers(self, device, dtype):
+        import torch
+        key = (str(device), dtype)
+        b = self._bufs.get(key)
+        if b is None:
+            send = torch.zeros((self.ncomp, self.m), dtype=dtype, device=device)
+            recv = torch.empty((self.world, self.ncomp, self.m), dtype=dtype, device=device)
+            b = self._bufs[key] = (send, recv)
+        return b
+
+    def _keep_index(self, device):
+        """positions of the real entries in a flattened (world, m) segment table"""
+        import torch
+        k = self._keep.get(str(device))
+        if k is None:
+            idx = np.concatenate([r * self.m + np.arange(s) for r, s in enumerate(self.sizes)]) \
+                if self.nt else np.zeros(0, dtype=np.int64)
+            k = self._keep[str(device)] = torch.as_tensor(idx, dtype=torch.int64, device=device)
+        return k
+
+    def __call__(self, parts):
+        """parts: tuple of `ncomp` 1-D torch tensors (this rank's shard of each result)"""
+        import torch
+        if self.world == 1:
+            return tuple(parts)
+        t0 = parts[0]
+        via_host = t0.is_cuda and self.dist.get_backend(self.group) == "gloo"
+        dev = torch.device("cpu") if via_host else t0.device
+        send, recv = self._buffers(dev, t0.dtype)
+        n = self.sizes[self.rank]
+        for c, p in enumerate(parts):
+            send[c, :n].copy_(p)
+        self.dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+        even = self.nt == self.m * self.world
+        out = []
+        for c in range(self.ncomp):
+            seg = recv[:, c, :].reshape(-1)
+            full = seg if even else seg.index_select(0, self._keep_index(dev))
+            if full.untyped_storage().data_ptr() == recv.untyped_storage().data_ptr():
+                full = full.clone()        # a view: the receive buffer is reused by the next call
+            out.append(full.to(t0.device) if via_host else full)
+        return tuple(out)
+
+
 def allgather_density(local, n_total, dist=None, group=None):
     """All-gather a 1-D (or (c, n_local)) density shard into the full density.
 
     Shards may be ragged (n_total not divisible by the world size): they are padded to
     the largest shard for the collective and trimmed afterwards."""
     import torch
-    if dist is None:
-        import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
+    dist, rank, world = _dist_state(dist, group)
+    if world == 1:
         return local
-    world = dist.get_world_size(group)
-    sizes = shard_sizes(n_total, world)
     t = local if isinstance(local, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(local))
-    lead = tuple(t.shape[:-1])
-    m = max(sizes)
-    pad = torch.zeros(lead + (m,), dtype=t.dtype, device=t.device)
-    pad[..., :t.shape[-1]] = t
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad.contiguous(), group=group)
-    full = torch.cat([o[..., :s] for o, s in zip(out, sizes)], dim=-1)
+    lead = t.shape[:-1]
+    ncomp = int(np.prod(lead)) if len(lead) else 1
+    g = ResultGather(n_total, ncomp, dist, group)
+    parts = t.reshape(ncomp, -1)
+    full = torch.stack(list(g(tuple(parts[c] for c in range(ncomp))))).reshape(tuple(lead) + (int(n_total),))
     if isinstance(local, torch.Tensor):
         return full
     return full.cpu().numpy()
 
 
 class ShardedLayerApply:
-    """`Layer_Apply(src, trg, ch)` over N ranks.
+    """`Layer_Apply(src, trg, ch)` over N ranks, each rank holding a shard of the density.
 
     apply_fn(src, tx_local, ty_local, density_full) -> local result (array or tuple of
     arrays).  `trg` is sharded once at construction (the solver evaluates onto fixed
@@ -59,19 +137,17 @@ class ShardedLayerApply:
 
     def __init__(self, apply_fn, trg_x, trg_y, rank=None, world=None, dist=None, group=None,
                  wrap_targets=None):
-        if dist is None:
-            import torch.distributed as dist
-        self.dist = dist
+        self.dist, r, w = _dist_state(dist, group)
         self.group = group
-        inited = dist.is_available() and dist.is_initialized()
-        self.rank = (dist.get_rank(group) if inited else 0) if rank is None else rank
-        self.world = (dist.get_world_size(group) if inited else 1) if world is None else world
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
         self.nt = int(len(trg_x))
         self.slice = target_slice(self.nt, self.rank, self.world)
         tx, ty = trg_x[self.slice], trg_y[self.slice]
         # wrap_targets: e.g. DeviceTargets, to keep the shard resident in HBM
         self.targets = wrap_targets(tx, ty) if wrap_targets else (tx, ty)
         self.apply_fn = apply_fn
+        self._gathers = {}
 
     def __call__(self, src, density_local, n_density_total, gather_result=False):
         dens = allgather_density(density_local, n_density_total, self.dist, self.group)
@@ -84,60 +160,101 @@ class ShardedLayerApply:
 
     def gather(self, local):
         """Assemble the full-length result on every rank (when the FFT owner needs the
-        whole grid).  Tuples (Stokes u, v, p) are gathered component-wise."""
-        if isinstance(local, tuple):
-            return tuple(self.gather(c) for c in local)
+        whole grid).  Tuples (Stokes u, v, p) travel in one collective."""
         import torch
-        t = local if isinstance(local, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(local))
-        sizes = shard_sizes(self.nt, self.world)
-        m = max(sizes)
-        pad = torch.zeros(m, dtype=t.dtype, device=t.device)
-        pad[:t.shape[0]] = t
-        out = [torch.empty_like(pad) for _ in range(self.world)]
-        self.dist.all_gather(out, pad, group=self.group)
-        full = torch.cat([o[:s] for o, s in zip(out, sizes)])
-        return full if isinstance(local, torch.Tensor) else full.cpu().numpy()
+        parts = local if isinstance(local, tuple) else (local,)
+        as_t = tuple(p if isinstance(p, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(p))
+                     for p in parts)
+        g = self._gathers.get(len(parts))
+        if g is None:
+            g = self._gathers[len(parts)] = ResultGather(self.nt, len(parts), self.dist, self.group)
+        full = g(as_t)
+        full = tuple(f if isinstance(p, torch.Tensor) else f.cpu().numpy() for f, p in zip(full, parts))
+        return full if isinstance(local, tuple) else full[0]
 
 
-def _all_gather_padded(t, sizes, dist, group=None):
-    """all_gather of ragged 1-D shards of a torch tensor (device tensors over RCCL; with
-    the gloo backend, which the CPU / one-GPU rehearsals use, through host memory)."""
-    import torch
-    m = max(sizes)
-    backend = dist.get_backend(group)
-    via_host = t.is_cuda and backend == "gloo"
-    src = t.cpu() if via_host else t
-    pad = torch.zeros(m, dtype=src.dtype, device=src.device)
-    pad[:src.shape[0]] = src
-    out = [torch.empty_like(pad) for _ in sizes]
-    dist.all_gather(out, pad, group=group)
-    full = torch.cat([o[:s] for o, s in zip(out, sizes)])
-    return full.to(t.device) if via_host else full
+def make_sharded_evaluator(layer_apply, targets, wrap_targets, dist=None, group=None,
+                           min_pairs=0.0):
+    """`evaluate(sources, density)` onto a FIXED target set, every rank holding the full
+    (replicated) density.
+
+    Single process: one dense sum onto the resident target set.  Under torch.distributed
+    (one process per GPU) each rank evaluates its contiguous slice of the targets and the
+    slices are all-gathered into preallocated buffers (`ResultGather`).  Used for the
+    solvers' Grid_Evaluator onto grid_pnai (reference multi_boundary/scalar.py:63-71), for
+    the example-level correction sum onto grid_and_radial_pts (reference
+    examples/interior_poisson.py:84-92) and for correct()'s radial sums (reference
+    internals/scalar.py:95-116).  `layer_apply(src, trg, density)` returns a device tensor
+    or a tuple of them (Stokes u, v, p).  Sums with fewer than `min_pairs` source-target
+    pairs are evaluated by every rank in full (no collective)."""
+    dist, rank, world = _dist_state(dist, group)
+    nt = int(len(targets.x))
+    state = {}
+
+    def resident():
+        if "all" not in state:
+            state["all"] = wrap_targets(targets.x, targets.y)
+        return state["all"]
+
+    if world == 1:
+        return lambda sources, density: layer_apply(sources, resident(), density)
+    sl = target_slice(nt, rank, world)
+
+    def evaluator(sources, density):
+        if nt * float(sources.N) < min_pairs:
+            return layer_apply(sources, resident(), density)
+        if "local" not in state:
+            state["local"] = wrap_targets(targets.x[sl], targets.y[sl])
+        out = layer_apply(sources, state["local"], density)
+        parts = out if isinstance(out, tuple) else (out,)
+        g = state.get(len(parts))
+        if g is None:
+            g = state[len(parts)] = ResultGather(nt, len(parts), dist, group)
+        full = g(parts)
+        return full if isinstance(out, tuple) else full[0]
+    return evaluator
 
 
 def make_pnai_evaluator(layer_apply, sources, targets, wrap_targets, dist=None, group=None):
-    """The solvers' `Grid_Evaluator(density)` onto a fixed target set (grid_pnai).
+    """The solvers' `Grid_Evaluator(density)` onto grid_pnai: `make_sharded_evaluator`
+    bound to the solver's grid sources (BASELINE configs 4 and 5)."""
+    ev = make_sharded_evaluator(layer_apply, targets, wrap_targets, dist, group)
+    return lambda density: ev(sources, density)
 
-    Single process: one dense sum onto the resident target set.  Under
-    torch.distributed (one process per GPU, every rank holding the replicated solver
-    state and hence the full density) each rank evaluates its contiguous slice of the
-    targets and the slices are all-gathered — the only collective of a solve
-    (BASELINE configs 4 and 5).  `layer_apply(src, trg, density)` returns a device
-    tensor or a tuple of them (Stokes u, v, p)."""
-    if dist is None:
-        import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        resident = wrap_targets(targets.x, targets.y)
-        return lambda density: layer_apply(sources, resident, density)
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    nt = int(len(targets.x))
-    sl = target_slice(nt, rank, world)
-    local = wrap_targets(targets.x[sl], targets.y[sl])
-    sizes = shard_sizes(nt, world)
 
-    def evaluator(density):
-        out = layer_apply(sources, local, density)
-        if isinstance(out, tuple):
-            return tuple(_all_gather_padded(o, sizes, dist, group) for o in out)
-        return _all_gather_padded(out, sizes, dist, group)
-    return evaluator
+# -- per-boundary work distributed over ranks ------------------------------------------------
+def owner_of(i, world):
+    """rank that runs the annular solve / QFS solves of boundary i"""
+    return i % world
+
+
+def exchange_owned(values, shapes, dist=None, group=None, device=None, extra=None):
+    """Every rank contributes the arrays of the boundaries it owns (`values[i]`, shape
+    `shapes[i]`, ignored where `owner_of(i) != rank`) and receives those of all boundaries.
+
+    One all-reduce(SUM) of a zero-filled flat buffer: each position is written by exactly
+    one rank, and x + 0 + ... + 0 == x exactly, so this is a gather with no per-boundary
+    collectives and no ragged bookkeeping.  `extra`: an optional small vector with one entry
+    per boundary (zero for the boundaries of other ranks) that rides along.  Returns the
+    list of numpy arrays (and the summed `extra` when given).  `device`: where the
+    collective runs (a CUDA device for the nccl backend; gloo uses host memory)."""
+    import torch
+    dist, rank, world = _dist_state(dist, group)
+    if world == 1:
+        vals = [np.asarray(v, dtype=np.float64).reshape(s) for v, s in zip(values, shapes)]
+        return vals if extra is None else (vals, np.asarray(extra, dtype=np.float64))
+    sizes = [int(np.prod(s)) for s in shapes]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n_extra = 0 if extra is None else len(extra)
+    flat = np.zeros(int(off[-1]) + n_extra)
+    for i, (v, s) in enumerate(zip(values, shapes)):
+        if owner_of(i, world) == rank:
+            flat[off[i]:off[i + 1]] = np.asarray(v, dtype=np.float64).reshape(-1)
+    if n_extra:
+        flat[off[-1]:] = np.asarray(extra, dtype=np.float64)
+    on_dev = dist.get_backend(group) != "gloo" and device is not None
+    t = torch.as_tensor(flat, device=device) if on_dev else torch.from_numpy(flat)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    flat = t.cpu().numpy() if on_dev else flat
+    vals = [flat[off[i]:off[i + 1]].reshape(s).copy() for i, s in enumerate(shapes)]
+    return vals if extra is None else (vals, flat[off[-1]:].copy())

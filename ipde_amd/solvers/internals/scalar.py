@@ -31,6 +31,25 @@ class ScalarHelper(object):
         from ...layer_potentials import DeviceTargets
         self._interface_dev = DeviceTargets(self.ebdy.interface)
         self._radial_dev = DeviceTargets(self.ebdy.radial_targ)
+        # set by the multi-boundary solver: True when every rank of a torch.distributed job
+        # runs this helper's whole flow (single boundary), so that the M*N x N radial sum of
+        # correct() can be split over the ranks like the grid sum
+        self.shard_radial_sums = False
+        self._radial_sharded = None
+
+    def _radial_sum(self, src, density):
+        """Layer_Apply onto the radial targets (reference :113-114), target-sharded under
+        torch.distributed when the sum is large enough to pay for the all-gather"""
+        if not self.shard_radial_sums:
+            return self.Layer_Apply(src, self._radial_dev, density)
+        if self._radial_sharded is None:
+            from ... import sharding
+            from ...layer_potentials import DeviceTargets
+            from ...pybie2d_compat import PointSet
+            self._radial_sharded = sharding.make_sharded_evaluator(
+                lambda s, t, d: self.Layer_Apply(s, t, d), self.ebdy.radial_targ,
+                lambda x, y: DeviceTargets(PointSet(x=x, y=y)), min_pairs=sharding.MIN_PAIRS_TO_SHARD)
+        return self._radial_sharded(src, density)
 
     def _annular_ctx(self):
         if not self._private_ctx:
@@ -113,6 +132,6 @@ class ScalarHelper(object):
     def finish_correct(self, sigma_r_adj):
         sigma_r_tot = sigma_r_adj + self.sigma_r
         src = self.interface_qfs_r.source
-        rslp = self.Layer_Apply(src, self._radial_dev, sigma_r_tot).cpu().numpy()
+        rslp = self._radial_sum(src, sigma_r_tot).cpu().numpy()
         self.ur = self.ur + rslp.reshape(self.ur.shape)
         return self.ur

@@ -32,6 +32,22 @@ class VectorHelper(object):
         from ...layer_potentials import DeviceTargets
         self._interface_dev = DeviceTargets(self.ebdy.interface)
         self._radial_dev = DeviceTargets(self.ebdy.radial_targ)
+        self.shard_radial_sums = False     # see ScalarHelper
+        self._radial_sharded = None
+
+    def _radial_sum(self, src, density):
+        """(u, v, p) of the stokeslet sum onto the radial targets, target-sharded under
+        torch.distributed when every rank runs this helper (see ScalarHelper._radial_sum)"""
+        if not self.shard_radial_sums:
+            return self.Layer_Apply(src, self._radial_dev, density)
+        if self._radial_sharded is None:
+            from ... import sharding
+            from ...layer_potentials import DeviceTargets
+            from ...pybie2d_compat import PointSet
+            self._radial_sharded = sharding.make_sharded_evaluator(
+                lambda s, t, d: self.Layer_Apply(s, t, d), self.ebdy.radial_targ,
+                lambda x, y: DeviceTargets(PointSet(x=x, y=y)), min_pairs=sharding.MIN_PAIRS_TO_SHARD)
+        return self._radial_sharded(src, density)
 
     def _extract_extra_kwargs(self, **kwargs):
         pass
@@ -152,7 +168,7 @@ class VectorHelper(object):
             sigma_r_tot = sigma_r_adj + self.sigma_r
         src = self.interface_qfs_r.source
         import torch
-        rslp = torch.stack(list(self.Layer_Apply(src, self._radial_dev, sigma_r_tot))).cpu().numpy()
+        rslp = torch.stack(list(self._radial_sum(src, sigma_r_tot))).cpu().numpy()
         self.ur = self.ur + rslp[0].reshape(self.ur.shape)
         self.vr = self.vr + rslp[1].reshape(self.ur.shape)
         self.pr = self.pr + rslp[2].reshape(self.pr.shape) + p_shift

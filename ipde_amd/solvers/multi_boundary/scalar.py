@@ -18,7 +18,7 @@ from ...qfs import call_many, u2s_many
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...device import prewarm_wait
-from ...sharding import make_pnai_evaluator
+from ...sharding import make_pnai_evaluator, exchange_owned, owner_of, is_distributed, _dist_state
 from ...spectral import get_plan
 
 
@@ -52,6 +52,38 @@ def _concurrent_helpers(solver):
     return ok
 
 
+def _owned(solver):
+    """Indices of the boundaries whose annular / QFS work this rank does, and whether that
+    work is distributed at all.  One process, or a single boundary: every rank does
+    everything (replicated, no exchange).  Several boundaries under torch.distributed:
+    boundary i belongs to rank i mod world (reference multi_boundary/scalar.py:98-101 loops
+    over independent helpers); the densities and the annular solutions are exchanged with
+    sharding.exchange_owned."""
+    n = len(solver.helpers)
+    _, rank, world = _dist_state()
+    if world == 1 or n == 1 or not solver.DISTRIBUTE_BOUNDARIES:
+        return list(range(n)), False
+    return [i for i in range(n) if owner_of(i, world) == rank], True
+
+
+def _run_owned(solver, mine, method_start, method_finish, args, solve_many, **kwargs):
+    """start_* on the owned helpers (concurrently when they have contexts of their own),
+    the QFS solves of all of them in one batched substitution, finish_* — results by
+    boundary index (None for the boundaries of other ranks)"""
+    helpers = [solver.helpers[i] for i in mine]
+    margs = [(solver.helpers[i],) + tuple(args[i]) for i in mine]
+    start = lambda a: getattr(a[0], method_start)(*a[1:], **kwargs)
+    if method_start == 'start_call' and len(mine) > 1 and solver._concurrent_helpers():
+        reqs = list(solver._pool.map(start, margs))
+    else:
+        reqs = [start(a) for a in margs]
+    res = _finish_all(helpers, method_finish, reqs, solve_many)
+    out = [None] * len(solver.helpers)
+    for i, r in zip(mine, res):
+        out[i] = r
+    return out
+
+
 class ScalarSolver(object):
     def __init__(self, ebdyc, solver_type='spectral', helpers=None, grid_backend='hip'):
         self.ebdyc = ebdyc
@@ -76,11 +108,16 @@ class ScalarSolver(object):
         self._define_grid_evaluator()
 
     CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other
+    DISTRIBUTE_BOUNDARIES = True  # under torch.distributed: boundary i on rank i mod world
 
     def _concurrent_helpers(self):
         return _concurrent_helpers(self)
 
     def _collect_grid_sources(self):
+        # with a single boundary every rank runs the whole helper flow: its radial sums can
+        # then be sharded collectively (helpers evaluate them through sharded evaluators)
+        for helper in self.helpers:
+            helper.shard_radial_sums = len(self.helpers) == 1 and is_distributed()
         self.grid_sources = BoundaryCollection()
         for helper in self.helpers:
             self.grid_sources.add(helper.interface_qfs_g.source, 'i' if helper.interior else 'e')
@@ -178,24 +215,27 @@ class ScalarSolver(object):
             all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         bvl, bxl, byl = e.v2l(all_bvs[0]), e.v2l(all_bvs[1]), e.v2l(all_bvs[2])
         # annular solves boundary by boundary, then the QFS solves of all boundaries in one
-        # batched substitution (qfs.call_many)
-        args = list(zip(self.helpers, fr_list, bvl, bxl, byl))
-        start = lambda a: a[0].start_call(*a[1:], **kwargs)
-        if self._concurrent_helpers():
-            # (a library context and a host thread per boundary: see VectorSolver)
-            reqs = list(self._pool.map(start, args))
-        else:
-            reqs = [start(a) for a in args]
-        sigmag_list = _finish_all(self.helpers, 'finish_call', reqs, call_many)
-        self.iteration_counts = [helper.iterations_last_call for helper in self.helpers]
+        # batched substitution (qfs.call_many); under torch.distributed each rank does this
+        # for the boundaries it owns and the grid-side densities are exchanged
+        mine, distributed = _owned(self)
+        args = list(zip(fr_list, bvl, bxl, byl))
+        sigmag_list = _run_owned(self, mine, 'start_call', 'finish_call', args, call_many, **kwargs)
+        its = [float(h.iterations_last_call) if i in mine else 0.0 for i, h in enumerate(self.helpers)]
+        if distributed:
+            sigmag_list, its = exchange_owned(sigmag_list, [(h.interface_qfs_g.source.N,) for h in self.helpers],
+                                              device=self._dev, extra=its)
+        self.iteration_counts = [int(i) for i in its]
         sigmag = np.concatenate(sigmag_list)
         out = self.evaluate_to_grid_pnai(sigmag)                 # device, len(grid_pnai)
         n_pna = e.grid_pna.N
         ucf = uc.view(-1)
         ucf[self._pna_idx] += out[:n_pna]
         bus = e.v2l(out[n_pna:].cpu().numpy())
-        reqs = [helper.start_correct(bu) for helper, bu in zip(self.helpers, bus)]
-        urs = _finish_all(self.helpers, 'finish_correct', reqs, u2s_many)
+        urs = _run_owned(self, mine, 'start_correct', 'finish_correct', [(bu,) for bu in bus], u2s_many)
+        if distributed:
+            urs = exchange_owned(urs, [h.ebdy.radial_shape for h in self.helpers], device=self._dev)
+            for h, ur in zip(self.helpers, urs):
+                h.ur = ur
         for ur, (idx, xi, t) in zip(urs, self._ia):
             ucf[idx] = chebyshev_fourier_eval(ur, xi, t)
         ucf *= self._phys_d.view(-1)

@@ -14,9 +14,9 @@ from ...interp import periodic_interp2d, chebyshev_fourier_eval
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...qfs import call_many, u2s_many
-from .scalar import _finish_all, _concurrent_helpers
+from .scalar import _finish_all, _concurrent_helpers, _owned, _run_owned
 from ...device import prewarm_wait
-from ...sharding import make_pnai_evaluator
+from ...sharding import make_pnai_evaluator, exchange_owned, is_distributed
 from ...spectral import get_plan
 
 
@@ -44,11 +44,14 @@ class VectorSolver(object):
         self._make_device_state()
 
     CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other
+    DISTRIBUTE_BOUNDARIES = True  # under torch.distributed: boundary i on rank i mod world
 
     def _concurrent_helpers(self):
         return _concurrent_helpers(self)
 
     def _collect_grid_sources(self):
+        for helper in self.helpers:
+            helper.shard_radial_sums = len(self.helpers) == 1 and is_distributed()
         self.grid_sources = BoundaryCollection()
         for helper in self.helpers:
             self.grid_sources.add(helper.interface_qfs_g.source, 'i' if helper.interior else 'e')
@@ -152,18 +155,20 @@ class VectorSolver(object):
         bvals = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         bul, bvl, btxxl, btxyl, btyyl = (e.v2l(b) for b in bvals)
         # annular solves boundary by boundary, then the QFS solves of all boundaries in one
-        # batched substitution (qfs.call_many)
-        args = list(zip(self.helpers, fur_list, fvr_list, bul, bvl, btxxl, btxyl, btyyl))
-        start = lambda a: a[0].start_call(*a[1:], **kwargs)
-        if self._concurrent_helpers():
-            # every annular solver has its own library context (stream, buffers, plans): the
-            # latency-bound GMRES solves of the boundaries overlap on the GPU, each driven by
-            # its own host thread (the library call releases the GIL)
-            reqs = list(self._pool.map(start, args))
-        else:
-            reqs = [start(a) for a in args]
-        sigmag_list = _finish_all(self.helpers, 'finish_call', reqs, call_many)
-        self.iteration_counts = [helper.iterations_last_call for helper in self.helpers]
+        # batched substitution (qfs.call_many).  Every annular solver has its own library
+        # context (stream, buffers, plans): the latency-bound GMRES solves of the boundaries
+        # overlap on the GPU, each driven by its own host thread (the library call releases the
+        # GIL).  Under torch.distributed boundary i is rank (i mod world)'s; the grid-side
+        # densities and, at the end, the annular solutions are exchanged.
+        mine, distributed = _owned(self)
+        args = list(zip(fur_list, fvr_list, bul, bvl, btxxl, btxyl, btyyl))
+        sigmag_list = _run_owned(self, mine, 'start_call', 'finish_call', args, call_many, **kwargs)
+        its = [float(h.iterations_last_call) if i in mine else 0.0 for i, h in enumerate(self.helpers)]
+        if distributed:
+            sigmag_list, its = exchange_owned(
+                sigmag_list, [(2, h.interface_qfs_g.source.N) for h in self.helpers],
+                device=self._dev, extra=its)
+        self.iteration_counts = [int(i) for i in its]
         sigmag = np.column_stack(sigmag_list)
         out = self.Grid_Evaluator(sigmag)                          # device (u, v, p) on grid_pnai
         n_pna = e.grid_pna.N
@@ -172,9 +177,15 @@ class VectorSolver(object):
             f[self._pna_idx] += o[:n_pna]
         bus, bvs, bps = (e.v2l(o) for o in torch.stack([o[n_pna:] for o in out]).cpu().numpy())
         single_ebdy = len(e) == 1
-        reqs = [helper.start_correct(bu, bv, bp, single_ebdy)
-                for helper, bu, bv, bp in zip(self.helpers, bus, bvs, bps)]
-        urs, vrs, prs = zip(*_finish_all(self.helpers, 'finish_correct', reqs, u2s_many))
+        res = _run_owned(self, mine, 'start_correct', 'finish_correct',
+                         [(bu, bv, bp, single_ebdy) for bu, bv, bp in zip(bus, bvs, bps)], u2s_many)
+        if distributed:
+            shapes = [(3,) + tuple(h.ebdy.radial_shape) for h in self.helpers]
+            res = exchange_owned([None if r is None else np.stack(r) for r in res], shapes,
+                                 device=self._dev)
+            for h, r in zip(self.helpers, res):
+                h.ur, h.vr, h.pr = r[0], r[1], r[2]
+        urs, vrs, prs = zip(*res)
         for k, (f, rs) in enumerate(zip(fields, (urs, vrs, prs))):
             for r, (idx, xi, t) in zip(rs, self._ia):
                 f[idx] = chebyshev_fourier_eval(r, xi, t)

@@ -149,3 +149,51 @@ def test_stokes_solver_matches_oracle_mid_size():
     ur, ut, p = S.solve(rag, fr, ft, z, z, z, z, tol=1e-12, maxiter=300, restart=100)
     our, out, op = O.solve(orag, fr, ft, z, z, z, z, tol=1e-12, maxiter=300, restart=100)
     assert rel_err(ur, our) < 1e-8 and rel_err(ut, out) < 1e-8 and rel_err(p, op) < 1e-8
+
+
+def test_gmres_argument_checks(gs, scalar_geo):
+    """restart beyond the pinned Hessenberg buffer and tol <= 0 are refused (status, no
+    overrun); a restart larger than maxiter is clamped to it"""
+    from ipde_amd._lib import IpdeHipError
+    from ipde_amd.annular.poisson import AnnularPoissonSolver
+    aag, rag = scalar_geo
+    S = AnnularPoissonSolver(aag)
+    args = (rag, gs["po_force"], gs["po_ig"], gs["po_og"])
+    with pytest.raises(IpdeHipError, match="invalid argument"):
+        S.solve(*args, tol=1e-12, maxiter=5000, restart=3000)
+    with pytest.raises(IpdeHipError, match="invalid argument"):
+        S.solve(*args, tol=0.0, maxiter=50, restart=20)
+    u = S.solve(*args, tol=1e-13, maxiter=200, restart=10 ** 6)    # clamped to maxiter = 200
+    assert rel_err(u, gs["po_sol_ref"]) < 1e-10
+
+
+def test_plan_creation_from_two_threads_on_private_contexts():
+    """Two host threads, each with a library context of its own, create (never-seen-before)
+    batched 1-D and 2-D rocFFT plans at the same time and run them: plan creation is
+    serialised inside the library (g_rocfft_plan_mutex), results are those of numpy."""
+    import threading
+    import torch
+    from ipde_amd.device import private_context
+    from ipde_amd.spectral import GridPlan, fft1
+    errs = []
+
+    def work(seed, n1, n2):
+        try:
+            ctx = private_context()
+            rng = np.random.default_rng(seed)
+            a = rng.standard_normal((7, n1)) + 1j * rng.standard_normal((7, n1))
+            got = fft1(a, -1, ctx=ctx)
+            assert rel_err(got, np.fft.fft(a, axis=1)) < 1e-13
+            f = rng.standard_normal((n2, n2 + 2))
+            plan = GridPlan(n2, n2 + 2, 0.1, 0.1, ctx)
+            assert rel_err(plan.fft2(f), np.fft.fft2(f)) < 1e-13
+            plan.close()
+        except Exception as e:       # pragma: no cover
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work, args=(1, 1234, 118)),
+          threading.Thread(target=work, args=(2, 1238, 122))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs

@@ -63,3 +63,22 @@ def test_embedded_boundary_warns_when_the_annulus_folds():
                                  heaviside=SlepianMollifier(24).step)
         assert (len(w) > 0) == expect
         assert (e.min_radial_jacobian < 0.25) == expect
+
+
+def test_prewarm_wait_raises_instead_of_carrying_on(monkeypatch):
+    """the join of the warm-up thread must not fall through on a timeout (it exists so that
+    rocFFT plan creation is never entered from two threads)"""
+    import queue
+    import pytest
+    from ipde_amd import device
+    from ipde_amd._lib import IpdeHipError
+    q = queue.Queue()
+    q.put(lambda: None)                 # a job nobody will ever finish
+    monkeypatch.setitem(device._warm, "queue", q)
+    monkeypatch.setitem(device._warm, "thread", None)
+    monkeypatch.setattr(device, "PREWARM_TIMEOUT_S", 0.2)
+    with pytest.raises(IpdeHipError, match="warm-up"):
+        device.prewarm_wait()
+    q.get()
+    q.task_done()
+    device.prewarm_wait()               # idle queue: returns at once

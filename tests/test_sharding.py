@@ -145,3 +145,110 @@ def test_pnai_evaluator_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(r, True) for r in range(world)], results
+
+
+def _worker_new_paths(rank, world, port, q):
+    """ResultGather (preallocated all_gather_into_tensor, one collective per tuple),
+    make_sharded_evaluator with its small-sum bypass, exchange_owned, and the solvers'
+    boundary-ownership helpers (_owned / _run_owned) on stub helpers."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from ipde_amd import sharding
+        from ipde_amd.sharding import ResultGather, make_sharded_evaluator, exchange_owned, owner_of
+        from oracle import layer_potentials as olp
+        from util import Curve, Points
+        ok = True
+        # ragged (1001) and even (world * 50) lengths, 1 and 3 components, buffers reused
+        for nt in (1001, world * 50, 2, 0):
+            for ncomp in (1, 3):
+                g = ResultGather(nt, ncomp)
+                sl = target_slice(nt, rank, world)
+                for rep in range(2):
+                    full = [torch.arange(nt, dtype=torch.float64) * (c + 1) + rep for c in range(ncomp)]
+                    got = g(tuple(f[sl] for f in full))
+                    ok = ok and all(torch.equal(a, b) for a, b in zip(got, full))
+                    first = got if rep == 0 else first
+                # results of the first call must not alias the reused receive buffer
+                ok = ok and all(torch.equal(a, torch.arange(nt, dtype=torch.float64) * (c + 1))
+                                for c, a in enumerate(first))
+        # sharded evaluator: sharded path and the min_pairs bypass give the same numbers
+        c = Curve(64, a=0.2, f=5)
+        rng = np.random.default_rng(0)
+        trg = Points(rng.uniform(-0.5, 0.5, 1001), rng.uniform(-0.5, 0.5, 1001))
+        sigma = rng.standard_normal(c.N)
+        calls = []
+
+        def la(src, t, d):
+            calls.append(t.N)
+            return torch.as_tensor(olp.laplace_layer_apply(src.x, src.y, t.x, t.y, charge=d,
+                                                           weights=src.weights))
+        ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=sigma, weights=c.weights)
+        ev = make_sharded_evaluator(la, trg, lambda x, y: Points(x, y))
+        ok = ok and np.allclose(ev(c, sigma).numpy(), ref, rtol=0, atol=1e-13) and calls[-1] < 1001
+        ev = make_sharded_evaluator(la, trg, lambda x, y: Points(x, y), min_pairs=1e9)
+        ok = ok and np.allclose(ev(c, sigma).numpy(), ref, rtol=0, atol=1e-13) and calls[-1] == 1001
+        # exchange_owned: ragged per-boundary arrays + a ride-along vector
+        nb = 5
+        shapes = [(3 + i, 2) for i in range(nb)]
+        truth = [np.random.default_rng(i).standard_normal(s) for i, s in enumerate(shapes)]
+        vals = [t if owner_of(i, world) == rank else None for i, t in enumerate(truth)]
+        extra = [float(10 + i) if owner_of(i, world) == rank else 0.0 for i in range(nb)]
+        got, ex = exchange_owned(vals, shapes, extra=extra)
+        ok = ok and all(np.array_equal(a, b) for a, b in zip(got, truth))
+        ok = ok and np.array_equal(ex, 10.0 + np.arange(nb))
+        # the solvers' ownership helpers on stub helpers
+        from ipde_amd.solvers.multi_boundary.scalar import _owned, _run_owned
+
+        class Helper:
+            def __init__(self, i):
+                self.i = i
+                self.started = 0
+
+            def start_call(self, a, b, scale=1.0):
+                self.started += 1
+                return [("req", self.i, a + b, scale)]
+
+            def finish_call(self, res):
+                return np.full(4, res)
+
+        class Solver:
+            DISTRIBUTE_BOUNDARIES = True
+            helpers = [Helper(i) for i in range(nb)]
+
+            def _concurrent_helpers(self):
+                return False
+        s = Solver()
+        mine, distributed = _owned(s)
+        ok = ok and distributed and mine == [i for i in range(nb) if i % world == rank]
+        solve_many = lambda reqs: [r[1] * 100 + r[2] * r[3] for r in reqs]
+        out = _run_owned(s, mine, 'start_call', 'finish_call', [(i, 1) for i in range(nb)], solve_many,
+                         scale=2.0)
+        ok = ok and all((out[i] is None) == (i not in mine) for i in range(nb))
+        ok = ok and all(h.started == (1 if i in mine else 0) for i, h in enumerate(s.helpers))
+        full = exchange_owned(out, [(4,)] * nb)
+        ok = ok and all(np.array_equal(full[i], np.full(4, i * 100 + (i + 1) * 2.0)) for i in range(nb))
+        one = Solver()
+        one.helpers = one.helpers[:1]
+        ok = ok and _owned(one) == ([0], False)       # a single boundary stays replicated
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bool(ok)))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_exchange_and_ownership_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_new_paths, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, True) for r in range(world)], results

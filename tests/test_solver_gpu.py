@@ -80,8 +80,20 @@ def test_stokes_multiply_connected():
     import multi_stokes
     ue, ve, pe, scale, T = multi_stokes.run(nb=600, M=14)
     print(ue, ve, pe, scale, T)
-    assert max(ue, ve) / scale < 5e-6
-    assert pe < 5e-3
+    # at n_b = 600 the strongly curved outer annulus limits the resolution (measured 1.2e-6 /
+    # 1.1e-3); the kernels' own accuracy shows at n_b = 800 below and at configs[4] size in
+    # tests/test_configs_gpu.py
+    assert max(ue, ve) / scale < 3e-6
+    assert pe < 3e-3
+
+
+def test_stokes_multiply_connected_resolved():
+    """the same problem at the example's default resolution (n_b = 800, M = 14)"""
+    import multi_stokes
+    ue, ve, pe, scale, T = multi_stokes.run(nb=800, M=14)
+    print(ue, ve, pe, scale, T)
+    assert max(ue, ve) / scale < 1e-10
+    assert pe < 5e-7
 
 
 def test_concurrent_annular_solves_equal_sequential_ones():
