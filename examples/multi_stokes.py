@@ -39,7 +39,7 @@ def v2f(x):
 
 
 def run(nb=800, M=14, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes=True,
-        return_fields=False, simple=False, warm=False, grid_backend=None):
+        return_fields=False, simple=False, warm=False, grid_backend=None, ng=None):
     T = {}
     t0 = time.perf_counter()
     MOL = SlepianMollifier(1.5 * M)
@@ -53,7 +53,8 @@ def run(nb=800, M=14, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes
     bdys = [GSB(*arc_length_parameterize(bd.x, bd.y)) for bd in bdys]
     bdy1 = bdys[0]
     bh = min(bd.dt * bd.speed.min() for bd in bdys)
-    ng = 2 * int(0.5 * 2 * L // bh)
+    if ng is None:      # grid spacing matched to the boundary spacing (reference :48-52)
+        ng = 2 * int(0.5 * 2 * L // bh)
     grid = Grid([-L, L], ng, [-L, L], ng, x_endpoints=[True, False], y_endpoints=[True, False])
     ebdys = [EmbeddedBoundary(bd, bd is bdy1, M, bh, pad_zone=0, heaviside=MOL.step, qfs_tolerance=1e-14)
              for bd in bdys]

@@ -9,7 +9,7 @@ interpolations and derivatives evaluate on the device.
 import numpy as np
 
 from .device import prewarm
-from .embedded_function import EmbeddedFunction
+from .embedded_function import EmbeddedFunction, BoundaryFunction  # noqa: F401  (re-exported: reference examples import it from here)
 from .near import grid_inside_curve, local_coordinates, points_inside_curve
 from .pybie2d_compat import Grid, PointSet
 from .utilities import affine_transformation

@@ -21,10 +21,17 @@ def setit(n, dictionary, default):
 
 
 class EmbeddedBoundary(object):
-    def __init__(self, bdy, interior, M, h, **kwargs):
+    def __init__(self, bdy, interior, M, h, *legacy, **kwargs):
         # library loads and the length-N 1-D FFT kernels (annular solver, radial
         # interpolation) compile while the host does the geometry set-up
         prewarm(fft1=((M, bdy.N),))
+        # old call form (reference examples/interior_modified_helmholtz.py:41):
+        # EmbeddedBoundary(bdy, interior, M, h, pad_zone, heaviside)
+        if len(legacy) > 2:
+            raise TypeError("EmbeddedBoundary(bdy, interior, M, h[, pad_zone[, heaviside]], **kwargs)")
+        for name, val in zip(('pad_zone', 'heaviside'), legacy):
+            kwargs.setdefault(name, val)
+        self._solo = None
         """bdy: Global_Smooth_Boundary; interior: bool; M: radial modes; h: radial grid
         spacing (radial_width = M*h).  kwargs as the reference (:106-112): pad_zone,
         heaviside, qfs_tolerance, coordinate_tolerance, ... (unknown ones are kept)."""
@@ -148,6 +155,29 @@ class EmbeddedBoundary(object):
         arts = affine_transformation(self.radial_rv, lbh, 0, -1, 1)
         self.radial_cutoff = self.heaviside(arts)
         return self._near
+
+    # -- the old single-boundary API (reference examples/interior_modified_helmholtz.py:44-56:
+    # `ebdy.register_grid(grid)` on a bare boundary, then ebdy.phys / ebdy.ext / ...) through a
+    # one-boundary collection built on demand
+    def solo_collection(self):
+        if self._solo is None or self._solo.grid is not self.grid:
+            from .ebdy_collection import EmbeddedBoundaryCollection
+            c = EmbeddedBoundaryCollection([self])
+            c.register_grid(self.grid)
+            self._solo = c
+        return self._solo
+
+    phys = property(lambda self: self.solo_collection().phys)
+    ext = property(lambda self: self.solo_collection().ext)
+    grid_step = property(lambda self: self.solo_collection().grid_step)
+    grid_in_annulus = property(lambda self: self.solo_collection().in_annulus)
+    grid_not_in_annulus = property(lambda self: self.solo_collection().phys_not_in_annulus)
+
+    def interpolate_grid_to_interface(self, f, order=np.inf, cutoff=None):
+        return self.solo_collection().interpolate_grid_to_interface(f, order=order, cutoff=cutoff)
+
+    def interpolate_radial_to_grid(self, fr, f):
+        return self.interpolate_radial_to_grid1(fr, f)
 
     def register_ia_inds(self, phys_inds):
         self.ia_inds = phys_inds[self.grid_ia_xind, self.grid_ia_yind]

@@ -61,6 +61,25 @@ class Global_Smooth_Boundary(PointSet):
         self.max_h = np.max(self.weights)
         self.area = 0.5 * np.sum((self.x * self.normal_x + self.y * self.normal_y) * self.weights)
 
+    # self-interaction forms as METHODS: the call shape of the pybie2d generation the
+    # reference's single-boundary code was written against
+    # (ipde/solvers/single_boundary/interior/modified_helmholtz.py:36,
+    # examples/interior_modified_helmholtz.py:73,76).  That generation scaled the
+    # modified-Helmholtz double layer by k^2 (the example pairs it with a jump of k^2/2;
+    # SURVEY §9.13): `Modified_Helmholtz_DLP_Self_Form` keeps that scaling so the old
+    # scripts stay consistent; everything else in this package is unscaled.
+    def Laplace_SLP_Self_Form(self):
+        return Laplace_Layer_Singular_Form(self, ifcharge=True)
+
+    def Laplace_DLP_Self_Form(self):
+        return Laplace_Layer_Singular_Form(self, ifdipole=True)
+
+    def Modified_Helmholtz_SLP_Self_Form(self, k=1.0):
+        return Modified_Helmholtz_Layer_Singular_Form(self, k=k, ifcharge=True)
+
+    def Modified_Helmholtz_DLP_Self_Form(self, k=1.0):
+        return k * k * Modified_Helmholtz_Layer_Singular_Form(self, k=k, ifdipole=True)
+
     def generate_resampled_boundary(self, new_N):
         return Global_Smooth_Boundary(c=fourier_resample(self.c, new_N))
 

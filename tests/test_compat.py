@@ -1,0 +1,187 @@
+"""The drop-in import surface: every module path and attribute chain the
+reference's example scripts resolve at import time must resolve here after
+`ipde_amd.compat.install()`, to this package's objects.  The names are listed in this file
+(they are the public API names of ipde / pybie2d / qfs / personal_utilities that
+examples/interior_poisson.py, interior_modified_helmholtz.py, multi_stokes.py and
+multi_modified_helmholtz_update_to_sparse.py of the reference use)."""
+import importlib
+import subprocess
+import sys
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+FROM_IMPORTS = [
+    ("ipde.embedded_boundary", "EmbeddedBoundary"),
+    ("ipde.ebdy_collection", "EmbeddedBoundaryCollection"),
+    ("ipde.ebdy_collection", "BoundaryFunction"),
+    ("ipde.embedded_function", "EmbeddedFunction"),
+    ("ipde.embedded_function", "BoundaryFunction"),
+    ("ipde.heavisides", "SlepianMollifier"),
+    ("ipde.derivatives", "fd_x_4"), ("ipde.derivatives", "fd_y_4"), ("ipde.derivatives", "fourier"),
+    ("ipde.utilities", "fft2"), ("ipde.utilities", "ifft2"), ("ipde.utilities", "mfft"),
+    ("ipde.utilities", "affine_transformation"),
+    ("ipde.solvers.multi_boundary.poisson", "PoissonSolver"),
+    ("ipde.solvers.multi_boundary.modified_helmholtz", "ModifiedHelmholtzSolver"),
+    ("ipde.solvers.multi_boundary.stokes", "StokesSolver"),
+    ("ipde.solvers.internals.poisson", "PoissonHelper"),
+    ("ipde.solvers.internals.modified_helmholtz", "ModifiedHelmholtzHelper"),
+    ("ipde.solvers.internals.stokes", "StokesHelper"),
+    ("ipde.solvers.single_boundary.interior.modified_helmholtz", "ModifiedHelmholtzSolver"),
+    ("ipde.solvers.single_boundary.interior.poisson", "PoissonSolver"),
+    ("ipde.annular.annular", "ApproximateAnnularGeometry"),
+    ("ipde.annular.annular_full", "RealAnnularGeometry"),
+    ("ipde.annular.poisson", "AnnularPoissonSolver"),
+    ("ipde.annular.modified_helmholtz", "AnnularModifiedHelmholtzSolver"),
+    ("ipde.annular.stokes", "AnnularStokesSolver"),
+    ("ipde.grid_evaluators.laplace_grid_evaluator", "LaplaceFreespaceGridEvaluator"),
+    ("ipde.grid_evaluators.laplace_grid_evaluator", "LaplaceGridBackend"),
+    ("ipde.grid_evaluators.modified_helmholtz_grid_evaluator", "ModifiedHelmholtzGridBackend"),
+    ("qfs.two_d_qfs", "QFS_Evaluator"),
+    ("qfs.stokes_qfs", "Stokes_QFS"),
+    ("qfs.laplace_qfs", "Laplace_QFS"),
+    ("qfs.modified_helmholtz_qfs", "Modified_Helmholtz_QFS"),
+    ("personal_utilities.arc_length_reparametrization", "arc_length_parameterize"),
+]
+
+PYBIE2D_CHAINS = [
+    "misc.curve_descriptions.star",
+    "misc.curve_descriptions.squished_circle",
+    "boundaries.global_smooth_boundary.global_smooth_boundary.Global_Smooth_Boundary",
+    "boundaries.collection.BoundaryCollection",
+    "grid.Grid",
+    "point_set.PointSet",
+    "kernels.high_level.laplace.Laplace_Layer_Singular_Form",
+    "kernels.high_level.laplace.Laplace_Layer_Form",
+    "kernels.high_level.laplace.Laplace_Layer_Apply",
+    "kernels.high_level.modified_helmholtz.Modified_Helmholtz_Layer_Form",
+    "kernels.high_level.modified_helmholtz.Modified_Helmholtz_Layer_Apply",
+    "kernels.high_level.stokes.Stokes_Layer_Singular_Form",
+    "kernels.high_level.stokes.Stokes_Layer_Form",
+    "kernels.high_level.stokes.Stokes_Layer_Apply",
+]
+
+_CHECK = r"""
+import sys, importlib
+sys.path.insert(0, %r)
+import ipde_amd.compat as C
+filled = C.install()
+assert C.install() == []                      # idempotent
+sys.path.insert(0, %r)
+from test_compat import FROM_IMPORTS, PYBIE2D_CHAINS
+for mod, name in FROM_IMPORTS:
+    m = importlib.import_module(mod)
+    obj = getattr(m, name)
+    real = importlib.import_module("ipde_amd" + mod[4:]) if mod.startswith("ipde") else None
+    if real is not None:
+        assert m is real, mod                 # an alias of the SAME module object, not a copy
+        assert real.__spec__.name.startswith("ipde_amd"), real.__spec__.name
+import pybie2d
+for chain in PYBIE2D_CHAINS:
+    obj = pybie2d
+    for part in chain.split("."):
+        obj = getattr(obj, part)
+    assert callable(obj), chain
+    importlib.import_module("pybie2d." + chain.rsplit(".", 1)[0])
+import ipde_amd.pybie2d_compat as P, ipde_amd.layer_potentials as L
+assert pybie2d.kernels.high_level.laplace.Laplace_Layer_Apply is L.Laplace_Layer_Apply
+assert pybie2d.misc.curve_descriptions.star is P.star
+# classes are identical through both names
+from ipde.embedded_boundary import EmbeddedBoundary
+from ipde_amd.embedded_boundary import EmbeddedBoundary as E2
+assert EmbeddedBoundary is E2
+print("ok", sorted(filled))
+"""
+
+
+def test_every_reference_import_name_resolves():
+    """in a fresh interpreter (install() edits sys.modules / sys.meta_path)"""
+    out = subprocess.run([sys.executable, "-c", _CHECK % (ROOT, os.path.join(ROOT, "tests"))],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.strip().endswith("ok ['ipde', 'personal_utilities', 'pybie2d', 'qfs']")
+
+
+def test_legacy_embedded_boundary_call_form_and_self_forms():
+    """EmbeddedBoundary(bdy, interior, M, h, pad_zone, heaviside) positionally, and the
+    boundary's *_Self_Form methods (old pybie2d generation; the modified-Helmholtz double
+    layer carries that generation's k^2)"""
+    from ipde_amd.embedded_boundary import EmbeddedBoundary
+    from ipde_amd.heavisides import SlepianMollifier
+    from ipde_amd.pybie2d_compat import (star, Global_Smooth_Boundary as GSB,
+                                         Modified_Helmholtz_Layer_Singular_Form,
+                                         Laplace_Layer_Singular_Form)
+    bdy = GSB(c=star(300, a=0.1, f=5))
+    mol = SlepianMollifier(12)
+    e = EmbeddedBoundary(bdy, True, 6, bdy.dt * bdy.speed.min(), 0, mol.step)
+    assert e.pad_zone == 0 and e.heaviside == mol.step
+    with pytest.raises(TypeError):
+        EmbeddedBoundary(bdy, True, 6, 0.01, 0, mol.step, "extra")
+    k = 2.0
+    D = Modified_Helmholtz_Layer_Singular_Form(bdy, k=k, ifdipole=True)
+    assert np.allclose(bdy.Modified_Helmholtz_DLP_Self_Form(k=k), k * k * D, rtol=0, atol=1e-15)
+    assert np.array_equal(bdy.Modified_Helmholtz_SLP_Self_Form(k=k),
+                          Modified_Helmholtz_Layer_Singular_Form(bdy, k=k, ifcharge=True))
+    assert np.array_equal(bdy.Laplace_DLP_Self_Form(), Laplace_Layer_Singular_Form(bdy, ifdipole=True))
+
+
+@pytest.mark.gpu
+def test_single_boundary_adapter_drives_the_old_example_flow():
+    """The flow of the reference's examples/interior_modified_helmholtz.py (:28-101) written
+    against the names that script imports (through ipde_amd.compat): bare EmbeddedBoundary +
+    register_grid, single-boundary ModifiedHelmholtzSolver(ebdy, k)(f, fr), the double-layer
+    correction with that script's k^2 convention, MH_Layer_Apply onto solver.radp / gridpa."""
+    import ipde_amd.compat as C
+    C.install()
+    import pybie2d
+    from ipde.embedded_boundary import EmbeddedBoundary
+    from ipde.heavisides import SlepianMollifier
+    from ipde.solvers.single_boundary.interior.modified_helmholtz import ModifiedHelmholtzSolver
+    from qfs.two_d_qfs import QFS_Evaluator
+    from personal_utilities.arc_length_reparametrization import arc_length_parameterize
+    star = pybie2d.misc.curve_descriptions.star
+    GSB = pybie2d.boundaries.global_smooth_boundary.global_smooth_boundary.Global_Smooth_Boundary
+    Grid = pybie2d.grid.Grid
+    MH_Layer_Form = pybie2d.kernels.high_level.modified_helmholtz.Modified_Helmholtz_Layer_Form
+    MH_Layer_Apply = pybie2d.kernels.high_level.modified_helmholtz.Modified_Helmholtz_Layer_Apply
+    nb, helmholtz_k, M = 600, 2.0, 16
+    MOL = SlepianMollifier(1.5 * M)
+    bdy = GSB(c=star(nb, a=0.1, f=5))
+    bdy = GSB(*arc_length_parameterize(bdy.x, bdy.y))
+    bh = bdy.dt * bdy.speed.min()
+    ng = 2 * int(0.5 * 2.4 // bh)
+    grid = Grid([-1.2, 1.2], ng, [-1.2, 1.2], ng, x_endpoints=[True, False], y_endpoints=[True, False])
+    ebdy = EmbeddedBoundary(bdy, True, M, bh * 1, 0, MOL.step)
+    ebdy.register_grid(grid)
+    k = np.pi / 3
+    solution_func = lambda x, y: np.exp(np.sin(k * x)) * np.sin(k * y)
+    force_func = lambda x, y: helmholtz_k ** 2 * solution_func(x, y) \
+        - k ** 2 * np.exp(np.sin(k * x)) * np.sin(k * y) * (np.cos(k * x) ** 2 - np.sin(k * x) - 1.0)
+    f = force_func(ebdy.grid.xg, ebdy.grid.yg) * ebdy.phys
+    fr = force_func(ebdy.radial_x, ebdy.radial_y)
+    ua = solution_func(ebdy.grid.xg, ebdy.grid.yg) * ebdy.phys
+    uar = solution_func(ebdy.radial_x, ebdy.radial_y)
+    bc = solution_func(ebdy.bdy.x, ebdy.bdy.y)
+    solver = ModifiedHelmholtzSolver(ebdy, helmholtz_k, solver_type='spectral')
+    ue, uer = solver(f, fr, tol=1e-12, verbose=False)
+    assert ue.shape == grid.shape and uer.shape == (M, nb)
+    assert not np.any(ue[ebdy.ext])
+    A = bdy.Modified_Helmholtz_DLP_Self_Form(k=helmholtz_k) - 0.5 * np.eye(bdy.N) * helmholtz_k ** 2
+    bv = solver.get_bv(uer)
+    tau = np.linalg.solve(A, bc - bv)
+    Singular_DLP = lambda src, _: src.Modified_Helmholtz_DLP_Self_Form(k=helmholtz_k) \
+        - 0.5 * np.eye(src.N) * helmholtz_k ** 2
+    Naive_SLP = lambda src, trg: MH_Layer_Form(src, trg, k=helmholtz_k, ifcharge=True)
+    qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [Singular_DLP, ], Naive_SLP, on_surface=True, form_b2c=False)
+    sigma = qfs([tau, ])
+    rslp = MH_Layer_Apply(ebdy.bdy_qfs.interior_source_bdy, solver.radp, charge=sigma, k=helmholtz_k)
+    gslp = MH_Layer_Apply(ebdy.bdy_qfs.interior_source_bdy, solver.gridpa, charge=sigma, k=helmholtz_k)
+    uer += rslp.reshape(uer.shape)
+    ue[ebdy.phys] += gslp
+    rerr = np.abs(uer - uar).max()
+    gerr = np.abs(ue - ua)[ebdy.phys].max()
+    print(gerr, rerr)
+    assert gerr < 1e-11 and rerr < 1e-11
