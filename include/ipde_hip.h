@@ -78,7 +78,8 @@ const char* ipde_last_error(ipde_ctx* ctx);
 /* Average duration in ms of the dominant kernel of the LAST layer-potential
    apply, measured with hipEvents on the context's stream (0 if timing is off). */
 /* Tuning knobs (kernel geometry variants); never changes results beyond rounding.
-   Names: "laplace_variant", "stokes_variant", "dense_pairs", "annular_grouped". */
+   Names: "laplace_variant", "stokes_variant", "dense_pairs", "annular_grouped",
+   "fft2d" (1: hand-written 2-D FFT pipeline on power-of-two grids, 0: rocFFT). */
 int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value);
 /* Current value of a knob (so that a caller can restore what it found). */
 int ipde_ctx_get_option(ipde_ctx* ctx, const char* name, int* value);

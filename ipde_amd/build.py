@@ -27,6 +27,7 @@ SOURCES = [
     "layer_modhelm.hip",
     "layer_stokes.hip",
     "spectral.hip",
+    "fft2d.hip",
     "annular.hip",
     "ewald.hip",
     "dense.hip",

@@ -1,0 +1,591 @@
+// Hand-written 2-D real FFT pipeline for the periodic grid operators on
+// power-of-two grids: three kernels per "ifft2(fft2(f) * S).real" instead of rocFFT's nine.
+//
+//   row_r2c   : every grid row (ny reals) -> packed half spectrum row (ny/2 complex, the real
+//               Nyquist entry in the imaginary part of entry 0), one pass over HBM: the
+//               packed-real trick (a length ny/2 complex FFT + one butterfly with the
+//               mirrored entry) entirely in registers / LDS.
+//   col_kernel: for a block of C = 4 adjacent ky columns: forward length-nx FFT, multiply by
+//               the (Hermitian-symmetrised, scaled) operator symbol, inverse FFT — the
+//               spectrum never goes back to HBM between the two transforms.  Global access is
+//               64-byte row segments of the row-major half spectrum (measured 5.5 / 6.0 TB/s
+//               read / write with enough workgroups, profiles/r02_segment_bw_probe.txt);
+//               blocks are handed out XCD-aware so neighbouring blocks share L2 lines.
+//   row_c2r   : packed half spectrum rows -> real rows (mirror butterfly + length ny/2 FFT).
+//
+// HBM traffic: 3 x (read + write of one field) = 201 MB at 2048^2 against 604 MB for the
+// rocFFT pipeline it replaces (profiles/r02_fft_rocfft_breakdown.json).  Roofline: HBM.
+//
+// The FFT itself: Stockham autosort, three passes (radix 16 / 8 / 4 butterflies in
+// registers), a thread holds P = 16 (8) points in the "strided natural" layout
+// a[t + T q]; between passes the points travel through LDS (one complex slot per point,
+// ds_write_b128 / ds_read_b128), positions padded by one slot every 16 so that the radix-16
+// scatter (lane stride 16 slots) is bank-conflict free.  First-pass inputs and last-pass
+// outputs stay in registers in natural order, so operator symbols and the real-transform
+// butterflies index plainly.  64-thread transforms own their LDS region: no barriers.
+//
+// Sizes: nx in {512, 1024, 2048, 4096}, ny in {1024, 2048, 4096, 8192}; everything else
+// stays on the rocFFT path (spectral.hip).
+#include "ipde_common.h"
+#include "fft2d.h"
+
+namespace {
+
+struct cd {
+    double x, y;
+};
+__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cmul(cd a, cd b) {
+    return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+__device__ __forceinline__ cd cconj(cd a) { return cd{a.x, -a.y}; }
+// multiply by exp(SIGN * i * pi / 2) = SIGN * i
+template <int SIGN>
+__device__ __forceinline__ cd rot90(cd a) {
+    return SIGN > 0 ? cd{-a.y, a.x} : cd{a.y, -a.x};
+}
+// multiply by the constant (c, SIGN * s)
+template <int SIGN>
+__device__ __forceinline__ cd mulc(cd a, double c, double s) {
+    return SIGN > 0 ? cd{a.x * c - a.y * s, a.x * s + a.y * c} : cd{a.x * c + a.y * s, a.y * c - a.x * s};
+}
+
+#define C_PI8 0.92387953251128675613   // cos(pi/8)
+#define S_PI8 0.38268343236508977173   // sin(pi/8)
+#define R_HALF 0.70710678118654752440  // sqrt(1/2)
+
+// ---- small DFTs, natural-order output, w = exp(SIGN 2 pi i / R) -----------------------
+template <int SIGN>
+__device__ __forceinline__ void dft4(cd& a, cd& b, cd& c, cd& d) {
+    cd s0 = a + c, s1 = a - c, s2 = b + d, s3 = rot90<SIGN>(b - d);
+    a = s0 + s2;
+    b = s1 + s3;
+    c = s0 - s2;
+    d = s1 - s3;
+}
+
+template <int R, int SIGN>
+struct Dft;
+
+template <int SIGN>
+struct Dft<4, SIGN> {
+    static __device__ __forceinline__ void run(cd (&u)[4]) { dft4<SIGN>(u[0], u[1], u[2], u[3]); }
+};
+
+// n = n0 + 2 n1, k = k1 + 4 k0
+template <int SIGN>
+struct Dft<8, SIGN> {
+    static __device__ __forceinline__ void run(cd (&u)[8]) {
+        cd e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6];   // n0 = 0
+        cd o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];   // n0 = 1
+        dft4<SIGN>(e0, e1, e2, e3);
+        dft4<SIGN>(o0, o1, o2, o3);
+        o1 = mulc<SIGN>(o1, R_HALF, R_HALF);
+        o2 = rot90<SIGN>(o2);
+        o3 = mulc<SIGN>(o3, -R_HALF, R_HALF);
+        u[0] = e0 + o0;
+        u[4] = e0 - o0;
+        u[1] = e1 + o1;
+        u[5] = e1 - o1;
+        u[2] = e2 + o2;
+        u[6] = e2 - o2;
+        u[3] = e3 + o3;
+        u[7] = e3 - o3;
+    }
+};
+
+// n = n0 + 4 n1, k = k1 + 4 k0
+template <int SIGN>
+struct Dft<16, SIGN> {
+    static __device__ __forceinline__ void run(cd (&u)[16]) {
+        cd y[4][4];
+#pragma unroll
+        for (int n0 = 0; n0 < 4; ++n0) {
+            y[n0][0] = u[n0];
+            y[n0][1] = u[n0 + 4];
+            y[n0][2] = u[n0 + 8];
+            y[n0][3] = u[n0 + 12];
+            dft4<SIGN>(y[n0][0], y[n0][1], y[n0][2], y[n0][3]);
+        }
+        // twiddles W16^(n0 k1)
+        y[1][1] = mulc<SIGN>(y[1][1], C_PI8, S_PI8);
+        y[1][2] = mulc<SIGN>(y[1][2], R_HALF, R_HALF);
+        y[1][3] = mulc<SIGN>(y[1][3], S_PI8, C_PI8);
+        y[2][1] = mulc<SIGN>(y[2][1], R_HALF, R_HALF);
+        y[2][2] = rot90<SIGN>(y[2][2]);
+        y[2][3] = mulc<SIGN>(y[2][3], -R_HALF, R_HALF);
+        y[3][1] = mulc<SIGN>(y[3][1], S_PI8, C_PI8);
+        y[3][2] = mulc<SIGN>(y[3][2], -R_HALF, R_HALF);
+        y[3][3] = mulc<SIGN>(y[3][3], -C_PI8, -S_PI8);
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            dft4<SIGN>(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
+            u[k1] = y[0][k1];
+            u[k1 + 4] = y[1][k1];
+            u[k1 + 8] = y[2][k1];
+            u[k1 + 12] = y[3][k1];
+        }
+    }
+};
+
+// ---- pass twiddles: u[r] *= w^r, powers by products of depth <= 4 -------------------------
+template <int R>
+__device__ __forceinline__ void twiddle(cd (&u)[R], cd w1) {
+    cd w2 = cmul(w1, w1);
+    u[1] = cmul(u[1], w1);
+    u[2] = cmul(u[2], w2);
+    cd w3 = cmul(w2, w1);
+    u[3] = cmul(u[3], w3);
+    if constexpr (R > 4) {
+        cd w4 = cmul(w2, w2);
+        u[4] = cmul(u[4], w4);
+        u[5] = cmul(u[5], cmul(w4, w1));
+        u[6] = cmul(u[6], cmul(w4, w2));
+        u[7] = cmul(u[7], cmul(w4, w3));
+        if constexpr (R > 8) {
+            cd w8 = cmul(w4, w4);
+            u[8] = cmul(u[8], w8);
+            u[9] = cmul(u[9], cmul(w8, w1));
+            u[10] = cmul(u[10], cmul(w8, w2));
+            u[11] = cmul(u[11], cmul(w8, w3));
+            cd w12 = cmul(w8, w4);
+            u[12] = cmul(u[12], w12);
+            u[13] = cmul(u[13], cmul(w12, w1));
+            u[14] = cmul(u[14], cmul(w12, w2));
+            u[15] = cmul(u[15], cmul(w12, w3));
+        }
+    }
+}
+
+// ---- FFT configurations -------------------------------------------------------------------
+template <int N>
+struct Cfg;
+template <>
+struct Cfg<512> {
+    static constexpr int T = 64, P = 8, R1 = 8, R2 = 8, R3 = 8;
+};
+template <>
+struct Cfg<1024> {
+    static constexpr int T = 64, P = 16, R1 = 16, R2 = 4, R3 = 16;
+};
+template <>
+struct Cfg<2048> {
+    static constexpr int T = 128, P = 16, R1 = 16, R2 = 8, R3 = 16;
+};
+template <>
+struct Cfg<4096> {
+    static constexpr int T = 256, P = 16, R1 = 16, R2 = 16, R3 = 16;
+};
+
+__device__ __forceinline__ int padpos(int p) { return p + (p >> 4); }
+template <int N>
+constexpr int lds_slots() {
+    return N + N / 16;
+}
+
+// One Stockham pass on the thread's registers.  Slot convention: butterfly i (of P/R) takes
+// slots {i + (P/R) r}; its output r goes back to the same slot.
+template <int N, int T, int P, int R, int NS, int SIGN>
+__device__ __forceinline__ void pass_compute(cd (&v)[P], int t, const cd* __restrict__ tw) {
+    constexpr int nb = P / R;
+#pragma unroll
+    for (int i = 0; i < nb; ++i) {
+        cd u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = v[i + nb * r];
+        if (NS > 1) {
+            const int j = t + T * i;
+            const int k = j & (NS - 1);
+            cd w1 = tw[k * (N / (NS * R))];   // exp(-2 pi i k / (NS R))
+            if (SIGN > 0) w1.y = -w1.y;
+            twiddle<R>(u, w1);
+        }
+        Dft<R, SIGN>::run(u);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[i + nb * r] = u[r];
+    }
+}
+
+// Where output r of butterfly i of a (non-final) pass lives in the next pass's natural order.
+template <int T, int R, int NS>
+__device__ __forceinline__ int outpos(int t, int i, int r) {
+    const int j = t + T * i;
+    return (j / NS) * (NS * R) + (j & (NS - 1)) + r * NS;
+}
+
+// WAVE: the LDS region is private to one wavefront (a 64-thread transform): LDS operations
+// of a wave execute in order, no workgroup barrier needed.
+template <bool WAVE>
+__device__ __forceinline__ void lds_sync() {
+    if (WAVE)
+        __builtin_amdgcn_wave_barrier();
+    else
+        __syncthreads();
+}
+
+// The one data-movement primitive: every thread writes its P complex values to LDS slots
+// wpos(s) and then reads the values at slots rpos(q) (slots are already padded, absolute).
+template <int P, bool WAVE, typename WP, typename RP>
+__device__ __forceinline__ void lds_permute(const cd (&in)[P], cd (&out)[P], cd* __restrict__ buf,
+                                            WP wpos, RP rpos) {
+#pragma unroll
+    for (int s = 0; s < P; ++s) buf[wpos(s)] = in[s];
+    lds_sync<WAVE>();
+#pragma unroll
+    for (int q = 0; q < P; ++q) out[q] = buf[rpos(q)];
+    lds_sync<WAVE>();
+}
+
+// Length-N FFT of the points held as v[q] = a[t + T q] by the T threads of one transform;
+// result in the same layout, natural order, unnormalised.  tw[m] = exp(-2 pi i m / N);
+// buf: this transform's lds_slots<N>() complex slots.
+template <int N, int SIGN, bool WAVE>
+__device__ __forceinline__ void fft_regs(cd (&v)[Cfg<N>::P], int t, const cd* __restrict__ tw,
+                                         cd* __restrict__ buf) {
+    using G = Cfg<N>;
+    constexpr int T = G::T, P = G::P;
+    auto natural = [&](int q) { return padpos(t + T * q); };
+    pass_compute<N, T, P, G::R1, 1, SIGN>(v, t, tw);
+    lds_permute<P, WAVE>(v, v, buf,
+                         [&](int s) { return padpos(outpos<T, G::R1, 1>(t, s % (P / G::R1), s / (P / G::R1))); },
+                         natural);
+    pass_compute<N, T, P, G::R2, G::R1, SIGN>(v, t, tw);
+    lds_permute<P, WAVE>(v, v, buf,
+                         [&](int s) { return padpos(outpos<T, G::R2, G::R1>(t, s % (P / G::R2), s / (P / G::R2))); },
+                         natural);
+    pass_compute<N, T, P, G::R3, G::R1 * G::R2, SIGN>(v, t, tw);
+}
+
+// value at the mirrored natural index (N - k) mod N for every k the thread holds
+template <int N, bool WAVE>
+__device__ __forceinline__ void gather_mirror(const cd (&v)[Cfg<N>::P], cd (&out)[Cfg<N>::P], int t,
+                                              cd* __restrict__ buf) {
+    constexpr int T = Cfg<N>::T, P = Cfg<N>::P;
+    lds_permute<P, WAVE>(v, out, buf, [&](int q) { return padpos(t + T * q); },
+                              [&](int q) { return padpos((N - (t + T * q)) & (N - 1)); });
+}
+
+// ---- operator symbols (the arithmetic of spectral.hip's scalar_symbol_kernel) --------------
+__device__ __forceinline__ double wavenumber(int i, int n, double dk) {
+    int s = (i < (n + 1) / 2) ? i : i - n;
+    return (double)s * dk;
+}
+// Hermitian-symmetrised effective symbol (S(k) + conj S(-k)) / 2: what `.real` of the complex
+// pipeline amounts to.  `-k` as the complex pipeline sees it maps a Nyquist index onto itself,
+// so the even real symbols are unchanged and the odd imaginary ones lose their Nyquist row /
+// column (spectral.hip's scalar_symbol_kernel evaluates the same thing the long way).
+template <int SYM>
+__device__ __forceinline__ cd effective_symbol(int i, int j, int nx, int ny, double dkx, double dky,
+                                               double k2h) {
+    const double kx = wavenumber(i, nx, dkx), ky = wavenumber(j, ny, dky);
+    if (SYM == FFT2D_SYM_POISSON) {
+        return (i == 0 && j == 0) ? cd{0.0, 0.0} : cd{1.0 / (-kx * kx - ky * ky), 0.0};
+    } else if (SYM == FFT2D_SYM_MODHELM) {
+        return cd{1.0 / (k2h - (-kx * kx - ky * ky)), 0.0};
+    } else if (SYM == FFT2D_SYM_DX) {
+        return cd{0.0, (2 * i == nx) ? 0.0 : kx};
+    } else if (SYM == FFT2D_SYM_DY) {
+        return cd{0.0, (2 * j == ny) ? 0.0 : ky};
+    }
+    return cd{1.0, 0.0};
+}
+
+// The half spectrum is kept PACKED: W[row][k], k = 0 .. ny/2 - 1, with the (real) Nyquist
+// entry k = ny/2 stored in the imaginary part of the (real) k = 0 entry.  Rows are then
+// exactly ny/2 complex numbers (16 KiB at ny = 2048, line aligned) and the column pass has
+// ny/8 blocks of four columns — 256 at ny = 2048, one per CU — instead of one more.
+
+// ---- kernel A: rows, real -> packed half spectrum -------------------------------------------
+template <int NY>
+__global__ __launch_bounds__(256) void row_r2c_kernel(const double* __restrict__ f,
+                                                      cd* __restrict__ W, const cd* __restrict__ tw_h,
+                                                      const cd* __restrict__ tw_ny) {
+    constexpr int H = NY / 2;
+    using G = Cfg<H>;
+    constexpr int T = G::T, P = G::P, RPW = 256 / T;
+    extern __shared__ double lds_raw[];
+    cd* lds = (cd*)lds_raw;
+    const int tid = threadIdx.x, sub = tid / T, t = tid % T;
+    const int64_t row = (int64_t)blockIdx.x * RPW + sub;
+    cd* buf = lds + sub * lds_slots<H>();
+    const double2* src = (const double2*)(f + row * NY);
+    cd v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        double2 a = src[t + T * q];
+        v[q] = cd{a.x, a.y};
+    }
+    fft_regs<H, -1, (T == 64)>(v, t, tw_h, buf);
+    cd m[P];   // Z[(H - k) mod H]
+    gather_mirror<H, (T == 64)>(v, m, t, buf);
+    cd* dst = W + row * H;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int k = t + T * q;
+        cd zk = v[q], zm = cconj(m[q]);
+        cd e = cd{0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
+        cd d = cd{0.5 * (zk.x - zm.x), 0.5 * (zk.y - zm.y)};
+        cd w = tw_ny[k];   // exp(-2 pi i k / NY)
+        cd wd = cmul(w, d);
+        cd X = cd{e.x + wd.y, e.y - wd.x};   // e - i w d
+        if (k == 0) X = cd{zk.x + zk.y, zk.x - zk.y};   // {X[0], X[ny/2]}, both real
+        dst[k] = X;
+    }
+}
+
+// ---- kernel C: rows, packed half spectrum -> real --------------------------------------------
+// out = (unnormalised c2r) / 2 : the missing factor 2 is folded into the symbol's scale
+template <int NY>
+__global__ __launch_bounds__(256) void row_c2r_kernel(const cd* __restrict__ W, double* __restrict__ out,
+                                                      const cd* __restrict__ tw_h,
+                                                      const cd* __restrict__ tw_ny) {
+    constexpr int H = NY / 2;
+    using G = Cfg<H>;
+    constexpr int T = G::T, P = G::P, RPW = 256 / T;
+    extern __shared__ double lds_raw[];
+    cd* lds = (cd*)lds_raw;
+    const int tid = threadIdx.x, sub = tid / T, t = tid % T;
+    const int64_t row = (int64_t)blockIdx.x * RPW + sub;
+    cd* buf = lds + sub * lds_slots<H>();
+    const cd* src = W + row * H;
+    cd v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) v[q] = src[t + T * q];
+    cd m[P];   // X[H - k]
+    gather_mirror<H, (T == 64)>(v, m, t, buf);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int k = t + T * q;
+        cd xk = v[q], xm = cconj(m[q]);
+        if (k == 0) {   // unpack {X[0], X[ny/2]}
+            xm = cd{xk.y, 0.0};
+            xk = cd{xk.x, 0.0};
+        }
+        cd e = cd{0.5 * (xk.x + xm.x), 0.5 * (xk.y + xm.y)};
+        cd d = cd{0.5 * (xk.x - xm.x), 0.5 * (xk.y - xm.y)};
+        cd w = cconj(tw_ny[k]);   // exp(+2 pi i k / NY)
+        cd wd = cmul(w, d);
+        v[q] = cd{e.x - wd.y, e.y + wd.x};   // e + i w d
+    }
+    fft_regs<H, +1, (T == 64)>(v, t, tw_h, buf);
+    double2* dst = (double2*)(out + row * NY);
+#pragma unroll
+    for (int q = 0; q < P; ++q) dst[t + T * q] = double2{v[q].x, v[q].y};
+}
+
+// ---- kernel B: columns, forward FFT x symbol x inverse FFT in one pass ------------------------
+// MODE 0: fused (forward, symbol, inverse); 1: forward only; 2: inverse only.
+// Column 0 carries two real columns (ky = 0 in the real part, the Nyquist ky in the imaginary
+// part): its transform G = F0 + i FH is split with the mirrored entry, F0 = (G(k) + conj
+// G(-k)) / 2, FH = (G(k) - conj G(-k)) / 2i, each half gets its own symbol, and U0 + i UH
+// goes back through the inverse transform (both results are real sequences again).
+template <int NX, int C, int SYM, int MODE>
+__global__ __launch_bounds__(C* Cfg<NX>::T) void col_kernel(cd* __restrict__ W, int pitch,
+                                                           int nblocks, int ny, double dkx,
+                                                           double dky, double k2h, double scale,
+                                                           const cd* __restrict__ tw_x) {
+    using G = Cfg<NX>;
+    // column regions are offset by 4 slots (16 banks) from one another: the 16 lanes of a
+    // ds_read_b128 group (4 columns x 4 values of t) then hit 16 different 4-bank slots
+    constexpr int T = G::T, P = G::P, NPC = lds_slots<NX>() + 4;
+    extern __shared__ double lds_raw[];
+    cd* lds = (cd*)lds_raw;
+    // XCD-aware hand-out: workgroup w runs on XCD w % 8; give each XCD a contiguous range of
+    // column blocks so that blocks sharing 128-byte lines share an L2
+    const int per = (nblocks + 7) / 8;
+    const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (blk >= nblocks) return;
+    // Thread layout: column = tid % C, t = tid / C.  A load instruction then covers 64 / C rows
+    // x C columns (64-byte row segments), and the values a thread loads, rows t + T i of its
+    // column, ARE the strided natural layout of that column's transform: no staging permute on
+    // the way in or out.  (The T threads of a column sit in every wave: all LDS exchanges are
+    // workgroup-wide.)
+    const int tid = threadIdx.x;
+    const int col = tid % C, t = tid / C;
+    const int j0 = blk * C;
+    cd* base = W + j0 + col;
+    cd v[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) v[i] = base[(int64_t)(t + T * i) * pitch];
+    cd* buf = lds + col * NPC;
+    if (MODE != 2) fft_regs<NX, -1, false>(v, t, tw_x, buf);
+    if (MODE == 0) {
+        const int j = j0 + col;
+        if (blk == 0) {   // (uniform over the workgroup)
+            cd m[P];
+            gather_mirror<NX, false>(v, m, t, buf);
+            if (col == 0) {
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    const int i = t + T * q;
+                    cd g = v[q], gm = cconj(m[q]);
+                    cd f0 = cd{0.5 * (g.x + gm.x), 0.5 * (g.y + gm.y)};
+                    cd fh = cd{0.5 * (g.y - gm.y), -0.5 * (g.x - gm.x)};   // (g - gm) / 2i
+                    cd u0 = cmul(f0, effective_symbol<SYM>(i, 0, NX, ny, dkx, dky, k2h));
+                    cd uh = cmul(fh, effective_symbol<SYM>(i, ny / 2, NX, ny, dkx, dky, k2h));
+                    v[q] = cd{(u0.x - uh.y) * scale, (u0.y + uh.x) * scale};   // u0 + i uh
+                }
+            }
+        }
+        if (!(blk == 0 && col == 0)) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                cd S = effective_symbol<SYM>(t + T * q, j, NX, ny, dkx, dky, k2h);
+                cd o = cmul(v[q], S);
+                v[q] = cd{o.x * scale, o.y * scale};
+            }
+        }
+    }
+    if (MODE != 1) fft_regs<NX, +1, false>(v, t, tw_x, buf);
+#pragma unroll
+    for (int i = 0; i < P; ++i) base[(int64_t)(t + T * i) * pitch] = v[i];
+}
+
+template <typename K>
+int allow_lds(ipde_ctx* ctx, K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return IPDE_OK;
+}
+
+template <int NY>
+int launch_rows(ipde_ctx* ctx, const Fft2dPlan& p, bool forward, const double* f, cd* W, double* out) {
+    constexpr int H = NY / 2, T = Cfg<H>::T, RPW = 256 / T;
+    const size_t lds = (size_t)RPW * lds_slots<H>() * sizeof(cd);
+    const dim3 grid((unsigned)(p.nx / RPW));
+    if (forward) {
+        IPDE_TRY(allow_lds(ctx, row_r2c_kernel<NY>, lds));
+        hipLaunchKernelGGL(row_r2c_kernel<NY>, grid, dim3(256), lds, ctx->stream, f, W,
+                           (const cd*)p.tw_h, (const cd*)p.tw_ny);
+    } else {
+        IPDE_TRY(allow_lds(ctx, row_c2r_kernel<NY>, lds));
+        hipLaunchKernelGGL(row_c2r_kernel<NY>, grid, dim3(256), lds, ctx->stream, (const cd*)W,
+                           out, (const cd*)p.tw_h, (const cd*)p.tw_ny);
+    }
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
+// columns per workgroup: 4 (64-byte row segments); 2 at nx = 4096, where four 4096-point
+// columns would need 1024 threads at <= 128 VGPRs
+template <int NX>
+constexpr int cols_per_block() {
+    return NX >= 4096 ? 2 : 4;
+}
+
+template <int NX, int SYM, int MODE>
+int launch_cols_t(ipde_ctx* ctx, const Fft2dPlan& p, cd* W, double k2h, double scale) {
+    constexpr int C = cols_per_block<NX>(), T = Cfg<NX>::T;
+    const size_t lds = (size_t)C * (lds_slots<NX>() + 4) * sizeof(cd);
+    const int nblocks = (int)(p.pitch / C);
+    const unsigned grid = (unsigned)(((nblocks + 7) / 8) * 8);
+    auto k = col_kernel<NX, C, SYM, MODE>;
+    IPDE_TRY(allow_lds(ctx, k, lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(C * T), lds, ctx->stream, W, (int)p.pitch, nblocks, (int)p.ny,
+                       2.0 * M_PI / (p.nx * p.hx), 2.0 * M_PI / (p.ny * p.hy), k2h, scale,
+                       (const cd*)p.tw_x);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
+template <int NX>
+int launch_cols(ipde_ctx* ctx, const Fft2dPlan& p, int sym, int mode, cd* W, double k2h, double scale) {
+    if (mode == 1) return launch_cols_t<NX, FFT2D_SYM_NONE, 1>(ctx, p, W, k2h, scale);
+    if (mode == 2) return launch_cols_t<NX, FFT2D_SYM_NONE, 2>(ctx, p, W, k2h, scale);
+    switch (sym) {
+        case FFT2D_SYM_POISSON: return launch_cols_t<NX, FFT2D_SYM_POISSON, 0>(ctx, p, W, k2h, scale);
+        case FFT2D_SYM_MODHELM: return launch_cols_t<NX, FFT2D_SYM_MODHELM, 0>(ctx, p, W, k2h, scale);
+        case FFT2D_SYM_DX: return launch_cols_t<NX, FFT2D_SYM_DX, 0>(ctx, p, W, k2h, scale);
+        case FFT2D_SYM_DY: return launch_cols_t<NX, FFT2D_SYM_DY, 0>(ctx, p, W, k2h, scale);
+        default: return launch_cols_t<NX, FFT2D_SYM_NONE, 0>(ctx, p, W, k2h, scale);
+    }
+}
+
+}  // namespace
+
+bool fft2d_supported(int64_t nx, int64_t ny) {
+    const bool okx = nx == 512 || nx == 1024 || nx == 2048 || nx == 4096;
+    const bool oky = ny == 1024 || ny == 2048 || ny == 4096 || ny == 8192;
+    return okx && oky;
+}
+
+static int upload_twiddles(ipde_ctx* ctx, void** d, int64_t n, int64_t count) {
+    std::vector<double> h(2 * (size_t)count);
+    for (int64_t m = 0; m < count; ++m) {
+        long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
+        h[2 * m] = (double)cosl(a);
+        h[2 * m + 1] = (double)sinl(a);
+    }
+    IPDE_HIP_CHECK(ctx, hipMalloc(d, h.size() * sizeof(double)));
+    IPDE_HIP_CHECK(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    return IPDE_OK;
+}
+
+int fft2d_plan_init(ipde_ctx* ctx, Fft2dPlan& p, int64_t nx, int64_t ny, double hx, double hy) {
+    p.nx = nx;
+    p.ny = ny;
+    p.hx = hx;
+    p.hy = hy;
+    p.pitch = ny / 2;   // packed half spectrum: the Nyquist entry rides in Im W[.][0]
+    IPDE_TRY(upload_twiddles(ctx, &p.tw_x, nx, nx));
+    IPDE_TRY(upload_twiddles(ctx, &p.tw_h, ny / 2, ny / 2));
+    IPDE_TRY(upload_twiddles(ctx, &p.tw_ny, ny, ny / 2));
+    for (auto& w : p.W) {
+        const size_t bytes = (size_t)nx * p.pitch * 2 * sizeof(double);
+        IPDE_HIP_CHECK(ctx, hipMalloc(&w, bytes));
+    }
+    p.ready = true;
+    return IPDE_OK;
+}
+
+void fft2d_plan_free(Fft2dPlan& p) {
+    for (void* q : {p.tw_x, p.tw_h, p.tw_ny})
+        if (q) (void)hipFree(q);
+    for (auto& w : p.W)
+        if (w) (void)hipFree(w);
+    p = Fft2dPlan();
+}
+
+int fft2d_rows_forward(ipde_ctx* ctx, const Fft2dPlan& p, const double* f, int slot) {
+    cd* W = (cd*)p.W[slot];
+    switch (p.ny) {
+        case 1024: return launch_rows<1024>(ctx, p, true, f, W, nullptr);
+        case 2048: return launch_rows<2048>(ctx, p, true, f, W, nullptr);
+        case 4096: return launch_rows<4096>(ctx, p, true, f, W, nullptr);
+        case 8192: return launch_rows<8192>(ctx, p, true, f, W, nullptr);
+    }
+    return IPDE_ERR_INVALID;
+}
+
+int fft2d_rows_inverse(ipde_ctx* ctx, const Fft2dPlan& p, int slot, double* out) {
+    cd* W = (cd*)p.W[slot];
+    switch (p.ny) {
+        case 1024: return launch_rows<1024>(ctx, p, false, nullptr, W, out);
+        case 2048: return launch_rows<2048>(ctx, p, false, nullptr, W, out);
+        case 4096: return launch_rows<4096>(ctx, p, false, nullptr, W, out);
+        case 8192: return launch_rows<8192>(ctx, p, false, nullptr, W, out);
+    }
+    return IPDE_ERR_INVALID;
+}
+
+int fft2d_cols(ipde_ctx* ctx, const Fft2dPlan& p, int slot, int sym, int mode, double k2h, double scale) {
+    cd* W = (cd*)p.W[slot];
+    switch (p.nx) {
+        case 512: return launch_cols<512>(ctx, p, sym, mode, W, k2h, scale);
+        case 1024: return launch_cols<1024>(ctx, p, sym, mode, W, k2h, scale);
+        case 2048: return launch_cols<2048>(ctx, p, sym, mode, W, k2h, scale);
+        case 4096: return launch_cols<4096>(ctx, p, sym, mode, W, k2h, scale);
+    }
+    return IPDE_ERR_INVALID;
+}
+
+// u = ifft2(fft2(f) * S).real for the analytic scalar symbols: rows, fused columns, rows.
+int fft2d_scalar_solve(ipde_ctx* ctx, const Fft2dPlan& p, int sym, double k2h, const double* f,
+                       double* u) {
+    IPDE_TRY(fft2d_rows_forward(ctx, p, f, 0));
+    // row_c2r returns half of the unnormalised inverse: 2 / (nx ny) in all
+    IPDE_TRY(fft2d_cols(ctx, p, 0, sym, 0, k2h, 2.0 / ((double)p.nx * (double)p.ny)));
+    return fft2d_rows_inverse(ctx, p, 0, u);
+}

@@ -7,6 +7,7 @@
 // and reproduce the `.real` projection exactly by Hermitian-symmetrising the
 // effective symbol (matters only on the Nyquist row/column of odd symbols).
 #include "ipde_common.h"
+#include "fft2d.h"
 #include <rocfft/rocfft.h>
 #include <mutex>
 
@@ -40,6 +41,7 @@ struct ipde_fft_plan {
     void* work = nullptr;
     size_t work_bytes = 0;
     double2* spec[3] = {nullptr, nullptr, nullptr};
+    Fft2dPlan fast;   // hand-written pipeline (power-of-two grids), fft2d.hip
     double* rbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // host staging
     double2* cbuf[2] = {nullptr, nullptr};                            // host staging (complex)
 };
@@ -341,6 +343,12 @@ int scalar_solve(ipde_fft_plan* p, int loc, double k2h, const double* f, double*
     IPDE_TRY(stage_real_in(p, loc, 0, f, &d_f));
     IPDE_TRY(stage_real_out(p, loc, 1, u, &d_u));
     IPDE_TRY(stage_cplx_out(p, loc, 0, uhat, &d_uh));
+    if (p->fast.ready && ctx->opt_fft2d && !uhat) {
+        // three hand-written kernels: rows r2c, fused column FFT * symbol * inverse FFT, rows c2r
+        IPDE_TRY(fft2d_scalar_solve(ctx, p->fast, SYM, k2h, d_f, d_u));
+        IPDE_TRY(finish_real_out(p, loc, 1, u));
+        return finish_sync(p, loc);
+    }
     IPDE_TRY(exec(p, p->r2c, (void*)d_f, p->spec[0]));
     const double N = (double)p->nx * (double)p->ny;
     hipLaunchKernelGGL((scalar_symbol_kernel<SYM>), dim3(nblk(p->nx * p->nyh)), dim3(256), 0,
@@ -380,6 +388,7 @@ extern "C" int ipde_fft_plan2d_create(ipde_ctx* ctx, int64_t nx, int64_t ny, dou
         if (hipMalloc((void**)&p->spec[i], (size_t)nx * p->nyh * sizeof(double2)) != hipSuccess)
             st = IPDE_ERR_ALLOC;
     }
+    if (st == IPDE_OK && fft2d_supported(nx, ny)) st = fft2d_plan_init(ctx, p->fast, nx, ny, hx, hy);
     if (st != IPDE_OK) {
         ipde_fft_plan2d_destroy(p);
         return st;
@@ -398,6 +407,7 @@ extern "C" int ipde_fft_plan2d_destroy(ipde_fft_plan* p) {
     if (p->c2c_b) rocfft_plan_destroy(p->c2c_b);
     if (p->info) rocfft_execution_info_destroy(p->info);
     if (p->work) hipFree(p->work);
+    fft2d_plan_free(p->fast);
     for (auto& s : p->spec)
         if (s) hipFree(s);
     for (auto& s : p->rbuf)
