@@ -209,7 +209,7 @@ extern "C" int ipde_ewald_create(ipde_ctx* ctx, int kind, double k, double h, in
 }
 
 extern "C" int ipde_ewald_destroy(ipde_ewald* e) {
-    if (!e) return IPDE_OK;
+    if (!e) return IPDE_ERR_INVALID;   // like every other destroy entry point
     hipFree(e->d_tab);
     hipFree(e->d_flag);
     delete e;

@@ -126,7 +126,7 @@ def _warm_worker():
 
 def prewarm(grid_shape=None, h=None, wait=False, fft1=()):
     """Pay the one-time library costs of a first solve in ONE background thread while the
-    host does geometry set-up: hipFFT / rocSOLVER loads (first torch.fft call ~1 s), the
+    host does geometry set-up: rocBLAS / rocSOLVER loads (first GEMM / LU call), the
     rocFFT kernels of the batched 1-D transforms `fft1` = ((batch, n), ...) (annular solver,
     radial interpolation) and, if the grid is given, of the 2-D grid solve (~1.6 s of
     run-time compilation at 2048^2).  Jobs run strictly one after the other, and every
@@ -146,8 +146,6 @@ def prewarm(grid_shape=None, h=None, wait=False, fft1=()):
         (a @ a).sum().item()
         b = torch.ones((64, 64), dtype=torch.float64, device=d) + torch.eye(64, dtype=torch.float64, device=d)
         (b @ b).sum().item()
-        torch.fft.fft(a, dim=1).sum().item()
-        torch.fft.fft2(b).sum().item()
         LU, piv = torch.linalg.lu_factor(b)
         torch.linalg.lu_solve(LU, piv, b[:, :1]).sum().item()
 

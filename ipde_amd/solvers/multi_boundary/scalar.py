@@ -194,7 +194,7 @@ class ScalarSolver(object):
 
     def __call__(self, f, **kwargs):
         """f: EmbeddedFunction -> EmbeddedFunction (reference :72-117)."""
-        prewarm_wait()      # torch.fft below: never concurrently with the warm-up thread
+        prewarm_wait()      # FFT plans below: never concurrently with the warm-up thread
         e = self.ebdyc
         Nx, Ny = self.grid.shape
         fr_list = f.get_radial_value_list()
@@ -211,7 +211,8 @@ class ScalarSolver(object):
             all_bvs = periodic_interp2d_gradient(uch, self._ifx_d, self._ify_d, self._ikx_d,
                                                   self._iky_d).cpu().numpy()
         else:
-            stack = torch.stack([torch.fft.fft2(g) for g in (uc, self.dx(uc), self.dy(uc))])
+            # (the library's own D2Z plan: one rocFFT in the process, no torch.fft)
+            stack = torch.stack([self.plan.fft2(g.contiguous()) for g in (uc, self.dx(uc), self.dy(uc))])
             all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         bvl, bxl, byl = e.v2l(all_bvs[0]), e.v2l(all_bvs[1]), e.v2l(all_bvs[2])
         # annular solves boundary by boundary, then the QFS solves of all boundaries in one

@@ -131,7 +131,7 @@ class VectorSolver(object):
 
     def __call__(self, fu, fv, **kwargs):
         """fu, fv: EmbeddedFunctions -> (u, v, p) EmbeddedFunctions (reference :57-112)."""
-        prewarm_wait()      # torch.fft below: never concurrently with the warm-up thread
+        prewarm_wait()      # FFT plans below: never concurrently with the warm-up thread
         e = self.ebdyc
         Nx, Ny = self.grid.shape
         fur_list = fu.get_radial_value_list()
@@ -145,12 +145,13 @@ class VectorSolver(object):
         uc, vc, pc = (a.contiguous() for a in self._grid_solve(fc[0], fc[1]))
         # velocity and stress of the grid solution on every interface node (:66-82)
         if self.interpolation_order == np.inf:
-            uh, vh, ph = torch.fft.fft2(uc), torch.fft.fft2(vc), torch.fft.fft2(pc)
+            # full spectra of the real fields through the library's D2Z plan (no torch.fft)
+            uh, vh, ph = self.plan.fft2(uc), self.plan.fft2(vc), self.plan.fft2(pc)
             stack = torch.stack([uh, vh, 2 * self._ikx_d * uh - ph,
                                  self._iky_d * uh + self._ikx_d * vh, 2 * self._iky_d * vh - ph])
         else:
             ucx, ucy, vcx, vcy = self.dx(uc), self.dy(uc), self.dx(vc), self.dy(vc)
-            stack = torch.stack([torch.fft.fft2(g) for g in
+            stack = torch.stack([self.plan.fft2(g.contiguous()) for g in
                                  (uc, vc, 2 * ucx - pc, ucy + vcx, 2 * vcy - pc)])
         bvals = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         bul, bvl, btxxl, btxyl, btyyl = (e.v2l(b) for b in bvals)
