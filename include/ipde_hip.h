@@ -184,6 +184,21 @@ int ipde_stokes_grid_solve(ipde_fft_plan* plan, int loc,
  * (axis 0) or 1j*ky (axis 1): out = ifft2(fft2(f)*ik).real
  */
 int ipde_fourier_deriv(ipde_fft_plan* plan, int loc, const double* f, int axis, double* out);
+
+/* Grid -> scattered points (the step after the grid solve in ScalarSolver.__call__, reference
+ * ipde/solvers/multi_boundary/scalar.py:80-88: values and gradient of the grid solution on
+ * all interface nodes; three finufft type-2 transforms there).
+ * ipde_fft_plan2d_keep_spectrum(plan, 1, &ok): subsequent ipde_poisson_grid_solve /
+ * ipde_modhelm_grid_solve calls WITHOUT a uhat output keep fft2(f) * symbol on the device
+ * (ok = 0: this grid size has no such path — power-of-two sizes up to 2048 x 4096 do —, use
+ * uhat and the caller's own evaluation).
+ * ipde_grid_interp: out3 (3, np) row-major = u, du/dx, du/dy at the points (x, y), given in
+ * box units [0, 2 pi) as ebdyc.interfaces_x_transf / interfaces_y_transf; derivatives in
+ * physical units.  Oversampled (2x) inverse transform + 16 x 16 window gather, ~1e-14. */
+int ipde_fft_plan2d_keep_spectrum(ipde_fft_plan* plan, int on, int* supported);
+int ipde_grid_interp(ipde_fft_plan* plan, int loc, int64_t np, const double* x, const double* y,
+                     double* out3);
+
 /* general symbol: out = ifft2(fft2(f) * sym).real with sym a full (nx,ny)
    complex array (the reference accepts any broadcastable ik) */
 int ipde_fourier_multiply(ipde_fft_plan* plan, int loc, const double* f,

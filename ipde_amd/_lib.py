@@ -73,6 +73,8 @@ SIGNATURES = {
     "ipde_stokes_grid_solve": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "ipde_fourier_deriv": (_int, [_vp, _int, _vp, _int, _vp]),
     "ipde_fourier_multiply": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "ipde_fft_plan2d_keep_spectrum": (_int, [_vp, _int, ctypes.POINTER(_int)]),
+    "ipde_grid_interp": (_int, [_vp, _int, _i64, _vp, _vp, _vp]),
     "ipde_dense_lu_solve": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ipde_dense_lu_solve_batch": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "ipde_chebfourier_gather": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -127,7 +129,8 @@ def load():
 
 def _uses_fft(name):
     """entry points that may create or run rocFFT plans"""
-    return name.startswith(("ipde_fft", "ipde_fourier", "ipde_annular")) or name.endswith("_grid_solve")
+    return name.startswith(("ipde_fft", "ipde_fourier", "ipde_annular", "ipde_grid_interp")) \
+        or name.endswith("_grid_solve")
 
 
 class _Library(object):

@@ -28,6 +28,7 @@ SOURCES = [
     "layer_stokes.hip",
     "spectral.hip",
     "fft2d.hip",
+    "nufft.hip",
     "annular.hip",
     "ewald.hip",
     "dense.hip",

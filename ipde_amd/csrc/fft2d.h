@@ -23,5 +23,17 @@ void fft2d_plan_free(Fft2dPlan& p);
 int fft2d_rows_forward(ipde_ctx* ctx, const Fft2dPlan& p, const double* f, int slot);
 int fft2d_rows_inverse(ipde_ctx* ctx, const Fft2dPlan& p, int slot, double* out);
 // columns of W[slot] in place; mode 0: forward * symbol * scale, inverse; 1: forward; 2: inverse
-int fft2d_cols(ipde_ctx* ctx, const Fft2dPlan& p, int slot, int sym, int mode, double k2h, double scale);
-int fft2d_scalar_solve(ipde_ctx* ctx, const Fft2dPlan& p, int sym, double k2h, const double* f, double* u);
+// spec_slot >= 0 (mode 0): also store the post-symbol spectrum in W[spec_slot]; ncols > 0: only
+// the leading ncols columns (the rest are zeros, e.g. a zero-padded spectrum)
+int fft2d_cols(ipde_ctx* ctx, const Fft2dPlan& p, int slot, int sym, int mode, double k2h, double scale,
+               int spec_slot = -1, int64_t ncols = 0);
+int fft2d_scalar_solve(ipde_ctx* ctx, const Fft2dPlan& p, int sym, double k2h, const double* f, double* u,
+                       bool keep_spectrum = false);
+
+// grid -> scattered points through an oversampled inverse transform (nufft.hip)
+struct GridInterp;
+bool grid_interp_supported(int64_t nx, int64_t ny);
+int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double hy, GridInterp** out);
+void grid_interp_destroy(GridInterp* gi);
+int grid_interp_eval(GridInterp* gi, const void* spec, int loc, int64_t np, const double* px,
+                     const double* py, double dkx, double dky, double* out);

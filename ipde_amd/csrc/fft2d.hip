@@ -384,7 +384,8 @@ template <int NX, int C, int SYM, int MODE>
 __global__ __launch_bounds__(C* Cfg<NX>::T) void col_kernel(cd* __restrict__ W, int pitch,
                                                            int nblocks, int ny, double dkx,
                                                            double dky, double k2h, double scale,
-                                                           const cd* __restrict__ tw_x) {
+                                                           const cd* __restrict__ tw_x,
+                                                           cd* __restrict__ spec_out) {
     using G = Cfg<NX>;
     // column regions are offset by 4 slots (16 banks) from one another: the 16 lanes of a
     // ds_read_b128 group (4 columns x 4 values of t) then hit 16 different 4-bank slots
@@ -437,6 +438,11 @@ __global__ __launch_bounds__(C* Cfg<NX>::T) void col_kernel(cd* __restrict__ W, 
             }
         }
     }
+    if (MODE == 0 && spec_out) {   // keep fft2(f) * symbol * scale (packed) for the interpolation
+        cd* so = spec_out + j0 + col;
+#pragma unroll
+        for (int q = 0; q < P; ++q) so[(int64_t)(t + T * q) * pitch] = v[q];
+    }
     if (MODE != 1) fft_regs<NX, +1, false>(v, t, tw_x, buf);
 #pragma unroll
     for (int i = 0; i < P; ++i) base[(int64_t)(t + T * i) * pitch] = v[i];
@@ -476,30 +482,33 @@ constexpr int cols_per_block() {
 }
 
 template <int NX, int SYM, int MODE>
-int launch_cols_t(ipde_ctx* ctx, const Fft2dPlan& p, cd* W, double k2h, double scale) {
+int launch_cols_t(ipde_ctx* ctx, const Fft2dPlan& p, cd* W, double k2h, double scale, cd* spec_out,
+                  int64_t ncols) {
     constexpr int C = cols_per_block<NX>(), T = Cfg<NX>::T;
     const size_t lds = (size_t)C * (lds_slots<NX>() + 4) * sizeof(cd);
-    const int nblocks = (int)(p.pitch / C);
+    // (ncols < pitch: only the leading columns are transformed, the others are known zeros)
+    const int nblocks = (int)((ncols + C - 1) / C);
     const unsigned grid = (unsigned)(((nblocks + 7) / 8) * 8);
     auto k = col_kernel<NX, C, SYM, MODE>;
     IPDE_TRY(allow_lds(ctx, k, lds));
     hipLaunchKernelGGL(k, dim3(grid), dim3(C * T), lds, ctx->stream, W, (int)p.pitch, nblocks, (int)p.ny,
                        2.0 * M_PI / (p.nx * p.hx), 2.0 * M_PI / (p.ny * p.hy), k2h, scale,
-                       (const cd*)p.tw_x);
+                       (const cd*)p.tw_x, spec_out);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }
 
 template <int NX>
-int launch_cols(ipde_ctx* ctx, const Fft2dPlan& p, int sym, int mode, cd* W, double k2h, double scale) {
-    if (mode == 1) return launch_cols_t<NX, FFT2D_SYM_NONE, 1>(ctx, p, W, k2h, scale);
-    if (mode == 2) return launch_cols_t<NX, FFT2D_SYM_NONE, 2>(ctx, p, W, k2h, scale);
+int launch_cols(ipde_ctx* ctx, const Fft2dPlan& p, int sym, int mode, cd* W, double k2h, double scale,
+                cd* so, int64_t nc) {
+    if (mode == 1) return launch_cols_t<NX, FFT2D_SYM_NONE, 1>(ctx, p, W, k2h, scale, so, nc);
+    if (mode == 2) return launch_cols_t<NX, FFT2D_SYM_NONE, 2>(ctx, p, W, k2h, scale, so, nc);
     switch (sym) {
-        case FFT2D_SYM_POISSON: return launch_cols_t<NX, FFT2D_SYM_POISSON, 0>(ctx, p, W, k2h, scale);
-        case FFT2D_SYM_MODHELM: return launch_cols_t<NX, FFT2D_SYM_MODHELM, 0>(ctx, p, W, k2h, scale);
-        case FFT2D_SYM_DX: return launch_cols_t<NX, FFT2D_SYM_DX, 0>(ctx, p, W, k2h, scale);
-        case FFT2D_SYM_DY: return launch_cols_t<NX, FFT2D_SYM_DY, 0>(ctx, p, W, k2h, scale);
-        default: return launch_cols_t<NX, FFT2D_SYM_NONE, 0>(ctx, p, W, k2h, scale);
+        case FFT2D_SYM_POISSON: return launch_cols_t<NX, FFT2D_SYM_POISSON, 0>(ctx, p, W, k2h, scale, so, nc);
+        case FFT2D_SYM_MODHELM: return launch_cols_t<NX, FFT2D_SYM_MODHELM, 0>(ctx, p, W, k2h, scale, so, nc);
+        case FFT2D_SYM_DX: return launch_cols_t<NX, FFT2D_SYM_DX, 0>(ctx, p, W, k2h, scale, so, nc);
+        case FFT2D_SYM_DY: return launch_cols_t<NX, FFT2D_SYM_DY, 0>(ctx, p, W, k2h, scale, so, nc);
+        default: return launch_cols_t<NX, FFT2D_SYM_NONE, 0>(ctx, p, W, k2h, scale, so, nc);
     }
 }
 
@@ -570,22 +579,27 @@ int fft2d_rows_inverse(ipde_ctx* ctx, const Fft2dPlan& p, int slot, double* out)
     return IPDE_ERR_INVALID;
 }
 
-int fft2d_cols(ipde_ctx* ctx, const Fft2dPlan& p, int slot, int sym, int mode, double k2h, double scale) {
+int fft2d_cols(ipde_ctx* ctx, const Fft2dPlan& p, int slot, int sym, int mode, double k2h, double scale,
+               int spec_slot, int64_t ncols) {
     cd* W = (cd*)p.W[slot];
+    cd* so = spec_slot >= 0 ? (cd*)p.W[spec_slot] : nullptr;
+    const int64_t nc = ncols > 0 ? ncols : p.pitch;
     switch (p.nx) {
-        case 512: return launch_cols<512>(ctx, p, sym, mode, W, k2h, scale);
-        case 1024: return launch_cols<1024>(ctx, p, sym, mode, W, k2h, scale);
-        case 2048: return launch_cols<2048>(ctx, p, sym, mode, W, k2h, scale);
-        case 4096: return launch_cols<4096>(ctx, p, sym, mode, W, k2h, scale);
+        case 512: return launch_cols<512>(ctx, p, sym, mode, W, k2h, scale, so, nc);
+        case 1024: return launch_cols<1024>(ctx, p, sym, mode, W, k2h, scale, so, nc);
+        case 2048: return launch_cols<2048>(ctx, p, sym, mode, W, k2h, scale, so, nc);
+        case 4096: return launch_cols<4096>(ctx, p, sym, mode, W, k2h, scale, so, nc);
     }
     return IPDE_ERR_INVALID;
 }
 
 // u = ifft2(fft2(f) * S).real for the analytic scalar symbols: rows, fused columns, rows.
+// keep_spectrum: W[1] receives fft2(f) * S * 2 / (nx ny), packed, for fft2d-based interpolation.
 int fft2d_scalar_solve(ipde_ctx* ctx, const Fft2dPlan& p, int sym, double k2h, const double* f,
-                       double* u) {
+                       double* u, bool keep_spectrum) {
     IPDE_TRY(fft2d_rows_forward(ctx, p, f, 0));
     // row_c2r returns half of the unnormalised inverse: 2 / (nx ny) in all
-    IPDE_TRY(fft2d_cols(ctx, p, 0, sym, 0, k2h, 2.0 / ((double)p.nx * (double)p.ny)));
+    IPDE_TRY(fft2d_cols(ctx, p, 0, sym, 0, k2h, 2.0 / ((double)p.nx * (double)p.ny),
+                        keep_spectrum ? 1 : -1, 0));
     return fft2d_rows_inverse(ctx, p, 0, u);
 }

@@ -1,0 +1,284 @@
+// Grid -> scattered points: u, du/dx, du/dy of the periodic grid solution at the interface
+// nodes, from the spectrum the grid solve has just produced (reference
+// ipde/solvers/multi_boundary/scalar.py:80-88, three finufft type-2 transforms there).
+//
+// A type-2 non-uniform FFT built on the hand-written pipeline of fft2d.hip:
+//   pad     : the packed half spectrum (nx, ny/2) of fft2(f) * symbol, times the field's
+//             multiplier (1, i kx, i ky), divided by the transform of the window, goes into
+//             the (2 nx, 2 ny) oversampled spectrum; the two Nyquist lines are split half /
+//             half between +N/2 and -N/2 and the corner mode goes to the (+,+)/(-,-) pair,
+//             which is what `.real` of the complex sum with fft-ordered wavenumbers amounts to;
+//   inverse : column pass over the ny/2 + 1 non-zero columns only, then rows c2r, 4096^2 for a
+//             2048^2 grid;
+//   gather  : one wavefront per point, a w x w patch of the fine grid against the window
+//             "exponential of semicircle" exp(beta (sqrt(1 - z^2) - 1)), beta = 2.30 w (the
+//             FINUFFT window: its transform is computed by Gauss-Legendre quadrature at set-up).
+// O(n^2 log n) instead of the O(N_b n^2) complex GEMM it replaces (ipde_amd/interp.py keeps the
+// GEMM as the checker and for grids outside fft2d's sizes).  Derivatives are separate
+// transforms of i k F: differentiating the window instead would amplify the aliasing error by
+// N_fine / k.
+// Roofline: HBM (the fine-grid passes); the gather touches 3 w^2 doubles per point.
+#include "ipde_common.h"
+#include "fft2d.h"
+#include <cmath>
+
+namespace {
+
+struct cd {
+    double x, y;
+};
+
+// Gauss-Legendre nodes / weights on [-1, 1] (Newton on P_n)
+void gauss_legendre(int n, std::vector<double>& x, std::vector<double>& w) {
+    x.resize(n);
+    w.resize(n);
+    for (int i = 0; i < n; ++i) {
+        long double z = cosl(3.14159265358979323846264338327950288L * (i + 0.75L) / (n + 0.5L));
+        long double pp = 1;
+        for (int it = 0; it < 100; ++it) {
+            long double p1 = 1, p2 = 0;
+            for (int j = 1; j <= n; ++j) {
+                long double p3 = p2;
+                p2 = p1;
+                p1 = ((2 * j - 1) * z * p2 - (j - 1) * p3) / j;
+            }
+            pp = n * (z * p1 - p2) / (z * z - 1);
+            long double dz = p1 / pp;
+            z -= dz;
+            if (fabsl(dz) < 1e-19L) break;
+        }
+        x[i] = (double)z;
+        w[i] = (double)(2 / ((1 - z * z) * pp * pp));
+    }
+}
+
+// h_f / psihat(k): psi(x) = phi(x / a), phi(z) = exp(beta (sqrt(1 - z^2) - 1)) on |z| <= 1,
+// a = w h_f / 2; psihat(k) = a int_{-1}^{1} phi(z) cos(k a z) dz.  Index units: the box is
+// [0, 2 pi), h_f = 2 pi / nf, k integer.
+void window_factors(int64_t nf, int w, double beta, int64_t nk, std::vector<double>& r) {
+    std::vector<double> gx, gw;
+    gauss_legendre(160, gx, gw);
+    const long double hf = 2.0L * 3.14159265358979323846264338327950288L / (long double)nf;
+    const long double a = 0.5L * w * hf;
+    r.resize(nk);
+    for (int64_t k = 0; k < nk; ++k) {
+        long double s = 0;
+        for (size_t q = 0; q < gx.size(); ++q) {
+            long double z = gx[q];
+            s += (long double)gw[q] * expl((long double)beta * (sqrtl(1 - z * z) - 1)) * cosl((long double)k * a * z);
+        }
+        r[k] = (double)(hf / (a * s));
+    }
+}
+
+// Packed coarse spectrum S (nx, ny/2) -> packed fine half spectrum D (2 nx, ny) [columns
+// 0 .. ny/2 written, all 2 nx rows], one thread per (fine row, column).
+// field 0: value, 1: d/dx, 2: d/dy.
+__global__ __launch_bounds__(256) void nufft_pad_kernel(const cd* __restrict__ S, cd* __restrict__ D,
+                                                        int nx, int ny, const double* __restrict__ rx,
+                                                        const double* __restrict__ ry, int field,
+                                                        double dkx, double dky) {
+    const int H = ny / 2;             // coarse packed width
+    const int ncol = H + 1;           // fine columns that receive data: ky = 0 .. ny/2
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)2 * nx * ncol) return;
+    const int fi = (int)(idx / ncol), j = (int)(idx - (int64_t)fi * ncol);
+    // fine row fi carries kx = fi (fi <= nx/2) or fi - 2 nx (fi >= 3 nx / 2); nothing between
+    int kx;
+    if (fi <= nx / 2)
+        kx = fi;
+    else if (fi >= 2 * nx - nx / 2)
+        kx = fi - 2 * nx;
+    else {
+        D[(int64_t)fi * ny + j] = cd{0.0, 0.0};
+        return;
+    }
+    const int ci = (kx + nx) % nx;    // coarse row (both +nx/2 and -nx/2 read the Nyquist row nx/2)
+    cd v;
+    if (j == 0 || j == H) {
+        // unpack column 0: G = U0 + i UH, U0 = (G + conj Gm)/2, UH = (G - conj Gm)/2i
+        cd g = S[(int64_t)ci * H], gm = S[(int64_t)((nx - ci) % nx) * H];
+        v = (j == 0) ? cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)}
+                     : cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
+    } else {
+        v = S[(int64_t)ci * H + j];
+    }
+    double wgt = rx[kx < 0 ? -kx : kx] * ry[j];
+    const bool nyqx = 2 * (kx < 0 ? -kx : kx) == nx, nyqy = (j == H);
+    if (nyqx && nyqy) {
+        // the corner mode: Re(F e^{-i(Nx/2 x + Ny/2 y)}) = F cos(Nx/2 x + Ny/2 y) is the pair
+        // (+,+) / (-,-) alone — half at (+Nx/2, +Ny/2), nothing at (-Nx/2, +Ny/2)
+        wgt = kx > 0 ? 0.5 * wgt : 0.0;
+    } else if (nyqx || nyqy) {
+        wgt *= 0.5;   // a Nyquist line: half at +N/2, half at -N/2 (cos(N/2 x) times the rest)
+    }
+    v.x *= wgt;
+    v.y *= wgt;
+    if (field == 1) v = cd{-v.y * (kx * dkx), v.x * (kx * dkx)};
+    if (field == 2) v = cd{-v.y * (j * dky), v.x * (j * dky)};
+    // fine column 0 is packed too: its imaginary part is the fine Nyquist column, which is zero;
+    // U0 is Hermitian in kx, so storing it as is keeps the packing consistent
+    D[(int64_t)fi * ny + j] = v;
+}
+
+// One wavefront per point: out[f][p] = sum_{a,b} g_f[ix + a][iy + b] psi(x - x_a) psi(y - y_b)
+template <int W>
+__global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restrict__ g0,
+                                                          const double* __restrict__ g1,
+                                                          const double* __restrict__ g2, int nfx,
+                                                          int nfy, const double* __restrict__ px,
+                                                          const double* __restrict__ py, int64_t np,
+                                                          double beta, double* __restrict__ out) {
+    const int64_t p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double TWO_PI = 6.283185307179586476925286766559;
+    const double hfx = TWO_PI / nfx, hfy = TWO_PI / nfy;
+    double x = px[p], y = py[p];
+    x -= TWO_PI * floor(x / TWO_PI);
+    y -= TWO_PI * floor(y / TWO_PI);
+    // first node of the patch: the W nodes nearest to the point
+    const int ix0 = (int)ceil(x / hfx - 0.5 * W), iy0 = (int)ceil(y / hfy - 0.5 * W);
+    auto psi = [&](double z) {
+        double q = 1.0 - z * z;
+        return q > 0.0 ? exp(beta * (sqrt(q) - 1.0)) : 0.0;
+    };
+    // lane -> column b = lane % 16 (W <= 16: one column per lane of a 16-lane row group),
+    // rows a = lane / 16 + 4 r
+    constexpr int WB = 16;
+    static_assert(W <= WB, "patch wider than a 16-lane group");
+    const int b = lane % WB, a0 = lane / WB;
+    const double wy = (b < W) ? psi((y - (iy0 + b) * hfy) / (0.5 * W * hfy)) : 0.0;
+    const int jy = ((iy0 + b) % nfy + nfy) % nfy;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < (W + 3) / 4; ++r) {
+        const int a = a0 + 4 * r;
+        if (a < W && b < W) {
+            const double wx = psi((x - (ix0 + a) * hfx) / (0.5 * W * hfx));
+            const int jx = ((ix0 + a) % nfx + nfx) % nfx;
+            const int64_t o = (int64_t)jx * nfy + jy;
+            const double ww = wx * wy;
+            s0 = fma(ww, g0[o], s0);
+            s1 = fma(ww, g1[o], s1);
+            s2 = fma(ww, g2[o], s2);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s0 += __shfl_xor(s0, m);
+        s1 += __shfl_xor(s1, m);
+        s2 += __shfl_xor(s2, m);
+    }
+    if (lane == 0) {
+        out[p] = s0;
+        out[np + p] = s1;
+        out[2 * np + p] = s2;
+    }
+}
+
+}  // namespace
+
+struct GridInterp {
+    ipde_ctx* ctx = nullptr;
+    int64_t nx = 0, ny = 0;
+    int w = 16;
+    double beta = 0;
+    Fft2dPlan fine;               // (2 nx, 2 ny): W[0..2] = the three fields' fine half spectra
+    double* d_rx = nullptr;       // h_f / psihat_x(k), k = 0 .. nx/2
+    double* d_ry = nullptr;       // k = 0 .. ny/2
+    double* g[3] = {nullptr, nullptr, nullptr};   // fine real grids
+    double* stage = nullptr;      // host-call staging (points, results)
+    size_t stage_bytes = 0;
+};
+
+bool grid_interp_supported(int64_t nx, int64_t ny) {
+    return fft2d_supported(nx, ny) && fft2d_supported(2 * nx, 2 * ny);
+}
+
+void grid_interp_destroy(GridInterp* gi) {
+    if (!gi) return;
+    fft2d_plan_free(gi->fine);
+    if (gi->d_rx) (void)hipFree(gi->d_rx);
+    if (gi->d_ry) (void)hipFree(gi->d_ry);
+    for (auto& g : gi->g)
+        if (g) (void)hipFree(g);
+    if (gi->stage) (void)hipFree(gi->stage);
+    delete gi;
+}
+
+int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double hy, GridInterp** out) {
+    GridInterp* gi = new GridInterp();
+    gi->ctx = ctx;
+    gi->nx = nx;
+    gi->ny = ny;
+    gi->w = 16;
+    gi->beta = 2.30 * gi->w;
+    int st = fft2d_plan_init(ctx, gi->fine, 2 * nx, 2 * ny, 0.5 * hx, 0.5 * hy);
+    std::vector<double> rx, ry;
+    window_factors(2 * nx, gi->w, gi->beta, nx / 2 + 1, rx);
+    window_factors(2 * ny, gi->w, gi->beta, ny / 2 + 1, ry);
+    auto up = [&](double** d, const std::vector<double>& h) {
+        if (st == IPDE_OK && hipMalloc((void**)d, h.size() * sizeof(double)) != hipSuccess) st = IPDE_ERR_ALLOC;
+        if (st == IPDE_OK && hipMemcpy(*d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+            st = IPDE_ERR_HIP;
+    };
+    up(&gi->d_rx, rx);
+    up(&gi->d_ry, ry);
+    const size_t gbytes = (size_t)4 * nx * ny * sizeof(double);
+    for (auto& g : gi->g)
+        if (st == IPDE_OK && hipMalloc((void**)&g, gbytes) != hipSuccess) st = IPDE_ERR_ALLOC;
+    // columns ny/2 + 1 .. ny - 1 of the fine half spectra are never written: zero once
+    for (auto& w : gi->fine.W)
+        if (st == IPDE_OK && w && hipMemset(w, 0, (size_t)2 * nx * ny * 2 * sizeof(double)) != hipSuccess)
+            st = IPDE_ERR_HIP;
+    if (st != IPDE_OK) {
+        grid_interp_destroy(gi);
+        return st;
+    }
+    *out = gi;
+    return IPDE_OK;
+}
+
+// spec: packed coarse spectrum (nx, ny/2) = fft2(f) * symbol * 2 / (nx ny) (fft2d_scalar_solve's
+// kept spectrum).  px, py: points in box units [0, 2 pi); out: (3, np) = u, du/dx, du/dy with the
+// derivatives in physical units (dkx, dky = 2 pi / box length).
+int grid_interp_eval(GridInterp* gi, const void* spec, int loc, int64_t np, const double* px,
+                     const double* py, double dkx, double dky, double* out) {
+    ipde_ctx* ctx = gi->ctx;
+    const int64_t nx = gi->nx, ny = gi->ny;
+    const double *d_px = px, *d_py = py;
+    double* d_out = out;
+    if (loc == IPDE_HOST) {
+        const size_t need = (size_t)5 * np * sizeof(double);
+        if (need > gi->stage_bytes) {
+            if (gi->stage) (void)hipFree(gi->stage);
+            IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->stage, need));
+            gi->stage_bytes = need;
+        }
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(gi->stage, px, np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(gi->stage + np, py, np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        d_px = gi->stage;
+        d_py = gi->stage + np;
+        d_out = gi->stage + 2 * np;
+    }
+    const int64_t nthreads = 2 * nx * (ny / 2 + 1);
+    for (int f = 0; f < 3; ++f) {
+        hipLaunchKernelGGL(nufft_pad_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0,
+                           ctx->stream, (const cd*)spec, (cd*)gi->fine.W[f], (int)nx, (int)ny,
+                           (const double*)gi->d_rx, (const double*)gi->d_ry, f, dkx, dky);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+        // the kept spectrum carries 2 / (nx ny) (= the grid solve's normalisation with the factor
+        // 2 of row_c2r folded in), which is exactly what this inverse needs as well
+        IPDE_TRY(fft2d_cols(ctx, gi->fine, f, FFT2D_SYM_NONE, 2, 0.0, 1.0, -1, ny / 2 + 1));
+        IPDE_TRY(fft2d_rows_inverse(ctx, gi->fine, f, gi->g[f]));
+    }
+    hipLaunchKernelGGL(nufft_gather_kernel<16>, dim3((unsigned)np), dim3(64), 0, ctx->stream,
+                       (const double*)gi->g[0], (const double*)gi->g[1], (const double*)gi->g[2],
+                       (int)(2 * nx), (int)(2 * ny), d_px, d_py, np, gi->beta, d_out);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    if (loc == IPDE_HOST) {
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, 3 * np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return IPDE_OK;
+}

@@ -42,6 +42,8 @@ struct ipde_fft_plan {
     size_t work_bytes = 0;
     double2* spec[3] = {nullptr, nullptr, nullptr};
     Fft2dPlan fast;   // hand-written pipeline (power-of-two grids), fft2d.hip
+    bool keep_spec = false, have_spec = false;   // fast.W[1] holds the last solve's spectrum
+    GridInterp* interp = nullptr;                // created by the first ipde_grid_interp
     double* rbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // host staging
     double2* cbuf[2] = {nullptr, nullptr};                            // host staging (complex)
 };
@@ -345,7 +347,8 @@ int scalar_solve(ipde_fft_plan* p, int loc, double k2h, const double* f, double*
     IPDE_TRY(stage_cplx_out(p, loc, 0, uhat, &d_uh));
     if (p->fast.ready && ctx->opt_fft2d && !uhat) {
         // three hand-written kernels: rows r2c, fused column FFT * symbol * inverse FFT, rows c2r
-        IPDE_TRY(fft2d_scalar_solve(ctx, p->fast, SYM, k2h, d_f, d_u));
+        IPDE_TRY(fft2d_scalar_solve(ctx, p->fast, SYM, k2h, d_f, d_u, p->keep_spec));
+        p->have_spec = p->keep_spec;
         IPDE_TRY(finish_real_out(p, loc, 1, u));
         return finish_sync(p, loc);
     }
@@ -408,6 +411,7 @@ extern "C" int ipde_fft_plan2d_destroy(ipde_fft_plan* p) {
     if (p->info) rocfft_execution_info_destroy(p->info);
     if (p->work) hipFree(p->work);
     fft2d_plan_free(p->fast);
+    grid_interp_destroy(p->interp);
     for (auto& s : p->spec)
         if (s) hipFree(s);
     for (auto& s : p->rbuf)
@@ -416,6 +420,33 @@ extern "C" int ipde_fft_plan2d_destroy(ipde_fft_plan* p) {
         if (s) hipFree(s);
     delete p;
     return IPDE_OK;
+}
+
+extern "C" int ipde_fft_plan2d_keep_spectrum(ipde_fft_plan* p, int on, int* supported) {
+    if (!p) return IPDE_ERR_INVALID;
+    const bool ok = p->fast.ready && p->ctx->opt_fft2d && grid_interp_supported(p->nx, p->ny);
+    if (supported) *supported = ok ? 1 : 0;
+    p->keep_spec = ok && on;
+    if (!p->keep_spec) p->have_spec = false;
+    return IPDE_OK;
+}
+
+extern "C" int ipde_grid_interp(ipde_fft_plan* p, int loc, int64_t np, const double* x, const double* y,
+                                double* out3) {
+    if (!p) return IPDE_ERR_INVALID;
+    ipde_ctx* ctx = p->ctx;
+    IPDE_CHECK_ARG(ctx, loc == IPDE_HOST || loc == IPDE_DEVICE);
+    IPDE_CHECK_ARG(ctx, np >= 0 && (np == 0 || (x && y && out3)));
+    if (!p->have_spec) {
+        IPDE_SET_ERR(ctx, "ipde_grid_interp: no kept spectrum (ipde_fft_plan2d_keep_spectrum, then a "
+                          "scalar grid solve on this plan)");
+        return IPDE_ERR_INVALID;
+    }
+    if (np == 0) return IPDE_OK;
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!p->interp) IPDE_TRY(grid_interp_create(ctx, p->nx, p->ny, p->hx, p->hy, &p->interp));
+    return grid_interp_eval(p->interp, p->fast.W[1], loc, np, x, y, 2.0 * M_PI / (p->nx * p->hx),
+                            2.0 * M_PI / (p->ny * p->hy), out3);
 }
 
 extern "C" int ipde_poisson_grid_solve(ipde_fft_plan* p, int loc, const double* f, double* u,

@@ -41,6 +41,8 @@ class ModifiedHelmholtzSolver(ScalarSolver):
 
     def _grid_solve(self, fc):
         """fc: device (Nx, Ny) -> (uch, uc) on the device"""
+        if self._fast_interp:     # the spectrum stays inside the plan (plan.interp_gradient)
+            return None, self.plan.modhelm_solve(fc.contiguous(), self.k)
         uch, uc = self.plan.modhelm_solve(fc.contiguous(), self.k, want_uhat=True)
         return uch, uc
 

@@ -25,6 +25,8 @@ class PoissonSolver(ScalarSolver):
             self._bumpy_src = bumpy
         integral = fc.sum() * (self.grid.xh * self.grid.yh)
         fc = fc - integral * self._bumpy_d
+        if self._fast_interp:     # the spectrum stays inside the plan (plan.interp_gradient)
+            return None, self.plan.poisson_solve(fc.contiguous())
         uch, uc = self.plan.poisson_solve(fc.contiguous(), want_uhat=True)
         return uch, uc
 

@@ -101,6 +101,11 @@ class ScalarSolver(object):
         self._get_specific_operators()
         self._set_derivative_method()
         self.interpolation_order = 3 if self.solver_type == 'fourth' else np.inf
+        # values and gradient of the grid solution on the interfaces: through the library's
+        # oversampled-FFT interpolation when the plan has it (power-of-two grids), else from the
+        # full spectrum by the dense Fourier sums of ipde_amd.interp
+        self._fast_interp = self.USE_FAST_INTERP and self.interpolation_order == np.inf \
+            and self.plan.keep_spectrum(True)
         self.grid_step = self.ebdyc.grid_step
         self._define_layer_apply()
         self._collect_grid_sources()
@@ -109,6 +114,7 @@ class ScalarSolver(object):
 
     CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other
     DISTRIBUTE_BOUNDARIES = True  # under torch.distributed: boundary i on rank i mod world
+    USE_FAST_INTERP = True        # False: always the dense Fourier sums (the checker)
 
     def _concurrent_helpers(self):
         return _concurrent_helpers(self)
@@ -205,9 +211,13 @@ class ScalarSolver(object):
         fc = fg.view(Nx, Ny) * self._grid_step_d
         uch, uc = self._grid_solve(fc)
         uc = uc.contiguous()
-        if self.interpolation_order == np.inf:
-            # values and gradient on all interface nodes from the spectrum (:80-88); the
-            # three fields share one set of exponential matrices
+        if self.interpolation_order == np.inf and uch is None:
+            # values and gradient on all interface nodes (:80-88) from the spectrum the grid
+            # solve left on the device: 2x oversampled inverse FFT + window gather (csrc/nufft.hip)
+            all_bvs = self.plan.interp_gradient(self._ifx_d, self._ify_d).cpu().numpy()
+        elif self.interpolation_order == np.inf:
+            # the same from the full spectrum by dense Fourier sums; the three fields share one
+            # set of exponential matrices
             all_bvs = periodic_interp2d_gradient(uch, self._ifx_d, self._ify_d, self._ikx_d,
                                                   self._iky_d).cpu().numpy()
         else:

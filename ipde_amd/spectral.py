@@ -35,6 +35,26 @@ class GridPlan:
             raise ValueError("grid shape %s does not match the plan %s" % (tuple(f.shape), self.shape))
         return loc, f
 
+    # -- spectrum kept on the device for interpolation to points -----------------
+    def keep_spectrum(self, on=True):
+        """Ask the scalar grid solves on this plan (called without want_uhat) to keep
+        fft2(f) * symbol on the device for `interp_gradient`.  Returns False if this grid
+        size has no such path (then use want_uhat and ipde_amd.interp)."""
+        ok = ctypes.c_int()
+        self.ctx.check(self.ctx.lib.ipde_fft_plan2d_keep_spectrum(self.handle, int(bool(on)),
+                                                                  ctypes.byref(ok)))
+        return bool(ok.value)
+
+    def interp_gradient(self, x, y):
+        """(3, P): the last kept grid solution, its x and its y derivative at the points
+        (x, y) given in box units [0, 2 pi) (reference multi_boundary/scalar.py:80-88)"""
+        loc = location_of(x, y)
+        x, y = as_f64(x, loc), as_f64(y, loc)
+        n = int(x.shape[0])
+        out = empty_like_loc((3, n), loc, self.ctx)
+        self.ctx.check(self.ctx.lib.ipde_grid_interp(self.handle, loc, n, ptr(x), ptr(y), ptr(out)))
+        return out
+
     # -- grid solves ----------------------------------------------------------
     def poisson_solve(self, f, want_uhat=False):
         """u = ifft2(fft2(f) * ilap).real  (multi_boundary/poisson.py:30-38; f demeaned

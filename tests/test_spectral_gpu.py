@@ -148,3 +148,78 @@ def test_hand_written_fft_pipeline_against_oracle(ctx, shape):
     uh, u = plan.poisson_solve(f, want_uhat=True)
     assert rel_err(u, u_ref) < TOL and rel_err(uh, uh_ref) < TOL
     plan.close()
+
+
+@pytest.mark.parametrize("shape,npts", [((512, 1024), 700), ((2048, 2048), 4096)])
+def test_grid_interp_against_dense_fourier_sums(shape, npts):
+    """Values and gradient of the grid solution at scattered points: the oversampled-FFT
+    interpolation of csrc/nufft.hip (what the solvers use on power-of-two grids) against the
+    exact dense Fourier sums of ipde_amd.interp (the checker), <= 1e-13 of each field's
+    maximum; timing of both printed."""
+    import time
+    import torch
+    from ipde_amd.spectral import GridPlan
+    from ipde_amd.interp import periodic_interp2d_gradient
+    nx, ny = shape
+    hx, hy = 3.0 / nx, 2.6 / ny
+    x = torch.arange(nx, dtype=torch.float64, device="cuda") * hx
+    y = torch.arange(ny, dtype=torch.float64, device="cuda") * hy
+    X, Y = torch.meshgrid(x, y, indexing="ij")
+    # a smooth periodic forcing plus a little broadband content down to the Nyquist lines
+    g = torch.Generator(device="cuda").manual_seed(5)
+    f = torch.exp(torch.sin(2 * np.pi * X / 3.0)) * torch.cos(4 * np.pi * Y / 2.6) \
+        + 1e-3 * torch.randn(nx, ny, dtype=torch.float64, device="cuda", generator=g)
+    f -= f.mean()
+    plan = GridPlan(nx, ny, hx, hy)
+    assert plan.keep_spectrum(True)
+    u = plan.poisson_solve(f)
+    rng = np.random.default_rng(8)
+    px = torch.as_tensor(rng.uniform(0, 2 * np.pi, npts), device="cuda")
+    py = torch.as_tensor(rng.uniform(0, 2 * np.pi, npts), device="cuda")
+    px[0], py[0], px[1], py[1] = 0.0, 0.0, 2 * np.pi * (1 - 1e-12), 1e-9     # box corners / wrap
+    got = plan.interp_gradient(px, py)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = plan.interp_gradient(px, py)
+    torch.cuda.synchronize()
+    t_fft = time.perf_counter() - t0
+    # the checker: same spectrum by the rocFFT path of the library, dense sums
+    plan.keep_spectrum(False)
+    uh, u2 = plan.poisson_solve(f, want_uhat=True)
+    kx = torch.as_tensor(np.fft.fftfreq(nx, hx / (2 * np.pi)), device="cuda")
+    ky = torch.as_tensor(np.fft.fftfreq(ny, hy / (2 * np.pi)), device="cuda")
+    ref = periodic_interp2d_gradient(uh, px, py, 1j * kx[:, None], 1j * ky)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ref = periodic_interp2d_gradient(uh, px, py, 1j * kx[:, None], 1j * ky)
+    torch.cuda.synchronize()
+    t_gemm = time.perf_counter() - t0
+    print("grid %s, %d points: oversampled FFT %.3f ms, dense sums %.3f ms" % (shape, npts, 1e3 * t_fft, 1e3 * t_gemm))
+    for k in range(3):
+        err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+        assert err < 1e-13, (k, err)
+    # host arrays in, host arrays out
+    plan.keep_spectrum(True)
+    plan.poisson_solve(f)
+    got_h = plan.interp_gradient(px.cpu().numpy(), py.cpu().numpy())
+    assert isinstance(got_h, np.ndarray) and np.array_equal(got_h, got.cpu().numpy())
+    # and the value row is the grid solution at grid points
+    ii, jj = 37, ny - 5
+    at = plan.interp_gradient(np.array([2 * np.pi * ii / nx]), np.array([2 * np.pi * jj / ny]))
+    assert abs(at[0, 0] - float(u[ii, jj])) < 1e-13 * float(u.abs().max())
+    plan.close()
+
+
+def test_grid_interp_needs_a_kept_spectrum_and_a_supported_grid():
+    from ipde_amd._lib import IpdeHipError
+    from ipde_amd.spectral import GridPlan
+    plan = GridPlan(48, 40, 0.1, 0.1)
+    assert plan.keep_spectrum(True) is False          # not a power-of-two grid: dense sums
+    with pytest.raises(IpdeHipError, match="no kept spectrum"):
+        plan.interp_gradient(np.zeros(3), np.zeros(3))
+    plan.close()
+    plan = GridPlan(512, 1024, 0.1, 0.1)
+    assert plan.keep_spectrum(True) is True
+    with pytest.raises(IpdeHipError, match="no kept spectrum"):    # no solve yet
+        plan.interp_gradient(np.zeros(3), np.zeros(3))
+    plan.close()
