@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (must precede loading libipde_hip.so, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libipde_hip.so")
+# (IPDE_HIP_LIBRARY: an alternative build of the same ABI, for A/B measurements)
+LIB_PATH = os.environ.get("IPDE_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libipde_hip.so")
 
 IPDE_HOST = 0
 IPDE_DEVICE = 1
