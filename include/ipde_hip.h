@@ -79,7 +79,8 @@ const char* ipde_last_error(ipde_ctx* ctx);
    apply, measured with hipEvents on the context's stream (0 if timing is off). */
 /* Tuning knobs (kernel geometry variants); never changes results beyond rounding.
    Names: "laplace_variant", "stokes_variant", "dense_pairs", "annular_grouped",
-   "fft2d" (1: hand-written 2-D FFT pipeline on power-of-two grids, 0: rocFFT). */
+   "fft2d" (1: hand-written 2-D FFT pipeline on power-of-two grids, 0: rocFFT),
+   "interp_shifted" (1: ipde_grid_interp through four shifted coarse transforms at any size). */
 int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value);
 /* Current value of a knob (so that a caller can restore what it found). */
 int ipde_ctx_get_option(ipde_ctx* ctx, const char* name, int* value);
@@ -190,7 +191,7 @@ int ipde_fourier_deriv(ipde_fft_plan* plan, int loc, const double* f, int axis, 
  * all interface nodes; three finufft type-2 transforms there).
  * ipde_fft_plan2d_keep_spectrum(plan, 1, &ok): subsequent ipde_poisson_grid_solve /
  * ipde_modhelm_grid_solve calls WITHOUT a uhat output keep fft2(f) * symbol on the device
- * (ok = 0: this grid size has no such path — power-of-two sizes up to 2048 x 4096 do —, use
+ * (ok = 0: this grid size has no such path — power-of-two sizes up to 4096 x 8192 do —, use
  * uhat and the caller's own evaluation).
  * ipde_grid_interp: out3 (3, np) row-major = u, du/dx, du/dy at the points (x, y), given in
  * box units [0, 2 pi) as ebdyc.interfaces_x_transf / interfaces_y_transf; derivatives in

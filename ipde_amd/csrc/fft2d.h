@@ -35,5 +35,8 @@ struct GridInterp;
 bool grid_interp_supported(int64_t nx, int64_t ny);
 int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double hy, GridInterp** out);
 void grid_interp_destroy(GridInterp* gi);
-int grid_interp_eval(GridInterp* gi, const void* spec, int loc, int64_t np, const double* px,
+// coarse: the grid's own plan; its W[1] holds the kept spectrum, W[2] is scratch
+int grid_interp_eval(GridInterp* gi, const Fft2dPlan& coarse, int loc, int64_t np, const double* px,
                      const double* py, double dkx, double dky, double* out);
+// test hook: force the shifted-copies variant (four coarse transforms) on the next create
+void grid_interp_force_shifted(bool on);

@@ -121,8 +121,89 @@ __global__ __launch_bounds__(256) void nufft_pad_kernel(const cd* __restrict__ S
     D[(int64_t)fi * ny + j] = v;
 }
 
+
+// --- the same fine-grid samples WITHOUT a fine-grid transform ---------------------------------
+// A 2x oversampled inverse transform of a zero-padded spectrum is four coarse-size inverse
+// transforms: fine sample (2m + a, 2n + b) = coarse sample (m, n) of the field shifted by
+// (a h/2, b h/2), i.e. of the spectrum times e^{i pi (a kx / nx + b ky / ny)}.  Used when the
+// fine size is beyond the FFT kernels (coarse 4096: BASELINE configs[3], [4]): same window, same
+// gather, no 8192-point transforms and no zeros moved through HBM.
+//
+// D (nx, ny/2) packed <- S packed, for shift (a, b) and field (0: value, 1: d/dx, 2: d/dy).
+// The Nyquist lines are cosines: cos(N/2 x) sampled at the half-shifted points vanishes and its
+// derivative survives only there; the corner mode F cos(Nx/2 x + Ny/2 y) (see the pad kernel)
+// depends on a + b.
+__device__ __forceinline__ cd cis_pi(double t) {   // e^{i pi t}
+    double sn, cs;
+    sincospi(t, &sn, &cs);
+    return cd{cs, sn};
+}
+__device__ __forceinline__ cd cmulz(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+__global__ __launch_bounds__(256) void nufft_shift_kernel(const cd* __restrict__ S, cd* __restrict__ D,
+                                                          int nx, int ny, const double* __restrict__ rx,
+                                                          const double* __restrict__ ry, int field,
+                                                          int a, int b, double dkx, double dky) {
+    const int H = ny / 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)nx * H) return;
+    const int i = (int)(idx / H), j = (int)(idx - (int64_t)i * H);
+    const int kx = (i < nx / 2) ? i : i - nx;        // (row nx/2: kx = -nx/2, handled as a cosine)
+    const bool nyqx = (2 * i == nx);
+    const double wx = rx[kx < 0 ? -kx : kx];
+    // factor of a 1-D mode along x: interior e^{i pi a kx / nx} (times i kx for d/dx); the Nyquist
+    // cosine: value 1 / 0 at shift 0 / 1, derivative 0 / -(nx/2) dkx
+    auto xfac = [&](int der) -> cd {
+        if (nyqx) {
+            if (!der) return cd{a ? 0.0 : wx, 0.0};
+            return cd{a ? -0.5 * nx * dkx * wx : 0.0, 0.0};
+        }
+        cd ph = a ? cis_pi((double)kx / nx) : cd{1.0, 0.0};
+        ph.x *= wx;
+        ph.y *= wx;
+        return der ? cd{-ph.y * (kx * dkx), ph.x * (kx * dkx)} : ph;
+    };
+    auto yfac = [&](int jj, int der) -> cd {         // jj in 0 .. H; jj == H: the Nyquist cosine
+        const double wy = ry[jj];
+        if (jj == H) {
+            if (!der) return cd{b ? 0.0 : wy, 0.0};
+            return cd{b ? -0.5 * ny * dky * wy : 0.0, 0.0};
+        }
+        cd ph = b ? cis_pi((double)jj / ny) : cd{1.0, 0.0};
+        ph.x *= wy;
+        ph.y *= wy;
+        return der ? cd{-ph.y * (jj * dky), ph.x * (jj * dky)} : ph;
+    };
+    const int dx = (field == 1), dy = (field == 2);
+    if (j > 0) {
+        D[idx] = cmulz(cmulz(S[idx], xfac(dx)), yfac(j, dy));
+        return;
+    }
+    // column 0 carries ky = 0 (U0) and the Nyquist column (UH): unpack with the mirrored row,
+    // treat both, pack again (both stay Hermitian in kx: the factors are e^{i odd(kx)} or real)
+    cd g = S[(int64_t)i * H], gm = S[(int64_t)((nx - i) % nx) * H];
+    cd u0 = cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)};
+    cd uh = cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
+    u0 = cmulz(cmulz(u0, xfac(dx)), yfac(0, dy));
+    if (nyqx) {
+        // the corner: F cos(A + B), A = pi m + pi a/2, B = pi n + pi b/2
+        const int sft = a + b;
+        double f;
+        if (field == 0)
+            f = sft == 0 ? 1.0 : (sft == 1 ? 0.0 : -1.0);
+        else
+            f = sft == 1 ? -(field == 1 ? 0.5 * nx * dkx : 0.5 * ny * dky) : 0.0;
+        f *= wx * ry[H];
+        uh = cd{uh.x * f, uh.y * f};
+    } else {
+        uh = cmulz(cmulz(uh, xfac(dx)), yfac(H, dy));
+    }
+    D[idx] = cd{u0.x - uh.y, u0.y + uh.x};           // U0 + i UH
+}
+
 // One wavefront per point: out[f][p] = sum_{a,b} g_f[ix + a][iy + b] psi(x - x_a) psi(y - y_b)
-template <int W>
+// SUB: the fine grid is stored as four coarse sub-grids [2 a + b][m][n] (fine (2m + a, 2n + b))
+template <int W, bool SUB>
 __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restrict__ g0,
                                                           const double* __restrict__ g1,
                                                           const double* __restrict__ g2, int nfx,
@@ -156,7 +237,8 @@ __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restri
         if (a < W && b < W) {
             const double wx = psi((x - (ix0 + a) * hfx) / (0.5 * W * hfx));
             const int jx = ((ix0 + a) % nfx + nfx) % nfx;
-            const int64_t o = (int64_t)jx * nfy + jy;
+            const int64_t o = SUB ? ((int64_t)(2 * (jx & 1) + (jy & 1)) * (nfx / 2) + (jx >> 1)) * (nfy / 2) + (jy >> 1)
+                                  : (int64_t)jx * nfy + jy;
             const double ww = wx * wy;
             s0 = fma(ww, g0[o], s0);
             s1 = fma(ww, g1[o], s1);
@@ -183,6 +265,7 @@ struct GridInterp {
     int64_t nx = 0, ny = 0;
     int w = 16;
     double beta = 0;
+    bool shifted = false;         // fine size beyond the FFT kernels: four shifted coarse transforms
     Fft2dPlan fine;               // (2 nx, 2 ny): W[0..2] = the three fields' fine half spectra
     double* d_rx = nullptr;       // h_f / psihat_x(k), k = 0 .. nx/2
     double* d_ry = nullptr;       // k = 0 .. ny/2
@@ -191,9 +274,10 @@ struct GridInterp {
     size_t stage_bytes = 0;
 };
 
-bool grid_interp_supported(int64_t nx, int64_t ny) {
-    return fft2d_supported(nx, ny) && fft2d_supported(2 * nx, 2 * ny);
-}
+bool grid_interp_supported(int64_t nx, int64_t ny) { return fft2d_supported(nx, ny); }
+
+static bool g_force_shifted = false;
+void grid_interp_force_shifted(bool on) { g_force_shifted = on; }
 
 void grid_interp_destroy(GridInterp* gi) {
     if (!gi) return;
@@ -213,7 +297,8 @@ int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double 
     gi->ny = ny;
     gi->w = 16;
     gi->beta = 2.30 * gi->w;
-    int st = fft2d_plan_init(ctx, gi->fine, 2 * nx, 2 * ny, 0.5 * hx, 0.5 * hy);
+    gi->shifted = g_force_shifted || !fft2d_supported(2 * nx, 2 * ny);
+    int st = gi->shifted ? IPDE_OK : fft2d_plan_init(ctx, gi->fine, 2 * nx, 2 * ny, 0.5 * hx, 0.5 * hy);
     std::vector<double> rx, ry;
     window_factors(2 * nx, gi->w, gi->beta, nx / 2 + 1, rx);
     window_factors(2 * ny, gi->w, gi->beta, ny / 2 + 1, ry);
@@ -229,7 +314,7 @@ int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double 
         if (st == IPDE_OK && hipMalloc((void**)&g, gbytes) != hipSuccess) st = IPDE_ERR_ALLOC;
     // columns ny/2 + 1 .. ny - 1 of the fine half spectra are never written: zero once
     for (auto& w : gi->fine.W)
-        if (st == IPDE_OK && w && hipMemset(w, 0, (size_t)2 * nx * ny * 2 * sizeof(double)) != hipSuccess)
+        if (!gi->shifted && st == IPDE_OK && w && hipMemset(w, 0, (size_t)2 * nx * ny * 2 * sizeof(double)) != hipSuccess)
             st = IPDE_ERR_HIP;
     if (st != IPDE_OK) {
         grid_interp_destroy(gi);
@@ -242,8 +327,9 @@ int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double 
 // spec: packed coarse spectrum (nx, ny/2) = fft2(f) * symbol * 2 / (nx ny) (fft2d_scalar_solve's
 // kept spectrum).  px, py: points in box units [0, 2 pi); out: (3, np) = u, du/dx, du/dy with the
 // derivatives in physical units (dkx, dky = 2 pi / box length).
-int grid_interp_eval(GridInterp* gi, const void* spec, int loc, int64_t np, const double* px,
+int grid_interp_eval(GridInterp* gi, const Fft2dPlan& coarse, int loc, int64_t np, const double* px,
                      const double* py, double dkx, double dky, double* out) {
+    const void* spec = coarse.W[1];
     ipde_ctx* ctx = gi->ctx;
     const int64_t nx = gi->nx, ny = gi->ny;
     const double *d_px = px, *d_py = py;
@@ -261,6 +347,24 @@ int grid_interp_eval(GridInterp* gi, const void* spec, int loc, int64_t np, cons
         d_py = gi->stage + np;
         d_out = gi->stage + 2 * np;
     }
+    if (gi->shifted) {
+        // W[2] of the coarse plan is scratch; sub-grid (a, b) of field f lands in g[f] + (2a+b) nx ny
+        const int64_t nth = nx * (ny / 2);
+        for (int f = 0; f < 3; ++f)
+            for (int ab = 0; ab < 4; ++ab) {
+                hipLaunchKernelGGL(nufft_shift_kernel, dim3((unsigned)ceil_div64(nth, 256)), dim3(256), 0,
+                                   ctx->stream, (const cd*)spec, (cd*)coarse.W[2], (int)nx, (int)ny,
+                                   (const double*)gi->d_rx, (const double*)gi->d_ry, f, ab >> 1, ab & 1,
+                                   dkx, dky);
+                IPDE_HIP_CHECK(ctx, hipGetLastError());
+                IPDE_TRY(fft2d_cols(ctx, coarse, 2, FFT2D_SYM_NONE, 2, 0.0, 1.0));
+                IPDE_TRY(fft2d_rows_inverse(ctx, coarse, 2, gi->g[f] + (int64_t)ab * nx * ny));
+            }
+        hipLaunchKernelGGL((nufft_gather_kernel<16, true>), dim3((unsigned)np), dim3(64), 0, ctx->stream,
+                           (const double*)gi->g[0], (const double*)gi->g[1], (const double*)gi->g[2],
+                           (int)(2 * nx), (int)(2 * ny), d_px, d_py, np, gi->beta, d_out);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+    } else {
     const int64_t nthreads = 2 * nx * (ny / 2 + 1);
     for (int f = 0; f < 3; ++f) {
         hipLaunchKernelGGL(nufft_pad_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0,
@@ -272,10 +376,11 @@ int grid_interp_eval(GridInterp* gi, const void* spec, int loc, int64_t np, cons
         IPDE_TRY(fft2d_cols(ctx, gi->fine, f, FFT2D_SYM_NONE, 2, 0.0, 1.0, -1, ny / 2 + 1));
         IPDE_TRY(fft2d_rows_inverse(ctx, gi->fine, f, gi->g[f]));
     }
-    hipLaunchKernelGGL(nufft_gather_kernel<16>, dim3((unsigned)np), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL((nufft_gather_kernel<16, false>), dim3((unsigned)np), dim3(64), 0, ctx->stream,
                        (const double*)gi->g[0], (const double*)gi->g[1], (const double*)gi->g[2],
                        (int)(2 * nx), (int)(2 * ny), d_px, d_py, np, gi->beta, d_out);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
+    }
     if (loc == IPDE_HOST) {
         IPDE_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, 3 * np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -444,8 +444,11 @@ extern "C" int ipde_grid_interp(ipde_fft_plan* p, int loc, int64_t np, const dou
     }
     if (np == 0) return IPDE_OK;
     IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (!p->interp) IPDE_TRY(grid_interp_create(ctx, p->nx, p->ny, p->hx, p->hy, &p->interp));
-    return grid_interp_eval(p->interp, p->fast.W[1], loc, np, x, y, 2.0 * M_PI / (p->nx * p->hx),
+    if (!p->interp) {
+        grid_interp_force_shifted(ctx->opt_interp_shifted != 0);
+        IPDE_TRY(grid_interp_create(ctx, p->nx, p->ny, p->hx, p->hy, &p->interp));
+    }
+    return grid_interp_eval(p->interp, p->fast, loc, np, x, y, 2.0 * M_PI / (p->nx * p->hx),
                             2.0 * M_PI / (p->ny * p->hy), out3);
 }
 

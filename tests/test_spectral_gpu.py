@@ -150,12 +150,15 @@ def test_hand_written_fft_pipeline_against_oracle(ctx, shape):
     plan.close()
 
 
-@pytest.mark.parametrize("shape,npts", [((512, 1024), 700), ((2048, 2048), 4096)])
-def test_grid_interp_against_dense_fourier_sums(shape, npts):
+@pytest.mark.parametrize("shape,npts,shifted", [((512, 1024), 700, 0), ((2048, 2048), 4096, 0),
+                                                ((512, 1024), 700, 1), ((2048, 1024), 900, 1),
+                                                ((4096, 4096), 600, 0)])
+def test_grid_interp_against_dense_fourier_sums(ctx, shape, npts, shifted):
     """Values and gradient of the grid solution at scattered points: the oversampled-FFT
     interpolation of csrc/nufft.hip (what the solvers use on power-of-two grids) against the
     exact dense Fourier sums of ipde_amd.interp (the checker), <= 1e-13 of each field's
-    maximum; timing of both printed."""
+    maximum; timing of both printed.  shifted = 1 forces the variant that grids of 4096 points
+    a side use by themselves (four half-cell-shifted coarse transforms instead of one fine one)."""
     import time
     import torch
     from ipde_amd.spectral import GridPlan
@@ -170,6 +173,7 @@ def test_grid_interp_against_dense_fourier_sums(shape, npts):
     f = torch.exp(torch.sin(2 * np.pi * X / 3.0)) * torch.cos(4 * np.pi * Y / 2.6) \
         + 1e-3 * torch.randn(nx, ny, dtype=torch.float64, device="cuda", generator=g)
     f -= f.mean()
+    ctx.set_option("interp_shifted", shifted)
     plan = GridPlan(nx, ny, hx, hy)
     assert plan.keep_spectrum(True)
     u = plan.poisson_solve(f)
@@ -208,6 +212,7 @@ def test_grid_interp_against_dense_fourier_sums(shape, npts):
     at = plan.interp_gradient(np.array([2 * np.pi * ii / nx]), np.array([2 * np.pi * jj / ny]))
     assert abs(at[0, 0] - float(u[ii, jj])) < 1e-13 * float(u.abs().max())
     plan.close()
+    ctx.set_option("interp_shifted", 0)
 
 
 def test_grid_interp_needs_a_kept_spectrum_and_a_supported_grid():
