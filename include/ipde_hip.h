@@ -199,6 +199,17 @@ int ipde_fourier_deriv(ipde_fft_plan* plan, int loc, const double* f, int axis, 
 int ipde_fft_plan2d_keep_spectrum(ipde_fft_plan* plan, int on, int* supported);
 int ipde_grid_interp(ipde_fft_plan* plan, int loc, int64_t np, const double* x, const double* y,
                      double* out3);
+/* The same for linear combinations of real grid fields and their first derivatives — the Stokes
+ * solver's velocity and stress T = grad u + grad u^T - p I of the grid solution on the
+ * interfaces (ipde/solvers/multi_boundary/vector.py:66-82, five type-2 NUFFTs there).
+ * fields: nin <= 3 pointers to (nx, ny) real arrays; output k (k < nout <= 8) is the sum over
+ * its terms q = term_start[k] .. term_start[k+1]-1 (1 to 3 of them) of
+ * term_coef[q] * D^{term_der[q]} fields[term_src[q]], der 0: value, 1: d/dx, 2: d/dy.
+ * out (nout, np).  Power-of-two grids of the fft2d pipeline only (IPDE_ERR_INVALID otherwise). */
+int ipde_grid_interp_fields(ipde_fft_plan* plan, int loc, int nin, const double* const* fields,
+                            int nout, const int* term_start, const int* term_src,
+                            const int* term_der, const double* term_coef, int64_t np,
+                            const double* x, const double* y, double* out);
 
 /* general symbol: out = ifft2(fft2(f) * sym).real with sym a full (nx,ny)
    complex array (the reference accepts any broadcastable ik) */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ipde_fourier_multiply": (_int, [_vp, _int, _vp, _vp, _vp]),
     "ipde_fft_plan2d_keep_spectrum": (_int, [_vp, _int, ctypes.POINTER(_int)]),
     "ipde_grid_interp": (_int, [_vp, _int, _i64, _vp, _vp, _vp]),
+    "ipde_grid_interp_fields": (_int, [_vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ipde_dense_lu_solve": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ipde_dense_lu_solve_batch": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "ipde_chebfourier_gather": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -38,5 +38,9 @@ void grid_interp_destroy(GridInterp* gi);
 // coarse: the grid's own plan; its W[1] holds the kept spectrum, W[2] is scratch
 int grid_interp_eval(GridInterp* gi, const Fft2dPlan& coarse, int loc, int64_t np, const double* px,
                      const double* py, double dkx, double dky, double* out);
+int grid_interp_fields(GridInterp* gi, const Fft2dPlan& coarse, int nin, const double* const* d_fields,
+                       int nout, const int* term_start, const int* term_src, const int* term_der,
+                       const double* term_coef, int loc_points, int64_t np, const double* px,
+                       const double* py, double dkx, double dky, double* out);
 // test hook: force the shifted-copies variant (four coarse transforms) on the next create
 void grid_interp_force_shifted(bool on);

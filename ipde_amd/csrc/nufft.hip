@@ -28,6 +28,15 @@ struct cd {
     double x, y;
 };
 
+// one output field = sum of up to three terms coef * D^der [spectrum src], der 0: value, 1: d/dx,
+// 2: d/dy (e.g. the Stokes stress component 2 du/dx - p)
+struct Combo {
+    int n;
+    const cd* src[3];
+    int der[3];
+    double coef[3];
+};
+
 // Gauss-Legendre nodes / weights on [-1, 1] (Newton on P_n)
 void gauss_legendre(int n, std::vector<double>& x, std::vector<double>& w) {
     x.resize(n);
@@ -71,13 +80,12 @@ void window_factors(int64_t nf, int w, double beta, int64_t nk, std::vector<doub
     }
 }
 
-// Packed coarse spectrum S (nx, ny/2) -> packed fine half spectrum D (2 nx, ny) [columns
-// 0 .. ny/2 written, all 2 nx rows], one thread per (fine row, column).
-// field 0: value, 1: d/dx, 2: d/dy.
-__global__ __launch_bounds__(256) void nufft_pad_kernel(const cd* __restrict__ S, cd* __restrict__ D,
-                                                        int nx, int ny, const double* __restrict__ rx,
-                                                        const double* __restrict__ ry, int field,
-                                                        double dkx, double dky) {
+// Packed coarse spectra -> packed fine half spectrum D (2 nx, ny) [columns 0 .. ny/2 written, all
+// 2 nx rows] of one output field (a Combo), one thread per (fine row, column).
+__global__ __launch_bounds__(256) void nufft_pad_kernel(Combo cb, cd* __restrict__ D, int nx, int ny,
+                                                        const double* __restrict__ rx,
+                                                        const double* __restrict__ ry, double dkx,
+                                                        double dky) {
     const int H = ny / 2;             // coarse packed width
     const int ncol = H + 1;           // fine columns that receive data: ky = 0 .. ny/2
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -94,15 +102,6 @@ __global__ __launch_bounds__(256) void nufft_pad_kernel(const cd* __restrict__ S
         return;
     }
     const int ci = (kx + nx) % nx;    // coarse row (both +nx/2 and -nx/2 read the Nyquist row nx/2)
-    cd v;
-    if (j == 0 || j == H) {
-        // unpack column 0: G = U0 + i UH, U0 = (G + conj Gm)/2, UH = (G - conj Gm)/2i
-        cd g = S[(int64_t)ci * H], gm = S[(int64_t)((nx - ci) % nx) * H];
-        v = (j == 0) ? cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)}
-                     : cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
-    } else {
-        v = S[(int64_t)ci * H + j];
-    }
     double wgt = rx[kx < 0 ? -kx : kx] * ry[j];
     const bool nyqx = 2 * (kx < 0 ? -kx : kx) == nx, nyqy = (j == H);
     if (nyqx && nyqy) {
@@ -112,13 +111,29 @@ __global__ __launch_bounds__(256) void nufft_pad_kernel(const cd* __restrict__ S
     } else if (nyqx || nyqy) {
         wgt *= 0.5;   // a Nyquist line: half at +N/2, half at -N/2 (cos(N/2 x) times the rest)
     }
-    v.x *= wgt;
-    v.y *= wgt;
-    if (field == 1) v = cd{-v.y * (kx * dkx), v.x * (kx * dkx)};
-    if (field == 2) v = cd{-v.y * (j * dky), v.x * (j * dky)};
+    cd acc{0.0, 0.0};
+    for (int t = 0; t < cb.n; ++t) {
+        const cd* S = cb.src[t];
+        cd v;
+        if (j == 0 || j == H) {
+            // unpack column 0: G = U0 + i UH, U0 = (G + conj Gm)/2, UH = (G - conj Gm)/2i
+            cd g = S[(int64_t)ci * H], gm = S[(int64_t)((nx - ci) % nx) * H];
+            v = (j == 0) ? cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)}
+                         : cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
+        } else {
+            v = S[(int64_t)ci * H + j];
+        }
+        const double c = wgt * cb.coef[t];
+        v.x *= c;
+        v.y *= c;
+        if (cb.der[t] == 1) v = cd{-v.y * (kx * dkx), v.x * (kx * dkx)};
+        if (cb.der[t] == 2) v = cd{-v.y * (j * dky), v.x * (j * dky)};
+        acc.x += v.x;
+        acc.y += v.y;
+    }
     // fine column 0 is packed too: its imaginary part is the fine Nyquist column, which is zero;
     // U0 is Hermitian in kx, so storing it as is keeps the packing consistent
-    D[(int64_t)fi * ny + j] = v;
+    D[(int64_t)fi * ny + j] = acc;
 }
 
 
@@ -140,10 +155,10 @@ __device__ __forceinline__ cd cis_pi(double t) {   // e^{i pi t}
 }
 __device__ __forceinline__ cd cmulz(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
-__global__ __launch_bounds__(256) void nufft_shift_kernel(const cd* __restrict__ S, cd* __restrict__ D,
-                                                          int nx, int ny, const double* __restrict__ rx,
-                                                          const double* __restrict__ ry, int field,
-                                                          int a, int b, double dkx, double dky) {
+__global__ __launch_bounds__(256) void nufft_shift_kernel(Combo cb, cd* __restrict__ D, int nx, int ny,
+                                                          const double* __restrict__ rx,
+                                                          const double* __restrict__ ry, int a, int b,
+                                                          double dkx, double dky) {
     const int H = ny / 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)nx * H) return;
@@ -174,40 +189,51 @@ __global__ __launch_bounds__(256) void nufft_shift_kernel(const cd* __restrict__
         ph.y *= wy;
         return der ? cd{-ph.y * (jj * dky), ph.x * (jj * dky)} : ph;
     };
-    const int dx = (field == 1), dy = (field == 2);
-    if (j > 0) {
-        D[idx] = cmulz(cmulz(S[idx], xfac(dx)), yfac(j, dy));
-        return;
+    cd acc0{0.0, 0.0}, acch{0.0, 0.0};
+    for (int t = 0; t < cb.n; ++t) {
+        const cd* S = cb.src[t];
+        const int dx = (cb.der[t] == 1), dy = (cb.der[t] == 2);
+        const double c = cb.coef[t];
+        if (j > 0) {
+            cd v = cmulz(cmulz(S[idx], xfac(dx)), yfac(j, dy));
+            acc0.x += c * v.x;
+            acc0.y += c * v.y;
+            continue;
+        }
+        // column 0 carries ky = 0 (U0) and the Nyquist column (UH): unpack with the mirrored row,
+        // treat both, pack again (both stay Hermitian in kx: the factors are e^{i odd(kx)} or real)
+        cd g = S[(int64_t)i * H], gm = S[(int64_t)((nx - i) % nx) * H];
+        cd u0 = cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)};
+        cd uh = cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
+        u0 = cmulz(cmulz(u0, xfac(dx)), yfac(0, dy));
+        if (nyqx) {
+            // the corner: F cos(A + B), A = pi m + pi a/2, B = pi n + pi b/2
+            const int sft = a + b;
+            double f;
+            if (cb.der[t] == 0)
+                f = sft == 0 ? 1.0 : (sft == 1 ? 0.0 : -1.0);
+            else
+                f = sft == 1 ? -(cb.der[t] == 1 ? 0.5 * nx * dkx : 0.5 * ny * dky) : 0.0;
+            f *= wx * ry[H];
+            uh = cd{uh.x * f, uh.y * f};
+        } else {
+            uh = cmulz(cmulz(uh, xfac(dx)), yfac(H, dy));
+        }
+        acc0.x += c * u0.x;
+        acc0.y += c * u0.y;
+        acch.x += c * uh.x;
+        acch.y += c * uh.y;
     }
-    // column 0 carries ky = 0 (U0) and the Nyquist column (UH): unpack with the mirrored row,
-    // treat both, pack again (both stay Hermitian in kx: the factors are e^{i odd(kx)} or real)
-    cd g = S[(int64_t)i * H], gm = S[(int64_t)((nx - i) % nx) * H];
-    cd u0 = cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)};
-    cd uh = cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
-    u0 = cmulz(cmulz(u0, xfac(dx)), yfac(0, dy));
-    if (nyqx) {
-        // the corner: F cos(A + B), A = pi m + pi a/2, B = pi n + pi b/2
-        const int sft = a + b;
-        double f;
-        if (field == 0)
-            f = sft == 0 ? 1.0 : (sft == 1 ? 0.0 : -1.0);
-        else
-            f = sft == 1 ? -(field == 1 ? 0.5 * nx * dkx : 0.5 * ny * dky) : 0.0;
-        f *= wx * ry[H];
-        uh = cd{uh.x * f, uh.y * f};
-    } else {
-        uh = cmulz(cmulz(uh, xfac(dx)), yfac(H, dy));
-    }
-    D[idx] = cd{u0.x - uh.y, u0.y + uh.x};           // U0 + i UH
+    D[idx] = (j > 0) ? acc0 : cd{acc0.x - acch.y, acc0.y + acch.x};   // U0 + i UH
 }
 
-// One wavefront per point: out[f][p] = sum_{a,b} g_f[ix + a][iy + b] psi(x - x_a) psi(y - y_b)
 // SUB: the fine grid is stored as four coarse sub-grids [2 a + b][m][n] (fine (2m + a, 2n + b))
 template <int W, bool SUB>
 __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restrict__ g0,
                                                           const double* __restrict__ g1,
-                                                          const double* __restrict__ g2, int nfx,
-                                                          int nfy, const double* __restrict__ px,
+                                                          const double* __restrict__ g2, int nf,
+                                                          int nfx, int nfy,
+                                                          const double* __restrict__ px,
                                                           const double* __restrict__ py, int64_t np,
                                                           double beta, double* __restrict__ out) {
     const int64_t p = blockIdx.x;
@@ -241,8 +267,8 @@ __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restri
                                   : (int64_t)jx * nfy + jy;
             const double ww = wx * wy;
             s0 = fma(ww, g0[o], s0);
-            s1 = fma(ww, g1[o], s1);
-            s2 = fma(ww, g2[o], s2);
+            if (nf > 1) s1 = fma(ww, g1[o], s1);
+            if (nf > 2) s2 = fma(ww, g2[o], s2);
         }
     }
 #pragma unroll
@@ -253,8 +279,8 @@ __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restri
     }
     if (lane == 0) {
         out[p] = s0;
-        out[np + p] = s1;
-        out[2 * np + p] = s2;
+        if (nf > 1) out[np + p] = s1;
+        if (nf > 2) out[2 * np + p] = s2;
     }
 }
 
@@ -270,6 +296,7 @@ struct GridInterp {
     double* d_rx = nullptr;       // h_f / psihat_x(k), k = 0 .. nx/2
     double* d_ry = nullptr;       // k = 0 .. ny/2
     double* g[3] = {nullptr, nullptr, nullptr};   // fine real grids
+    void* spec[3] = {nullptr, nullptr, nullptr};  // packed spectra of input fields (grid_interp_fields)
     double* stage = nullptr;      // host-call staging (points, results)
     size_t stage_bytes = 0;
 };
@@ -286,6 +313,8 @@ void grid_interp_destroy(GridInterp* gi) {
     if (gi->d_ry) (void)hipFree(gi->d_ry);
     for (auto& g : gi->g)
         if (g) (void)hipFree(g);
+    for (auto& q : gi->spec)
+        if (q) (void)hipFree(q);
     if (gi->stage) (void)hipFree(gi->stage);
     delete gi;
 }
@@ -324,66 +353,137 @@ int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double 
     return IPDE_OK;
 }
 
-// spec: packed coarse spectrum (nx, ny/2) = fft2(f) * symbol * 2 / (nx ny) (fft2d_scalar_solve's
-// kept spectrum).  px, py: points in box units [0, 2 pi); out: (3, np) = u, du/dx, du/dy with the
-// derivatives in physical units (dkx, dky = 2 pi / box length).
-int grid_interp_eval(GridInterp* gi, const Fft2dPlan& coarse, int loc, int64_t np, const double* px,
-                     const double* py, double dkx, double dky, double* out) {
-    const void* spec = coarse.W[1];
+// The core: nout output fields, each a Combo over packed coarse spectra, at np points.
+// d_px, d_py, d_out: device; out (nout, np).  Three fields per sweep (the g buffers).
+static int interp_combos(GridInterp* gi, const Fft2dPlan& coarse, int nout, const Combo* combos,
+                         int64_t np, const double* d_px, const double* d_py, double dkx, double dky,
+                         double* d_out) {
     ipde_ctx* ctx = gi->ctx;
     const int64_t nx = gi->nx, ny = gi->ny;
-    const double *d_px = px, *d_py = py;
-    double* d_out = out;
+    for (int f0 = 0; f0 < nout; f0 += 3) {
+        const int nf = nout - f0 < 3 ? nout - f0 : 3;
+        for (int f = 0; f < nf; ++f) {
+            const Combo& cb = combos[f0 + f];
+            if (gi->shifted) {
+                // W[2] of the coarse plan is scratch; sub-grid (a, b) lands in g[f] + (2a+b) nx ny
+                const int64_t nth = nx * (ny / 2);
+                for (int ab = 0; ab < 4; ++ab) {
+                    hipLaunchKernelGGL(nufft_shift_kernel, dim3((unsigned)ceil_div64(nth, 256)), dim3(256),
+                                       0, ctx->stream, cb, (cd*)coarse.W[2], (int)nx, (int)ny,
+                                       (const double*)gi->d_rx, (const double*)gi->d_ry, ab >> 1, ab & 1,
+                                       dkx, dky);
+                    IPDE_HIP_CHECK(ctx, hipGetLastError());
+                    IPDE_TRY(fft2d_cols(ctx, coarse, 2, FFT2D_SYM_NONE, 2, 0.0, 1.0));
+                    IPDE_TRY(fft2d_rows_inverse(ctx, coarse, 2, gi->g[f] + (int64_t)ab * nx * ny));
+                }
+            } else {
+                const int64_t nthreads = 2 * nx * (ny / 2 + 1);
+                hipLaunchKernelGGL(nufft_pad_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0,
+                                   ctx->stream, cb, (cd*)gi->fine.W[f], (int)nx, (int)ny,
+                                   (const double*)gi->d_rx, (const double*)gi->d_ry, dkx, dky);
+                IPDE_HIP_CHECK(ctx, hipGetLastError());
+                IPDE_TRY(fft2d_cols(ctx, gi->fine, f, FFT2D_SYM_NONE, 2, 0.0, 1.0, -1, ny / 2 + 1));
+                IPDE_TRY(fft2d_rows_inverse(ctx, gi->fine, f, gi->g[f]));
+            }
+        }
+        double* o = d_out + (int64_t)f0 * np;
+        if (gi->shifted)
+            hipLaunchKernelGGL((nufft_gather_kernel<16, true>), dim3((unsigned)np), dim3(64), 0, ctx->stream,
+                               (const double*)gi->g[0], (const double*)gi->g[1], (const double*)gi->g[2], nf,
+                               (int)(2 * nx), (int)(2 * ny), d_px, d_py, np, gi->beta, o);
+        else
+            hipLaunchKernelGGL((nufft_gather_kernel<16, false>), dim3((unsigned)np), dim3(64), 0, ctx->stream,
+                               (const double*)gi->g[0], (const double*)gi->g[1], (const double*)gi->g[2], nf,
+                               (int)(2 * nx), (int)(2 * ny), d_px, d_py, np, gi->beta, o);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return IPDE_OK;
+}
+
+static int stage_points(GridInterp* gi, int loc, int64_t np, int nout, const double* px, const double* py,
+                        double* out, const double** d_px, const double** d_py, double** d_out) {
+    ipde_ctx* ctx = gi->ctx;
+    *d_px = px;
+    *d_py = py;
+    *d_out = out;
     if (loc == IPDE_HOST) {
-        const size_t need = (size_t)5 * np * sizeof(double);
+        const size_t need = (size_t)(2 + nout) * np * sizeof(double);
         if (need > gi->stage_bytes) {
             if (gi->stage) (void)hipFree(gi->stage);
+            gi->stage = nullptr;
+            gi->stage_bytes = 0;
             IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->stage, need));
             gi->stage_bytes = need;
         }
         IPDE_HIP_CHECK(ctx, hipMemcpyAsync(gi->stage, px, np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         IPDE_HIP_CHECK(ctx, hipMemcpyAsync(gi->stage + np, py, np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        d_px = gi->stage;
-        d_py = gi->stage + np;
-        d_out = gi->stage + 2 * np;
+        *d_px = gi->stage;
+        *d_py = gi->stage + np;
+        *d_out = gi->stage + 2 * np;
     }
-    if (gi->shifted) {
-        // W[2] of the coarse plan is scratch; sub-grid (a, b) of field f lands in g[f] + (2a+b) nx ny
-        const int64_t nth = nx * (ny / 2);
-        for (int f = 0; f < 3; ++f)
-            for (int ab = 0; ab < 4; ++ab) {
-                hipLaunchKernelGGL(nufft_shift_kernel, dim3((unsigned)ceil_div64(nth, 256)), dim3(256), 0,
-                                   ctx->stream, (const cd*)spec, (cd*)coarse.W[2], (int)nx, (int)ny,
-                                   (const double*)gi->d_rx, (const double*)gi->d_ry, f, ab >> 1, ab & 1,
-                                   dkx, dky);
-                IPDE_HIP_CHECK(ctx, hipGetLastError());
-                IPDE_TRY(fft2d_cols(ctx, coarse, 2, FFT2D_SYM_NONE, 2, 0.0, 1.0));
-                IPDE_TRY(fft2d_rows_inverse(ctx, coarse, 2, gi->g[f] + (int64_t)ab * nx * ny));
-            }
-        hipLaunchKernelGGL((nufft_gather_kernel<16, true>), dim3((unsigned)np), dim3(64), 0, ctx->stream,
-                           (const double*)gi->g[0], (const double*)gi->g[1], (const double*)gi->g[2],
-                           (int)(2 * nx), (int)(2 * ny), d_px, d_py, np, gi->beta, d_out);
-        IPDE_HIP_CHECK(ctx, hipGetLastError());
-    } else {
-    const int64_t nthreads = 2 * nx * (ny / 2 + 1);
-    for (int f = 0; f < 3; ++f) {
-        hipLaunchKernelGGL(nufft_pad_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0,
-                           ctx->stream, (const cd*)spec, (cd*)gi->fine.W[f], (int)nx, (int)ny,
-                           (const double*)gi->d_rx, (const double*)gi->d_ry, f, dkx, dky);
-        IPDE_HIP_CHECK(ctx, hipGetLastError());
-        // the kept spectrum carries 2 / (nx ny) (= the grid solve's normalisation with the factor
-        // 2 of row_c2r folded in), which is exactly what this inverse needs as well
-        IPDE_TRY(fft2d_cols(ctx, gi->fine, f, FFT2D_SYM_NONE, 2, 0.0, 1.0, -1, ny / 2 + 1));
-        IPDE_TRY(fft2d_rows_inverse(ctx, gi->fine, f, gi->g[f]));
-    }
-    hipLaunchKernelGGL((nufft_gather_kernel<16, false>), dim3((unsigned)np), dim3(64), 0, ctx->stream,
-                       (const double*)gi->g[0], (const double*)gi->g[1], (const double*)gi->g[2],
-                       (int)(2 * nx), (int)(2 * ny), d_px, d_py, np, gi->beta, d_out);
-    IPDE_HIP_CHECK(ctx, hipGetLastError());
-    }
+    return IPDE_OK;
+}
+
+static int finish_points(GridInterp* gi, int loc, int64_t np, int nout, double* out, const double* d_out) {
+    ipde_ctx* ctx = gi->ctx;
     if (loc == IPDE_HOST) {
-        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, 3 * np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, (size_t)nout * np * sizeof(double), hipMemcpyDeviceToHost,
+                                           ctx->stream));
         IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return IPDE_OK;
+}
+
+// The kept spectrum of the last scalar grid solve (coarse.W[1] = fft2(f) * symbol * 2 / (nx ny),
+// packed): out (3, np) = u, du/dx, du/dy at the points (box units [0, 2 pi)), derivatives in
+// physical units (dkx, dky = 2 pi / box length).
+int grid_interp_eval(GridInterp* gi, const Fft2dPlan& coarse, int loc, int64_t np, const double* px,
+                     const double* py, double dkx, double dky, double* out) {
+    const double *d_px, *d_py;
+    double* d_out;
+    IPDE_TRY(stage_points(gi, loc, np, 3, px, py, out, &d_px, &d_py, &d_out));
+    // (the kept spectrum carries the grid solve's 2 / (nx ny): exactly what the inverse needs)
+    Combo cb[3];
+    for (int f = 0; f < 3; ++f) cb[f] = Combo{1, {(const cd*)coarse.W[1], nullptr, nullptr}, {f, 0, 0}, {1.0, 0.0, 0.0}};
+    IPDE_TRY(interp_combos(gi, coarse, 3, cb, np, d_px, d_py, dkx, dky, d_out));
+    return finish_points(gi, loc, np, 3, out, d_out);
+}
+
+// Linear combinations of real grid fields and their first derivatives at points (the Stokes
+// solver's velocity and stress on the interfaces, reference multi_boundary/vector.py:66-82):
+// d_fields: nin device (nx, ny) arrays; output k = sum over its terms of coef * D^der [field src].
+int grid_interp_fields(GridInterp* gi, const Fft2dPlan& coarse, int nin, const double* const* d_fields,
+                       int nout, const int* term_start, const int* term_src, const int* term_der,
+                       const double* term_coef, int loc_points, int64_t np, const double* px,
+                       const double* py, double dkx, double dky, double* out) {
+    ipde_ctx* ctx = gi->ctx;
+    const int64_t nx = gi->nx, ny = gi->ny;
+    if (nin > 3 || nout > 8) return IPDE_ERR_INVALID;
+    for (int k = 0; k < nin; ++k) {
+        if (!gi->spec[k])
+            IPDE_HIP_CHECK(ctx, hipMalloc(&gi->spec[k], (size_t)nx * (ny / 2) * 2 * sizeof(double)));
+        Fft2dPlan tmp = coarse;          // same tables, the spectrum goes to our own buffer
+        tmp.W[0] = gi->spec[k];
+        IPDE_TRY(fft2d_rows_forward(ctx, tmp, d_fields[k], 0));
+        IPDE_TRY(fft2d_cols(ctx, tmp, 0, FFT2D_SYM_NONE, 1, 0.0, 1.0));
+    }
+    Combo cb[8];
+    const double norm = 2.0 / ((double)nx * (double)ny);   // forward transforms are unnormalised
+    for (int f = 0; f < nout; ++f) {
+        const int n = term_start[f + 1] - term_start[f];
+        if (n < 1 || n > 3) return IPDE_ERR_INVALID;
+        cb[f].n = n;
+        for (int t = 0; t < 3; ++t) {
+            const int q = term_start[f] + (t < n ? t : 0);
+            if (term_src[q] < 0 || term_src[q] >= nin || term_der[q] < 0 || term_der[q] > 2) return IPDE_ERR_INVALID;
+            cb[f].src[t] = (const cd*)gi->spec[term_src[q]];
+            cb[f].der[t] = term_der[q];
+            cb[f].coef[t] = t < n ? term_coef[q] * norm : 0.0;
+        }
+    }
+    const double *d_px, *d_py;
+    double* d_out;
+    IPDE_TRY(stage_points(gi, loc_points, np, nout, px, py, out, &d_px, &d_py, &d_out));
+    IPDE_TRY(interp_combos(gi, coarse, nout, cb, np, d_px, d_py, dkx, dky, d_out));
+    return finish_points(gi, loc_points, np, nout, out, d_out);
 }

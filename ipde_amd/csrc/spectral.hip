@@ -452,6 +452,37 @@ extern "C" int ipde_grid_interp(ipde_fft_plan* p, int loc, int64_t np, const dou
                             2.0 * M_PI / (p->ny * p->hy), out3);
 }
 
+extern "C" int ipde_grid_interp_fields(ipde_fft_plan* p, int loc, int nin, const double* const* fields,
+                                       int nout, const int* term_start, const int* term_src,
+                                       const int* term_der, const double* term_coef, int64_t np,
+                                       const double* x, const double* y, double* out) {
+    if (!p) return IPDE_ERR_INVALID;
+    ipde_ctx* ctx = p->ctx;
+    IPDE_CHECK_ARG(ctx, loc == IPDE_HOST || loc == IPDE_DEVICE);
+    IPDE_CHECK_ARG(ctx, nin >= 1 && nin <= 3 && nout >= 1 && nout <= 8 && fields && term_start &&
+                            term_src && term_der && term_coef);
+    IPDE_CHECK_ARG(ctx, np >= 0 && (np == 0 || (x && y && out)));
+    if (!(p->fast.ready && ctx->opt_fft2d && grid_interp_supported(p->nx, p->ny))) {
+        IPDE_SET_ERR(ctx, "ipde_grid_interp_fields: no fft2d path for a %lld x %lld grid",
+                     (long long)p->nx, (long long)p->ny);
+        return IPDE_ERR_INVALID;
+    }
+    if (np == 0) return IPDE_OK;
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const double* d_f[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < nin; ++k) {
+        IPDE_CHECK_ARG(ctx, fields[k] != nullptr);
+        IPDE_TRY(stage_real_in(p, loc, k, fields[k], &d_f[k]));
+    }
+    if (!p->interp) {
+        grid_interp_force_shifted(ctx->opt_interp_shifted != 0);
+        IPDE_TRY(grid_interp_create(ctx, p->nx, p->ny, p->hx, p->hy, &p->interp));
+    }
+    return grid_interp_fields(p->interp, p->fast, nin, d_f, nout, term_start, term_src, term_der,
+                              term_coef, loc, np, x, y, 2.0 * M_PI / (p->nx * p->hx),
+                              2.0 * M_PI / (p->ny * p->hy), out);
+}
+
 extern "C" int ipde_poisson_grid_solve(ipde_fft_plan* p, int loc, const double* f, double* u,
                                        double* uhat) {
     return scalar_solve<SYM_POISSON>(p, loc, 0.0, f, u, uhat);

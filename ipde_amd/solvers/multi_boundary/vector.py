@@ -38,6 +38,10 @@ class VectorSolver(object):
         self._get_specific_operators()
         self._set_derivative_method()
         self.interpolation_order = 3 if self.solver_type == 'fourth' else np.inf
+        # velocity and stress of the grid solution on the interfaces through the library's
+        # oversampled-FFT interpolation where the plan has it (power-of-two grids)
+        self._fast_interp = self.USE_FAST_INTERP and self.interpolation_order == np.inf \
+            and self.plan.keep_spectrum(False)
         self.grid_step = self.ebdyc.grid_step
         self._define_layer_apply()
         self._collect_grid_sources()
@@ -45,6 +49,10 @@ class VectorSolver(object):
 
     CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other
     DISTRIBUTE_BOUNDARIES = True  # under torch.distributed: boundary i on rank i mod world
+    USE_FAST_INTERP = True        # False: always the dense Fourier sums (the checker)
+    # u, v, T_xx = 2 u_x - p, T_xy = u_y + v_x, T_yy = 2 v_y - p as (coef, field, derivative) terms
+    _STRESS_FIELDS = [[(1.0, 0, 0)], [(1.0, 1, 0)], [(2.0, 0, 1), (-1.0, 2, 0)],
+                      [(1.0, 0, 2), (1.0, 1, 1)], [(2.0, 1, 2), (-1.0, 2, 0)]]
 
     def _concurrent_helpers(self):
         return _concurrent_helpers(self)
@@ -144,7 +152,10 @@ class VectorSolver(object):
         fc = fg.view(2, Nx, Ny) * self._grid_step_d
         uc, vc, pc = (a.contiguous() for a in self._grid_solve(fc[0], fc[1]))
         # velocity and stress of the grid solution on every interface node (:66-82)
-        if self.interpolation_order == np.inf:
+        if self._fast_interp:
+            bvals = self.plan.interp_fields([uc, vc, pc], self._STRESS_FIELDS, self._ifx_d,
+                                            self._ify_d).cpu().numpy()
+        elif self.interpolation_order == np.inf:
             # full spectra of the real fields through the library's D2Z plan (no torch.fft)
             uh, vh, ph = self.plan.fft2(uc), self.plan.fft2(vc), self.plan.fft2(pc)
             stack = torch.stack([uh, vh, 2 * self._ikx_d * uh - ph,
@@ -153,7 +164,8 @@ class VectorSolver(object):
             ucx, ucy, vcx, vcy = self.dx(uc), self.dy(uc), self.dx(vc), self.dy(vc)
             stack = torch.stack([self.plan.fft2(g.contiguous()) for g in
                                  (uc, vc, 2 * ucx - pc, ucy + vcx, 2 * vcy - pc)])
-        bvals = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
+        if not self._fast_interp:
+            bvals = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
         bul, bvl, btxxl, btxyl, btyyl = (e.v2l(b) for b in bvals)
         # annular solves boundary by boundary, then the QFS solves of all boundaries in one
         # batched substitution (qfs.call_many).  Every annular solver has its own library

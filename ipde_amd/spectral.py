@@ -39,7 +39,8 @@ class GridPlan:
     def keep_spectrum(self, on=True):
         """Ask the scalar grid solves on this plan (called without want_uhat) to keep
         fft2(f) * symbol on the device for `interp_gradient`.  Returns False if this grid
-        size has no such path (then use want_uhat and ipde_amd.interp)."""
+        size has no such path (then use want_uhat and ipde_amd.interp).  keep_spectrum(False)
+        switches it off and still reports whether the path exists (`interp_fields` needs it)."""
         ok = ctypes.c_int()
         self.ctx.check(self.ctx.lib.ipde_fft_plan2d_keep_spectrum(self.handle, int(bool(on)),
                                                                   ctypes.byref(ok)))
@@ -53,6 +54,31 @@ class GridPlan:
         n = int(x.shape[0])
         out = empty_like_loc((3, n), loc, self.ctx)
         self.ctx.check(self.ctx.lib.ipde_grid_interp(self.handle, loc, n, ptr(x), ptr(y), ptr(out)))
+        return out
+
+    def interp_fields(self, fields, outputs, x, y):
+        """Linear combinations of real grid fields and their first derivatives at the points
+        (x, y) (box units [0, 2 pi)).  fields: list of up to three (nx, ny) arrays; outputs: list
+        of lists of (coef, field index, der) with der 0: value, 1: d/dx, 2: d/dy.  Returns
+        (len(outputs), P).  E.g. the Stokes stress xx: [(2.0, 0, 1), (-1.0, 2, 0)]."""
+        loc = location_of(x, y, *fields)
+        x, y = as_f64(x, loc), as_f64(y, loc)
+        fields = [self._real_in(f)[1] for f in fields]
+        n = int(x.shape[0])
+        ptrs = (ctypes.c_void_p * len(fields))(*[ptr(f) for f in fields])
+        start, src, der, coef = [0], [], [], []
+        for terms in outputs:
+            for c, k, d in terms:
+                coef.append(float(c))
+                src.append(int(k))
+                der.append(int(d))
+            start.append(len(src))
+        arr = lambda v, t: (t * len(v))(*v)
+        out = empty_like_loc((len(outputs), n), loc, self.ctx)
+        self.ctx.check(self.ctx.lib.ipde_grid_interp_fields(
+            self.handle, loc, len(fields), ptrs, len(outputs), arr(start, ctypes.c_int),
+            arr(src, ctypes.c_int), arr(der, ctypes.c_int), arr(coef, ctypes.c_double), n, ptr(x), ptr(y),
+            ptr(out)))
         return out
 
     # -- grid solves ----------------------------------------------------------

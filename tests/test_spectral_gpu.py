@@ -228,3 +228,52 @@ def test_grid_interp_needs_a_kept_spectrum_and_a_supported_grid():
     with pytest.raises(IpdeHipError, match="no kept spectrum"):    # no solve yet
         plan.interp_gradient(np.zeros(3), np.zeros(3))
     plan.close()
+
+
+@pytest.mark.parametrize("shape,npts,shifted", [((512, 1024), 500, 0), ((1024, 1024), 900, 1),
+                                                ((2048, 2048), 3000, 0)])
+def test_grid_interp_fields_against_dense_fourier_sums(ctx, shape, npts, shifted):
+    """ipde_grid_interp_fields: the five interface fields of the Stokes solver (u, v and the
+    stress T = grad u + grad u^T - p I of three real grid fields) against the dense Fourier sums
+    of ipde_amd.interp on the same multiplied spectra (reference multi_boundary/vector.py:66-82)."""
+    import torch
+    from ipde_amd.spectral import GridPlan
+    from ipde_amd.interp import periodic_interp2d
+    from ipde_amd.solvers.multi_boundary.vector import VectorSolver
+    nx, ny = shape
+    hx, hy = 3.1 / nx, 2.9 / ny
+    x = torch.arange(nx, dtype=torch.float64, device="cuda") * hx
+    y = torch.arange(ny, dtype=torch.float64, device="cuda") * hy
+    X, Y = torch.meshgrid(x, y, indexing="ij")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    a, b = 2 * np.pi / 3.1, 2 * np.pi / 2.9
+    # (a little broadband content down to the Nyquist lines; the window's error scales with the
+    # l1 norm of the spectrum, which white noise inflates by sqrt(nx ny) over smooth fields)
+    noise = lambda: 1e-6 * torch.randn(nx, ny, dtype=torch.float64, device="cuda", generator=g)
+    u = torch.exp(torch.sin(a * X)) * torch.cos(2 * b * Y) + noise()
+    v = torch.sin(3 * a * X + 0.2) * torch.exp(torch.cos(b * Y)) + noise()
+    p = torch.cos(a * X) * torch.sin(b * Y + 0.7) + noise()
+    rng = np.random.default_rng(3)
+    px = torch.as_tensor(rng.uniform(0, 2 * np.pi, npts), device="cuda")
+    py = torch.as_tensor(rng.uniform(0, 2 * np.pi, npts), device="cuda")
+    ctx.set_option("interp_shifted", shifted)
+    plan = GridPlan(nx, ny, hx, hy)
+    got = plan.interp_fields([u, v, p], VectorSolver._STRESS_FIELDS, px, py)
+    ikx = torch.as_tensor(1j * np.fft.fftfreq(nx, hx / (2 * np.pi)), device="cuda")[:, None]
+    iky = torch.as_tensor(1j * np.fft.fftfreq(ny, hy / (2 * np.pi)), device="cuda")
+    uh, vh, ph = plan.fft2(u), plan.fft2(v), plan.fft2(p)
+    stack = torch.stack([uh, vh, 2 * ikx * uh - ph, iky * uh + ikx * vh, 2 * iky * vh - ph])
+    ref = periodic_interp2d(stack, px, py, real_part=True)
+    for k in range(5):
+        err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+        # values: 1e-13.  Stress rows: the two sides differentiate spectra from two different
+        # forward FFTs (fft2d here, rocFFT in the checker), whose rounding floors differ by
+        # ~1e-16 max|F| per mode; i k amplifies that by up to k_max ~ n: a few 1e-16 n
+        # (measured 2e-13 at 512 x 1024, 8e-13 at 2048^2; the Stokes tolerance is 1e-10)
+        assert err < (1e-13 if k < 2 else 1e-15 * max(nx, ny)), (k, err)
+    # host arrays
+    got_h = plan.interp_fields([a_.cpu().numpy() for a_ in (u, v, p)], VectorSolver._STRESS_FIELDS,
+                               px.cpu().numpy(), py.cpu().numpy())
+    assert isinstance(got_h, np.ndarray) and np.abs(got_h - got.cpu().numpy()).max() < 1e-12
+    plan.close()
+    ctx.set_option("interp_shifted", 0)
