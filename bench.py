@@ -169,6 +169,9 @@ def main():
                     help="strong (default): one 2048^2 target list split over the ranks; "
                          "weak: one 2048^2 grid per rank")
     ap.add_argument("--no-fft", action="store_true", help="skip the spectral-path measurement")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="all ranks on cuda:0, collectives over gloo through host memory: exercises the "
+                         "N > 1 code path on a one-GPU box (a rehearsal, not a measurement)")
     args = ap.parse_args()
 
     # RCCL writes a version banner to stdout when the communicator is created:
@@ -185,11 +188,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    rehearse = args.rehearse_shared_gpu
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run the process group is always created (also for a
     # single rank), so the collective path can be exercised on a one-GPU box
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
-    if use_dist:
+    if use_dist and rehearse:
+        dist.init_process_group("gloo")
+    elif use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ipde_amd.device import get_context
@@ -208,14 +216,25 @@ def main():
     sy = torch.as_tensor(c.y, device=dev)
     w = torch.as_tensor(c.weights, device=dev)
     sig_full = torch.as_tensor(sigma, device=dev)
+    if NBDY % world:
+        raise SystemExit("the boundary density (%d nodes) is split evenly: --gpus must divide it" % NBDY)
     shard = NBDY // world
     sig_shard = sig_full[rank * shard:(rank + 1) * shard].contiguous()
     gathered = torch.empty(NBDY, dtype=torch.float64, device=dev)
     out = torch.empty(dt.N, dtype=torch.float64, device=dev)
+    if rehearse:     # gloo moves host memory
+        sig_shard_h, gathered_h = sig_shard.cpu(), torch.empty(NBDY, dtype=torch.float64)
+
+    def gather_density():
+        if rehearse:
+            dist.all_gather_into_tensor(gathered_h, sig_shard_h)
+            gathered.copy_(gathered_h)
+        else:
+            dist.all_gather_into_tensor(gathered, sig_shard)
 
     def step():
         if use_dist:
-            dist.all_gather_into_tensor(gathered, sig_shard)
+            gather_density()
             dens = gathered
         else:
             dens = sig_full
@@ -248,10 +267,13 @@ def main():
     kernel_ms_avg = float(np.mean(kms))
     ctx.enable_timing(False)
 
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def allreduce_max(x):
+        tt = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
+
+    if use_dist:
+        elapsed = allreduce_max(elapsed)
 
     # strong: the whole job evaluates the one target list once per step
     pairs_per_step = float(NBDY) * (float(trg.N) if strong else float(dt.N) * world)
@@ -261,18 +283,21 @@ def main():
         fence()
         t0 = time.perf_counter()
         for _ in range(50):
-            dist.all_gather_into_tensor(gathered, sig_shard)
+            gather_density()
         torch.cuda.synchronize()
         collective_ms = 1e3 * (time.perf_counter() - t0) / 50
     value = pairs_per_step * args.steps / elapsed
-    # parity spot check inside the bench run (not timed): 2048 targets vs the oracle
+    # parity spot check inside the bench run (not timed): on EVERY rank 2048 targets of its own
+    # slice against the C oracle; the line reports the worst rank
+    import oracle
+    idx = np.random.default_rng(1 + rank).choice(dt.N, min(2048, dt.N), replace=False)
+    ref = oracle.c_laplace_apply(c.x, c.y, trg.x[sl][idx], trg.y[sl][idx], w_sigma=sigma * c.weights)
+    got = out.cpu().numpy()[idx]
+    parity = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+    if use_dist:
+        parity = allreduce_max(parity)
     result = None
     if rank == 0:
-        import oracle
-        idx = np.random.default_rng(1).choice(dt.N, 2048, replace=False)
-        ref = oracle.c_laplace_apply(c.x, c.y, trg.x[sl][idx], trg.y[sl][idx], w_sigma=sigma * c.weights)
-        got = out.cpu().numpy()[idx]
-        parity = float(np.max(np.abs(got - ref)) / float(torch.max(torch.abs(out))))
         kpairs = float(NBDY) * float(dt.N) / (kernel_ms_avg * 1e-3)
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside
         # this process; the number is the rocprofv3 FETCH_SIZE / WRITE_SIZE measurement of this
@@ -301,7 +326,8 @@ def main():
                 "n_targets_per_gpu": int(dt.N),
                 "parallelism": ("one target list split into %d contiguous slice(s), " % world if strong
                                 else "one full grid per rank (%d rank(s)), " % world)
-                               + ("density all-gather over RCCL each step" if use_dist
+                               + (("density all-gather over gloo (shared-GPU REHEARSAL, not a measurement)"
+                                   if rehearse else "density all-gather over RCCL each step") if use_dist
                                   else "single process, no collective"),
                 "kernel_variant": args.variant,
             },

@@ -146,12 +146,24 @@ struct LayerGeom {
 static inline LayerGeom ipde_layer_geom(int64_t ns, int64_t nt, int nt_per_block, int num_cu) {
     LayerGeom g;
     g.gx = ceil_div64(nt, nt_per_block);
+    // One block per CU at a time (the LDS table), so a launch runs in ceil(blocks / CUs) rounds
+    // of (sources per block) each.  Few target blocks — interface-sized lists, or 1/8 of the
+    // 2048^2 list on one of 8 GPUs: 126 blocks on 256 CUs — leave CUs idle or end in a nearly
+    // empty round; splitting the sources nchunk ways turns that into rounds of 1/nchunk length.
+    // Pick the split with the least (rounds x length), 0.5 % per extra block for its table load
+    // and the partial-sum pass.
     int nchunk = 1;
-    const int64_t want_blocks = 2 * (int64_t)num_cu;
-    if (g.gx < want_blocks) {
-        nchunk = (int)std::min<int64_t>(ceil_div64(want_blocks, g.gx), ceil_div64(ns, 64));
-        if (nchunk < 1) nchunk = 1;
-        if (nchunk > 1024) nchunk = 1024;
+    if (g.gx < 8 * (int64_t)num_cu) {
+        const int cmax = (int)std::min<int64_t>(512, std::max<int64_t>(1, ceil_div64(ns, 64)));
+        double best = 1e300;
+        for (int c = 1; c <= cmax; ++c) {
+            const double rounds = (double)ceil_div64(g.gx * c, num_cu);
+            const double cost = rounds * (1.0 / c + 0.005);
+            if (cost < best * (1.0 - 1e-9)) {
+                best = cost;
+                nchunk = c;
+            }
+        }
     }
     g.ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
     g.chunk = (int)(ceil_div64(ceil_div64(ns, nchunk), IPDE_SRC_PAD) * IPDE_SRC_PAD);

@@ -91,3 +91,27 @@ def test_config4_two_rank_rehearsal_mid_size():
     res = _run_sharded("stokes", ["--nb", "1200", "--M", "14"], 29563)
     print(res)
     assert res["world"] == 2 and res["error"] < 1e-10
+
+
+def test_bench_strong_scaling_path_two_ranks_shared_gpu():
+    """bench.py's N > 1 path (the driver runs it on a multi-GPU node): two ranks share the one
+    GPU, gloo collectives — the 2048^2 target list is split in two, the density all-gathered
+    every step, every rank's slice checked against the C oracle inside the run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-full-solve",
+           "--no-fft", "--rehearse-shared-gpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                       # ONE JSON line, from rank 0
+    res = json.loads(lines[0])
+    print(res["value"], res["ms_per_step"], res["config"])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    cfg = res["config"]
+    assert abs(2 * cfg["n_targets_per_gpu"] - cfg["n_targets_total"]) <= 1
+    assert cfg["n_targets_total"] == 4129988
+    assert res["parity_max_rel_err_vs_oracle"] < 1e-12
+    assert res["collective_ms_per_step"] is not None
+    # two ranks time-share one GPU: the job's rate is about the one-rank rate (not double)
+    assert 1.5e12 < res["value"] < 4e12
