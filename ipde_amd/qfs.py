@@ -79,7 +79,7 @@ class _QFS(object):
             import torch
             as_dev = lambda M: M if isinstance(M, torch.Tensor) else torch.as_tensor(M, device=self._dev)
             self._A = as_dev(A)
-            self._fact = _DeviceLU(*_factor(self._A))
+            self._fact = _lu_async(self._A)
             self._S = None if S is None else as_dev(S)
             if D is not None:
                 D = as_dev(D)
@@ -210,6 +210,56 @@ def _factor(A):
     return torch.linalg.lu_factor(A)
 
 
+_lu_pool = None
+ASYNC_FACTORISATION = True     # False: factor where the matrix is built (one after the other)
+
+
+def _lu_async(A):
+    """_DeviceLU of A, factored in the background: rocSOLVER's getrf is ~37 000 column-level
+    launches at n = 4096 (65 ms, host-launch bound) and a set-up holds several independent
+    matrices — the two QFS systems of every interface, the example's boundary integral
+    equation — so each factorisation runs on a pool thread with a stream of its own while the
+    host goes on assembling the next matrix; the first use joins it."""
+    if not ASYNC_FACTORISATION:
+        return _DeviceLU(*_factor(A))
+    return _AsyncLU(A)
+
+
+class _AsyncLU(object):
+    def __init__(self, A):
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        global _lu_pool
+        if _lu_pool is None:
+            _lu_pool = ThreadPoolExecutor(4, thread_name_prefix="ipde-lu")
+        ready = torch.cuda.Event()
+        ready.record()                 # A is complete on the caller's stream from here on
+        dev = A.device
+
+        def work():
+            torch.cuda.set_device(dev)
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                s.wait_event(ready)
+                obj = _DeviceLU(*_factor(A))
+                done = torch.cuda.Event()
+                done.record(s)
+            return obj, done
+        self._obj = None
+        self._fut = _lu_pool.submit(work)
+
+    def _get(self):
+        if self._obj is None:
+            import torch
+            obj, done = self._fut.result()
+            torch.cuda.current_stream().wait_event(done)
+            self._obj, self._fut = obj, None
+        return self._obj
+
+    def __getattr__(self, name):       # ctx, n, LU, perm, solve, _subst: the realised object's
+        return getattr(self._get(), name)
+
+
 class _DeviceLU(object):
     """Substitution with rocSOLVER's factors through the library's own blocked kernels
     (csrc/dense.hip): plain substitution is backward stable where the library TRSM is
@@ -292,7 +342,7 @@ class DenseSolver(object):
             import torch
             self._A = A.to(self._dev) if isinstance(A, torch.Tensor) \
                 else torch.as_tensor(np.ascontiguousarray(A), device=self._dev)
-            self._fact = _DeviceLU(*_factor(self._A))
+            self._fact = _lu_async(self._A)
         else:
             self._lu = scipy.linalg.lu_factor(A)
 
@@ -482,7 +532,7 @@ class QFS_Evaluator(object):
         if self._dev is not None:
             import torch
             self._A = torch.as_tensor(A, device=self._dev)
-            self._fact = _DeviceLU(*_factor(self._A))
+            self._fact = _lu_async(self._A)
             self.b2c_mats = [torch.as_tensor(B, device=self._dev) for B in self.b2c_mats]
         else:
             self._lu = scipy.linalg.lu_factor(A)
