@@ -81,12 +81,18 @@ class AnnularModifiedHelmholtzSolver(object):
             self.ctx.handle, self.M, self.n, float(self.k), *[ptr(m) for m in mats],
             ctypes.byref(h)))
         self.handle = h
+        self.ctx.adopt(self)
         self._rag_id = None
+
+    def _release(self):
+        """free the library handle (also called by the owning context before it goes)"""
+        h, self.handle = self.handle, None
+        if h and self.ctx.handle:
+            self.ctx.lib.ipde_annular_scalar_destroy(h)
 
     def __del__(self):
         try:
-            if self.handle and self.ctx.handle:
-                self.ctx.lib.ipde_annular_scalar_destroy(self.handle)
+            self._release()
         except Exception:
             pass
 

@@ -79,11 +79,17 @@ class AnnularStokesSolver(object):
             self.ctx.handle, self.M, self.n, float(mu), *[ptr(m) for m in mats], ptr(kinv),
             ctypes.byref(h)))
         self.handle = h
+        self.ctx.adopt(self)
+
+    def _release(self):
+        """free the library handle (also called by the owning context before it goes)"""
+        h, self.handle = self.handle, None
+        if h and self.ctx.handle:
+            self.ctx.lib.ipde_annular_stokes_destroy(h)
 
     def __del__(self):
         try:
-            if self.handle and self.ctx.handle:
-                self.ctx.lib.ipde_annular_stokes_destroy(self.handle)
+            self._release()
         except Exception:
             pass
 

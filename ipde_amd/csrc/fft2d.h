@@ -29,6 +29,8 @@ int fft2d_cols(ipde_ctx* ctx, const Fft2dPlan& p, int slot, int sym, int mode, d
                int spec_slot = -1, int64_t ncols = 0);
 int fft2d_scalar_solve(ipde_ctx* ctx, const Fft2dPlan& p, int sym, double k2h, const double* f, double* u,
                        bool keep_spectrum = false);
+int fft2d_stokes_solve(ipde_ctx* ctx, const Fft2dPlan& p, const double* fu, const double* fv, double* u,
+                       double* v, double* pr);
 
 // grid -> scattered points through an oversampled inverse transform (nufft.hip)
 struct GridInterp;

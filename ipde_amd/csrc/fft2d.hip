@@ -448,6 +448,99 @@ __global__ __launch_bounds__(C* Cfg<NX>::T) void col_kernel(cd* __restrict__ W, 
     for (int i = 0; i < P; ++i) base[(int64_t)(t + T * i) * pitch] = v[i];
 }
 
+// ---- Stokes symbols on packed half spectra ---------------------------------------------------
+// Fu, Fv (after the forward column pass) -> U, V in place and P into Pb, all scaled:
+//   ph = ilap (ikx fu + iky fv); uh = ilap (ikx ph - fu); vh = ilap (iky ph - fv)
+// evaluated at k and at -k (the Nyquist index maps onto itself) and symmetrised, which is what
+// `.real` of the reference's complex ifft2 amounts to (multi_boundary/stokes.py:34-45; the same
+// arithmetic as spectral.hip's stokes_symbol_kernel).  Column 0 carries ky = 0 and the Nyquist
+// column packed: unpacked with the mirrored row, each half gets its own symbols, packed again.
+__device__ __forceinline__ double wavenumber_neg(int i, int n, double dk) {
+    if ((n & 1) == 0 && i == n / 2) return wavenumber(i, n, dk);
+    return -wavenumber(i, n, dk);
+}
+struct Sym2 {
+    cd a, b;   // out = a fu + b fv
+};
+__device__ __forceinline__ void stokes_symbols(double kx, double ky, bool is00, Sym2& P, Sym2& U,
+                                               Sym2& V) {
+    const double il = is00 ? 0.0 : 1.0 / (-kx * kx - ky * ky);
+    const cd ikx{0.0, kx}, iky{0.0, ky};
+    P.a = cd{0.0, il * kx};
+    P.b = cd{0.0, il * ky};
+    cd t = cmul(ikx, P.a);
+    U.a = cd{il * (t.x - 1.0), il * t.y};
+    t = cmul(ikx, P.b);
+    U.b = cd{il * t.x, il * t.y};
+    t = cmul(iky, P.a);
+    V.a = cd{il * t.x, il * t.y};
+    t = cmul(iky, P.b);
+    V.b = cd{il * (t.x - 1.0), il * t.y};
+}
+__device__ __forceinline__ cd sym_eff(cd s, cd sn) { return cd{0.5 * (s.x + sn.x), 0.5 * (s.y - sn.y)}; }
+
+__device__ __forceinline__ void stokes_apply_mode(int i, int j, int nx, int ny, double dkx, double dky,
+                                                  cd fu, cd fv, double scale, cd& u, cd& v, cd& p) {
+    const bool is00 = (i == 0 && j == 0);
+    Sym2 P, U, V, Pn, Un, Vn;
+    stokes_symbols(wavenumber(i, nx, dkx), wavenumber(j, ny, dky), is00, P, U, V);
+    stokes_symbols(wavenumber_neg(i, nx, dkx), wavenumber_neg(j, ny, dky), is00, Pn, Un, Vn);
+    auto app = [&](const Sym2& s, const Sym2& sn) {
+        cd x = cmul(sym_eff(s.a, sn.a), fu), y = cmul(sym_eff(s.b, sn.b), fv);
+        return cd{(x.x + y.x) * scale, (x.y + y.y) * scale};
+    };
+    p = app(P, Pn);
+    u = app(U, Un);
+    v = app(V, Vn);
+}
+
+__global__ __launch_bounds__(256) void stokes_packed_symbol_kernel(cd* __restrict__ Fu,
+                                                                   cd* __restrict__ Fv,
+                                                                   cd* __restrict__ Pb, int nx, int ny,
+                                                                   double dkx, double dky, double scale) {
+    const int H = ny / 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)nx * H) return;
+    const int i = (int)(idx / H), j = (int)(idx - (int64_t)i * H);
+    cd u, v, p;
+    if (j > 0) {
+        stokes_apply_mode(i, j, nx, ny, dkx, dky, Fu[idx], Fv[idx], scale, u, v, p);
+    } else {
+        // both rows i and nx - i read each other's packed entry before either writes: the pair
+        // is handled by ONE thread (the lower index; i = 0 and i = nx/2 are their own mirrors)
+        const int im = (nx - i) % nx;
+        if (im < i) return;
+        auto unpack = [](cd g, cd gm, cd& f0, cd& fh) {
+            f0 = cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)};
+            fh = cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
+        };
+        const int64_t a = (int64_t)i * H, b = (int64_t)im * H;
+        cd gu = Fu[a], gum = Fu[b], gv = Fv[a], gvm = Fv[b];
+        for (int side = 0; side < (im == i ? 1 : 2); ++side) {
+            const int r = side ? im : i;
+            cd fu0, fuh, fv0, fvh;
+            if (side == 0) {
+                unpack(gu, gum, fu0, fuh);
+                unpack(gv, gvm, fv0, fvh);
+            } else {
+                unpack(gum, gu, fu0, fuh);
+                unpack(gvm, gv, fv0, fvh);
+            }
+            cd u0, v0, p0, uh, vh, ph;
+            stokes_apply_mode(r, 0, nx, ny, dkx, dky, fu0, fv0, scale, u0, v0, p0);
+            stokes_apply_mode(r, H, nx, ny, dkx, dky, fuh, fvh, scale, uh, vh, ph);
+            const int64_t o = (int64_t)r * H;
+            Fu[o] = cd{u0.x - uh.y, u0.y + uh.x};
+            Fv[o] = cd{v0.x - vh.y, v0.y + vh.x};
+            Pb[o] = cd{p0.x - ph.y, p0.y + ph.x};
+        }
+        return;
+    }
+    Fu[idx] = u;
+    Fv[idx] = v;
+    Pb[idx] = p;
+}
+
 template <typename K>
 int allow_lds(ipde_ctx* ctx, K kernel, size_t bytes) {
     if (bytes > 48 * 1024)
@@ -602,4 +695,23 @@ int fft2d_scalar_solve(ipde_ctx* ctx, const Fft2dPlan& p, int sym, double k2h, c
     IPDE_TRY(fft2d_cols(ctx, p, 0, sym, 0, k2h, 2.0 / ((double)p.nx * (double)p.ny),
                         keep_spectrum ? 1 : -1, 0));
     return fft2d_rows_inverse(ctx, p, 0, u);
+}
+
+// (uc, vc, pc) of the Stokes grid solve: two forward transforms, the symbols, three inverse.
+int fft2d_stokes_solve(ipde_ctx* ctx, const Fft2dPlan& p, const double* fu, const double* fv, double* u,
+                       double* v, double* pr) {
+    IPDE_TRY(fft2d_rows_forward(ctx, p, fu, 0));
+    IPDE_TRY(fft2d_rows_forward(ctx, p, fv, 1));
+    IPDE_TRY(fft2d_cols(ctx, p, 0, FFT2D_SYM_NONE, 1, 0.0, 1.0));
+    IPDE_TRY(fft2d_cols(ctx, p, 1, FFT2D_SYM_NONE, 1, 0.0, 1.0));
+    const int64_t n = p.nx * (p.ny / 2);
+    hipLaunchKernelGGL(stokes_packed_symbol_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+                       ctx->stream, (cd*)p.W[0], (cd*)p.W[1], (cd*)p.W[2], (int)p.nx, (int)p.ny,
+                       2.0 * M_PI / (p.nx * p.hx), 2.0 * M_PI / (p.ny * p.hy),
+                       2.0 / ((double)p.nx * (double)p.ny));
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    for (int k = 0; k < 3; ++k) IPDE_TRY(fft2d_cols(ctx, p, k, FFT2D_SYM_NONE, 2, 0.0, 1.0));
+    IPDE_TRY(fft2d_rows_inverse(ctx, p, 0, u));
+    IPDE_TRY(fft2d_rows_inverse(ctx, p, 1, v));
+    return fft2d_rows_inverse(ctx, p, 2, pr);
 }

@@ -538,6 +538,15 @@ extern "C" int ipde_stokes_grid_solve(ipde_fft_plan* p, int loc, const double* f
     IPDE_TRY(stage_real_out(p, loc, 2, u, &d_u));
     IPDE_TRY(stage_real_out(p, loc, 3, v, &d_v));
     IPDE_TRY(stage_real_out(p, loc, 4, pr, &d_p));
+    if (p->fast.ready && ctx->opt_fft2d) {
+        // hand-written pipeline (fft2d.hip): the kept scalar spectrum, if any, is overwritten
+        p->have_spec = false;
+        IPDE_TRY(fft2d_stokes_solve(ctx, p->fast, d_fu, d_fv, d_u, d_v, d_p));
+        IPDE_TRY(finish_real_out(p, loc, 2, u));
+        IPDE_TRY(finish_real_out(p, loc, 3, v));
+        IPDE_TRY(finish_real_out(p, loc, 4, pr));
+        return finish_sync(p, loc);
+    }
     IPDE_TRY(exec(p, p->r2c, (void*)d_fu, p->spec[0]));
     IPDE_TRY(exec(p, p->r2c, (void*)d_fv, p->spec[1]));
     const double N = (double)p->nx * (double)p->ny;

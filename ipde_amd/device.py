@@ -7,6 +7,7 @@ memory only — every computation on this path is a kernel of libipde_hip.so.
 import ctypes
 import threading
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -31,8 +32,23 @@ class Context:
         _lib.check(self.lib.ipde_ctx_create(self.device, ctypes.byref(h)))
         self.handle = h
         self._plans = {}
+        # objects holding library handles created on this context (annular solvers, Ewald
+        # cores): the context releases them before it goes, whatever order the garbage
+        # collector finds them in
+        self._children = weakref.WeakSet()
 
     _private = False
+
+    def adopt(self, owner):
+        """register an object with a `_release()` method that frees its library handle"""
+        self._children.add(owner)
+
+    def _release_children(self):
+        for c in list(self._children):
+            try:
+                c._release()
+            except Exception:
+                pass
 
     def __del__(self):
         # private contexts (private_context()) go with their owner — the owner holds the only
@@ -40,6 +56,7 @@ class Context:
         try:
             import sys
             if self._private and self.handle and not sys.is_finalizing():
+                self._release_children()
                 h, self.handle = self.handle, None
                 self.lib.ipde_ctx_destroy(h)
         except Exception:
@@ -78,6 +95,7 @@ class Context:
 
     def close(self):
         if self.handle:
+            self._release_children()
             for p in list(self._plans.values()):
                 p.close()
             self._plans.clear()

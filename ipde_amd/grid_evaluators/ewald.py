@@ -166,11 +166,17 @@ class EwaldCore(object):
             0.0 if self.helmholtz_k is None else self.helmholtz_k, self.h, self.sw,
             ptr(tab), NI, DEG, ctypes.byref(hdl)))
         self.handle = hdl
+        self.ctx.adopt(self)
+
+    def _release(self):
+        """free the library handle (also called by the owning context before it goes)"""
+        h, self.handle = self.handle, None
+        if h and self.ctx.handle:
+            self.ctx.lib.ipde_ewald_destroy(h)
 
     def __del__(self):
         try:
-            if self.handle and self.ctx.handle:
-                self.ctx.lib.ipde_ewald_destroy(self.handle)
+            self._release()
         except Exception:
             pass
 

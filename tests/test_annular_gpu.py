@@ -197,3 +197,21 @@ def test_plan_creation_from_two_threads_on_private_contexts():
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_context_releases_its_solver_handles_first(gs, scalar_geo):
+    """a private context that goes away before the solvers created on it frees their library
+    handles itself (no leak, no use of a dead context afterwards)"""
+    import gc
+    from ipde_amd.device import private_context
+    from ipde_amd.annular.poisson import AnnularPoissonSolver
+    aag, rag = scalar_geo
+    ctx = private_context()
+    S = AnnularPoissonSolver(aag, ctx=ctx)
+    u = S.solve(rag, gs["po_force"], gs["po_ig"], gs["po_og"], tol=1e-13, maxiter=200, restart=60)
+    assert rel_err(u, gs["po_sol_ref"]) < 1e-10
+    assert S in ctx._children and S.handle
+    ctx.close()
+    assert S.handle is None and ctx.handle is None
+    del S, ctx
+    gc.collect()

@@ -143,6 +143,19 @@ def test_hand_written_fft_pipeline_against_oracle(ctx, shape):
         finally:
             ctx.set_option("fft2d", 1)
         assert rel_err(got_h, lib) < 1e-13, name
+    # Stokes grid solve (two forward, packed symbols, three inverse transforms)
+    g2 = rng.standard_normal(shape)
+    g2 -= g2.mean()
+    ref3 = osp.stokes_grid_solve(f, g2, hx, hy)
+    got3 = plan.stokes_solve(f, g2)
+    got3d = plan.stokes_solve(fd, torch.as_tensor(g2, device="cuda"))
+    ctx.set_option("fft2d", 0)
+    try:
+        lib3 = plan.stokes_solve(f, g2)
+    finally:
+        ctx.set_option("fft2d", 1)
+    for a, b, c, r in zip(got3, got3d, lib3, ref3):
+        assert rel_err(a, r) < TOL and np.array_equal(b.cpu().numpy(), a) and rel_err(a, c) < 1e-13
     # the wanted-spectrum variant keeps returning fft2(f) * symbol on these sizes too
     uh_ref, u_ref = osp.poisson_grid_solve(f, hx, hy)
     uh, u = plan.poisson_solve(f, want_uhat=True)
