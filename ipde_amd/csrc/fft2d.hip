@@ -271,6 +271,16 @@ __device__ __forceinline__ double wavenumber(int i, int n, double dk) {
     int s = (i < (n + 1) / 2) ? i : i - n;
     return (double)s * dk;
 }
+// 1 / x to ~1 ulp in 5 instructions: the v_rcp_f64 seed (about 27 bits) and two Newton steps,
+// against ~14 for the IEEE division (no denormal / inf handling needed: |x| is O(1 .. 1e7))
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
 // Hermitian-symmetrised effective symbol (S(k) + conj S(-k)) / 2: what `.real` of the complex
 // pipeline amounts to.  `-k` as the complex pipeline sees it maps a Nyquist index onto itself,
 // so the even real symbols are unchanged and the odd imaginary ones lose their Nyquist row /
@@ -280,9 +290,9 @@ __device__ __forceinline__ cd effective_symbol(int i, int j, int nx, int ny, dou
                                                double k2h) {
     const double kx = wavenumber(i, nx, dkx), ky = wavenumber(j, ny, dky);
     if (SYM == FFT2D_SYM_POISSON) {
-        return (i == 0 && j == 0) ? cd{0.0, 0.0} : cd{1.0 / (-kx * kx - ky * ky), 0.0};
+        return (i == 0 && j == 0) ? cd{0.0, 0.0} : cd{fast_rcp(-kx * kx - ky * ky), 0.0};
     } else if (SYM == FFT2D_SYM_MODHELM) {
-        return cd{1.0 / (k2h - (-kx * kx - ky * ky)), 0.0};
+        return cd{fast_rcp(k2h - (-kx * kx - ky * ky)), 0.0};
     } else if (SYM == FFT2D_SYM_DX) {
         return cd{0.0, (2 * i == nx) ? 0.0 : kx};
     } else if (SYM == FFT2D_SYM_DY) {
