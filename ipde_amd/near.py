@@ -63,6 +63,17 @@ class CurveEvaluator(object):
         return out[0], out[1], out[2]
 
 
+def _query_workers():
+    """threads for the k-d tree query: the CPUs this process may run on, at most 16 (workers=-1
+    starts one thread per CPU of the machine — 256 on the GPU hosts — whatever the share is)"""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:      # pragma: no cover
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
 def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30, on_device=True):
     """(r, t, found) of the points (px, py); found = within ~1.5*width of the curve and
     Newton converged.  r is the signed distance along the outward normal."""
@@ -72,7 +83,7 @@ def local_coordinates(bdy, px, py, width, tol=1e-14, maxiter=30, on_device=True)
     fine = ev.f[0]
     tree = cKDTree(np.column_stack([fine.real, fine.imag]))
     dist, j = tree.query(np.column_stack([px, py]), distance_upper_bound=1.5 * width + 2 * bdy.max_h,
-                         workers=-1)
+                         workers=_query_workers())
     found = np.isfinite(dist)
     r = np.full(px.shape, np.nan)
     t = np.full(px.shape, np.nan)

@@ -185,3 +185,25 @@ def test_single_boundary_adapter_drives_the_old_example_flow():
     gerr = np.abs(ue - ua)[ebdy.phys].max()
     print(gerr, rerr)
     assert gerr < 1e-10 and rerr < 1e-10      # (n_b = 600 resolution: measured 1.6e-11, 1.8e-11)
+
+
+def test_compat_runner_executes_a_script_written_against_the_reference_names(tmp_path):
+    """`python -m ipde_amd.compat script.py args`: the script sees the reference's module
+    names, its own __main__ and argv"""
+    script = tmp_path / "their_script.py"
+    script.write_text(
+        "import sys\n"
+        "import pybie2d\n"
+        "from ipde.heavisides import SlepianMollifier\n"
+        "from ipde.utilities import affine_transformation\n"
+        "from personal_utilities.arc_length_reparametrization import arc_length_parameterize\n"
+        "star = pybie2d.misc.curve_descriptions.star\n"
+        "GSB = pybie2d.boundaries.global_smooth_boundary.global_smooth_boundary.Global_Smooth_Boundary\n"
+        "b = GSB(c=star(64, a=0.1, f=3))\n"
+        "b2 = GSB(*arc_length_parameterize(b.x, b.y))\n"
+        "assert __name__ == '__main__' and sys.argv[1:] == ['--flag', '7']\n"
+        "print('ran', b2.N, float(b2.speed.max() - b2.speed.min()) < 1e-3 * b2.speed.max(), SlepianMollifier(8).step(0.0))\n")
+    out = subprocess.run([sys.executable, "-m", "ipde_amd.compat", str(script), "--flag", "7"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ran 64 True 0.5" in out.stdout

@@ -290,3 +290,23 @@ def test_grid_interp_fields_against_dense_fourier_sums(ctx, shape, npts, shifted
     assert isinstance(got_h, np.ndarray) and np.abs(got_h - got.cpu().numpy()).max() < 1e-12
     plan.close()
     ctx.set_option("interp_shifted", 0)
+
+
+def test_grid_interp_fields_argument_checks():
+    from ipde_amd._lib import IpdeHipError
+    from ipde_amd.spectral import GridPlan
+    z = np.zeros(4)
+    plan = GridPlan(48, 40, 0.1, 0.1)                  # no fft2d path at this size
+    with pytest.raises(IpdeHipError, match="no fft2d path"):
+        plan.interp_fields([np.zeros((48, 40))], [[(1.0, 0, 0)]], z, z)
+    plan.close()
+    plan = GridPlan(512, 1024, 0.1, 0.1)
+    f = np.zeros((512, 1024))
+    with pytest.raises(IpdeHipError, match="invalid argument"):      # a field index out of range
+        plan.interp_fields([f], [[(1.0, 1, 0)]], z, z)
+    with pytest.raises(IpdeHipError, match="invalid argument"):      # four terms in one output
+        plan.interp_fields([f], [[(1.0, 0, 0)] * 4], z, z)
+    with pytest.raises(ValueError):                                  # wrong grid shape
+        plan.interp_fields([np.zeros((8, 8))], [[(1.0, 0, 0)]], z, z)
+    assert plan.interp_fields([f], [[(1.0, 0, 1)]], np.zeros(0), np.zeros(0)).shape == (1, 0)
+    plan.close()
