@@ -62,10 +62,14 @@ def main():
     ctx.enable_timing(True)
 
     def rec(name, fn, flops_per_pair):
-        fn()
-        sync()
-        fn()
-        ms = ctx.last_kernel_ms()
+        # three warm-up launches (clocks), then the median of five hipEvent kernel times
+        ts = []
+        for i in range(8):
+            fn()
+            sync()
+            if i >= 3:
+                ts.append(ctx.last_kernel_ms())
+        ms = float(np.median(ts))
         out[name] = {"kernel_ms": ms, "pairs_per_s": pairs / (ms * 1e-3),
                      "algorithmic_tflops": pairs * flops_per_pair / (ms * 1e-3) / 1e12}
 
