@@ -95,6 +95,40 @@ def ffourier_multiply(fh, m):
     return fft(m * ifft(fh))
 
 
+# Transforms that zero entry N//2 + 1 instead of dropping the Nyquist column (ipde/utilities.py
+# :103-121; imported by ipde/annular/stokes.py).  Like the reference's, they zero that entry of
+# their INPUT in place.
+def pfourier_multiply(fh, m):
+    pos = int(fh.shape[1] // 2 + 1)
+    fh[:, pos] = 0.0
+    oh = fft(m * ifft(fh))
+    oh[:, pos] = 0.0
+    return oh
+
+
+def pfft(f):
+    pos = int(f.shape[1] // 2 + 1)
+    fh = fft(f)
+    fh[:, pos] = 0.0
+    return fh
+
+
+def pifft(fh):
+    pos = int(fh.shape[1] // 2 + 1)
+    fh[:, pos] = 0.0
+    return ifft(fh)
+
+
+def pifftr(fh):
+    return pifft(fh).real
+
+
+def fast_LU_solve(LU, b):
+    """zgetrs without scipy's argument checks (ipde/utilities.py:68-76; complex factors)"""
+    from scipy.linalg.lapack import zgetrs
+    return zgetrs(LU[0], LU[1], b)[0]
+
+
 class SimpleFourierFilter(object):
     """Fourier filter of a periodic vector (ipde/utilities.py:126-162); tiny 1-D
     boundary data, host side."""

@@ -437,6 +437,43 @@ def golden_layer_kernels():
     print("layer_kernels.npz", len(out))
 
 
+def golden_utilities():
+    """ipde/utilities.py (a12): the FFT aliases (numpy's here: mkl_fft is absent), the
+    Nyquist-dropping and Nyquist-zeroing transforms, the small host helpers."""
+    import scipy.linalg
+    import ipde.utilities as U
+    rng = np.random.default_rng(505)
+    out = {}
+    a = rng.standard_normal((6, 32)) + 1j * rng.standard_normal((6, 32))
+    r = rng.standard_normal((5, 24))
+    g = rng.standard_normal((20, 18)) + 1j * rng.standard_normal((20, 18))
+    m = rng.standard_normal((6, 32))
+    out["a"], out["r"], out["g"], out["m"] = a, r, g, m
+    out["fft"], out["ifft"] = U.fft(a), U.ifft(a)
+    out["fft2"], out["ifft2"] = U.fft2(g), U.ifft2(g)
+    out["fft2_real"] = U.fft2(g.real.copy())
+    out["mfft"] = U.mfft(r)
+    out["mifft"], out["mifftr"] = U.mifft(out["mfft"]), U.mifftr(out["mfft"])
+    ah = U.mfft(a)                                           # (6, 31)
+    out["fourier_multiply"] = U.fourier_multiply(ah.copy(), m)
+    out["ffourier_multiply"] = U.ffourier_multiply(a.copy(), m)
+    out["pfourier_multiply"] = U.pfourier_multiply(a.copy(), m)
+    out["pfft"], out["pifft"], out["pifftr"] = U.pfft(r), U.pifft(a.copy()), U.pifftr(a.copy())
+    out["fast_dot_mv"] = U.fast_dot(m, m[0])
+    out["fast_dot_vm"] = U.fast_dot(m[:, 0], m)
+    out["fast_dot_mm"] = U.fast_dot(m[:, :6], m)
+    out["concat"] = U.concat(r[0], 3.0, [1.0, 2.0])
+    out["affine"] = U.affine_transformation(r[0], -2.0, 3.0, 0.0, 2 * np.pi)
+    xc, x, rat = U.get_chebyshev_nodes(-0.3, 0.1, 12)
+    out["cheb_unscaled"], out["cheb_scaled"], out["cheb_ratio"] = xc, x, np.array([rat])
+    A = rng.standard_normal((7, 7)) + 1j * rng.standard_normal((7, 7))
+    b = rng.standard_normal(7) + 1j * rng.standard_normal(7)
+    out["lu_A"], out["lu_b"] = A, b
+    out["fast_LU_solve"] = U.fast_LU_solve(scipy.linalg.lu_factor(A), b)
+    np.savez(os.path.join(OUT, "utilities.npz"), **out)
+    print("utilities.npz", len(out))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be regenerated where it is")
@@ -447,5 +484,6 @@ if __name__ == "__main__":
     golden_annular_stokes()
     golden_slepian()
     golden_grid_evaluator_kernels()
+    golden_utilities()
     _install_absent_package_finder()
     golden_layer_kernels()

@@ -23,7 +23,10 @@ FROM_IMPORTS = [
     ("ipde.heavisides", "SlepianMollifier"),
     ("ipde.derivatives", "fd_x_4"), ("ipde.derivatives", "fd_y_4"), ("ipde.derivatives", "fourier"),
     ("ipde.utilities", "fft2"), ("ipde.utilities", "ifft2"), ("ipde.utilities", "mfft"),
-    ("ipde.utilities", "affine_transformation"),
+    ("ipde.utilities", "affine_transformation"), ("ipde.utilities", "fast_dot"), ("ipde.utilities", "concat"),
+    ("ipde.utilities", "fast_LU_solve"), ("ipde.utilities", "mifft"), ("ipde.utilities", "mifftr"),
+    ("ipde.utilities", "fourier_multiply"), ("ipde.utilities", "pfourier_multiply"),
+    ("ipde.utilities", "pfft"), ("ipde.utilities", "pifft"), ("ipde.utilities", "pifftr"),
     ("ipde.solvers.multi_boundary.poisson", "PoissonSolver"),
     ("ipde.solvers.multi_boundary.modified_helmholtz", "ModifiedHelmholtzSolver"),
     ("ipde.solvers.multi_boundary.stokes", "StokesSolver"),
