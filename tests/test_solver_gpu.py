@@ -248,3 +248,32 @@ def test_interpolate_to_points():
     assert len(ebdyc.registered_partitions) == 1
     ebdyc.interpolate_to_points(f, x, y)
     assert len(ebdyc.registered_partitions) == 1
+
+
+@pytest.mark.parametrize("problem", ["poisson", "modhelm"])
+def test_power_of_two_grid_paths_equal_the_general_ones(problem):
+    """On a 1024^2 grid the solvers take the hand-written FFT pipeline and the oversampled-FFT
+    interface interpolation; the same solve with the rocFFT path + dense Fourier sums (the
+    round-1 route, still what other grid sizes use) must give the same solution, and both the
+    manufactured one."""
+    import interior_poisson
+    import interior_modified_helmholtz as imh
+    from ipde_amd.device import get_context
+    from ipde_amd.solvers.multi_boundary.scalar import ScalarSolver
+    ctx = get_context()
+    run = (lambda: interior_poisson.run(nb=1500, M=16, Ns=[1024, 1024], solver_tol=1e-13)) \
+        if problem == "poisson" else \
+        (lambda: imh.run(nb=1500, M=16, helmholtz_k=5.0, Ns=[1024, 1024], solver_tol=1e-13))
+    err, scale, solver, ue, T = run()
+    assert solver._fast_interp and list(T['grid']) == [1024, 1024]
+    ScalarSolver.USE_FAST_INTERP = False
+    ctx.set_option("fft2d", 0)
+    try:
+        err0, scale0, solver0, ue0, _ = run()
+    finally:
+        ScalarSolver.USE_FAST_INTERP = True
+        ctx.set_option("fft2d", 1)
+    assert not solver0._fast_interp
+    print(problem, err / scale, err0 / scale0)
+    assert err / scale < 1e-11 and err0 / scale0 < 1e-11
+    assert np.abs(np.asarray(ue) - np.asarray(ue0)).max() < 1e-12 * scale
