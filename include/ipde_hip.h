@@ -191,11 +191,12 @@ int ipde_fourier_deriv(ipde_fft_plan* plan, int loc, const double* f, int axis, 
  * all interface nodes; three finufft type-2 transforms there).
  * ipde_fft_plan2d_keep_spectrum(plan, 1, &ok): subsequent ipde_poisson_grid_solve /
  * ipde_modhelm_grid_solve calls WITHOUT a uhat output keep fft2(f) * symbol on the device
- * (ok = 0: this grid size has no such path — power-of-two sizes up to 4096 x 8192 do —, use
- * uhat and the caller's own evaluation).
+ * (ok = 0: this grid size has no such path — every size up to 2048 x 4096 and the power-of-two
+ * sizes up to 4096 x 8192 do —, use uhat and the caller's own evaluation).
  * ipde_grid_interp: out3 (3, np) row-major = u, du/dx, du/dy at the points (x, y), given in
  * box units [0, 2 pi) as ebdyc.interfaces_x_transf / interfaces_y_transf; derivatives in
- * physical units.  Oversampled (2x) inverse transform + 16 x 16 window gather, ~1e-14. */
+ * physical units.  Oversampled (2x .. 4x: the fine grid is a power of two) inverse transform +
+ * 16 x 16 window gather, ~1e-14. */
 int ipde_fft_plan2d_keep_spectrum(ipde_fft_plan* plan, int on, int* supported);
 int ipde_grid_interp(ipde_fft_plan* plan, int loc, int64_t np, const double* x, const double* y,
                      double* out3);
@@ -205,7 +206,7 @@ int ipde_grid_interp(ipde_fft_plan* plan, int loc, int64_t np, const double* x, 
  * fields: nin <= 3 pointers to (nx, ny) real arrays; output k (k < nout <= 8) is the sum over
  * its terms q = term_start[k] .. term_start[k+1]-1 (1 to 3 of them) of
  * term_coef[q] * D^{term_der[q]} fields[term_src[q]], der 0: value, 1: d/dx, 2: d/dy.
- * out (nout, np).  Power-of-two grids of the fft2d pipeline only (IPDE_ERR_INVALID otherwise). */
+ * out (nout, np).  Grid sizes as for ipde_grid_interp (IPDE_ERR_INVALID otherwise). */
 int ipde_grid_interp_fields(ipde_fft_plan* plan, int loc, int nin, const double* const* fields,
                             int nout, const int* term_start, const int* term_src,
                             const int* term_der, const double* term_coef, int64_t np,

@@ -35,7 +35,15 @@ int fft2d_stokes_solve(ipde_ctx* ctx, const Fft2dPlan& p, const double* fu, cons
 // grid -> scattered points through an oversampled inverse transform (nufft.hip)
 struct GridInterp;
 bool grid_interp_supported(int64_t nx, int64_t ny);
-int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double hy, GridInterp** out);
+int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double hy, GridInterp** out,
+                       bool general = false);
+bool grid_interp_general_supported(int64_t nx, int64_t ny);
+int grid_interp_eval_general(GridInterp* gi, const void* spec, int loc, int64_t np, const double* px,
+                             const double* py, double dkx, double dky, double* out);
+int grid_interp_fields_general(GridInterp* gi, int nin, const void* const* specs, int nout,
+                               const int* term_start, const int* term_src, const int* term_der,
+                               const double* term_coef, int loc_points, int64_t np, const double* px,
+                               const double* py, double dkx, double dky, double* out);
 void grid_interp_destroy(GridInterp* gi);
 // coarse: the grid's own plan; its W[1] holds the kept spectrum, W[2] is scratch
 int grid_interp_eval(GridInterp* gi, const Fft2dPlan& coarse, int loc, int64_t np, const double* px,

@@ -14,7 +14,11 @@
 //             "exponential of semicircle" exp(beta (sqrt(1 - z^2) - 1)), beta = 2.30 w (the
 //             FINUFFT window: its transform is computed by Gauss-Legendre quadrature at set-up).
 // O(n^2 log n) instead of the O(N_b n^2) complex GEMM it replaces (ipde_amd/interp.py keeps the
-// GEMM as the checker and for grids outside fft2d's sizes).  Derivatives are separate
+// GEMM as the checker and for grids beyond 2048 x 4096 that are not powers of two).  Three
+// variants share the window and the gather: power-of-two grids feed the packed spectrum of the
+// fft2d grid solve into a 2x fine grid; 4096-point sides use four half-cell-shifted coarse
+// transforms instead of an 8192-point one; every other size takes rocFFT's half spectrum and a
+// fine grid of the next power of two >= 2 n (oversampling 2 .. 4, window shape to match).  Derivatives are separate
 // transforms of i k F: differentiating the window instead would amplify the aliasing error by
 // N_fine / k.
 // Roofline: HBM (the fine-grid passes); the gather touches 3 w^2 doubles per point.
@@ -137,6 +141,51 @@ __global__ __launch_bounds__(256) void nufft_pad_kernel(Combo cb, cd* __restrict
 }
 
 
+// General-size variant of the pad kernel: the coarse grid (nx, ny) is arbitrary (the spectra
+// are rocFFT's unpacked half spectra, (nx, ny/2 + 1)), the fine grid (nfx, nfy) is the next
+// power of two >= twice the coarse size (oversampling between 2 and 4).  Same Nyquist rules;
+// an odd size has no Nyquist line.
+__global__ __launch_bounds__(256) void nufft_pad_general_kernel(Combo cb, cd* __restrict__ D, int nx,
+                                                                int ny, int nfx, int nfy,
+                                                                const double* __restrict__ rx,
+                                                                const double* __restrict__ ry,
+                                                                double dkx, double dky) {
+    const int nyh = ny / 2 + 1, Hf = nfy / 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)nfx * nyh) return;
+    const int fi = (int)(idx / nyh), j = (int)(idx - (int64_t)fi * nyh);
+    const int kmaxp = nx / 2;                 // even: the split Nyquist; odd: (nx - 1) / 2
+    int kx;
+    if (fi <= kmaxp)
+        kx = fi;
+    else if (fi >= nfx - kmaxp)
+        kx = fi - nfx;
+    else {
+        D[(int64_t)fi * Hf + j] = cd{0.0, 0.0};
+        return;
+    }
+    const int akx = kx < 0 ? -kx : kx;
+    const bool nyqx = (nx % 2 == 0) && 2 * akx == nx, nyqy = (ny % 2 == 0) && 2 * j == ny;
+    const int ci = ((kx % nx) + nx) % nx;
+    double wgt = rx[akx] * ry[j];
+    if (nyqx && nyqy)
+        wgt = kx > 0 ? 0.5 * wgt : 0.0;
+    else if (nyqx || nyqy)
+        wgt *= 0.5;
+    cd acc{0.0, 0.0};
+    for (int t = 0; t < cb.n; ++t) {
+        cd v = cb.src[t][(int64_t)ci * nyh + j];
+        const double c = wgt * cb.coef[t];
+        v.x *= c;
+        v.y *= c;
+        if (cb.der[t] == 1) v = cd{-v.y * (kx * dkx), v.x * (kx * dkx)};
+        if (cb.der[t] == 2) v = cd{-v.y * (j * dky), v.x * (j * dky)};
+        acc.x += v.x;
+        acc.y += v.y;
+    }
+    D[(int64_t)fi * Hf + j] = acc;
+}
+
 // --- the same fine-grid samples WITHOUT a fine-grid transform ---------------------------------
 // A 2x oversampled inverse transform of a zero-padded spectrum is four coarse-size inverse
 // transforms: fine sample (2m + a, 2n + b) = coarse sample (m, n) of the field shifted by
@@ -235,7 +284,8 @@ __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restri
                                                           int nfx, int nfy,
                                                           const double* __restrict__ px,
                                                           const double* __restrict__ py, int64_t np,
-                                                          double beta, double* __restrict__ out) {
+                                                          double betax, double betay,
+                                                          double* __restrict__ out) {
     const int64_t p = blockIdx.x;
     const int lane = threadIdx.x;
     const double TWO_PI = 6.283185307179586476925286766559;
@@ -245,7 +295,7 @@ __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restri
     y -= TWO_PI * floor(y / TWO_PI);
     // first node of the patch: the W nodes nearest to the point
     const int ix0 = (int)ceil(x / hfx - 0.5 * W), iy0 = (int)ceil(y / hfy - 0.5 * W);
-    auto psi = [&](double z) {
+    auto psi = [&](double z, double beta) {
         double q = 1.0 - z * z;
         return q > 0.0 ? exp(beta * (sqrt(q) - 1.0)) : 0.0;
     };
@@ -254,14 +304,14 @@ __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restri
     constexpr int WB = 16;
     static_assert(W <= WB, "patch wider than a 16-lane group");
     const int b = lane % WB, a0 = lane / WB;
-    const double wy = (b < W) ? psi((y - (iy0 + b) * hfy) / (0.5 * W * hfy)) : 0.0;
+    const double wy = (b < W) ? psi((y - (iy0 + b) * hfy) / (0.5 * W * hfy), betay) : 0.0;
     const int jy = ((iy0 + b) % nfy + nfy) % nfy;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int r = 0; r < (W + 3) / 4; ++r) {
         const int a = a0 + 4 * r;
         if (a < W && b < W) {
-            const double wx = psi((x - (ix0 + a) * hfx) / (0.5 * W * hfx));
+            const double wx = psi((x - (ix0 + a) * hfx) / (0.5 * W * hfx), betax);
             const int jx = ((ix0 + a) % nfx + nfx) % nfx;
             const int64_t o = SUB ? ((int64_t)(2 * (jx & 1) + (jy & 1)) * (nfx / 2) + (jx >> 1)) * (nfy / 2) + (jy >> 1)
                                   : (int64_t)jx * nfy + jy;
@@ -290,7 +340,10 @@ struct GridInterp {
     ipde_ctx* ctx = nullptr;
     int64_t nx = 0, ny = 0;
     int w = 16;
-    double beta = 0;
+    double beta = 0, betax = 0, betay = 0;
+    int64_t nfx = 0, nfy = 0;     // fine grid
+    bool general = false;         // arbitrary coarse size, unpacked (rocFFT) spectra, fine = next
+                                  // power of two >= 2 n per axis
     bool shifted = false;         // fine size beyond the FFT kernels: four shifted coarse transforms
     Fft2dPlan fine;               // (2 nx, 2 ny): W[0..2] = the three fields' fine half spectra
     double* d_rx = nullptr;       // h_f / psihat_x(k), k = 0 .. nx/2
@@ -302,6 +355,21 @@ struct GridInterp {
 };
 
 bool grid_interp_supported(int64_t nx, int64_t ny) { return fft2d_supported(nx, ny); }
+
+static int64_t pow2_at_least(int64_t n) {
+    int64_t p = 1;
+    while (p < n) p *= 2;
+    return p;
+}
+static void general_fine_size(int64_t nx, int64_t ny, int64_t* nfx, int64_t* nfy) {
+    *nfx = std::max<int64_t>(512, pow2_at_least(2 * nx));
+    *nfy = std::max<int64_t>(1024, pow2_at_least(2 * ny));
+}
+bool grid_interp_general_supported(int64_t nx, int64_t ny) {
+    int64_t a, b;
+    general_fine_size(nx, ny, &a, &b);
+    return nx >= 8 && ny >= 8 && fft2d_supported(a, b);
+}
 
 static bool g_force_shifted = false;
 void grid_interp_force_shifted(bool on) { g_force_shifted = on; }
@@ -319,18 +387,34 @@ void grid_interp_destroy(GridInterp* gi) {
     delete gi;
 }
 
-int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double hy, GridInterp** out) {
+// general = true: arbitrary coarse size with unpacked spectra (see nufft_pad_general_kernel)
+int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double hy, GridInterp** out,
+                       bool general) {
     GridInterp* gi = new GridInterp();
     gi->ctx = ctx;
     gi->nx = nx;
     gi->ny = ny;
     gi->w = 16;
-    gi->beta = 2.30 * gi->w;
-    gi->shifted = g_force_shifted || !fft2d_supported(2 * nx, 2 * ny);
-    int st = gi->shifted ? IPDE_OK : fft2d_plan_init(ctx, gi->fine, 2 * nx, 2 * ny, 0.5 * hx, 0.5 * hy);
+    gi->general = general;
+    if (general) {
+        general_fine_size(nx, ny, &gi->nfx, &gi->nfy);
+        gi->shifted = false;
+    } else {
+        gi->nfx = 2 * nx;
+        gi->nfy = 2 * ny;
+        gi->shifted = g_force_shifted || !fft2d_supported(2 * nx, 2 * ny);
+    }
+    // window shape for an oversampling factor sigma (2.30 w at sigma = 2, the FINUFFT choice
+    // gamma pi w (1 - 1/(2 sigma)), gamma = 0.976)
+    auto beta_of = [&](double sigma) { return 0.976 * M_PI * gi->w * (1.0 - 0.5 / sigma); };
+    gi->betax = general ? beta_of((double)gi->nfx / nx) : 2.30 * gi->w;
+    gi->betay = general ? beta_of((double)gi->nfy / ny) : 2.30 * gi->w;
+    gi->beta = gi->betax;
+    int st = gi->shifted ? IPDE_OK
+                         : fft2d_plan_init(ctx, gi->fine, gi->nfx, gi->nfy, hx * nx / gi->nfx, hy * ny / gi->nfy);
     std::vector<double> rx, ry;
-    window_factors(2 * nx, gi->w, gi->beta, nx / 2 + 1, rx);
-    window_factors(2 * ny, gi->w, gi->beta, ny / 2 + 1, ry);
+    window_factors(gi->nfx, gi->w, gi->betax, nx / 2 + 1, rx);
+    window_factors(gi->nfy, gi->w, gi->betay, ny / 2 + 1, ry);
     auto up = [&](double** d, const std::vector<double>& h) {
         if (st == IPDE_OK && hipMalloc((void**)d, h.size() * sizeof(double)) != hipSuccess) st = IPDE_ERR_ALLOC;
         if (st == IPDE_OK && hipMemcpy(*d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
@@ -338,12 +422,13 @@ int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double 
     };
     up(&gi->d_rx, rx);
     up(&gi->d_ry, ry);
-    const size_t gbytes = (size_t)4 * nx * ny * sizeof(double);
+    const size_t gbytes = (size_t)gi->nfx * gi->nfy * sizeof(double);
     for (auto& g : gi->g)
         if (st == IPDE_OK && hipMalloc((void**)&g, gbytes) != hipSuccess) st = IPDE_ERR_ALLOC;
-    // columns ny/2 + 1 .. ny - 1 of the fine half spectra are never written: zero once
+    // the columns of the fine half spectra beyond the coarse band are never written: zero once
     for (auto& w : gi->fine.W)
-        if (!gi->shifted && st == IPDE_OK && w && hipMemset(w, 0, (size_t)2 * nx * ny * 2 * sizeof(double)) != hipSuccess)
+        if (!gi->shifted && st == IPDE_OK && w &&
+            hipMemset(w, 0, (size_t)gi->nfx * (gi->nfy / 2) * 2 * sizeof(double)) != hipSuccess)
             st = IPDE_ERR_HIP;
     if (st != IPDE_OK) {
         grid_interp_destroy(gi);
@@ -376,6 +461,16 @@ static int interp_combos(GridInterp* gi, const Fft2dPlan& coarse, int nout, cons
                     IPDE_TRY(fft2d_cols(ctx, coarse, 2, FFT2D_SYM_NONE, 2, 0.0, 1.0));
                     IPDE_TRY(fft2d_rows_inverse(ctx, coarse, 2, gi->g[f] + (int64_t)ab * nx * ny));
                 }
+            } else if (gi->general) {
+                const int64_t nthreads = gi->nfx * (ny / 2 + 1);
+                hipLaunchKernelGGL(nufft_pad_general_kernel, dim3((unsigned)ceil_div64(nthreads, 256)),
+                                   dim3(256), 0, ctx->stream, cb, (cd*)gi->fine.W[f], (int)nx, (int)ny,
+                                   (int)gi->nfx, (int)gi->nfy, (const double*)gi->d_rx,
+                                   (const double*)gi->d_ry, dkx, dky);
+                IPDE_HIP_CHECK(ctx, hipGetLastError());
+                IPDE_TRY(fft2d_cols(ctx, gi->fine, f, FFT2D_SYM_NONE, 2, 0.0, 1.0, -1, ny / 2 + 1));
+                IPDE_TRY(fft2d_rows_inverse(ctx, gi->fine, f, gi->g[f]));
+                continue;
             } else {
                 const int64_t nthreads = 2 * nx * (ny / 2 + 1);
                 hipLaunchKernelGGL(nufft_pad_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0,
@@ -390,11 +485,11 @@ static int interp_combos(GridInterp* gi, const Fft2dPlan& coarse, int nout, cons
         if (gi->shifted)
             hipLaunchKernelGGL((nufft_gather_kernel<16, true>), dim3((unsigned)np), dim3(64), 0, ctx->stream,
                                (const double*)gi->g[0], (const double*)gi->g[1], (const double*)gi->g[2], nf,
-                               (int)(2 * nx), (int)(2 * ny), d_px, d_py, np, gi->beta, o);
+                               (int)gi->nfx, (int)gi->nfy, d_px, d_py, np, gi->betax, gi->betay, o);
         else
             hipLaunchKernelGGL((nufft_gather_kernel<16, false>), dim3((unsigned)np), dim3(64), 0, ctx->stream,
                                (const double*)gi->g[0], (const double*)gi->g[1], (const double*)gi->g[2], nf,
-                               (int)(2 * nx), (int)(2 * ny), d_px, d_py, np, gi->beta, o);
+                               (int)gi->nfx, (int)gi->nfy, d_px, d_py, np, gi->betax, gi->betay, o);
         IPDE_HIP_CHECK(ctx, hipGetLastError());
     }
     return IPDE_OK;
@@ -485,5 +580,48 @@ int grid_interp_fields(GridInterp* gi, const Fft2dPlan& coarse, int nin, const d
     double* d_out;
     IPDE_TRY(stage_points(gi, loc_points, np, nout, px, py, out, &d_px, &d_py, &d_out));
     IPDE_TRY(interp_combos(gi, coarse, nout, cb, np, d_px, d_py, dkx, dky, d_out));
+    return finish_points(gi, loc_points, np, nout, out, d_out);
+}
+
+// ---- general grid sizes: spectra are rocFFT's unpacked half spectra (nx, ny/2 + 1) ----------------
+// spec: c_k = fft2(f)_k * symbol_k / (nx ny) (what spectral.hip's scalar solve leaves behind)
+int grid_interp_eval_general(GridInterp* gi, const void* spec, int loc, int64_t np, const double* px,
+                             const double* py, double dkx, double dky, double* out) {
+    const double *d_px, *d_py;
+    double* d_out;
+    IPDE_TRY(stage_points(gi, loc, np, 3, px, py, out, &d_px, &d_py, &d_out));
+    Combo cb[3];
+    // (the fine inverse returns half of the unnormalised sum: coefficient 2)
+    for (int f = 0; f < 3; ++f) cb[f] = Combo{1, {(const cd*)spec, nullptr, nullptr}, {f, 0, 0}, {2.0, 0.0, 0.0}};
+    Fft2dPlan none;
+    IPDE_TRY(interp_combos(gi, none, 3, cb, np, d_px, d_py, dkx, dky, d_out));
+    return finish_points(gi, loc, np, 3, out, d_out);
+}
+
+// specs[k]: UNNORMALISED half spectra (rocFFT r2c) of the nin input fields
+int grid_interp_fields_general(GridInterp* gi, int nin, const void* const* specs, int nout,
+                               const int* term_start, const int* term_src, const int* term_der,
+                               const double* term_coef, int loc_points, int64_t np, const double* px,
+                               const double* py, double dkx, double dky, double* out) {
+    if (nin > 3 || nout > 8) return IPDE_ERR_INVALID;
+    Combo cb[8];
+    const double norm = 2.0 / ((double)gi->nx * (double)gi->ny);
+    for (int f = 0; f < nout; ++f) {
+        const int n = term_start[f + 1] - term_start[f];
+        if (n < 1 || n > 3) return IPDE_ERR_INVALID;
+        cb[f].n = n;
+        for (int t = 0; t < 3; ++t) {
+            const int q = term_start[f] + (t < n ? t : 0);
+            if (term_src[q] < 0 || term_src[q] >= nin || term_der[q] < 0 || term_der[q] > 2) return IPDE_ERR_INVALID;
+            cb[f].src[t] = (const cd*)specs[term_src[q]];
+            cb[f].der[t] = term_der[q];
+            cb[f].coef[t] = t < n ? term_coef[q] * norm : 0.0;
+        }
+    }
+    const double *d_px, *d_py;
+    double* d_out;
+    IPDE_TRY(stage_points(gi, loc_points, np, nout, px, py, out, &d_px, &d_py, &d_out));
+    Fft2dPlan none;
+    IPDE_TRY(interp_combos(gi, none, nout, cb, np, d_px, d_py, dkx, dky, d_out));
     return finish_points(gi, loc_points, np, nout, out, d_out);
 }

@@ -44,6 +44,11 @@ struct ipde_fft_plan {
     Fft2dPlan fast;   // hand-written pipeline (power-of-two grids), fft2d.hip
     bool keep_spec = false, have_spec = false;   // fast.W[1] holds the last solve's spectrum
     GridInterp* interp = nullptr;                // created by the first ipde_grid_interp
+    // the same for grids outside fft2d's sizes (rocFFT path): the half spectrum is copied aside
+    bool have_spec_general = false;
+    double2* kept_half = nullptr;                // (nx, nyh): fft2(f) * symbol / (nx ny)
+    double2* gspec[3] = {nullptr, nullptr, nullptr};   // half spectra of ipde_grid_interp_fields' inputs
+    GridInterp* interp_general = nullptr;
     double* rbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // host staging
     double2* cbuf[2] = {nullptr, nullptr};                            // host staging (complex)
 };
@@ -349,6 +354,7 @@ int scalar_solve(ipde_fft_plan* p, int loc, double k2h, const double* f, double*
         // three hand-written kernels: rows r2c, fused column FFT * symbol * inverse FFT, rows c2r
         IPDE_TRY(fft2d_scalar_solve(ctx, p->fast, SYM, k2h, d_f, d_u, p->keep_spec));
         p->have_spec = p->keep_spec;
+        p->have_spec_general = false;
         IPDE_TRY(finish_real_out(p, loc, 1, u));
         return finish_sync(p, loc);
     }
@@ -359,6 +365,15 @@ int scalar_solve(ipde_fft_plan* p, int loc, double k2h, const double* f, double*
                        2.0 * M_PI / (p->nx * p->hx), 2.0 * M_PI / (p->ny * p->hy), k2h, 1.0 / N,
                        d_uh);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
+    p->have_spec = false;
+    p->have_spec_general = false;
+    if (p->keep_spec && grid_interp_general_supported(p->nx, p->ny)) {
+        // (the inverse transform may overwrite its input: the spectrum is copied aside)
+        const size_t bytes = (size_t)p->nx * p->nyh * sizeof(double2);
+        if (!p->kept_half) IPDE_HIP_CHECK(ctx, hipMalloc((void**)&p->kept_half, bytes));
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(p->kept_half, p->spec[0], bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        p->have_spec_general = true;
+    }
     IPDE_TRY(exec(p, p->c2r, p->spec[0], d_u));
     IPDE_TRY(finish_real_out(p, loc, 1, u));
     IPDE_TRY(finish_cplx_out(p, loc, 0, uhat));
@@ -412,6 +427,10 @@ extern "C" int ipde_fft_plan2d_destroy(ipde_fft_plan* p) {
     if (p->work) hipFree(p->work);
     fft2d_plan_free(p->fast);
     grid_interp_destroy(p->interp);
+    grid_interp_destroy(p->interp_general);
+    if (p->kept_half) hipFree(p->kept_half);
+    for (auto& q : p->gspec)
+        if (q) hipFree(q);
     for (auto& s : p->spec)
         if (s) hipFree(s);
     for (auto& s : p->rbuf)
@@ -424,10 +443,11 @@ extern "C" int ipde_fft_plan2d_destroy(ipde_fft_plan* p) {
 
 extern "C" int ipde_fft_plan2d_keep_spectrum(ipde_fft_plan* p, int on, int* supported) {
     if (!p) return IPDE_ERR_INVALID;
-    const bool ok = p->fast.ready && p->ctx->opt_fft2d && grid_interp_supported(p->nx, p->ny);
+    const bool ok = (p->fast.ready && p->ctx->opt_fft2d && grid_interp_supported(p->nx, p->ny)) ||
+                    grid_interp_general_supported(p->nx, p->ny);
     if (supported) *supported = ok ? 1 : 0;
     p->keep_spec = ok && on;
-    if (!p->keep_spec) p->have_spec = false;
+    if (!p->keep_spec) p->have_spec = p->have_spec_general = false;
     return IPDE_OK;
 }
 
@@ -437,13 +457,19 @@ extern "C" int ipde_grid_interp(ipde_fft_plan* p, int loc, int64_t np, const dou
     ipde_ctx* ctx = p->ctx;
     IPDE_CHECK_ARG(ctx, loc == IPDE_HOST || loc == IPDE_DEVICE);
     IPDE_CHECK_ARG(ctx, np >= 0 && (np == 0 || (x && y && out3)));
-    if (!p->have_spec) {
+    if (!p->have_spec && !p->have_spec_general) {
         IPDE_SET_ERR(ctx, "ipde_grid_interp: no kept spectrum (ipde_fft_plan2d_keep_spectrum, then a "
                           "scalar grid solve on this plan)");
         return IPDE_ERR_INVALID;
     }
     if (np == 0) return IPDE_OK;
     IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (p->have_spec_general) {
+        if (!p->interp_general)
+            IPDE_TRY(grid_interp_create(ctx, p->nx, p->ny, p->hx, p->hy, &p->interp_general, true));
+        return grid_interp_eval_general(p->interp_general, p->kept_half, loc, np, x, y,
+                                        2.0 * M_PI / (p->nx * p->hx), 2.0 * M_PI / (p->ny * p->hy), out3);
+    }
     if (!p->interp) {
         grid_interp_force_shifted(ctx->opt_interp_shifted != 0);
         IPDE_TRY(grid_interp_create(ctx, p->nx, p->ny, p->hx, p->hy, &p->interp));
@@ -462,7 +488,8 @@ extern "C" int ipde_grid_interp_fields(ipde_fft_plan* p, int loc, int nin, const
     IPDE_CHECK_ARG(ctx, nin >= 1 && nin <= 3 && nout >= 1 && nout <= 8 && fields && term_start &&
                             term_src && term_der && term_coef);
     IPDE_CHECK_ARG(ctx, np >= 0 && (np == 0 || (x && y && out)));
-    if (!(p->fast.ready && ctx->opt_fft2d && grid_interp_supported(p->nx, p->ny))) {
+    const bool fast = p->fast.ready && ctx->opt_fft2d && grid_interp_supported(p->nx, p->ny);
+    if (!fast && !grid_interp_general_supported(p->nx, p->ny)) {
         IPDE_SET_ERR(ctx, "ipde_grid_interp_fields: no fft2d path for a %lld x %lld grid",
                      (long long)p->nx, (long long)p->ny);
         return IPDE_ERR_INVALID;
@@ -473,6 +500,21 @@ extern "C" int ipde_grid_interp_fields(ipde_fft_plan* p, int loc, int nin, const
     for (int k = 0; k < nin; ++k) {
         IPDE_CHECK_ARG(ctx, fields[k] != nullptr);
         IPDE_TRY(stage_real_in(p, loc, k, fields[k], &d_f[k]));
+    }
+    if (!fast) {
+        // any grid size: rocFFT forward transforms, then the general-size interpolation
+        const void* specs[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < nin; ++k) {
+            if (!p->gspec[k])
+                IPDE_HIP_CHECK(ctx, hipMalloc((void**)&p->gspec[k], (size_t)p->nx * p->nyh * sizeof(double2)));
+            IPDE_TRY(exec(p, p->r2c, (void*)d_f[k], p->gspec[k]));
+            specs[k] = p->gspec[k];
+        }
+        if (!p->interp_general)
+            IPDE_TRY(grid_interp_create(ctx, p->nx, p->ny, p->hx, p->hy, &p->interp_general, true));
+        return grid_interp_fields_general(p->interp_general, nin, specs, nout, term_start, term_src, term_der,
+                                          term_coef, loc, np, x, y, 2.0 * M_PI / (p->nx * p->hx),
+                                          2.0 * M_PI / (p->ny * p->hy), out);
     }
     if (!p->interp) {
         grid_interp_force_shifted(ctx->opt_interp_shifted != 0);

@@ -165,7 +165,11 @@ def test_hand_written_fft_pipeline_against_oracle(ctx, shape):
 
 @pytest.mark.parametrize("shape,npts,shifted", [((512, 1024), 700, 0), ((2048, 2048), 4096, 0),
                                                 ((512, 1024), 700, 1), ((2048, 1024), 900, 1),
-                                                ((4096, 4096), 600, 0)])
+                                                ((4096, 4096), 600, 0),
+                                                # any other size: rocFFT spectrum, fine grid = next power
+                                                # of two >= 2 n (oversampling 2 .. 4), odd sizes too
+                                                ((48, 40), 300, 0), ((301, 255), 500, 0),
+                                                ((600, 900), 800, 0), ((1370, 1370), 2000, 0)])
 def test_grid_interp_against_dense_fourier_sums(ctx, shape, npts, shifted):
     """Values and gradient of the grid solution at scattered points: the oversampled-FFT
     interpolation of csrc/nufft.hip (what the solvers use on power-of-two grids) against the
@@ -231,10 +235,13 @@ def test_grid_interp_against_dense_fourier_sums(ctx, shape, npts, shifted):
 def test_grid_interp_needs_a_kept_spectrum_and_a_supported_grid():
     from ipde_amd._lib import IpdeHipError
     from ipde_amd.spectral import GridPlan
-    plan = GridPlan(48, 40, 0.1, 0.1)
-    assert plan.keep_spectrum(True) is False          # not a power-of-two grid: dense sums
+    plan = GridPlan(2500, 64, 0.1, 0.1)
+    assert plan.keep_spectrum(True) is False          # the 2x fine grid would need 8192 rows: dense sums
     with pytest.raises(IpdeHipError, match="no kept spectrum"):
         plan.interp_gradient(np.zeros(3), np.zeros(3))
+    plan.close()
+    plan = GridPlan(48, 40, 0.1, 0.1)                 # any moderate size has the path
+    assert plan.keep_spectrum(True) is True
     plan.close()
     plan = GridPlan(512, 1024, 0.1, 0.1)
     assert plan.keep_spectrum(True) is True
@@ -244,7 +251,8 @@ def test_grid_interp_needs_a_kept_spectrum_and_a_supported_grid():
 
 
 @pytest.mark.parametrize("shape,npts,shifted", [((512, 1024), 500, 0), ((1024, 1024), 900, 1),
-                                                ((2048, 2048), 3000, 0)])
+                                                ((2048, 2048), 3000, 0), ((301, 255), 400, 0),
+                                                ((1370, 1370), 1500, 0)])
 def test_grid_interp_fields_against_dense_fourier_sums(ctx, shape, npts, shifted):
     """ipde_grid_interp_fields: the five interface fields of the Stokes solver (u, v and the
     stress T = grad u + grad u^T - p I of three real grid fields) against the dense Fourier sums
@@ -296,9 +304,9 @@ def test_grid_interp_fields_argument_checks():
     from ipde_amd._lib import IpdeHipError
     from ipde_amd.spectral import GridPlan
     z = np.zeros(4)
-    plan = GridPlan(48, 40, 0.1, 0.1)                  # no fft2d path at this size
+    plan = GridPlan(2500, 64, 0.1, 0.1)                # no fine grid within the FFT kernels' sizes
     with pytest.raises(IpdeHipError, match="no fft2d path"):
-        plan.interp_fields([np.zeros((48, 40))], [[(1.0, 0, 0)]], z, z)
+        plan.interp_fields([np.zeros((2500, 64))], [[(1.0, 0, 0)]], z, z)
     plan.close()
     plan = GridPlan(512, 1024, 0.1, 0.1)
     f = np.zeros((512, 1024))
