@@ -249,12 +249,13 @@ class _AsyncLU(object):
         self._fut = _lu_pool.submit(work)
 
     def _get(self):
-        if self._obj is None:
+        obj = self._obj
+        if obj is None:
             import torch
-            obj, done = self._fut.result()
+            obj, done = self._fut.result()      # (a Future hands its result to any number of callers)
             torch.cuda.current_stream().wait_event(done)
-            self._obj, self._fut = obj, None
-        return self._obj
+            self._obj = obj
+        return obj
 
     def __getattr__(self, name):       # ctx, n, LU, perm, solve, _subst: the realised object's
         return getattr(self._get(), name)
