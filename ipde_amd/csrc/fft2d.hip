@@ -31,7 +31,8 @@
 
 namespace {
 
-struct cd {
+// (16-byte aligned: LDS exchanges are ds_read_b128 / ds_write_b128, not pairs of 8-byte accesses)
+struct alignas(16) cd {
     double x, y;
 };
 __device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void row_r2c_kernel(const double* __restrict__
     constexpr int H = NY / 2;
     using G = Cfg<H>;
     constexpr int T = G::T, P = G::P, RPW = 256 / T;
-    extern __shared__ double lds_raw[];
+    extern __shared__ double2 lds_raw[];   // (double2: the dynamic LDS base is 16-byte aligned)
     cd* lds = (cd*)lds_raw;
     const int tid = threadIdx.x, sub = tid / T, t = tid % T;
     const int64_t row = (int64_t)blockIdx.x * RPW + sub;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void row_c2r_kernel(const cd* __restrict__ W, 
     constexpr int H = NY / 2;
     using G = Cfg<H>;
     constexpr int T = G::T, P = G::P, RPW = 256 / T;
-    extern __shared__ double lds_raw[];
+    extern __shared__ double2 lds_raw[];   // (double2: the dynamic LDS base is 16-byte aligned)
     cd* lds = (cd*)lds_raw;
     const int tid = threadIdx.x, sub = tid / T, t = tid % T;
     const int64_t row = (int64_t)blockIdx.x * RPW + sub;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(C* Cfg<NX>::T) void col_kernel(cd* __restrict__ W, 
     // column regions are offset by 4 slots (16 banks) from one another: the 16 lanes of a
     // ds_read_b128 group (4 columns x 4 values of t) then hit 16 different 4-bank slots
     constexpr int T = G::T, P = G::P, NPC = lds_slots<NX>() + 4;
-    extern __shared__ double lds_raw[];
+    extern __shared__ double2 lds_raw[];   // (double2: the dynamic LDS base is 16-byte aligned)
     cd* lds = (cd*)lds_raw;
     // XCD-aware hand-out: workgroup w runs on XCD w % 8; give each XCD a contiguous range of
     // column blocks so that blocks sharing 128-byte lines share an L2
