@@ -269,6 +269,21 @@ int ipde_chebfourier_gather(ipde_ctx* ctx, int64_t M, int64_t nf, const double* 
                             const double* bary_w, int64_t npts, const double* xi, const double* t,
                             double* out);
 
+/*
+ * Radial -> grid interpolation, whole: what ipde/embedded_boundary.py:419-443 (`interpolate_radial_to_points`:
+ * Chebyshev analysis along r, FFT along t, one type-2 NUFFT per Chebyshev mode) does for ONE field
+ * of one boundary, for `nfld` fields that share their targets (the (u, v, p) of a Stokes solve,
+ * ipde/solvers/multi_boundary/stokes.py:104-110), in one call and without a host round trip:
+ *     out[f][idx ? idx[i] : i] = sum_m T_m(xi[i]) c^f_m(t[i]),   i < npts.
+ * fr: nfld x M x N doubles at `loc` — values on (M Chebyshev-Gauss nodes, lowest first) x
+ * (N equispaced t); bary_w: HOST, 16 barycentric weights; xi, t: DEVICE, npts doubles;
+ * idx: DEVICE, npts int64 scatter positions, or NULL; out: HOST array of nfld DEVICE pointers.
+ * Asynchronous on the context's stream.  nfld <= 8, M <= 512, N >= 16.
+ */
+int ipde_radial_to_grid(ipde_ctx* ctx, int loc, int64_t nfld, int64_t M, int64_t N, const double* fr,
+                        const double* bary_w, int64_t npts, const double* xi, const double* t,
+                        const int64_t* idx, double* const* out);
+
 /* ------------------------------------------------------------------------- */
 /* Ewald-type grid evaluator, first half                       */
 /*

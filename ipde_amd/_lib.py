@@ -80,6 +80,7 @@ SIGNATURES = {
     "ipde_dense_lu_solve": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ipde_dense_lu_solve_batch": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "ipde_chebfourier_gather": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "ipde_radial_to_grid": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ipde_curve_local_coordinates": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
     "ipde_ewald_create": (_int, [_vp, _int, _dbl, _dbl, _int, _vp, _int, _int, _c_void_pp]),
     "ipde_ewald_destroy": (_int, [_vp]),
@@ -131,7 +132,7 @@ def load():
 
 def _uses_fft(name):
     """entry points that may create or run rocFFT plans"""
-    return name.startswith(("ipde_fft", "ipde_fourier", "ipde_annular", "ipde_grid_interp")) \
+    return name.startswith(("ipde_fft", "ipde_fourier", "ipde_annular", "ipde_grid_interp", "ipde_radial_to_grid")) \
         or name.endswith("_grid_solve")
 
 

@@ -167,6 +167,10 @@ extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
     freebuf(ctx->partial);
     freebuf(ctx->scratch);
     for (auto& b : ctx->fftwork) freebuf(b);
+    for (auto& b : ctx->r2g) freebuf(b);
+    for (auto& kv : ctx->cheb_tab)
+        if (kv.second) hipFree(kv.second);
+    ctx->cheb_tab.clear();
     if (ctx->logtab.d_tab) hipFree(ctx->logtab.d_tab);
     if (ctx->d_ktab) hipFree(ctx->d_ktab);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);

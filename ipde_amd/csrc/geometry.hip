@@ -215,3 +215,212 @@ extern "C" int ipde_chebfourier_gather(ipde_ctx* ctx, int64_t M, int64_t nf, con
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Radial -> grid interpolation, whole (reference ipde/embedded_boundary.py:419-443; the
+// solvers call it once per boundary and field at the end of every solve,
+// ipde/solvers/multi_boundary/scalar.py:112-116).  One library call, six launches on the
+// context's stream, no host round trip:
+//   1. Chebyshev analysis along r.  For Chebyshev-Gauss nodes the inverse of the Vandermonde
+//      matrix is the discrete cosine sum  c_k = (2 - [k = 0])/M sum_j f_j cos(k theta_j):
+//      an M x M table per M, built once in long double and kept in HBM;
+//   2. forward FFT of the nf*M coefficient rows along t (rocFFT, batched);
+//   3. 16 phase-shifted copies of every spectrum, scaled by 1/N (row (s, r) will hold
+//      c_r(t_j + s h/16): transforms of the SAME length N, so no new FFT length);
+//   4. inverse FFT of the 16 nf M rows;
+//   5. real parts interleaved into the oversampled table cf[r][16 j + s];
+//   6. the gather: 16-point barycentric Lagrange along t, Chebyshev recurrence in xi, all
+//      fields of a point from one set of weights, written straight to out[f][idx[p]].
+namespace {
+
+constexpr int R2G_UP = 16;       // oversampling along t
+constexpr int R2G_MAXF = 8;      // fields per call
+
+struct R2gOut {
+    double* p[R2G_MAXF];
+};
+
+__global__ __launch_bounds__(256) void r2g_analysis_kernel(const double* __restrict__ fr,
+                                                           const double* __restrict__ tab, int M, int N,
+                                                           double2* __restrict__ c) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const int r = blockIdx.y;          // f*M + k
+    const int f = r / M, k = r - f * M;
+    const double* col = fr + (size_t)f * M * N + j;
+    const double* w = tab + (size_t)k * M;
+    double s = 0.0;
+    for (int m = 0; m < M; ++m) s = fma(w[m], col[(size_t)m * N], s);
+    c[(size_t)r * N + j] = make_double2(s, 0.0);
+}
+
+__global__ __launch_bounds__(256) void r2g_phase_kernel(const double2* __restrict__ ch, int R, int N,
+                                                        double2* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const int r = blockIdx.y;
+    const double2 v = ch[(size_t)r * N + k];
+    const int ks = (k < (N + 1) / 2) ? k : k - N;      // signed wavenumber (Nyquist negative)
+    const double sc = 1.0 / (double)N;
+    const double vr = v.x * sc, vi = v.y * sc;
+#pragma unroll
+    for (int s = 0; s < R2G_UP; ++s) {
+        double sn, cs;
+        sincospi((double)(s * (long long)ks) / (double)(R2G_UP / 2 * (long long)N), &sn, &cs);
+        out[((size_t)s * R + r) * N + k] = make_double2(vr * cs - vi * sn, vr * sn + vi * cs);
+    }
+}
+
+__global__ __launch_bounds__(256) void r2g_interleave_kernel(const double2* __restrict__ fine, int R, int N,
+                                                             double* __restrict__ cf) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const int r = blockIdx.y;
+    double v[R2G_UP];
+#pragma unroll
+    for (int s = 0; s < R2G_UP; ++s) v[s] = fine[((size_t)s * R + r) * N + j].x;
+    double4* o = (double4*)(cf + ((size_t)r * N + j) * R2G_UP);
+#pragma unroll
+    for (int q = 0; q < R2G_UP / 4; ++q) o[q] = make_double4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+__global__ __launch_bounds__(256) void r2g_gather_kernel(const double* __restrict__ cf, int nfld, int M, int nf,
+                                                         BaryW bw, long long n, const double* __restrict__ xi,
+                                                         const double* __restrict__ t,
+                                                         const long long* __restrict__ idx, R2gOut out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double twopi = 6.283185307179586476925286766559;
+    const double hf = twopi / (double)nf;
+    double tm = fmod(t[i], twopi);
+    if (tm < 0.0) tm += twopi;
+    const double s = tm / hf;
+    const long long i0 = (long long)floor(s) - (NLT / 2 - 1);
+    const double u = s - (double)i0;
+    double wt[NLT];
+    double wsum = 0.0;
+    int hit = -1;
+#pragma unroll
+    for (int j = 0; j < NLT; ++j) {
+        const double d = u - (double)j;
+        if (d == 0.0) hit = j;
+        wt[j] = bw.w[j] / (d == 0.0 ? 1.0 : d);
+        wsum += wt[j];
+    }
+    if (hit >= 0) {
+#pragma unroll
+        for (int j = 0; j < NLT; ++j) wt[j] = (j == hit) ? 1.0 : 0.0;
+        wsum = 1.0;
+    }
+    const double inv = 1.0 / wsum;
+    long long base = i0 % nf;
+    if (base < 0) base += nf;
+    int ix[NLT];
+#pragma unroll
+    for (int j = 0; j < NLT; ++j) {
+        int k = (int)(base + j);
+        ix[j] = k >= nf ? k - nf : k;
+        wt[j] *= inv;
+    }
+    const double x = xi[i];
+    const long long o = idx ? idx[i] : i;
+    for (int f = 0; f < nfld; ++f) {
+        double T0 = 1.0, T1 = x, acc = 0.0;
+        for (int m = 0; m < M; ++m) {
+            const double* row = cf + ((size_t)f * M + m) * nf;
+            double b = 0.0;
+#pragma unroll
+            for (int j = 0; j < NLT; ++j) b = fma(row[ix[j]], wt[j], b);
+            double Tm;
+            if (m == 0) {
+                Tm = 1.0;
+            } else if (m == 1) {
+                Tm = x;
+            } else {
+                Tm = 2.0 * x * T1 - T0;
+                T0 = T1;
+                T1 = Tm;
+            }
+            acc = fma(b, Tm, acc);
+        }
+        out.p[f][o] = acc;
+    }
+}
+
+int cheb_table(ipde_ctx* ctx, int M, const double** tab) {
+    auto it = ctx->cheb_tab.find(M);
+    if (it != ctx->cheb_tab.end()) {
+        *tab = it->second;
+        return IPDE_OK;
+    }
+    // nodes ascending: x_m = cos(theta_m), theta_m = pi (2 (M-1-m) + 1) / (2 M)
+    std::vector<double> h((size_t)M * M);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int k = 0; k < M; ++k)
+        for (int m = 0; m < M; ++m) {
+            const long double th = pi * (long double)(2 * (M - 1 - m) + 1) / (long double)(2 * M);
+            h[(size_t)k * M + m] = (double)((k == 0 ? 1.0L : 2.0L) / (long double)M * cosl((long double)k * th));
+        }
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, h.size() * sizeof(double)) != hipSuccess) {
+        IPDE_SET_ERR(ctx, "hipMalloc of the Chebyshev analysis table (M = %d) failed", M);
+        return IPDE_ERR_ALLOC;
+    }
+    // (synchronous copy from the stack-owned vector: once per M and context)
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(d);
+        IPDE_SET_ERR(ctx, "upload of the Chebyshev analysis table (M = %d) failed", M);
+        return IPDE_ERR_HIP;
+    }
+    ctx->cheb_tab[M] = d;
+    *tab = d;
+    return IPDE_OK;
+}
+
+}  // namespace
+
+int ipde_fft1_exec(ipde_ctx* ctx, int64_t batch, int64_t n, int direction, const void* in, void* out);  // spectral.hip
+
+extern "C" int ipde_radial_to_grid(ipde_ctx* ctx, int loc, int64_t nfld, int64_t M, int64_t N, const double* fr,
+                                   const double* bary_w, int64_t npts, const double* xi, const double* t,
+                                   const int64_t* idx, double* const* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, loc == IPDE_HOST || loc == IPDE_DEVICE);
+    IPDE_CHECK_ARG(ctx, nfld >= 1 && nfld <= R2G_MAXF && M >= 1 && M <= 512 && N >= NLT && N < (1 << 24));
+    IPDE_CHECK_ARG(ctx, nfld * M <= 65535 && fr && bary_w && npts >= 0 && out);
+    R2gOut o{};
+    for (int f = 0; f < nfld; ++f) {
+        IPDE_CHECK_ARG(ctx, out[f] != nullptr);
+        o.p[f] = out[f];
+    }
+    if (npts == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, xi && t);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int R = (int)(nfld * M);
+    const size_t rowsz = (size_t)R * N * sizeof(double2);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->r2g[0], rowsz));
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->r2g[1], rowsz));
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->r2g[2], R2G_UP * rowsz));
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->r2g[3], R2G_UP * rowsz));
+    const double* tab;
+    IPDE_TRY(cheb_table(ctx, (int)M, &tab));
+    const double* d_fr;
+    IPDE_TRY(ipde_stage_in(ctx, loc, 0, fr, (size_t)R * N, &d_fr));
+    double2* c = (double2*)ctx->r2g[0].p;
+    double2* ch = (double2*)ctx->r2g[1].p;
+    double2* ph = (double2*)ctx->r2g[2].p;
+    double2* fine = (double2*)ctx->r2g[3].p;
+    double* cf = (double*)ctx->r2g[2].p;      // the phase-shifted spectra are dead after step 4
+    const dim3 g((unsigned)((N + 255) / 256), (unsigned)R);
+    hipLaunchKernelGGL(r2g_analysis_kernel, g, dim3(256), 0, ctx->stream, d_fr, tab, (int)M, (int)N, c);
+    IPDE_TRY(ipde_fft1_exec(ctx, R, N, -1, c, ch));
+    hipLaunchKernelGGL(r2g_phase_kernel, g, dim3(256), 0, ctx->stream, ch, R, (int)N, ph);
+    IPDE_TRY(ipde_fft1_exec(ctx, (int64_t)R2G_UP * R, N, +1, ph, fine));
+    hipLaunchKernelGGL(r2g_interleave_kernel, g, dim3(256), 0, ctx->stream, fine, R, (int)N, cf);
+    BaryW bw;
+    for (int j = 0; j < NLT; ++j) bw.w[j] = bary_w[j];
+    hipLaunchKernelGGL(r2g_gather_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, cf,
+                       (int)nfld, (int)M, (int)(R2G_UP * N), bw, (long long)npts, xi, t, (const long long*)idx, o);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}

@@ -24,7 +24,7 @@ class EmbeddedBoundary(object):
     def __init__(self, bdy, interior, M, h, *legacy, **kwargs):
         # library loads and the length-N 1-D FFT kernels (annular solver, radial
         # interpolation) compile while the host does the geometry set-up
-        prewarm(fft1=((M, bdy.N),))
+        prewarm(fft1=((M, bdy.N), (16 * M, bdy.N)))
         # old call form (reference examples/interior_modified_helmholtz.py:41):
         # EmbeddedBoundary(bdy, interior, M, h, pad_zone, heaviside)
         if len(legacy) > 2:

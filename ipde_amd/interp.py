@@ -139,19 +139,46 @@ def _bary_host():
     return w
 
 
-_cheb_inv = {}
-_phase = {}
+def radial_to_grid(frs, xi, t, idx=None, outs=None, ctx=None):
+    """Several fields given on (M Chebyshev-Gauss nodes, lowest first) x (N equispaced t) of
+    ONE boundary, evaluated at the same scattered (xi in [-1, 1], t): one library call
+    (ipde_radial_to_grid, csrc/geometry.hip), no host round trip.
 
-
-def _cheb_inverse(M, ctx):
-    """V^{-1} of the Chebyshev-Gauss nodes (ascending), on the device, kept per M"""
-    key = (M, ctx.device)
-    VI = _cheb_inv.get(key)
-    if VI is None:
-        xc = np.polynomial.chebyshev.chebgauss(M)[0][::-1].copy()
-        VI = np.linalg.inv(np.polynomial.chebyshev.chebvander(xc, M - 1))
-        VI = _cheb_inv[key] = _dev(VI, ctx, torch.float64)
-    return VI
+    frs: list of (M, N) real arrays — numpy (staged by the library) or device tensors;
+    xi, t: device tensors (P,); idx: optional int64 device tensor (P,) of positions and
+    outs: list of 1-D device tensors — then outs[f][idx] = values (the radial -> grid
+    write of ipde/solvers/multi_boundary/scalar.py:112-116) and outs is returned;
+    otherwise a list of new (P,) tensors."""
+    import ctypes
+    from . import _lib
+    from .device import ptr
+    ctx = ctx or get_context()
+    dev = ctx.torch_device()
+    nf = len(frs)
+    on_dev = all(isinstance(f, torch.Tensor) for f in frs)
+    if on_dev:
+        M, N = frs[0].shape
+        stack = (frs[0] if nf == 1 else torch.stack(list(frs))).to(device=dev, dtype=torch.float64).contiguous()
+        loc = _lib.IPDE_DEVICE
+    else:
+        host = [f.cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f, dtype=np.float64) for f in frs]
+        M, N = host[0].shape
+        stack = np.ascontiguousarray(host[0] if nf == 1 else np.stack(host))
+        loc = _lib.IPDE_HOST
+    xi = _dev(xi, ctx, torch.float64).contiguous()
+    t = _dev(t, ctx, torch.float64).contiguous()
+    P = t.shape[0]
+    if outs is None:
+        assert idx is None
+        outs = [torch.empty(P, dtype=torch.float64, device=dev) for _ in range(nf)]
+    else:
+        assert len(outs) == nf and all(o.is_contiguous() and o.dtype == torch.float64 for o in outs)
+    if idx is not None:
+        assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.shape[0] == P
+    op = (ctypes.c_void_p * nf)(*[o.data_ptr() for o in outs])
+    ctx.check(ctx.lib.ipde_radial_to_grid(ctx.handle, loc, nf, M, N, ptr(stack), ptr(_bary_host()), P,
+                                          ptr(xi), ptr(t), ptr(idx), op))
+    return outs
 
 
 def chebyshev_fourier_eval(fr, xi, t, ctx=None):
@@ -163,32 +190,4 @@ def chebyshev_fourier_eval(fr, xi, t, ctx=None):
     batched 1-D transform) and read with 16-point barycentric Lagrange interpolation:
     worst-case error (a mode at the original Nyquist) ~1e-17, cost O(M P 16) instead of
     the O(M N P) dense Fourier sum (13.8 ms -> 1 ms per 2048^2 Poisson solve)."""
-    ctx = ctx or get_context()
-    fr = _dev(fr, ctx, torch.float64)
-    M, N = fr.shape
-    xi = _dev(xi, ctx, torch.float64)
-    t = _dev(t, ctx, torch.float64)
-    dev = fr.device
-    # Chebyshev coefficients along r: c = V^{-1} f  (nodes ascending)
-    c = _cheb_inverse(M, ctx) @ fr                                # (M, N)
-    ch = fft1(c, -1, ctx)                                         # (M, N) complex, unscaled
-    # 16x finer samples of the M rows as 16 phase-shifted inverse transforms of the SAME
-    # length N (row (s, m) holds f_m(t_j + s h/16)): no new FFT length, hence no new
-    # run-time kernel compilation in rocFFT, and the batch is still one library call
-    Nf = _UP_T * N
-    phase = _phase.get((N, dev))
-    if phase is None:
-        k = torch.fft.fftfreq(N, 1.0 / N, dtype=torch.float64, device=dev)
-        shift = torch.arange(_UP_T, dtype=torch.float64, device=dev) * (2 * np.pi / Nf)
-        phase = _phase[(N, dev)] = _cis(shift[:, None] * k[None, :])           # (16, N)
-    fine = fft1((phase[:, None, :] * ch[None, :, :]).reshape(_UP_T * M, N), +1, ctx).real
-    cf = fine.reshape(_UP_T, M, N).permute(1, 2, 0).reshape(M, Nf).contiguous()
-    # gather half: one HIP kernel, a thread per point (csrc/geometry.hip)
-    from .device import ptr
-    P = t.shape[0]
-    out = torch.empty(P, dtype=torch.float64, device=dev)
-    xi = xi.contiguous()
-    t = t.contiguous()
-    ctx.check(ctx.lib.ipde_chebfourier_gather(ctx.handle, M, Nf, ptr(cf), ptr(_bary_host()), P,
-                                              ptr(xi), ptr(t), ptr(out)))
-    return out
+    return radial_to_grid([fr], xi, t, ctx=ctx)[0]

@@ -13,11 +13,12 @@ import torch
 
 from ...derivatives import fd_x_4, fd_y_4
 from ...embedded_function import EmbeddedFunction, BoundaryFunction
-from ...interp import periodic_interp2d, periodic_interp2d_gradient, chebyshev_fourier_eval
+from ...interp import periodic_interp2d, periodic_interp2d_gradient, radial_to_grid
 from ...qfs import call_many, u2s_many
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...device import prewarm_wait
+from ... import hostio
 from ...sharding import make_pnai_evaluator, exchange_owned, owner_of, is_distributed, _dist_state
 from ...spectral import get_plan
 
@@ -149,7 +150,6 @@ class ScalarSolver(object):
             self._ia.append((idx, torch.as_tensor(ebdy.grid_ia_xi, device=dev),
                              torch.as_tensor(ebdy.grid_ia_t, device=dev)))
         self._pin_in = torch.empty(e.grid_phys.N, dtype=torch.float64, pin_memory=True)
-        self._pin_out = torch.empty(e.grid_phys.N, dtype=torch.float64, pin_memory=True)
 
     def _pnai_evaluator(self):
         """density -> potential on grid_pnai.  The solver evaluates onto the same target
@@ -205,9 +205,10 @@ class ScalarSolver(object):
         Nx, Ny = self.grid.shape
         fr_list = f.get_radial_value_list()
         # fc = (grid values) * grid_step on the full grid  (embedded_function.py:135-138)
-        self._pin_in.numpy()[:] = f['grid']
+        fp = torch.empty(e.grid_phys.N, dtype=torch.float64, device=self._dev)
+        hostio.upload(fp, f['grid'], self._pin_in)
         fg = torch.zeros(Nx * Ny, dtype=torch.float64, device=self._dev)
-        fg[self._phys_idx] = self._pin_in.to(self._dev, non_blocking=True)
+        fg[self._phys_idx] = fp
         fc = fg.view(Nx, Ny) * self._grid_step_d
         uch, uc = self._grid_solve(fc)
         uc = uc.contiguous()
@@ -248,11 +249,13 @@ class ScalarSolver(object):
             for h, ur in zip(self.helpers, urs):
                 h.ur = ur
         for ur, (idx, xi, t) in zip(urs, self._ia):
-            ucf[idx] = chebyshev_fourier_eval(ur, xi, t)
+            radial_to_grid([ur], xi, t, idx=idx, outs=[ucf])
         ucf *= self._phys_d.view(-1)
-        self._pin_out.copy_(ucf[self._phys_idx], non_blocking=False)
-        ue = EmbeddedFunction(e)
-        ue.load_data(self._pin_out.numpy(), urs)
+        # the answer is built over pinned memory: the device->host copy writes the caller's array
+        ue, block = hostio.pinned_function(e)
+        block[:e.grid_phys.N].copy_(ucf[self._phys_idx], non_blocking=False)
+        for i, ur in enumerate(urs):
+            ue[i] = ur
         return ue
 
     def _define_layer_apply(self):

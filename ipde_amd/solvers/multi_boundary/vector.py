@@ -10,12 +10,13 @@ import torch
 
 from ...derivatives import fd_x_4, fd_y_4
 from ...embedded_function import EmbeddedFunction
-from ...interp import periodic_interp2d, chebyshev_fourier_eval
+from ...interp import periodic_interp2d, radial_to_grid
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...qfs import call_many, u2s_many
 from .scalar import _finish_all, _concurrent_helpers, _owned, _run_owned
 from ...device import prewarm_wait
+from ... import hostio
 from ...sharding import make_pnai_evaluator, exchange_owned, is_distributed
 from ...spectral import get_plan
 
@@ -108,7 +109,6 @@ class VectorSolver(object):
                 lambda x, y: DeviceTargets(PointSet(x=x, y=y)))
             self.split_grid_evaluation = False
         self._pin_in = torch.empty((2, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
-        self._pin_out = torch.empty((3, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
 
     def _extract_extra_kwargs(self, **kwargs):
         pass
@@ -144,11 +144,11 @@ class VectorSolver(object):
         Nx, Ny = self.grid.shape
         fur_list = fu.get_radial_value_list()
         fvr_list = fv.get_radial_value_list()
-        pin = self._pin_in.numpy()
-        pin[0] = fu['grid']
-        pin[1] = fv['grid']
+        fp = torch.empty((2, e.grid_phys.N), dtype=torch.float64, device=self._dev)
+        hostio.upload(fp[0], fu['grid'], self._pin_in[0])
+        hostio.upload(fp[1], fv['grid'], self._pin_in[1])
         fg = torch.zeros((2, Nx * Ny), dtype=torch.float64, device=self._dev)
-        fg[:, self._phys_idx] = self._pin_in.to(self._dev, non_blocking=True)
+        fg[:, self._phys_idx] = fp
         fc = fg.view(2, Nx, Ny) * self._grid_step_d
         uc, vc, pc = (a.contiguous() for a in self._grid_solve(fc[0], fc[1]))
         # velocity and stress of the grid solution on every interface node (:66-82)
@@ -199,17 +199,18 @@ class VectorSolver(object):
             for h, r in zip(self.helpers, res):
                 h.ur, h.vr, h.pr = r[0], r[1], r[2]
         urs, vrs, prs = zip(*res)
-        for k, (f, rs) in enumerate(zip(fields, (urs, vrs, prs))):
-            for r, (idx, xi, t) in zip(rs, self._ia):
-                f[idx] = chebyshev_fourier_eval(r, xi, t)
+        # the answers are built over pinned memory: the device->host copies write the caller's arrays
+        made = [hostio.pinned_function(e) for _ in range(3)]
+        # the three fields of a boundary share their targets: one library call per boundary
+        for b, (idx, xi, t) in enumerate(self._ia):
+            radial_to_grid([urs[b], vrs[b], prs[b]], xi, t, idx=idx, outs=list(fields))
+        for (g, block), f, rs in zip(made, fields, (urs, vrs, prs)):
             f *= self._phys_d.view(-1)
-            self._pin_out[k].copy_(f[self._phys_idx], non_blocking=False)
-        res = []
-        for k, rs in enumerate((urs, vrs, prs)):
-            g = EmbeddedFunction(e)
-            g.load_data(self._pin_out[k].numpy().copy(), list(rs))
-            res.append(g)
-        return tuple(res)
+            block[:e.grid_phys.N].copy_(f[self._phys_idx], non_blocking=True)
+            for i, r in enumerate(rs):
+                g[i] = r
+        torch.cuda.current_stream(self._dev).synchronize()
+        return tuple(g for g, _ in made)
 
     def _define_layer_apply(self):
         self.Layer_Apply = self.helpers[0].Layer_Apply

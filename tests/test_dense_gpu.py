@@ -79,6 +79,67 @@ def test_chebyshev_fourier_eval_is_exact_for_full_band_data(M, N):
     assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("on_device", [False, True])
+def test_radial_to_grid_three_fields_scattered_into_grids(on_device):
+    """ipde_radial_to_grid with several fields sharing their targets and the write through an
+    index list (the end of a Stokes solve, reference multi_boundary/stokes.py:104-110): equals
+    the one-field evaluations, touches nothing outside idx, host and device inputs agree"""
+    import torch
+    from ipde_amd.interp import radial_to_grid, chebyshev_fourier_eval
+    rng = np.random.default_rng(11)
+    M, N, P, G = 14, 800, 5000, 20000
+    frs = [rng.standard_normal((M, N)) for _ in range(3)]
+    xi = torch.as_tensor(rng.uniform(-1, 1, P), device="cuda")
+    t = torch.as_tensor(rng.uniform(-7, 7, P), device="cuda")     # any real t: periodic
+    idx = torch.as_tensor(rng.permutation(G)[:P].astype(np.int64), device="cuda")
+    outs = [torch.full((G,), 7.0, dtype=torch.float64, device="cuda") for _ in range(3)]
+    inp = [torch.as_tensor(f, device="cuda") for f in frs] if on_device else frs
+    res = radial_to_grid(inp, xi, t, idx=idx, outs=outs)
+    assert res is outs
+    mask = torch.ones(G, dtype=torch.bool, device="cuda")
+    mask[idx] = False
+    for f, o in zip(frs, outs):
+        one = chebyshev_fourier_eval(f, xi, t)
+        assert torch.equal(o[idx], one)
+        assert bool((o[mask] == 7.0).all())
+    # against the direct sums
+    k = np.fft.fftfreq(N, 1.0 / N)
+    xc = np.polynomial.chebyshev.chebgauss(M)[0][::-1]
+    c = np.linalg.solve(np.polynomial.chebyshev.chebvander(xc, M - 1), frs[0])
+    ch = np.fft.fft(c, axis=1) / N
+    if N % 2 == 0:
+        ch[:, N // 2] = ch[:, N // 2].real      # cos(N/2 t) convention of the real interpolant
+    tt = t.cpu().numpy()[:200]
+    rows = (ch[:, :, None] * np.exp(1j * k[None, :, None] * tt[None, None, :])).sum(axis=1).real
+    ref = np.einsum('pm,mp->p', np.polynomial.chebyshev.chebvander(xi.cpu().numpy()[:200], M - 1), rows)
+    got = outs[0][idx].cpu().numpy()[:200]
+    assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+def test_radial_to_grid_argument_checks():
+    import ctypes
+    import torch
+    from ipde_amd import _lib
+    from ipde_amd.device import get_context, ptr
+    ctx = get_context()
+    z = torch.zeros(64, dtype=torch.float64, device="cuda")
+    w = np.ones(16)
+    op = (ctypes.c_void_p * 1)(z.data_ptr())
+    fr = np.zeros((4, 32))
+    call = lambda nf, M, N: ctx.lib.ipde_radial_to_grid(ctx.handle, _lib.IPDE_HOST, nf, M, N, ptr(fr), ptr(w), 8,
+                                                         ptr(z), ptr(z), None, op)
+    assert call(1, 4, 32) == _lib.IPDE_OK
+    assert call(0, 4, 32) == 1
+    assert call(9, 4, 32) == 1
+    assert call(1, 0, 32) == 1
+    assert call(1, 4, 8) == 1          # shorter than the stencil
+    assert ctx.lib.ipde_radial_to_grid(ctx.handle, 5, 1, 4, 32, ptr(fr), ptr(w), 8, ptr(z), ptr(z), None,
+                                       op) == 1
+    assert ctx.lib.ipde_radial_to_grid(None, _lib.IPDE_HOST, 1, 4, 32, ptr(fr), ptr(w), 8, ptr(z), ptr(z), None,
+                                       op) == 1
+    ctx.sync()
+
+
 @pytest.mark.parametrize("Nx,Ny", [(16, 16), (24, 17), (15, 32)])
 def test_periodic_interp2d_real_part_path(Nx, Ny):
     """half-spectrum evaluation == real part of the full complex sum, also for spectra
