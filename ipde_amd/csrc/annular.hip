@@ -428,7 +428,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     if (maxiter < 1) maxiter = 1;
     if (restart > maxiter) restart = maxiter;   // a cycle never runs longer than maxiter
     // one cycle's Hessenberg column travels through the context's pinned buffer
-    IPDE_CHECK_ARG(ctx, (size_t)(2 * restart + 4) * sizeof(cd) <= ctx->h_pinned_bytes);
+    IPDE_CHECK_ARG(ctx, (size_t)(2 * restart + 4) * sizeof(cd) + 16 <= ctx->h_pinned_bytes);   // (last 8 bytes: dense.hip)
     IPDE_CHECK_ARG(ctx, tol > 0.0);
     IPDE_TRY(gmres_reserve(ctx, g, NB, restart));
     IPDE_HIP_CHECK(ctx, hipMemsetAsync(g.x, 0, NB * sizeof(cd), st));

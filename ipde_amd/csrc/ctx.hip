@@ -173,6 +173,7 @@ extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
     ctx->cheb_tab.clear();
     if (ctx->logtab.d_tab) hipFree(ctx->logtab.d_tab);
     if (ctx->d_ktab) hipFree(ctx->d_ktab);
+    if (ctx->d_lu_abort) hipFree(ctx->d_lu_abort);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -202,6 +203,7 @@ static int* option_slot(ipde_ctx* ctx, const char* name) {
     if (!strcmp(name, "laplace_variant")) return &ctx->opt_laplace_variant;
     if (!strcmp(name, "stokes_variant")) return &ctx->opt_stokes_variant;
     if (!strcmp(name, "dense_pairs")) return &ctx->opt_dense_pairs;
+    if (!strcmp(name, "dense_persistent")) return &ctx->opt_dense_persistent;
     if (!strcmp(name, "annular_grouped")) return &ctx->opt_annular_grouped;
     if (!strcmp(name, "fft2d")) return &ctx->opt_fft2d;
     if (!strcmp(name, "interp_shifted")) return &ctx->opt_interp_shifted;

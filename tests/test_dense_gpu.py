@@ -21,13 +21,69 @@ def test_lu_solve_matches_lapack(n):
     ref = scipy.linalg.solve(A, b)
     assert np.abs(x - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
     assert np.abs(A @ x - b).max() < 1e-12 * n * max(1.0, np.abs(x).max())
-    # one 64-row block per launch instead of two: the same arithmetic, bit for bit
-    f.ctx.set_option("dense_pairs", 0)
+    # the default is one launch per triangular pass with in-launch hand-off of the solutions;
+    # a launch per block pair, and a launch per 64-row block: the same arithmetic, bit for bit
+    assert f.ctx.get_option("dense_persistent") == 1
     try:
+        f.ctx.set_option("dense_persistent", 0)
+        x2 = f._subst(torch.as_tensor(b, device="cuda")).cpu().numpy()
+        f.ctx.set_option("dense_pairs", 0)
         x1 = f._subst(torch.as_tensor(b, device="cuda")).cpu().numpy()
     finally:
         f.ctx.set_option("dense_pairs", 1)
-    assert np.array_equal(x, x1)
+        f.ctx.set_option("dense_persistent", 1)
+    assert np.array_equal(x, x2) and np.array_equal(x, x1)
+
+
+def test_persistent_substitution_large_batches_under_load_bitwise():
+    """the one-launch-per-pass substitution (in-launch hand-off through sentinel slots) on the
+    sizes of the solvers — 4096 (Poisson QFS), 6400 (Stokes, 2 x 3200) — in batches of mixed
+    sizes, repeated while another stream keeps the chip busy (hand-offs must not depend on
+    placement or timing): bit for bit the launch-per-step results, every time"""
+    import time
+    import torch
+    from ipde_amd.qfs import _DeviceLU
+    rng = np.random.default_rng(17)
+    sizes = [4096, 6400, 1600, 4096, 130, 6400]
+    As = [torch.as_tensor(rng.standard_normal((n, n)) + 0.1 * n * np.eye(n), device="cuda") for n in sizes]
+    bs = [torch.as_tensor(rng.standard_normal(n), device="cuda") for n in sizes]
+    fs = [_DeviceLU(*torch.linalg.lu_factor(A)) for A in As]
+    ctx = fs[0].ctx
+    ctx.set_option("dense_persistent", 0)
+    try:
+        ref = _DeviceLU._subst_batch(fs, bs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            _DeviceLU._subst_batch(fs, bs)
+        torch.cuda.synchronize()
+        t_step = (time.perf_counter() - t0) / 5
+    finally:
+        ctx.set_option("dense_persistent", 1)
+    got = _DeviceLU._subst_batch(fs, bs)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        _DeviceLU._subst_batch(fs, bs)
+    torch.cuda.synchronize()
+    t_pers = (time.perf_counter() - t0) / 5
+    print("batch of 6 (n up to 6400): %.3f ms per launch-per-step solve, %.3f ms persistent" % (t_step * 1e3, t_pers * 1e3))
+    # under load: a second stream streams through HBM and occupies CUs meanwhile
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big.mul_(1.0000001)
+        got = _DeviceLU._subst_batch(fs, bs)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+    torch.cuda.synchronize()
+    # the residual is LAPACK's
+    for A, b, x in zip(As, bs, got):
+        assert float((A @ x - b).abs().max()) < 1e-11 * A.shape[0]
 
 
 def test_lu_solve_is_backward_stable_on_qfs_matrix():
