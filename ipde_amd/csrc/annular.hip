@@ -348,6 +348,21 @@ __global__ __launch_bounds__(256) void cscale_copy_kernel(cd* __restrict__ y,
     y[k] = cd{s * v.x, s * v.y};
 }
 
+// y = x / sqrt(nrm2->x): the Arnoldi normalisation with the squared norm read where
+// multiaxpy_norm_kernel left it — the same sqrt and division the host used to do, so the same
+// value, and the whole iteration can be enqueued (or replayed from a graph) without the host.
+// A vanished norm (breakdown) leaves y alone, as the host path did.
+__global__ __launch_bounds__(256) void cscale_copy_rnorm_kernel(cd* __restrict__ y, const cd* __restrict__ x,
+                                                                int64_t n, const cd* __restrict__ nrm2) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const double hn = sqrt(fmax(nrm2->x, 0.0));
+    if (!(hn > 0.0)) return;
+    const double s = 1.0 / hn;
+    cd v = x[k];
+    y[k] = cd{s * v.x, s * v.y};
+}
+
 inline unsigned nb256(int64_t n) { return (unsigned)ceil_div64(n, 256); }
 
 // ---------------------------------------------------------------------------
@@ -371,11 +386,30 @@ struct GmresWork {
     double* nrmpart = nullptr;     // ceil(NB/256) block sums of multiaxpy_norm_kernel
     int restart_cap = 0;
     int64_t nb_cap = 0;
+    // one executable graph per inner iteration index j (the launches of an iteration depend on j
+    // and on nothing a solve changes: all buffers belong to the solver handle)
+    std::vector<hipGraphExec_t> iter_graph;
+    long long graph_sig = -1;     // (restart, stream, options) the graphs were captured for
+    int graph_failures = 0;       // captures that did not work out; three and the handle stays eager
+    // Captures run on a NON-blocking stream of their own (nothing executes during a capture): the
+    // context's stream is a blocking one, and while such a stream is capturing every legacy-stream
+    // operation of ANY thread — a hipMemset in another solver's set-up, a host framework's
+    // default-stream kernel — fails with "would make the legacy stream depend on a capturing
+    // blocking stream".  The graph is then launched on the context's stream.
+    hipStream_t cap_stream = nullptr;
 };
+
+void gmres_drop_graphs(GmresWork& g) {
+    for (hipGraphExec_t e : g.iter_graph)
+        if (e) hipGraphExecDestroy(e);
+    g.iter_graph.clear();
+    g.graph_sig = -1;
+}
 
 int gmres_reserve(ipde_ctx* ctx, GmresWork& g, int64_t NB, int restart) {
     if (g.V && restart <= g.restart_cap && NB <= g.nb_cap) return IPDE_OK;
     hipStreamSynchronize(ctx->stream);
+    gmres_drop_graphs(g);
     for (cd** p : {&g.V, &g.w, &g.z, &g.x, &g.t, &g.hdev})
         if (*p) {
             hipFree(*p);
@@ -391,7 +425,7 @@ int gmres_reserve(ipde_ctx* ctx, GmresWork& g, int64_t NB, int restart) {
     if (g.mdticket) hipFree(g.mdticket);
     IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.mdpart, (size_t)(restart + 2) * MD_SPLIT * sizeof(cd)));
     IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.mdticket, (size_t)(restart + 3) * sizeof(unsigned)));
-    IPDE_HIP_CHECK(ctx, hipMemset(g.mdticket, 0, (size_t)(restart + 3) * sizeof(unsigned)));
+    IPDE_HIP_CHECK(ctx, hipMemsetAsync(g.mdticket, 0, (size_t)(restart + 3) * sizeof(unsigned), ctx->stream));
     if (g.nrmpart) hipFree(g.nrmpart);
     IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g.nrmpart, (size_t)nb256(NB) * sizeof(double)));
     g.restart_cap = restart;
@@ -399,6 +433,9 @@ int gmres_reserve(ipde_ctx* ctx, GmresWork& g, int64_t NB, int restart) {
     return IPDE_OK;
 }
 void gmres_free(GmresWork& g) {
+    gmres_drop_graphs(g);
+    if (g.cap_stream) hipStreamDestroy(g.cap_stream);
+    g.cap_stream = nullptr;
     for (cd** p : {&g.V, &g.w, &g.z, &g.x, &g.t, &g.hdev, &g.mdpart})
         if (*p) {
             hipFree(*p);
@@ -447,6 +484,17 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
         *resid_out = 0.0;
         return IPDE_OK;
     }
+    // graphs of the inner iterations: valid for one (restart, stream, option set); the legacy
+    // default stream cannot be captured
+    bool use_graphs = ctx->opt_gmres_graphs && st != nullptr && g.graph_failures < 3;
+    {
+        const long long sig = ((long long)restart << 8) ^ ((long long)(uintptr_t)st << 20) ^
+                              (ctx->opt_annular_grouped ? 1 : 0);
+        if (g.graph_sig != sig) {
+            gmres_drop_graphs(g);
+            g.graph_sig = sig;
+        }
+    }
     std::vector<hc> H((size_t)(restart + 1) * restart), cs(restart), sn(restart), gv(restart + 1);
     bool converged = false;
     bool first_cycle = true;
@@ -480,33 +528,77 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
         gv[0] = hc{beta, 0.0};
         int j = 0;
         for (; j < restart && iters < maxiter; ++j) {
-            cd* vj = g.V + (size_t)j * NB;
-            IPDE_TRY(op.precond(vj, g.z));
-            IPDE_TRY(op.apply(g.z, g.w));
-            // CGS2
-            cd* h1 = g.hdev;
-            cd* h2 = g.hdev + (restart + 2);
-            hipLaunchKernelGGL(multidot_kernel, dim3(j + 1, MD_SPLIT), dim3(256), 0, st, (const cd*)g.V, NB,
-                               (const cd*)g.w, NB, h1, g.mdpart, g.mdticket);
-            hipLaunchKernelGGL(multiaxpy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.w,
-                               (const cd*)g.V, NB, (const cd*)h1, j + 1, NB);
-            hipLaunchKernelGGL(multidot_kernel, dim3(j + 1, MD_SPLIT), dim3(256), 0, st, (const cd*)g.V, NB,
-                               (const cd*)g.w, NB, h2, g.mdpart, g.mdticket);
-            hipLaunchKernelGGL(multiaxpy_norm_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.w, (const cd*)g.V, NB,
-                               (const cd*)h2, j + 1, NB, g.nrmpart, g.mdticket + (restart + 2),
-                               h1 + (j + 1));
-            IPDE_HIP_CHECK(ctx, hipGetLastError());
-            IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, g.hdev, (size_t)(2 * restart + 4) * sizeof(cd),
-                                               hipMemcpyDeviceToHost, st));
+            // Inner iteration j, everything up to the host's look at the new Hessenberg column:
+            // preconditioner, operator, CGS2, the column's way to pinned memory, and the
+            // normalisation of v_{j+1} (from the device-resident norm) — ~20 launches, no host value
+            // in between.  Option "gmres_graphs": the sequence is captured once per j into a hipGraph
+            // and replayed.  Measured (profiles/r02_gmres_graph_ab.txt): no gain — warm Poisson 2048^2
+            // 8.75 / 9.11 ms eager vs 9.02 / 8.94 replayed, 3-body Stokes 20.4 / 21.7 vs 20.4 / 20.7;
+            // the critical stream is bound by its own chain of 5-25 us kernels (the outer Stokes body:
+            // 21 kernels, 255 us per iteration), not by the host's launch rate.  Off by default.
+            auto enqueue = [&](hipStream_t st) -> int {
+                cd* vj = g.V + (size_t)j * NB;
+                IPDE_TRY(op.precond(vj, g.z));
+                IPDE_TRY(op.apply(g.z, g.w));
+                // CGS2
+                cd* h1 = g.hdev;
+                cd* h2 = g.hdev + (restart + 2);
+                hipLaunchKernelGGL(multidot_kernel, dim3(j + 1, MD_SPLIT), dim3(256), 0, st, (const cd*)g.V, NB,
+                                   (const cd*)g.w, NB, h1, g.mdpart, g.mdticket);
+                hipLaunchKernelGGL(multiaxpy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.w,
+                                   (const cd*)g.V, NB, (const cd*)h1, j + 1, NB);
+                hipLaunchKernelGGL(multidot_kernel, dim3(j + 1, MD_SPLIT), dim3(256), 0, st, (const cd*)g.V, NB,
+                                   (const cd*)g.w, NB, h2, g.mdpart, g.mdticket);
+                hipLaunchKernelGGL(multiaxpy_norm_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.w, (const cd*)g.V, NB,
+                                   (const cd*)h2, j + 1, NB, g.nrmpart, g.mdticket + (restart + 2),
+                                   h1 + (j + 1));
+                IPDE_HIP_CHECK(ctx, hipGetLastError());
+                IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, g.hdev, (size_t)(2 * restart + 4) * sizeof(cd),
+                                                   hipMemcpyDeviceToHost, st));
+                hipLaunchKernelGGL(cscale_copy_rnorm_kernel, dim3(nb256(NB)), dim3(256), 0, st,
+                                   g.V + (size_t)(j + 1) * NB, (const cd*)g.w, NB, (const cd*)(h1 + (j + 1)));
+                IPDE_HIP_CHECK(ctx, hipGetLastError());
+                return IPDE_OK;
+            };
+            bool replayed = false;
+            if (use_graphs) {
+                if ((int)g.iter_graph.size() <= j) g.iter_graph.resize(j + 1, nullptr);
+                hipGraphExec_t ex = g.iter_graph[j];
+                if (!ex) {
+                    bool ok = g.cap_stream != nullptr ||
+                              hipStreamCreateWithFlags(&g.cap_stream, hipStreamNonBlocking) == hipSuccess;
+                    if (ok) ok = hipStreamBeginCapture(g.cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                    if (ok) {
+                        ctx->stream = g.cap_stream;        // the operator's launches follow the context
+                        const int s_enq = enqueue(g.cap_stream);
+                        ctx->stream = st;
+                        hipGraph_t graph = nullptr;
+                        ok = hipStreamEndCapture(g.cap_stream, &graph) == hipSuccess && s_enq == IPDE_OK &&
+                             graph != nullptr;
+                        if (ok) ok = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) == hipSuccess;
+                        if (graph) hipGraphDestroy(graph);
+                    }
+                    if (ok) {
+                        g.iter_graph[j] = ex;
+                    } else {
+                        (void)hipGetLastError();       // the failed capture's error is not the solve's
+                        ex = nullptr;
+                        use_graphs = false;            // this solve goes on eagerly
+                        ++g.graph_failures;
+                    }
+                }
+                if (ex) {
+                    IPDE_HIP_CHECK(ctx, hipGraphLaunch(ex, st));
+                    replayed = true;
+                }
+            }
+            if (!replayed) IPDE_TRY(enqueue(st));
             IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
             hc* col = &H[(size_t)j * (restart + 1)];
             for (int i = 0; i <= j; ++i)
                 col[i] = hc{hp[i].x + hp[restart + 2 + i].x, hp[i].y + hp[restart + 2 + i].y};
             double hn = sqrt(fmax(hp[j + 1].x, 0.0));
             col[j + 1] = hc{hn, 0.0};
-            if (hn > 0.0)
-                hipLaunchKernelGGL(cscale_copy_kernel, dim3(nb256(NB)), dim3(256), 0, st,
-                                   g.V + (size_t)(j + 1) * NB, (const cd*)g.w, NB, 1.0 / hn);
             // Givens
             for (int i = 0; i < j; ++i) {
                 hc a = col[i], bb = col[i + 1];

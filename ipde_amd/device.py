@@ -5,6 +5,7 @@ workspace) or torch CUDA tensors (device; zero-copy).  torch is used for device
 memory only — every computation on this path is a kernel of libipde_hip.so.
 """
 import ctypes
+import os
 import threading
 import time
 import weakref
@@ -32,6 +33,11 @@ class Context:
         _lib.check(self.lib.ipde_ctx_create(self.device, ctypes.byref(h)))
         self.handle = h
         self._plans = {}
+        # IPDE_HIP_OPTIONS="name=value,...": tuning knobs of ipde_ctx_set_option for every context
+        # of the process (A/B measurements with unmodified scripts)
+        for item in filter(None, os.environ.get("IPDE_HIP_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            self.set_option(name.strip(), int(value))
         # objects holding library handles created on this context (annular solvers, Ewald
         # cores): the context releases them before it goes, whatever order the garbage
         # collector finds them in

@@ -215,3 +215,38 @@ def test_context_releases_its_solver_handles_first(gs, scalar_geo):
     assert S.handle is None and ctx.handle is None
     del S, ctx
     gc.collect()
+
+
+def test_gmres_graph_replay_is_bitwise_the_eager_solve(gs, scalar_geo, gst, stokes_geo):
+    """option "gmres_graphs" (csrc/annular.hip): the inner GMRES iterations captured into hipGraphs
+    at their first use and replayed afterwards — capture solve, replay solve and the default
+    launch-by-launch solve give the same bits, with restarts (restart < iterations) too"""
+    from ipde_amd.annular.modified_helmholtz import AnnularModifiedHelmholtzSolver
+    from ipde_amd.annular.stokes import AnnularStokesSolver
+    aag, rag = scalar_geo
+    S = AnnularModifiedHelmholtzSolver(aag, float(gs["mh_k"][0]))
+    args = (rag, gs["mh_force"], gs["mh_ig"], gs["mh_og"])
+    for kw in (dict(tol=1e-13, maxiter=200, restart=100), dict(tol=1e-13, maxiter=200, restart=4)):
+        eager = np.array(S.solve(*args, **kw))
+        it = S.iterations_last_call
+        S.ctx.set_option("gmres_graphs", 1)
+        try:
+            first = np.array(S.solve(*args, **kw))            # captures (and runs) the graphs
+            again = np.array(S.solve(*args, **kw))            # replays them
+        finally:
+            S.ctx.set_option("gmres_graphs", 0)
+        assert S.iterations_last_call == it
+        assert np.array_equal(first, again) and np.array_equal(first, eager)
+    aag, rag = stokes_geo
+    V = AnnularStokesSolver(aag, 1.0)
+    sargs = (rag, gst["fr"], gst["ft"], gst["irg"], gst["itg"], gst["org"], gst["otg"])
+    kw = dict(tol=1e-12, maxiter=300, restart=100)
+    c = [np.array(x) for x in V.solve(*sargs, **kw)]
+    V.ctx.set_option("gmres_graphs", 1)
+    try:
+        a = [np.array(x) for x in V.solve(*sargs, **kw)]
+        b = [np.array(x) for x in V.solve(*sargs, **kw)]
+    finally:
+        V.ctx.set_option("gmres_graphs", 0)
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
