@@ -210,6 +210,29 @@ __global__ __launch_bounds__(256) void prec_cplx_kernel(cd* __restrict__ out,
 // IN INDEX ORDER and resets the counter — one launch, and the result does not depend on the
 // order in which the blocks ran.
 constexpr int MD_SPLIT = 16;
+// Cross-workgroup reduction tails (multidot_kernel, multiaxpy_norm_kernel): every block leaves
+// its partial sum and draws a ticket, the block that draws the last one adds the partials up.
+// Hand-off per the CDNA4 guide (Guideline 16, "last adder" row of the sc1 table): the partials
+// are written by ONE lane with 8-byte agent-scope relaxed atomic stores (write-through), drained
+// with s_waitcnt vmcnt(0) before that lane's agent-scope ticket add, and read by the last block
+// with agent-scope relaxed atomic loads only after its own add has returned (other waves: after
+// the workgroup barrier).  No __threadfence: two of them (an L2 write-back and an L1
+// invalidate each, ~3.5 us) were most of these kernels' run time at the sizes of the annular
+// systems (multiaxpy_norm 23 us against 8 us for the same update without the norm).
+typedef __attribute__((address_space(1))) unsigned long long ann_gu64;
+typedef __attribute__((address_space(1))) unsigned int ann_gu32;
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    __hip_atomic_store((ann_gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((ann_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned draw_ticket(unsigned* t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's partial sums have left
+    return __hip_atomic_fetch_add((ann_gu32*)t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(256) void multidot_kernel(const cd* __restrict__ V, int64_t ld,
                                                        const cd* __restrict__ w, int64_t n,
                                                        cd* __restrict__ h, cd* __restrict__ partial,
@@ -218,6 +241,8 @@ __global__ __launch_bounds__(256) void multidot_kernel(const cd* __restrict__ V,
     const int64_t per = (n + MD_SPLIT - 1) / MD_SPLIT;
     const int64_t k0 = (int64_t)blockIdx.y * per, k1 = min(n, k0 + per);
     double sr = 0.0, si = 0.0;
+    // (unrolled: four pairs of loads in flight per thread; the sums keep their order)
+#pragma unroll 4
     for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
         cd a = v[k], b = w[k];
         sr = fma(a.x, b.x, sr);
@@ -241,22 +266,28 @@ __global__ __launch_bounds__(256) void multidot_kernel(const cd* __restrict__ V,
     if (threadIdx.x == 0) {
         double a = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         double b = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
-        partial[(size_t)blockIdx.x * MD_SPLIT + blockIdx.y] = cd{a, b};
-        __threadfence();
-        unsigned t = atomicAdd(&ticket[blockIdx.x], 1u);
-        last = (t == MD_SPLIT - 1);
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
-        double a = 0.0, b = 0.0;
-        const volatile double* p = (const volatile double*)(partial + (size_t)blockIdx.x * MD_SPLIT);
-        for (int i = 0; i < MD_SPLIT; ++i) {
-            a += p[2 * i];
-            b += p[2 * i + 1];
+        double* mine = (double*)(partial + (size_t)blockIdx.x * MD_SPLIT + blockIdx.y);
+        st_agent(mine, a);
+        st_agent(mine + 1, b);
+        last = draw_ticket(&ticket[blockIdx.x]) == MD_SPLIT - 1;
+        if (last) {        // (this lane's add has returned: every block's partials are out)
+            a = 0.0;
+            b = 0.0;
+            const double* p = (const double*)(partial + (size_t)blockIdx.x * MD_SPLIT);
+            double pr[MD_SPLIT], pi[MD_SPLIT];
+#pragma unroll
+            for (int i = 0; i < MD_SPLIT; ++i) {
+                pr[i] = ld_agent(p + 2 * i);
+                pi[i] = ld_agent(p + 2 * i + 1);
+            }
+#pragma unroll
+            for (int i = 0; i < MD_SPLIT; ++i) {
+                a += pr[i];
+                b += pi[i];
+            }
+            h[blockIdx.x] = cd{a, b};
+            __hip_atomic_store((ann_gu32*)&ticket[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        h[blockIdx.x] = cd{a, b};
-        ticket[blockIdx.x] = 0u;
     }
 }
 // w -= sum_i h[i] V_i
@@ -287,6 +318,7 @@ __global__ __launch_bounds__(256) void multiaxpy_norm_kernel(cd* __restrict__ w,
     double s = 0.0;
     if (k < n) {
         cd acc = w[k];
+#pragma unroll 4
         for (int i = 0; i < nv; ++i) {
             cd c = h[i];
             cd v = V[(size_t)i * ld + k];
@@ -308,20 +340,17 @@ __global__ __launch_bounds__(256) void multiaxpy_norm_kernel(cd* __restrict__ w,
     };
     double bs = block_sum(s);
     if (threadIdx.x == 0) {
-        partial[blockIdx.x] = bs;
-        __threadfence();
-        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        st_agent(&partial[blockIdx.x], bs);
+        last = draw_ticket(ticket) == gridDim.x - 1;
     }
-    __syncthreads();
+    __syncthreads();       // the last block's other waves read only behind this barrier
     if (!last) return;
-    __threadfence();
-    const volatile double* p = partial;
     double t = 0.0;
-    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += p[i];
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += ld_agent(&partial[i]);
     double tot = block_sum(t);
     if (threadIdx.x == 0) {
         *nrm2 = cd{tot, 0.0};
-        *ticket = 0u;
+        __hip_atomic_store((ann_gu32*)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // y = sum_i c[i] V_i  (c on device)

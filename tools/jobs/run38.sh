@@ -1,0 +1,9 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r02
+timeout -k 10 400 python3 -m pytest tests/test_annular_gpu.py tests/test_solver_gpu.py -m gpu -x -q 2>&1 | tail -5
+timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | tail -1
+timeout -k 10 300 python3 tools/profile_stokes_solve.py 2>&1 | tail -1
+timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | tail -1
+timeout -k 10 300 python3 tools/profile_stokes_solve.py 2>&1 | tail -1
