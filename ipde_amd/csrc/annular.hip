@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void mixc_kernel(cd* __restrict__ out, int ldo
     if (j >= n) return;
     const double* Ar = A + (size_t)a * ca;
     double sr = 0.0, si = 0.0;
+#pragma unroll 4
     for (int b = 0; b < ca; ++b) {
         cd v = in[(size_t)b * ldi + j];
         double w = Ar[b];
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void prec_scalar_kernel(cd* __restrict__ out,
     if (i >= n) return;
     const double* K = Kt + (size_t)j * M * n + i;
     double sr = 0.0, si = 0.0;
+#pragma unroll 4
     for (int k = 0; k < M; ++k) {
         double w = K[(size_t)k * n];
         cd v = x[(size_t)k * n + i];
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(256) void prec_cplx_kernel(cd* __restrict__ out,
     if (i >= ns) return;
     const cd* K = Kt + (size_t)j * B * ns + i;
     double sr = 0.0, si = 0.0;
+#pragma unroll 4
     for (int k = 0; k < B; ++k) {
         cd w = K[(size_t)k * ns];
         cd v = x[(size_t)k * ns + i];
@@ -1075,6 +1078,7 @@ __global__ __launch_bounds__(256) void mix_multi_kernel(MixBatch B, int n) {
             const double* Ar = T.A + (size_t)a * T.ca;
             if (T.cplx) {
                 const cd* in = (const cd*)T.in;
+#pragma unroll 4
                 for (int b = 0; b < T.ca; ++b) {
                     double v = in[(size_t)b * n + j].x;
                     if (T.Q) v *= T.Q[(size_t)b * n + j];
@@ -1082,6 +1086,7 @@ __global__ __launch_bounds__(256) void mix_multi_kernel(MixBatch B, int n) {
                 }
             } else {
                 const double* in = (const double*)T.in;
+#pragma unroll 4
                 for (int b = 0; b < T.ca; ++b) s = fma(Ar[b], in[(size_t)b * n + j], s);
             }
             if (T.P) s *= T.P[(size_t)a * n + j];
@@ -1159,6 +1164,7 @@ __global__ __launch_bounds__(256) void bc2_kernel(cd* __restrict__ out0, cd* __r
     const cd* in = blockIdx.z == 0 ? in0 : in1;
     const double* Ar = A + (size_t)a * ca;
     double sr = 0.0, si = 0.0;
+#pragma unroll 4
     for (int b = 0; b < ca; ++b) {
         cd v = in[(size_t)b * ldi + j];
         sr = fma(Ar[b], v.x, sr);

@@ -145,6 +145,9 @@ class EmbeddedBoundaryCollection(object):
 
     # -- splitters (reference :528-570) -----------------------------------------------
     def v2l(self, v):
+        if type(v).__module__.startswith('torch'):      # device vectors stay where they are
+            import torch
+            return list(torch.tensor_split(v, [int(i) for i in self.splitter]))
         return np.split(np.asarray(v), self.splitter)
 
     def v2l2(self, v):

@@ -148,10 +148,55 @@ def _xy(obj):
     return obj.x, obj.y
 
 
-def _weighted(density, weights):
+class _DeviceSource(object):
+    """x, y, weights (and normals) of a source curve resident in HBM.  The solvers apply the
+    same few source curves in every solve (the QFS source curves of the interfaces, their
+    collection): without this every apply re-sent four to six small arrays, ~30 us each."""
+    __slots__ = ("key", "x", "y", "weights", "normal_x", "normal_y")
+
+
+def _device_source(source, ctx):
+    """cached device copies of a source's geometry; rebuilt if the object's arrays were replaced"""
+    cache = source.__dict__.setdefault("_ipde_dev_source", {}) if hasattr(source, "__dict__") else {}
+    key = (id(source.x), id(source.y), id(source.weights))
+    d = cache.get(ctx.device)
+    if d is None or d.key != key:
+        d = _DeviceSource()
+        d.key = key
+        d.x = to_device(np.ascontiguousarray(source.x, dtype=np.float64).ravel(), ctx)
+        d.y = to_device(np.ascontiguousarray(source.y, dtype=np.float64).ravel(), ctx)
+        d.weights = to_device(np.ascontiguousarray(source.weights, dtype=np.float64).ravel(), ctx)
+        nx = getattr(source, "normal_x", None)
+        d.normal_x = None if nx is None else to_device(np.ascontiguousarray(nx, dtype=np.float64).ravel(), ctx)
+        ny = getattr(source, "normal_y", None)
+        d.normal_y = None if ny is None else to_device(np.ascontiguousarray(ny, dtype=np.float64).ravel(), ctx)
+        cache[ctx.device] = d
+    return d
+
+
+def _source_side(source, trg):
+    """the source's geometry where the targets are: the cached device copy for device-resident
+    targets, the object itself (host arrays) otherwise"""
+    if isinstance(trg.x, torch.Tensor) and trg.x.is_cuda:
+        return _device_source(source, getattr(trg, "ctx", None) or get_context())
+    return source
+
+
+def _weighted(density, weights, rows=None):
+    """density * weights; a device density stays on the device (weights: the cached device copy).
+    rows: reshape to (rows, -1) first (the (2, N) Stokes densities)."""
     if density is None:
         return None
-    return np.asarray(density, dtype=np.float64) * np.asarray(weights, dtype=np.float64)
+    if isinstance(density, torch.Tensor):
+        d = density.to(torch.float64)
+        w = weights if isinstance(weights, torch.Tensor) else torch.as_tensor(
+            np.asarray(weights, dtype=np.float64), device=d.device)
+        return (d.reshape(rows, -1) if rows else d.reshape(-1)) * w
+    if isinstance(weights, torch.Tensor):      # host density onto device-resident targets
+        d = torch.as_tensor(np.ascontiguousarray(density, dtype=np.float64), device=weights.device)
+        return (d.reshape(rows, -1) if rows else d.reshape(-1)) * weights
+    d = np.asarray(density, dtype=np.float64)
+    return (d.reshape(rows, -1) if rows else d) * np.asarray(weights, dtype=np.float64)
 
 
 def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=None, **kwargs):
@@ -165,11 +210,12 @@ def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=N
     tx, ty = _xy(trg)
     if charge is None and dipstr is None:
         raise ValueError("need a charge and/or a dipstr density")
-    return laplace_apply(source.x, source.y, tx, ty,
-                         w_sigma=_weighted(charge, source.weights),
-                         nx=None if dipstr is None else source.normal_x,
-                         ny=None if dipstr is None else source.normal_y,
-                         w_tau=_weighted(dipstr, source.weights),
+    src = _source_side(source, trg)
+    return laplace_apply(src.x, src.y, tx, ty,
+                         w_sigma=_weighted(charge, src.weights),
+                         nx=None if dipstr is None else src.normal_x,
+                         ny=None if dipstr is None else src.normal_y,
+                         w_tau=_weighted(dipstr, src.weights),
                          skip_coincident=self_eval)
 
 
@@ -184,11 +230,12 @@ def Modified_Helmholtz_Layer_Apply(source, target=None, k=1.0, charge=None, dips
     tx, ty = _xy(trg)
     if charge is None and dipstr is None:
         raise ValueError("need a charge and/or a dipstr density")
-    return modified_helmholtz_apply(source.x, source.y, tx, ty, k,
-                                    w_sigma=_weighted(charge, source.weights),
-                                    nx=None if dipstr is None else source.normal_x,
-                                    ny=None if dipstr is None else source.normal_y,
-                                    w_tau=_weighted(dipstr, source.weights),
+    src = _source_side(source, trg)
+    return modified_helmholtz_apply(src.x, src.y, tx, ty, k,
+                                    w_sigma=_weighted(charge, src.weights),
+                                    nx=None if dipstr is None else src.normal_x,
+                                    ny=None if dipstr is None else src.normal_y,
+                                    w_tau=_weighted(dipstr, src.weights),
                                     skip_coincident=self_eval)
 
 
@@ -203,13 +250,13 @@ def Stokes_Layer_Apply(source, target=None, forces=None, dipstr=None, pressure=T
     tx, ty = _xy(trg)
     if forces is None and dipstr is None:
         raise ValueError("need a forces and/or a dipstr density")
-    w = np.asarray(source.weights, dtype=np.float64)
-    f = None if forces is None else np.asarray(forces, dtype=np.float64).reshape(2, -1) * w
-    g = None if dipstr is None else np.asarray(dipstr, dtype=np.float64).reshape(2, -1) * w
-    return stokes_apply(source.x, source.y, tx, ty,
+    src = _source_side(source, trg)
+    f = _weighted(forces, src.weights, rows=2)
+    g = _weighted(dipstr, src.weights, rows=2)
+    return stokes_apply(src.x, src.y, tx, ty,
                         wfx=None if f is None else f[0], wfy=None if f is None else f[1],
-                        nx=None if g is None else source.normal_x,
-                        ny=None if g is None else source.normal_y,
+                        nx=None if g is None else src.normal_x,
+                        ny=None if g is None else src.normal_y,
                         wdx=None if g is None else g[0], wdy=None if g is None else g[1],
                         pressure=pressure, skip_coincident=self_eval)
 

@@ -125,8 +125,7 @@ class _QFS(object):
         densities = list(densities)
         if self._dev is not None:
             import torch
-            densities = [torch.as_tensor(np.ascontiguousarray(d, dtype=float), device=self._dev)
-                         for d in densities]
+            densities = [_on_device(d, self._dev) for d in densities]
             u = torch.zeros(self._nrow, dtype=torch.float64, device=self._dev)
         else:
             u = np.zeros(self._nrow)
@@ -154,6 +153,20 @@ class _QFS(object):
         return self._solve(np.asarray(u, dtype=float))
 
 
+def _on_device(d, dev):
+    """density as a flat fp64 device tensor (device tensors pass through: the solvers keep
+    their per-boundary vectors in HBM between the stages of a solve)"""
+    import torch
+    if isinstance(d, torch.Tensor):
+        return d.to(device=dev, dtype=torch.float64).reshape(-1)
+    return torch.as_tensor(np.ascontiguousarray(d, dtype=float), device=dev).reshape(-1)
+
+
+def _wants_device(densities):
+    import torch
+    return any(isinstance(d, torch.Tensor) for d in densities)
+
+
 def call_many(requests):
     """[q(densities) for q, densities in requests] — the QFS solves of one stage of a solver:
     the grid-side and the annulus-side system of every interface (reference
@@ -173,7 +186,8 @@ def call_many(requests):
         us = [q.boundary_limit(d) for q, d in zip(qs, ds)]
         xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps)
         for i, q, d, x in zip(idx, qs, ds, xs):
-            out[i] = q._post(x.cpu().numpy(), d)
+            # device densities in -> device density out (no host round trip)
+            out[i] = q._post(x if _wants_device(d) else x.cpu().numpy(), d)
     return out
 
 
@@ -194,11 +208,10 @@ def u2s_many(requests):
             out[i] = q.u2s(u)
     for steps, idx in groups.items():
         qs = [requests[i][0] for i in idx]
-        us = [torch.as_tensor(np.ascontiguousarray(requests[i][1], dtype=float), device=q._dev)
-              for q, i in zip(qs, idx)]
+        us = [_on_device(requests[i][1], q._dev) for q, i in zip(qs, idx)]
         xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps)
         for i, x in zip(idx, xs):
-            out[i] = x.cpu().numpy()
+            out[i] = x if isinstance(requests[i][1], torch.Tensor) else x.cpu().numpy()
     return out
 
 

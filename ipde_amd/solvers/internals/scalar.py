@@ -100,7 +100,42 @@ class ScalarHelper(object):
         """kwargs go to the annular solver (reference :68-94)."""
         return self.finish_call(*call_many(self.start_call(fr, bv, bx, by, **kwargs)))
 
+    # Device-resident form of the same two stages (the multi-boundary solver's default in a
+    # single process): interface data arrives as device tensors and every per-boundary vector
+    # — annular solution, jumps, densities, corrections — stays in HBM until the solve's one
+    # transfer of the answer; the arithmetic is the host form's, statement for statement.
+    def _device_constants(self):
+        c = getattr(self, '_dev_const', None)
+        if c is None:
+            import torch
+            dev = self._interface_dev.x.device
+            up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=float), device=dev)
+            iface = self.ebdy.interface
+            c = self._dev_const = dict(nx=up(iface.normal_x), ny=up(iface.normal_y),
+                                       in_est=up(self._in_estimator),
+                                       zero=torch.zeros(iface.N, dtype=torch.float64, device=dev))
+        return c
+
+    def _start_call_device(self, fr, bv, bx, by, **kwargs):
+        import torch
+        c = self._device_constants()
+        ucn = bx * c['nx'] + by * c['ny']
+        frd = fr if isinstance(fr, torch.Tensor) else \
+            torch.as_tensor(np.ascontiguousarray(fr, dtype=float), device=bv.device)
+        ur = self.annular_solver.solve(self.RAG, frd, c['zero'], c['zero'], **kwargs)
+        self.iterations_last_call = self.annular_solver.iterations_last_call
+        urn = torch.mv(ur.t(), c['in_est'])          # interface normal derivative (:83)
+        slp = urn - ucn
+        dlp = bv.clone()
+        if not self.interior:
+            slp = -slp
+            dlp = -dlp
+        self.ur = ur
+        return [(self.interface_qfs_g, [slp, dlp]), (self.interface_qfs_r, [slp, dlp])]
+
     def start_call(self, fr, bv, bx, by, **kwargs):
+        if type(bv).__module__.startswith('torch'):
+            return self._start_call_device(fr, bv, bx, by, **kwargs)
         ebdy = self.ebdy
         ucn = bx * ebdy.interface.normal_x + by * ebdy.interface.normal_y
         zer = np.zeros_like(bv)
@@ -126,12 +161,16 @@ class ScalarHelper(object):
 
     def start_correct(self, ub):
         src = self.interface_qfs_g.source
-        w = self.Layer_Apply(src, self._interface_dev, self.sigma_g).cpu().numpy()
+        w = self.Layer_Apply(src, self._interface_dev, self.sigma_g)
+        if not type(ub).__module__.startswith('torch'):
+            w = w.cpu().numpy()
         return [(self.interface_qfs_r, ub - w)]
 
     def finish_correct(self, sigma_r_adj):
         sigma_r_tot = sigma_r_adj + self.sigma_r
         src = self.interface_qfs_r.source
-        rslp = self._radial_sum(src, sigma_r_tot).cpu().numpy()
+        rslp = self._radial_sum(src, sigma_r_tot)
+        if not type(self.ur).__module__.startswith('torch'):
+            rslp = rslp.cpu().numpy()
         self.ur = self.ur + rslp.reshape(self.ur.shape)
         return self.ur

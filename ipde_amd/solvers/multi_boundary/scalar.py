@@ -116,6 +116,7 @@ class ScalarSolver(object):
     CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other
     DISTRIBUTE_BOUNDARIES = True  # under torch.distributed: boundary i on rank i mod world
     USE_FAST_INTERP = True        # False: always the dense Fourier sums (the checker)
+    DEVICE_FLOW = True            # False: per-boundary vectors travel as numpy between the stages (the round-1 flow)
 
     def _concurrent_helpers(self):
         return _concurrent_helpers(self)
@@ -215,16 +216,21 @@ class ScalarSolver(object):
         if self.interpolation_order == np.inf and uch is None:
             # values and gradient on all interface nodes (:80-88) from the spectrum the grid
             # solve left on the device: 2x oversampled inverse FFT + window gather (csrc/nufft.hip)
-            all_bvs = self.plan.interp_gradient(self._ifx_d, self._ify_d).cpu().numpy()
+            all_bvs = self.plan.interp_gradient(self._ifx_d, self._ify_d)
         elif self.interpolation_order == np.inf:
             # the same from the full spectrum by dense Fourier sums; the three fields share one
             # set of exponential matrices
-            all_bvs = periodic_interp2d_gradient(uch, self._ifx_d, self._ify_d, self._ikx_d,
-                                                  self._iky_d).cpu().numpy()
+            all_bvs = periodic_interp2d_gradient(uch, self._ifx_d, self._ify_d, self._ikx_d, self._iky_d)
         else:
             # (the library's own D2Z plan: one rocFFT in the process, no torch.fft)
             stack = torch.stack([self.plan.fft2(g.contiguous()) for g in (uc, self.dx(uc), self.dy(uc))])
-            all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
+            all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True)
+        # In one process the per-boundary vectors now stay in HBM through all the stages below
+        # (helpers' device forms, qfs.call_many / u2s_many and the layer applies pass device
+        # tensors through); the torch.distributed path keeps the host vectors its exchanges take.
+        device_flow = self.DEVICE_FLOW and not is_distributed() and not self.split_grid_evaluation
+        if not device_flow:
+            all_bvs = all_bvs.cpu().numpy()
         bvl, bxl, byl = e.v2l(all_bvs[0]), e.v2l(all_bvs[1]), e.v2l(all_bvs[2])
         # annular solves boundary by boundary, then the QFS solves of all boundaries in one
         # batched substitution (qfs.call_many); under torch.distributed each rank does this
@@ -237,12 +243,12 @@ class ScalarSolver(object):
             sigmag_list, its = exchange_owned(sigmag_list, [(h.interface_qfs_g.source.N,) for h in self.helpers],
                                               device=self._dev, extra=its)
         self.iteration_counts = [int(i) for i in its]
-        sigmag = np.concatenate(sigmag_list)
+        sigmag = torch.cat(list(sigmag_list)) if device_flow else np.concatenate(sigmag_list)
         out = self.evaluate_to_grid_pnai(sigmag)                 # device, len(grid_pnai)
         n_pna = e.grid_pna.N
         ucf = uc.view(-1)
         ucf[self._pna_idx] += out[:n_pna]
-        bus = e.v2l(out[n_pna:].cpu().numpy())
+        bus = e.v2l(out[n_pna:] if device_flow else out[n_pna:].cpu().numpy())
         urs = _run_owned(self, mine, 'start_correct', 'finish_correct', [(bu,) for bu in bus], u2s_many)
         if distributed:
             urs = exchange_owned(urs, [h.ebdy.radial_shape for h in self.helpers], device=self._dev)
@@ -253,9 +259,12 @@ class ScalarSolver(object):
         ucf *= self._phys_d.view(-1)
         # the answer is built over pinned memory: the device->host copy writes the caller's array
         ue, block = hostio.pinned_function(e)
-        block[:e.grid_phys.N].copy_(ucf[self._phys_idx], non_blocking=False)
-        for i, ur in enumerate(urs):
-            ue[i] = ur
+        for sl, ur in zip(ue.radial_slices, urs):
+            if isinstance(ur, torch.Tensor):     # device flow: the annular solutions' one transfer
+                block[sl].copy_(ur.reshape(-1), non_blocking=True)
+            else:
+                block[sl] = torch.from_numpy(np.ascontiguousarray(ur, dtype=float).reshape(-1))
+        block[:e.grid_phys.N].copy_(ucf[self._phys_idx], non_blocking=False)   # (in stream order: the last)
         return ue
 
     def _define_layer_apply(self):
