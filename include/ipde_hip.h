@@ -240,6 +240,18 @@ int ipde_dense_lu_solve(ipde_ctx* ctx, int64_t n, const double* lu, const int* p
 int ipde_dense_lu_solve_batch(ipde_ctx* ctx, int nsys, const int64_t* n, const double* const* lu,
                               const int* const* perm, const double* const* b, double* const* x);
 
+/*
+ * LU factorisation with partial pivoting (LAPACK dgetrf's pivot rule), in place on the TILED storage
+ * ipde_dense_lu_solve reads: what the reference's third-party `qfs` package obtains from host
+ * LAPACK for every interface (qfs.two_d_qfs.QFS_Evaluator -> scipy.linalg.lu_factor; call sites
+ * ipde/solvers/internals/poisson.py:18-25, stokes.py:21-24, examples/interior_poisson.py:87).
+ * tiles: DEVICE, (n_pad/64)^2 tiles of 64 x 64 doubles, tile (I, J) at ((I nb + J) 4096), element
+ * (r, c) of a tile at c*64 + r, the matrix padded with the identity to n_pad rows (a multiple of
+ * 128, at most 8192).  perm: DEVICE, n_pad ints: row i of P A is row perm[i] of A.
+ * Asynchronous on the context's stream.
+ */
+int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles, int* perm);
+
 /* ------------------------------------------------------------------------- */
 /* Closest-point coordinates of points near a closed curve  */
 /*

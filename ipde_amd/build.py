@@ -32,6 +32,7 @@ SOURCES = [
     "annular.hip",
     "ewald.hip",
     "dense.hip",
+    "lu_factor.hip",
     "geometry.hip",
 ]
 

@@ -168,6 +168,7 @@ extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
     freebuf(ctx->scratch);
     for (auto& b : ctx->fftwork) freebuf(b);
     for (auto& b : ctx->r2g) freebuf(b);
+    freebuf(ctx->lu_work);
     for (auto& kv : ctx->cheb_tab)
         if (kv.second) hipFree(kv.second);
     ctx->cheb_tab.clear();

@@ -215,12 +215,40 @@ def u2s_many(requests):
     return out
 
 
+OWN_FACTORISATION = True       # False: rocSOLVER getrf (torch.linalg.lu_factor) for every size
+OWN_FACTORISATION_MAX_ROWS = 8192
+
+
 def _factor(A):
-    """(LU, piv) of rocSOLVER (0.04 s at n = 4096, 0.27 s at 16 384 once the library is
-    loaded; a blocked variant built from its panel factorisation + GEMM updates was not
-    faster — measured)"""
+    """(LU, piv) of rocSOLVER — the factorisation of matrices beyond OWN_FACTORISATION_MAX_ROWS
+    padded rows (0.27 s at n = 16 384: ~37 000 column-level launches per 4096 columns, host-launch
+    bound; run on pool threads, see _lu_async)"""
     import torch
     return torch.linalg.lu_factor(A)
+
+
+def _tiled(M):
+    """(n, n) device matrix -> the tiled storage of csrc/dense.hip / lu_factor.hip: 64x64 tiles
+    contiguous, column-major inside a tile, identity padding to a multiple of 128 rows"""
+    import torch
+    n = int(M.shape[0])
+    nb = 2 * ((n + 127) // 128)
+    pad = torch.eye(nb * 64, dtype=torch.float64, device=M.device)
+    pad[:n, :n] = M
+    return pad.view(nb, 64, nb, 64).permute(0, 2, 3, 1).contiguous()
+
+
+def _own_lu(A):
+    """_DeviceLU of A through the library's own blocked factorisation (csrc/lu_factor.hip:
+    ipde_dense_lu_factor), enqueued on the context's stream — no host synchronisation, no pool
+    thread: ~260 launches, a few ms of GPU time at n = 4096."""
+    import torch
+    from .device import get_context, ptr
+    ctx = get_context(A.device.index)
+    T = _tiled(A)
+    perm = torch.empty(T.shape[0] * 64, dtype=torch.int32, device=A.device)
+    ctx.check(ctx.lib.ipde_dense_lu_factor(ctx.handle, T.shape[0] * 64, ptr(T), ptr(perm)))
+    return _DeviceLU.from_tiled(T, perm, int(A.shape[0]), ctx)
 
 
 _lu_pool = None
@@ -233,6 +261,8 @@ def _lu_async(A):
     matrices — the two QFS systems of every interface, the example's boundary integral
     equation — so each factorisation runs on a pool thread with a stream of its own while the
     host goes on assembling the next matrix; the first use joins it."""
+    if OWN_FACTORISATION and 128 * ((int(A.shape[0]) + 127) // 128) <= OWN_FACTORISATION_MAX_ROWS:
+        return _own_lu(A)
     if not ASYNC_FACTORISATION:
         return _DeviceLU(*_factor(A))
     return _AsyncLU(A)
@@ -285,12 +315,9 @@ class _DeviceLU(object):
         from .device import get_context
         self.ctx = get_context(LU.device.index)
         self.n = n = int(LU.shape[0])
-        nb = 2 * ((n + 127) // 128)      # an even number of 64-row blocks: two per launch
-        # 64x64 tiles stored contiguously, column-major inside a tile, identity padding
-        # (layout of ipde_dense_lu_solve)
-        pad = torch.eye(nb * 64, dtype=torch.float64, device=LU.device)
-        pad[:n, :n] = LU
-        self.LU = pad.view(nb, 64, nb, 64).permute(0, 2, 3, 1).contiguous()
+        # an even number of 64-row blocks (two per substitution step); 64x64 tiles stored
+        # contiguously, column-major inside a tile, identity padding (layout of ipde_dense_lu_solve)
+        self.LU = _tiled(LU)
         if perm is None:
             p = np.arange(self.n)
             for i, q in enumerate(piv.cpu().numpy() - 1):  # LAPACK ipiv -> permutation vector
@@ -298,6 +325,17 @@ class _DeviceLU(object):
                     p[i], p[q] = p[q], p[i]
             perm = torch.as_tensor(p, device=LU.device)
         self.perm = perm.to(torch.int32).contiguous()
+
+    @classmethod
+    def from_tiled(cls, T, perm, n, ctx):
+        """factors already in the tiled storage (ipde_dense_lu_factor); perm: int32 device tensor
+        over the padded rows — rows >= n are the identity padding and pivot on themselves"""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.n = n
+        self.LU = T
+        self.perm = perm[:n].contiguous()
+        return self
 
     def _subst(self, b):
         import torch

@@ -1,0 +1,127 @@
+"""ipde_dense_lu_factor (csrc/lu_factor.hip): the library's own blocked LU with partial pivoting
+on the tiled storage, against host LAPACK — pivots, factors, residuals; sizes around the tile and
+panel edges, both panel-kernel instantiations, and a QFS collocation matrix (cond ~1e12)."""
+import time
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+pytestmark = pytest.mark.gpu
+
+
+def _untile(T, n):
+    nb = T.shape[0]
+    return T.permute(0, 3, 1, 2).reshape(nb * 64, nb * 64)[:n, :n].cpu().numpy()
+
+
+def _lapack_perm(piv):
+    p = np.arange(len(piv))
+    for i, q in enumerate(piv):
+        if q != i:
+            p[i], p[q] = p[q], p[i]
+    return p
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 127, 128, 129, 300, 1000, 2050])
+def test_own_factorisation_matches_lapack(n):
+    import torch
+    from ipde_amd import qfs
+    rng = np.random.default_rng(100 + n)
+    A = rng.standard_normal((n, n))
+    b = rng.standard_normal(n)
+    f = qfs._own_lu(torch.as_tensor(A, device="cuda"))
+    lu, piv = scipy.linalg.lu_factor(A)
+    # the same pivots (random data: no ties), hence the same factors up to rounding
+    assert np.array_equal(f.perm.cpu().numpy(), _lapack_perm(piv))
+    mine = _untile(f.LU, n)
+    assert np.abs(mine - lu).max() < 1e-11 * max(1.0, np.abs(lu).max())
+    # identity padding untouched: unit diagonal, nothing else
+    full = f.LU.permute(0, 3, 1, 2).reshape(f.LU.shape[0] * 64, -1).cpu().numpy()
+    assert np.array_equal(full[n:, n:], np.eye(full.shape[0] - n))
+    assert not full[n:, :n].any() and not full[:n, n:].any()
+    x = f._subst(torch.as_tensor(b, device="cuda")).cpu().numpy()
+    ref = scipy.linalg.lu_solve((lu, piv), b)
+    assert np.abs(A @ x - b).max() < 20 * max(np.abs(A @ ref - b).max(), 1e-15 * n * np.abs(x).max())
+
+
+def test_own_factorisation_pivots_like_dgetf2_on_ties_and_zeros():
+    """first row of maximal |a| wins a tie; a column that is already zero below the diagonal
+    keeps the diagonal; integer data so every operation is exact"""
+    import torch
+    from ipde_amd import qfs
+    n = 70
+    A = np.zeros((n, n))
+    A[np.arange(n), np.arange(n)] = 2.0
+    A[5, 3] = -2.0        # tie with the diagonal of column 3: the diagonal (row 3) comes first
+    A[60, 10] = 4.0       # larger below: row 60 must come up
+    A[65, 64] = -8.0      # in the second panel
+    f = qfs._own_lu(torch.as_tensor(A, device="cuda"))
+    lu, piv = scipy.linalg.lu_factor(A)
+    assert np.array_equal(f.perm.cpu().numpy(), _lapack_perm(piv))
+    assert np.array_equal(_untile(f.LU, n), lu)
+
+
+def test_own_factorisation_on_qfs_matrix_has_lapack_residual():
+    import torch
+    from ipde_amd import qfs
+    from ipde_amd.pybie2d_compat import Global_Smooth_Boundary, star, Laplace_Layer_Form
+    b = Global_Smooth_Boundary(c=star(1000, a=0.2, f=5))
+    qb = qfs.QFS_Boundary(b, eps=1e-12)
+    A = Laplace_Layer_Form(qb.interior_source_bdy, b, ifcharge=True)
+    u = np.exp(np.cos(b.t)) + 0.3 * np.sin(3 * b.t)
+    Ad = torch.as_tensor(A, device="cuda")
+    x = qfs._own_lu(Ad)._subst(torch.as_tensor(u, device="cuda")).cpu().numpy()
+    xs = scipy.linalg.solve(A, u)
+    r, rs = np.abs(A @ x - u).max(), np.abs(A @ xs - u).max()
+    print("cond %.1e  residual own %.2e  LAPACK %.2e" % (np.linalg.cond(A), r, rs))
+    assert r < 50 * max(rs, 1e-15)
+
+
+@pytest.mark.parametrize("n", [4096, 5000])
+def test_own_factorisation_large_and_timing(n):
+    """n = 4096: the BASELINE boundary size (panel kernel with four rows per thread); 5000: the
+    eight-rows-per-thread instantiation.  Timed against rocSOLVER's getrf on the same matrix."""
+    import torch
+    from ipde_amd import qfs
+    rng = np.random.default_rng(n)
+    A = torch.as_tensor(rng.standard_normal((n, n)) + 0.05 * n * np.eye(n), device="cuda")
+    b = torch.as_tensor(rng.standard_normal(n), device="cuda")
+    f = qfs._own_lu(A)
+    x = f._subst(b)
+    res = float((A @ x - b).abs().max())
+    lu, piv = torch.linalg.lu_factor(A)
+    g = qfs._DeviceLU(lu, piv)
+    assert torch.equal(f.perm, g.perm)
+    res_lib = float((A @ g._subst(b) - b).abs().max())
+    assert res < 20 * max(res_lib, 1e-13)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        qfs._own_lu(A)
+    torch.cuda.synchronize()
+    t_own = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    for _ in range(3):
+        torch.linalg.lu_factor(A)
+    torch.cuda.synchronize()
+    t_lib = (time.perf_counter() - t0) / 3
+    print("n = %d: own factorisation (incl. tiling) %.1f ms, rocSOLVER getrf %.1f ms; residuals %.1e / %.1e"
+          % (n, t_own * 1e3, t_lib * 1e3, res, res_lib))
+
+
+def test_lu_factor_argument_checks():
+    import torch
+    from ipde_amd.device import get_context, ptr
+    ctx = get_context()
+    T = torch.eye(128, dtype=torch.float64, device="cuda")
+    p = torch.empty(128, dtype=torch.int32, device="cuda")
+    call = ctx.lib.ipde_dense_lu_factor
+    assert call(ctx.handle, 128, ptr(T), ptr(p)) == 0
+    assert call(ctx.handle, 64, ptr(T), ptr(p)) == 1          # not a multiple of 128
+    assert call(ctx.handle, 192, ptr(T), ptr(p)) == 1
+    assert call(ctx.handle, 8192 + 128, ptr(T), ptr(p)) == 1   # beyond the panel kernel's reach
+    assert call(ctx.handle, 128, None, ptr(p)) == 1
+    assert call(ctx.handle, 128, ptr(T), None) == 1
+    assert call(None, 128, ptr(T), ptr(p)) == 1
+    ctx.sync()
