@@ -21,6 +21,8 @@ The matrices are built (ipde_amd.dense_forms) and factored (rocSOLVER) on the GP
 per-call solve is the library's blocked substitution (csrc/dense.hip).  Host LAPACK
 without a GPU (CPU tests).
 """
+import os
+
 import numpy as np
 import scipy.linalg
 
@@ -215,7 +217,7 @@ def u2s_many(requests):
     return out
 
 
-OWN_FACTORISATION = True       # False: rocSOLVER getrf (torch.linalg.lu_factor) for every size
+OWN_FACTORISATION = os.environ.get("IPDE_OWN_LU", "1") != "0"   # False: rocSOLVER getrf (torch.linalg.lu_factor) for every size
 OWN_FACTORISATION_MAX_ROWS = 8192
 
 
@@ -241,7 +243,7 @@ def _tiled(M):
 def _own_lu(A):
     """_DeviceLU of A through the library's own blocked factorisation (csrc/lu_factor.hip:
     ipde_dense_lu_factor), enqueued on the context's stream — no host synchronisation, no pool
-    thread: ~260 launches, a few ms of GPU time at n = 4096."""
+    thread: ~260 launches, ~20 ms of GPU time at n = 4096."""
     import torch
     from .device import get_context, ptr
     ctx = get_context(A.device.index)
@@ -249,6 +251,57 @@ def _own_lu(A):
     perm = torch.empty(T.shape[0] * 64, dtype=torch.int32, device=A.device)
     ctx.check(ctx.lib.ipde_dense_lu_factor(ctx.handle, T.shape[0] * 64, ptr(T), ptr(perm)))
     return _DeviceLU.from_tiled(T, perm, int(A.shape[0]), ctx)
+
+
+_own_slots = {}        # device index -> [(private context, torch stream), ...], used round robin
+_own_next = [0]
+OWN_FACTORISATION_STREAMS = 4
+
+
+class _OwnAsyncLU(object):
+    """The own factorisation on a NON-blocking side stream (a private library context bound to a
+    torch stream): most of a factorisation is its single-workgroup panel kernel, so the two QFS
+    systems of every interface and the example's integral equation factor side by side, under the
+    host's geometry work and the default stream's kernels (on the context's own blocking stream
+    every default-stream operation of the set-up waited for them: +0.08 s).  The first use makes
+    the consumer's stream wait for the factorisation's event."""
+
+    def __init__(self, A):
+        import torch
+        from .device import get_context, private_context, ptr
+        dev = A.device.index
+        slots = _own_slots.setdefault(dev, [])
+        k = _own_next[0] % OWN_FACTORISATION_STREAMS
+        _own_next[0] += 1
+        while len(slots) <= k:
+            pctx = private_context(dev)
+            side = torch.cuda.Stream(device=A.device)
+            pctx.use_torch_stream(side)
+            slots.append((pctx, side))
+        pctx, side = slots[k]
+        T = _tiled(A)
+        perm = torch.empty(T.shape[0] * 64, dtype=torch.int32, device=A.device)
+        ready = torch.cuda.Event()
+        ready.record()                       # T is complete on the caller's stream from here on
+        side.wait_event(ready)
+        T.record_stream(side)
+        perm.record_stream(side)
+        pctx.check(pctx.lib.ipde_dense_lu_factor(pctx.handle, T.shape[0] * 64, ptr(T), ptr(perm)))
+        self._done = torch.cuda.Event()
+        self._done.record(side)
+        self._obj = _DeviceLU.from_tiled(T, perm, int(A.shape[0]), get_context(dev))
+        self._waited = False
+
+    def _get(self):
+        if not self._waited:
+            import torch
+            torch.cuda.current_stream().wait_event(self._done)
+            # (the library's own stream is a blocking one: it runs behind the default stream)
+            self._waited = True
+        return self._obj
+
+    def __getattr__(self, name):
+        return getattr(self._get(), name)
 
 
 _lu_pool = None
@@ -262,7 +315,7 @@ def _lu_async(A):
     equation — so each factorisation runs on a pool thread with a stream of its own while the
     host goes on assembling the next matrix; the first use joins it."""
     if OWN_FACTORISATION and 128 * ((int(A.shape[0]) + 127) // 128) <= OWN_FACTORISATION_MAX_ROWS:
-        return _own_lu(A)
+        return _OwnAsyncLU(A) if ASYNC_FACTORISATION else _own_lu(A)
     if not ASYNC_FACTORISATION:
         return _DeviceLU(*_factor(A))
     return _AsyncLU(A)
