@@ -28,7 +28,7 @@ from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
 from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver  # noqa: E402
 
 
-def run(nb=400, M=16, helmholtz_k=2.0, verbose=False):
+def run(nb=400, M=16, helmholtz_k=2.0, verbose=False, return_solution=False):
     T = {}
     t0 = time.perf_counter()
     MOL = SlepianMollifier(1.5 * M)
@@ -103,6 +103,8 @@ def run(nb=400, M=16, helmholtz_k=2.0, verbose=False):
     T['dof'] = int(ebdyc.dof)
     T['grid'] = list(grid.shape)
     T['gmres_iterations'] = solver.iteration_counts
+    if return_solution:
+        return float(err.max()), float(np.abs(np.asarray(ua)).max()), T, np.array(ue)
     return float(err.max()), float(np.abs(np.asarray(ua)).max()), T
 
 

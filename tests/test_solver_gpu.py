@@ -111,6 +111,28 @@ def test_concurrent_annular_solves_equal_sequential_ones():
         assert np.array_equal(np.asarray(a), np.asarray(b))
 
 
+def test_device_resident_helper_flow_equals_the_host_array_flow():
+    """ScalarSolver.DEVICE_FLOW: interface data, annular solutions, jumps, densities and
+    corrections stay in HBM between the stages (the default in one process) — against the flow
+    that carries them as numpy arrays, as the reference does and as the torch.distributed path
+    still does: the same solution to rounding (one estimator product is a device GEMV instead of
+    a host dot), single boundary and multiply connected"""
+    import interior_poisson
+    import multi_modified_helmholtz as mmh
+    from ipde_amd.solvers.multi_boundary.scalar import ScalarSolver
+    assert ScalarSolver.DEVICE_FLOW
+    _, scale, _, ue_dev, _ = interior_poisson.run(nb=600, M=16)
+    dev_m = mmh.run(nb=400, M=16, helmholtz_k=2.0, return_solution=True)
+    ScalarSolver.DEVICE_FLOW = False
+    try:
+        _, _, _, ue_host, _ = interior_poisson.run(nb=600, M=16)
+        host_m = mmh.run(nb=400, M=16, helmholtz_k=2.0, return_solution=True)
+    finally:
+        ScalarSolver.DEVICE_FLOW = True
+    assert np.abs(np.asarray(ue_dev) - np.asarray(ue_host)).max() < 1e-12 * scale
+    assert np.abs(np.asarray(dev_m[-1]) - np.asarray(host_m[-1])).max() < 1e-12 * dev_m[1]
+
+
 def _run_sharded(problem, extra, port):
     import json
     import subprocess
