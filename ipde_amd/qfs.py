@@ -598,6 +598,17 @@ class Stokes_QFS(_QFS):
 
     def _post(self, mu, densities):
         if self.interior:
+            if type(mu).__module__.startswith('torch'):
+                # device densities (the solvers' device-resident flow): the same calibration with
+                # the row vectors resident in HBM, no host value in between
+                import torch
+                c = getattr(self, '_p_dev', None)
+                if c is None:
+                    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=float), device=mu.device)
+                    c = self._p_dev = ([up(r) for r in self._p_rows], up(self._p_src), up(self._n_src))
+                rows, p_src, n_src = c
+                p_true = sum(torch.dot(r, _on_device(d, mu.device)) for r, d in zip(rows, densities))
+                return mu + (p_true - torch.dot(p_src, mu)) / self._p_null * n_src
             p_true = sum(r @ np.asarray(d, dtype=float) for r, d in zip(self._p_rows, densities))
             mu = mu + (p_true - self._p_src @ mu) / self._p_null * self._n_src
         return mu

@@ -10,7 +10,11 @@ from ...annular.annular_full import RealAnnularGeometry
 
 
 def v2f(x):
-    return x.reshape(2, x.size // 2)
+    return x.reshape(2, -1)
+
+
+def _is_dev(a):
+    return type(a).__module__.startswith('torch')
 
 
 class VectorHelper(object):
@@ -113,7 +117,65 @@ class VectorHelper(object):
         solution, QFS densities for both sides (reference :113-144)."""
         return self.finish_call(*call_many(self.start_call(fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs)))
 
+    # Device-resident form of the two stages (the multi-boundary solver's default in one process):
+    # the interface data arrive as device tensors and the annular solution, tractions, jumps,
+    # densities and corrections stay in HBM; the arithmetic is the host form's, statement for
+    # statement (radial derivative = D00 product, tangential derivative = the library's batched
+    # 1-D FFT on this helper's own context, estimators = matrix-vector products).
+    def _device_constants(self):
+        c = getattr(self, '_dev_const', None)
+        if c is None:
+            import torch
+            dev = self._interface_dev.x.device
+            up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=float), device=dev)
+            e, b, iface = self.ebdy, self.ebdy.bdy, self.ebdy.interface
+            c = self._dev_const = dict(
+                inx=up(iface.normal_x), iny=up(iface.normal_y), iw=up(iface.weights),
+                bnx=up(b.normal_x), bny=up(b.normal_y), btx=up(b.tangent_x), bty=up(b.tangent_y),
+                D00=up(e.D00), ik=torch.as_tensor(1j * np.asarray(e.radial_k, dtype=float), device=dev),
+                rs=up(e.radial_speed), irs=up(e.inverse_radial_speed), iv_est=up(self._iv_estimator),
+                zero=torch.zeros(b.N, dtype=torch.float64, device=dev))
+        return c
+
+    def _interface_traction_uvp_device(self, u, v, p):
+        """get_interface_traction_uvp (:65-112) on device tensors"""
+        import torch
+        from ...spectral import fft1
+        c = self._device_constants()
+        ctx = getattr(self.annular_solver, 'ctx', None)
+        tder = lambda f: fft1(fft1(f, -1, ctx) * c['ik'], +1, ctx).real      # (fft1 scales the inverse)
+        est = lambda X: torch.mv(X.t(), c['iv_est'])
+        Ur, Ut = u * c['bnx'] + v * c['bny'], u * c['btx'] + v * c['bty']
+        Urr = c['D00'] @ Ur
+        Urt = tder(Ur) * c['irs']
+        Utr = c['rs'] * (c['D00'] @ (Ut * c['irs']))
+        Tr = 2 * est(Urr) - est(p)
+        Tt = est(Utr) + est(Urt)
+        return Tr * c['bnx'] + Tt * c['btx'], Tr * c['bny'] + Tt * c['bty']
+
+    def _start_call_device(self, fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs):
+        import torch
+        c = self._device_constants()
+        btx = btxx * c['inx'] + btxy * c['iny']
+        bty = btxy * c['inx'] + btyy * c['iny']
+        f2 = torch.as_tensor(np.ascontiguousarray(np.stack([fur, fvr]), dtype=float), device=bu.device)
+        fr, ft = f2[0] * c['bnx'] + f2[1] * c['bny'], f2[0] * c['btx'] + f2[1] * c['bty']
+        z = c['zero']
+        rr, tr, pr = self.annular_solver.solve(self.RAG, fr, ft, z, z, z, z, **kwargs)
+        self.iterations_last_call = self.annular_solver.iterations_last_call
+        ur, vr = rr * c['bnx'] + tr * c['btx'], rr * c['bny'] + tr * c['bty']
+        rtx, rty = self._interface_traction_uvp_device(ur, vr, pr)
+        taus = torch.cat([rtx - btx, rty - bty])
+        taud = torch.cat([bu, bv])
+        if not self.interior:
+            taus = -taus
+            taud = -taud
+        self.ur, self.vr, self.pr = ur, vr, pr
+        return [(self.interface_qfs_g, [taus, taud]), (self.interface_qfs_r, [taus, taud])]
+
     def start_call(self, fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs):
+        if _is_dev(bu):
+            return self._start_call_device(fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs)
         ebdy = self.ebdy
         btx = btxx * ebdy.interface.normal_x + btxy * ebdy.interface.normal_y
         bty = btxy * ebdy.interface.normal_x + btyy * ebdy.interface.normal_y
@@ -150,12 +212,35 @@ class VectorHelper(object):
             return []
         import torch
         src = self.interface_qfs_g.source
+        w = self.Layer_Apply(src, self._interface_dev, self.sigma_g)
+        if _is_dev(ub):
+            self._pb_rest = pb - w[2]
+            return [(self.interface_qfs_r, torch.cat([ub - w[0], vb - w[1]]))]
         # (one device -> host transfer for the three fields, not three synchronisations)
-        w = torch.stack(list(self.Layer_Apply(src, self._interface_dev, self.sigma_g))).cpu().numpy()
+        w = torch.stack(list(w)).cpu().numpy()
         self._pb_rest = pb - w[2]
         return [(self.interface_qfs_r, np.concatenate([ub - w[0], vb - w[1]]))]
 
+    def _finish_correct_device(self, mu_adj=None):
+        import torch
+        if self._single:
+            sigma_r_tot = self.sigma_r
+            p_shift = 0.0
+        else:
+            sigma_r_adj = v2f(mu_adj)
+            p_adj = self.Layer_Apply(self.interface_qfs_r.source, self._interface_dev, sigma_r_adj)[2]
+            wi = self._device_constants()['iw']
+            p_shift = torch.sum((self._pb_rest - p_adj) * wi) / torch.sum(wi)
+            sigma_r_tot = sigma_r_adj + self.sigma_r
+        rslp = self._radial_sum(self.interface_qfs_r.source, sigma_r_tot)
+        self.ur = self.ur + rslp[0].reshape(self.ur.shape)
+        self.vr = self.vr + rslp[1].reshape(self.ur.shape)
+        self.pr = self.pr + rslp[2].reshape(self.pr.shape) + p_shift
+        return self.ur, self.vr, self.pr
+
     def finish_correct(self, mu_adj=None):
+        if _is_dev(self.ur):
+            return self._finish_correct_device(mu_adj)
         if self._single:
             sigma_r_tot = self.sigma_r
             p_shift = 0.0

@@ -259,11 +259,11 @@ class ScalarSolver(object):
         ucf *= self._phys_d.view(-1)
         # the answer is built over pinned memory: the device->host copy writes the caller's array
         ue, block = hostio.pinned_function(e)
-        for sl, ur in zip(ue.radial_slices, urs):
+        for i, (sl, ur) in enumerate(zip(ue.radial_slices, urs)):
             if isinstance(ur, torch.Tensor):     # device flow: the annular solutions' one transfer
                 block[sl].copy_(ur.reshape(-1), non_blocking=True)
             else:
-                block[sl] = torch.from_numpy(np.ascontiguousarray(ur, dtype=float).reshape(-1))
+                ue[i] = ur                       # (numpy copy: no torch CPU op, see VectorSolver)
         block[:e.grid_phys.N].copy_(ucf[self._phys_idx], non_blocking=False)   # (in stream order: the last)
         return ue
 

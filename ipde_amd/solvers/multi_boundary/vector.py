@@ -51,6 +51,7 @@ class VectorSolver(object):
     CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other
     DISTRIBUTE_BOUNDARIES = True  # under torch.distributed: boundary i on rank i mod world
     USE_FAST_INTERP = True        # False: always the dense Fourier sums (the checker)
+    DEVICE_FLOW = True            # False: per-boundary vectors travel as numpy between the stages
     # u, v, T_xx = 2 u_x - p, T_xy = u_y + v_x, T_yy = 2 v_y - p as (coef, field, derivative) terms
     _STRESS_FIELDS = [[(1.0, 0, 0)], [(1.0, 1, 0)], [(2.0, 0, 1), (-1.0, 2, 0)],
                       [(1.0, 0, 2), (1.0, 1, 1)], [(2.0, 1, 2), (-1.0, 2, 0)]]
@@ -152,9 +153,12 @@ class VectorSolver(object):
         fc = fg.view(2, Nx, Ny) * self._grid_step_d
         uc, vc, pc = (a.contiguous() for a in self._grid_solve(fc[0], fc[1]))
         # velocity and stress of the grid solution on every interface node (:66-82)
+        # In one process the per-boundary vectors stay in HBM through the stages below (see
+        # ScalarSolver.__call__); the torch.distributed path keeps the host arrays its exchanges take.
+        device_flow = self.DEVICE_FLOW and not is_distributed() and not self.split_grid_evaluation
+        host = (lambda t: t) if device_flow else (lambda t: t.cpu().numpy())
         if self._fast_interp:
-            bvals = self.plan.interp_fields([uc, vc, pc], self._STRESS_FIELDS, self._ifx_d,
-                                            self._ify_d).cpu().numpy()
+            bvals = host(self.plan.interp_fields([uc, vc, pc], self._STRESS_FIELDS, self._ifx_d, self._ify_d))
         elif self.interpolation_order == np.inf:
             # full spectra of the real fields through the library's D2Z plan (no torch.fft)
             uh, vh, ph = self.plan.fft2(uc), self.plan.fft2(vc), self.plan.fft2(pc)
@@ -165,7 +169,7 @@ class VectorSolver(object):
             stack = torch.stack([self.plan.fft2(g.contiguous()) for g in
                                  (uc, vc, 2 * ucx - pc, ucy + vcx, 2 * vcy - pc)])
         if not self._fast_interp:
-            bvals = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True).cpu().numpy()
+            bvals = host(periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True))
         bul, bvl, btxxl, btxyl, btyyl = (e.v2l(b) for b in bvals)
         # annular solves boundary by boundary, then the QFS solves of all boundaries in one
         # batched substitution (qfs.call_many).  Every annular solver has its own library
@@ -182,13 +186,16 @@ class VectorSolver(object):
                 sigmag_list, [(2, h.interface_qfs_g.source.N) for h in self.helpers],
                 device=self._dev, extra=its)
         self.iteration_counts = [int(i) for i in its]
-        sigmag = np.column_stack(sigmag_list)
+        sigmag = torch.cat(list(sigmag_list), dim=1) if device_flow else np.column_stack(sigmag_list)
         out = self.Grid_Evaluator(sigmag)                          # device (u, v, p) on grid_pnai
         n_pna = e.grid_pna.N
         fields = (uc.view(-1), vc.view(-1), pc.view(-1))
         for f, o in zip(fields, out):
             f[self._pna_idx] += o[:n_pna]
-        bus, bvs, bps = (e.v2l(o) for o in torch.stack([o[n_pna:] for o in out]).cpu().numpy())
+        if device_flow:
+            bus, bvs, bps = (e.v2l(o[n_pna:]) for o in out)
+        else:
+            bus, bvs, bps = (e.v2l(o) for o in torch.stack([o[n_pna:] for o in out]).cpu().numpy())
         single_ebdy = len(e) == 1
         res = _run_owned(self, mine, 'start_correct', 'finish_correct',
                          [(bu, bv, bp, single_ebdy) for bu, bv, bp in zip(bus, bvs, bps)], u2s_many)
@@ -207,8 +214,13 @@ class VectorSolver(object):
         for (g, block), f, rs in zip(made, fields, (urs, vrs, prs)):
             f *= self._phys_d.view(-1)
             block[:e.grid_phys.N].copy_(f[self._phys_idx], non_blocking=True)
-            for i, r in enumerate(rs):
-                g[i] = r
+            for i, (sl, r) in enumerate(zip(g.radial_slices, rs)):
+                if isinstance(r, torch.Tensor):      # device flow: the annular solutions' one transfer
+                    block[sl].copy_(r.reshape(-1), non_blocking=True)
+                else:
+                    # (a numpy copy: a torch CPU copy would wake torch's intra-op thread pool, whose
+                    # workers then spin beside the solver's own threads — measured: +12 ms per solve)
+                    g[i] = r
         torch.cuda.current_stream(self._dev).synchronize()
         return tuple(g for g, _ in made)
 

@@ -133,6 +133,28 @@ def test_device_resident_helper_flow_equals_the_host_array_flow():
     assert np.abs(np.asarray(dev_m[-1]) - np.asarray(host_m[-1])).max() < 1e-12 * dev_m[1]
 
 
+def test_stokes_device_resident_helper_flow_equals_the_host_array_flow():
+    """VectorSolver.DEVICE_FLOW (tractions, jumps, densities, pressure calibration and corrections
+    on device tensors) against the numpy flow, single boundary and three bodies: the same fields
+    to rounding (the QFS systems have condition ~1e13: agreement is relative to the fields' size)"""
+    import multi_stokes
+    from ipde_amd.solvers.multi_boundary.vector import VectorSolver
+    assert VectorSolver.DEVICE_FLOW
+    _, one_dev, _, _ = multi_stokes.run(nb=400, M=12, simple=True, return_fields=True)
+    _, dev, _, _ = multi_stokes.run(nb=800, M=14, return_fields=True)
+    VectorSolver.DEVICE_FLOW = False
+    try:
+        _, one_host, _, _ = multi_stokes.run(nb=400, M=12, simple=True, return_fields=True)
+        _, host, _, _ = multi_stokes.run(nb=800, M=14, return_fields=True)
+    finally:
+        VectorSolver.DEVICE_FLOW = True
+    for got, ref in ((one_dev, one_host), (dev, host)):
+        for a, b in zip(got, ref):
+            a, b = np.asarray(a), np.asarray(b)
+            print(np.abs(a - b).max(), np.abs(b).max())
+            assert np.abs(a - b).max() < 2e-8 * max(1.0, float(np.abs(b).max()))
+
+
 def _run_sharded(problem, extra, port):
     import json
     import subprocess

@@ -35,5 +35,8 @@ def wrapped(self, fu, fv, **kw):
 
 
 ms.StokesSolver.__call__ = wrapped
+if os.environ.get("IPDE_VECTOR_DEVICE_FLOW") is not None:      # A/B of the helper flow
+    from ipde_amd.solvers.multi_boundary.vector import VectorSolver
+    VectorSolver.DEVICE_FLOW = os.environ["IPDE_VECTOR_DEVICE_FLOW"] != "0"
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 800
 ms.run(nb, 14)
