@@ -118,6 +118,75 @@ __global__ __launch_bounds__(256) void caxpy_kernel(cd* __restrict__ y, const cd
     y[idx] = cd{fma(alpha, b.x, a.x), fma(alpha, b.y, a.y)};
 }
 
+// The scalar annular operator's radial mixes, fused per stage (one launch where there were two):
+// a job is  out[a][j] = colfac0[j] (A0 in0)[a][j]  (+ (A1 in1)[a][j], added the way the second of two
+// mixc_kernel launches with beta = 1 added it)  (- sub[a][j] for a < sub_rows, the way caxpy_kernel
+// subtracted it); blockIdx.z picks the job.  Products, sums and their order are those of the
+// separate kernels: bitwise the same operator (tests/test_annular_gpu.py goldens).
+struct MixcTerm {
+    const double* A;      // (rows, ca) row-major
+    const cd* in;         // (ca, n) complex, leading dimension n
+    const cd* colfac;     // nullable (n): factor on the sum
+    int ca;
+};
+struct MixcJob {
+    cd* out;
+    int rows;
+    int nterms;           // 1 or 2
+    MixcTerm t[2];
+    const cd* sub;        // nullable: out[a][j] -= sub[a][j] for a < sub_rows
+    int sub_rows;
+};
+struct MixcBatch {
+    MixcJob j[2];
+};
+__global__ __launch_bounds__(256) void mixc_fused_kernel(MixcBatch B, int n) {
+    const MixcJob& J = B.j[blockIdx.z];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int a = blockIdx.y;
+    if (j >= n || a >= J.rows) return;
+    cd o{0.0, 0.0};
+    for (int k = 0; k < J.nterms; ++k) {
+        const MixcTerm& T = J.t[k];
+        const double* Ar = T.A + (size_t)a * T.ca;
+        double sr = 0.0, si = 0.0;
+#pragma unroll 4
+        for (int b = 0; b < T.ca; ++b) {
+            cd v = T.in[(size_t)b * n + j];
+            double w = Ar[b];
+            sr = fma(w, v.x, sr);
+            si = fma(w, v.y, si);
+        }
+        cd s{sr, si};
+        if (T.colfac) s = cmul(s, T.colfac[j]);
+        cd t{1.0 * s.x, 1.0 * s.y};
+        if (k == 0) {
+            o = t;
+        } else {
+            o.x = fma(1.0, o.x, t.x);
+            o.y = fma(1.0, o.y, t.y);
+        }
+    }
+    if (J.sub && a < J.sub_rows) {
+        const cd b = J.sub[(size_t)a * n + j];
+        o.x = fma(-1.0, b.x, o.x);
+        o.y = fma(-1.0, b.y, o.y);
+    }
+    J.out[(size_t)a * n + j] = o;
+}
+
+// x[r][j] *= s * (r < rows0 ? F0 : F1)[r][j]: the two field multiplications of a stage in one launch
+__global__ __launch_bounds__(256) void cscale_field2_kernel(cd* __restrict__ x, int rows0, int rows1, int n,
+                                                            const double* __restrict__ F0,
+                                                            const double* __restrict__ F1, double s) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n0 = (int64_t)rows0 * n;
+    if (idx >= n0 + (int64_t)rows1 * n) return;
+    double f = s * (idx < n0 ? F0[idx] : F1[idx - n0]);
+    cd v = x[idx];
+    x[idx] = cd{v.x * f, v.y * f};
+}
+
 // real (rows,n) -> complex with zero imaginary part, times s
 __global__ __launch_bounds__(256) void r2c_copy_kernel(cd* __restrict__ y,
                                                        const double* __restrict__ x, int64_t n,
@@ -739,30 +808,33 @@ struct ipde_annular_scalar : public LinOp {
         const int m1 = M - 1, m2 = M - 2;
         dim3 b(256);
         // T1 = R01 (uh * iks), T2 = D01 uh
-        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), m1), b, 0, st, T, n, (const double*)R01, M, uh,
-                           n, n, (const cd*)iks, 1.0, 0.0);
-        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), m1), b, 0, st, T + (size_t)m1 * n, n,
-                           (const double*)D01, M, uh, n, n, (const cd*)nullptr, 1.0, 0.0);
+        {
+            MixcBatch Bq{};
+            Bq.j[0] = MixcJob{T, m1, 1, {MixcTerm{R01, uh, iks, M}, MixcTerm{}}, nullptr, 0};
+            Bq.j[1] = MixcJob{T + (size_t)m1 * n, m1, 1, {MixcTerm{D01, uh, nullptr, M}, MixcTerm{}}, nullptr, 0};
+            hipLaunchKernelGGL(mixc_fused_kernel, dim3(nb256(n), m1, 2), b, 0, st, Bq, n);
+        }
         IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, +1, T, U));
-        hipLaunchKernelGGL(cscale_field_kernel, dim3(nb256((int64_t)m1 * n)), b, 0, st, U, m1, n,
-                           (const double*)ipsi1, 1.0 / n);
-        hipLaunchKernelGGL(cscale_field_kernel, dim3(nb256((int64_t)m1 * n)), b, 0, st,
-                           U + (size_t)m1 * n, m1, n, (const double*)psi1, 1.0 / n);
+        hipLaunchKernelGGL(cscale_field2_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, U, m1, m1, n,
+                           (const double*)ipsi1, (const double*)psi1, 1.0 / n);
         IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, -1, U, T));
         // S = R12 (T1 * iks) + D12 T2   -> U[0:m2]
-        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), m2), b, 0, st, U, n, (const double*)R12, m1,
-                           (const cd*)T, n, n, (const cd*)iks, 1.0, 0.0);
-        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), m2), b, 0, st, U, n, (const double*)D12, m1,
-                           (const cd*)(T + (size_t)m1 * n), n, n, (const cd*)nullptr, 1.0, 1.0);
+        {
+            MixcBatch Bq{};
+            Bq.j[0] = MixcJob{U, m2, 2, {MixcTerm{R12, T, iks, m1}, MixcTerm{D12, T + (size_t)m1 * n, nullptr, m1}},
+                              nullptr, 0};
+            hipLaunchKernelGGL(mixc_fused_kernel, dim3(nb256(n), m2, 1), b, 0, st, Bq, n);
+        }
         IPDE_TRY(ipde_fft1_exec(ctx, m2, n, +1, U, T));
         hipLaunchKernelGGL(cscale_field_kernel, dim3(nb256((int64_t)m2 * n)), b, 0, st, T, m2, n,
                            (const double*)ipsi2, 1.0 / n);
         IPDE_TRY(ipde_fft1_exec(ctx, m2, n, -1, T, U));
         // out = B uh ; out[0:m2] -= luh
-        hipLaunchKernelGGL(mixc_kernel, dim3(nb256(n), M), b, 0, st, out, n, (const double*)Bmat, M,
-                           uh, n, n, (const cd*)nullptr, 1.0, 0.0);
-        hipLaunchKernelGGL(caxpy_kernel, dim3(nb256((int64_t)m2 * n)), b, 0, st, out, (const cd*)U,
-                           (int64_t)m2 * n, -1.0);
+        {
+            MixcBatch Bq{};
+            Bq.j[0] = MixcJob{out, M, 1, {MixcTerm{Bmat, uh, nullptr, M}, MixcTerm{}}, U, m2};
+            hipLaunchKernelGGL(mixc_fused_kernel, dim3(nb256(n), M, 1), b, 0, st, Bq, n);
+        }
         IPDE_HIP_CHECK(ctx, hipGetLastError());
         return IPDE_OK;
     }
