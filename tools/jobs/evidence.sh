@@ -7,6 +7,8 @@ export TMPDIR=/tmp
 O=gpurun_out/r02/final
 rm -rf $O
 mkdir -p $O
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
+timeout -k 10 1000 python3 -m pytest tests -m gpu -q 2>&1 | grep -v '^  File\|^Extension' | tail -4 > $O/gputest.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python tools/bench_kernels.py > $O/kernels.json 2> $O/kernels.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-full-solve > $O/bench_under_rocprof.json 2> $O/bench_trace.err
@@ -28,7 +30,7 @@ timeout -k 10 60 /tmp/lu_probe 4096 1 > $O/lu_subst_probe.txt
 timeout -k 10 60 /tmp/lu_panel_probe 4096 0 > $O/lu_panel_probe.txt
 timeout -k 10 60 /tmp/lu_panel_probe 4096 60 >> $O/lu_panel_probe.txt
 find $O -name "*_kernel_trace.csv" -size +20M -delete
-cat $O/poisson_warm_unprofiled.txt $O/stokes_warm_unprofiled.txt
+cat $O/smoke.txt $O/gputest.txt $O/poisson_warm_unprofiled.txt $O/stokes_warm_unprofiled.txt
 python3 -c "
 import json; b=json.load(open('$O/bench.json')); print(b['value'], b['ms_per_step'], b['roofline']['frac']); print(json.dumps(b['fft'])[:400]); print(json.dumps(b['full_poisson_solve'])[:600])"
 echo evidence done
