@@ -252,6 +252,15 @@ int ipde_dense_lu_solve_batch(ipde_ctx* ctx, int nsys, const int64_t* n, const d
  */
 int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles, int* perm);
 
+/*
+ * y = A x (accumulate = 0) or y += A x (1); A: DEVICE, row-major (m, n); x (n), y (m): DEVICE.  The
+ * matrix-vector products around the QFS solves — the one-sided boundary limit S sigma + D tau of
+ * qfs.two_d_qfs.QFS_Evaluator.__call__ (call sites ipde/solvers/internals/scalar.py:87-88,
+ * vector.py:133-134) and the residual of the refinement step.  Asynchronous on the context's stream.
+ */
+int ipde_dense_gemv(ipde_ctx* ctx, int64_t m, int64_t n, const double* A, const double* x, double* y,
+                    int accumulate);
+
 /* ------------------------------------------------------------------------- */
 /* Closest-point coordinates of points near a closed curve  */
 /*

@@ -79,7 +79,7 @@ class _QFS(object):
             # per-solve cost of three 4096^2 host LU back-substitutions was the largest
             # single item of a warm 2048^2 Poisson solve)
             import torch
-            as_dev = lambda M: M if isinstance(M, torch.Tensor) else torch.as_tensor(M, device=self._dev)
+            as_dev = lambda M: (M if isinstance(M, torch.Tensor) else torch.as_tensor(M, device=self._dev)).contiguous()
             self._A = as_dev(A)
             self._fact = _lu_async(self._A)
             self._S = None if S is None else as_dev(S)
@@ -128,7 +128,14 @@ class _QFS(object):
         if self._dev is not None:
             import torch
             densities = [_on_device(d, self._dev) for d in densities]
-            u = torch.zeros(self._nrow, dtype=torch.float64, device=self._dev)
+            u = None
+            i = 0
+            if self.slp:
+                u = _gemv(self._S, densities[i])
+                i += 1
+            if self.dlp:
+                u = _gemv(self._D, densities[i], u)
+            return u if u is not None else torch.zeros(self._nrow, dtype=torch.float64, device=self._dev)
         else:
             u = np.zeros(self._nrow)
         i = 0
@@ -153,6 +160,21 @@ class _QFS(object):
 
     def u2s(self, u):
         return self._solve(np.asarray(u, dtype=float))
+
+
+def _gemv(A, x, y=None):
+    """A x (or y += A x) on the device through the library's own kernel (csrc/dense.hip:
+    ipde_dense_gemv) — A: contiguous (m, n) fp64 device tensor"""
+    import torch
+    from .device import get_context, ptr
+    ctx = get_context(A.device.index)
+    A = A if A.is_contiguous() else A.contiguous()      # (the QFS objects keep theirs contiguous)
+    x = x.contiguous()
+    acc = y is not None
+    if y is None:
+        y = torch.empty(A.shape[0], dtype=torch.float64, device=A.device)
+    ctx.check(ctx.lib.ipde_dense_gemv(ctx.handle, A.shape[0], A.shape[1], ptr(A), ptr(x), ptr(y), int(acc)))
+    return y
 
 
 def _on_device(d, dev):
@@ -404,7 +426,7 @@ class _DeviceLU(object):
         has LAPACK's residual, so the QFS solves use none)"""
         x = self._subst(b)
         for _ in range(steps):
-            x = x + self._subst(b - A @ x)
+            x = x + self._subst(b - _gemv(A, x))
         return x
 
     @staticmethod
@@ -431,7 +453,7 @@ class _DeviceLU(object):
         """solve() for several systems together; facts: _DeviceLU objects"""
         xs = _DeviceLU._subst_batch(facts, bs)
         for _ in range(steps):
-            ds = _DeviceLU._subst_batch(facts, [b - A @ x for A, b, x in zip(As, bs, xs)])
+            ds = _DeviceLU._subst_batch(facts, [b - _gemv(A, x) for A, b, x in zip(As, bs, xs)])
             xs = [x + d for x, d in zip(xs, ds)]
         return xs
 

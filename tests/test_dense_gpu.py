@@ -306,6 +306,26 @@ def test_batched_substitution_equals_separate_solves():
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("m,n", [(1, 1), (5, 3), (64, 64), (257, 1023), (1000, 4096), (4096, 4096)])
+def test_gemv_matches_numpy(m, n):
+    """ipde_dense_gemv (y = A x, y += A x): the QFS boundary limits and refinement residuals"""
+    import torch
+    from ipde_amd.qfs import _gemv
+    rng = np.random.default_rng(m * 7 + n)
+    A, x, y0 = rng.standard_normal((m, n)), rng.standard_normal(n), rng.standard_normal(m)
+    Ad, xd = torch.as_tensor(A, device="cuda"), torch.as_tensor(x, device="cuda")
+    ref = A @ x
+    tol = 1e-14 * n * max(1.0, np.abs(A).max() * np.abs(x).max())
+    assert np.abs(_gemv(Ad, xd).cpu().numpy() - ref).max() <= tol
+    yd = torch.as_tensor(y0, device="cuda")
+    out = _gemv(Ad, xd, yd)
+    assert out is yd and np.abs(yd.cpu().numpy() - (y0 + ref)).max() <= tol
+    # an x that is not 16-byte aligned takes the scalar-load path: same sums up to their order
+    xo = torch.empty(n + 1, dtype=torch.float64, device="cuda")[1:]
+    xo.copy_(xd)
+    assert np.abs(_gemv(Ad, xo).cpu().numpy() - ref).max() <= tol
+
+
 def test_qfs_call_pair_equals_two_calls():
     from ipde_amd import qfs
     from ipde_amd.pybie2d_compat import Global_Smooth_Boundary, star
