@@ -305,6 +305,20 @@ int ipde_radial_to_grid(ipde_ctx* ctx, int loc, int64_t nfld, int64_t M, int64_t
                         const double* bary_w, int64_t npts, const double* xi, const double* t,
                         const int64_t* idx, double* const* out);
 
+/*
+ * Grid <-> list moves of the multi-boundary solvers (ipde/embedded_function.py:105-113,135-138 and
+ * ipde/solvers/multi_boundary/scalar.py:72-117 do them with numpy masks).  All arrays DEVICE; idx:
+ * int64 positions in the flat grid, each at most once.
+ *   ipde_grid_scatter   out = 0 (ngrid doubles); out[idx[i]] = src[i] * (scale ? scale[idx[i]] : 1)
+ *                       — the forcing's physical values times the grid step function
+ *   ipde_grid_add_at    out[idx[i]] += src[i]   — the dense sums' values onto grid_pna
+ *   ipde_grid_gather    out[i] = in[idx[i]]     — the physical values of the answer
+ */
+int ipde_grid_scatter(ipde_ctx* ctx, int64_t ngrid, int64_t nidx, const int64_t* idx, const double* src,
+                      const double* scale, double* out);
+int ipde_grid_add_at(ipde_ctx* ctx, int64_t nidx, const int64_t* idx, const double* src, double* out);
+int ipde_grid_gather(ipde_ctx* ctx, int64_t nidx, const int64_t* idx, const double* in, double* out);
+
 /* ------------------------------------------------------------------------- */
 /* Ewald-type grid evaluator, first half                       */
 /*

@@ -424,3 +424,75 @@ extern "C" int ipde_radial_to_grid(ipde_ctx* ctx, int loc, int64_t nfld, int64_t
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Grid <-> list moves of the multi-boundary solvers (reference ipde/embedded_function.py:105-113,
+// 135-138 and ipde/solvers/multi_boundary/scalar.py:72-117 do them with numpy masks): the forcing's
+// physical values onto the zero-filled grid times the grid step function, list values added at
+// listed grid points, listed grid points gathered.  One launch each, HBM bound.
+namespace {
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(long long n, const long long* __restrict__ idx,
+                                                           const double* __restrict__ src,
+                                                           const double* __restrict__ scale,
+                                                           double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long k = idx[i];
+    out[k] = scale ? src[i] * scale[k] : src[i];
+}
+
+__global__ __launch_bounds__(256) void grid_add_at_kernel(long long n, const long long* __restrict__ idx,
+                                                          const double* __restrict__ src, double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long k = idx[i];
+    out[k] = out[k] + src[i];
+}
+
+__global__ __launch_bounds__(256) void grid_gather_kernel(long long n, const long long* __restrict__ idx,
+                                                          const double* __restrict__ in, double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = in[idx[i]];
+}
+
+}  // namespace
+
+extern "C" int ipde_grid_scatter(ipde_ctx* ctx, int64_t ngrid, int64_t nidx, const int64_t* idx, const double* src,
+                                 const double* scale, double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ngrid >= 0 && nidx >= 0 && nidx <= ngrid && (ngrid == 0 || out));
+    IPDE_CHECK_ARG(ctx, nidx == 0 || (idx && src));
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ngrid) IPDE_HIP_CHECK(ctx, hipMemsetAsync(out, 0, (size_t)ngrid * sizeof(double), ctx->stream));
+    if (nidx)
+        hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)((nidx + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (long long)nidx, (const long long*)idx, src, scale, out);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
+extern "C" int ipde_grid_add_at(ipde_ctx* ctx, int64_t nidx, const int64_t* idx, const double* src, double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, nidx >= 0);
+    if (nidx == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, idx && src && out);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(grid_add_at_kernel, dim3((unsigned)((nidx + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (long long)nidx, (const long long*)idx, src, out);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
+extern "C" int ipde_grid_gather(ipde_ctx* ctx, int64_t nidx, const int64_t* idx, const double* in, double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, nidx >= 0);
+    if (nidx == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, idx && in && out);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(grid_gather_kernel, dim3((unsigned)((nidx + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (long long)nidx, (const long long*)idx, in, out);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}

@@ -18,7 +18,7 @@ from ...qfs import call_many, u2s_many
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...device import prewarm_wait
-from ... import hostio
+from ... import hostio, gridops
 from ...sharding import make_pnai_evaluator, exchange_owned, owner_of, is_distributed, _dist_state
 from ...spectral import get_plan
 
@@ -208,9 +208,7 @@ class ScalarSolver(object):
         # fc = (grid values) * grid_step on the full grid  (embedded_function.py:135-138)
         fp = torch.empty(e.grid_phys.N, dtype=torch.float64, device=self._dev)
         hostio.upload(fp, f['grid'], self._pin_in)
-        fg = torch.zeros(Nx * Ny, dtype=torch.float64, device=self._dev)
-        fg[self._phys_idx] = fp
-        fc = fg.view(Nx, Ny) * self._grid_step_d
+        fc = gridops.scatter(self._phys_idx, fp, Nx * Ny, scale=self._grid_step_d).view(Nx, Ny)
         uch, uc = self._grid_solve(fc)
         uc = uc.contiguous()
         if self.interpolation_order == np.inf and uch is None:
@@ -247,7 +245,7 @@ class ScalarSolver(object):
         out = self.evaluate_to_grid_pnai(sigmag)                 # device, len(grid_pnai)
         n_pna = e.grid_pna.N
         ucf = uc.view(-1)
-        ucf[self._pna_idx] += out[:n_pna]
+        gridops.add_at(self._pna_idx, out[:n_pna].contiguous(), ucf)
         bus = e.v2l(out[n_pna:] if device_flow else out[n_pna:].cpu().numpy())
         urs = _run_owned(self, mine, 'start_correct', 'finish_correct', [(bu,) for bu in bus], u2s_many)
         if distributed:
@@ -256,7 +254,8 @@ class ScalarSolver(object):
                 h.ur = ur
         for ur, (idx, xi, t) in zip(urs, self._ia):
             radial_to_grid([ur], xi, t, idx=idx, outs=[ucf])
-        ucf *= self._phys_d.view(-1)
+        # (only the physical points leave the device: the reference's masking of the rest, :117, has
+        # nothing to act on)
         # the answer is built over pinned memory: the device->host copy writes the caller's array
         ue, block = hostio.pinned_function(e)
         for i, (sl, ur) in enumerate(zip(ue.radial_slices, urs)):
@@ -264,7 +263,7 @@ class ScalarSolver(object):
                 block[sl].copy_(ur.reshape(-1), non_blocking=True)
             else:
                 ue[i] = ur                       # (numpy copy: no torch CPU op, see VectorSolver)
-        block[:e.grid_phys.N].copy_(ucf[self._phys_idx], non_blocking=False)   # (in stream order: the last)
+        block[:e.grid_phys.N].copy_(gridops.gather(self._phys_idx, ucf), non_blocking=False)   # (in stream order: the last)
         return ue
 
     def _define_layer_apply(self):

@@ -16,7 +16,7 @@ from ...pybie2d_compat import BoundaryCollection
 from ...qfs import call_many, u2s_many
 from .scalar import _finish_all, _concurrent_helpers, _owned, _run_owned
 from ...device import prewarm_wait
-from ... import hostio
+from ... import hostio, gridops
 from ...sharding import make_pnai_evaluator, exchange_owned, is_distributed
 from ...spectral import get_plan
 
@@ -148,9 +148,7 @@ class VectorSolver(object):
         fp = torch.empty((2, e.grid_phys.N), dtype=torch.float64, device=self._dev)
         hostio.upload(fp[0], fu['grid'], self._pin_in[0])
         hostio.upload(fp[1], fv['grid'], self._pin_in[1])
-        fg = torch.zeros((2, Nx * Ny), dtype=torch.float64, device=self._dev)
-        fg[:, self._phys_idx] = fp
-        fc = fg.view(2, Nx, Ny) * self._grid_step_d
+        fc = [gridops.scatter(self._phys_idx, fp[k], Nx * Ny, scale=self._grid_step_d).view(Nx, Ny) for k in (0, 1)]
         uc, vc, pc = (a.contiguous() for a in self._grid_solve(fc[0], fc[1]))
         # velocity and stress of the grid solution on every interface node (:66-82)
         # In one process the per-boundary vectors stay in HBM through the stages below (see
@@ -191,7 +189,7 @@ class VectorSolver(object):
         n_pna = e.grid_pna.N
         fields = (uc.view(-1), vc.view(-1), pc.view(-1))
         for f, o in zip(fields, out):
-            f[self._pna_idx] += o[:n_pna]
+            gridops.add_at(self._pna_idx, o[:n_pna].contiguous(), f)
         if device_flow:
             bus, bvs, bps = (e.v2l(o[n_pna:]) for o in out)
         else:
@@ -212,8 +210,7 @@ class VectorSolver(object):
         for b, (idx, xi, t) in enumerate(self._ia):
             radial_to_grid([urs[b], vrs[b], prs[b]], xi, t, idx=idx, outs=list(fields))
         for (g, block), f, rs in zip(made, fields, (urs, vrs, prs)):
-            f *= self._phys_d.view(-1)
-            block[:e.grid_phys.N].copy_(f[self._phys_idx], non_blocking=True)
+            block[:e.grid_phys.N].copy_(gridops.gather(self._phys_idx, f), non_blocking=True)
             for i, (sl, r) in enumerate(zip(g.radial_slices, rs)):
                 if isinstance(r, torch.Tensor):      # device flow: the annular solutions' one transfer
                     block[sl].copy_(r.reshape(-1), non_blocking=True)

@@ -318,3 +318,35 @@ def test_grid_interp_fields_argument_checks():
         plan.interp_fields([np.zeros((8, 8))], [[(1.0, 0, 0)]], z, z)
     assert plan.interp_fields([f], [[(1.0, 0, 1)]], np.zeros(0), np.zeros(0)).shape == (1, 0)
     plan.close()
+
+
+def test_grid_list_moves():
+    """ipde_grid_scatter / add_at / gather (csrc/geometry.hip): the mask operations of the
+    multi-boundary solvers (reference embedded_function.py:105-113,135-138), exact"""
+    import torch
+    from ipde_amd import gridops
+    from ipde_amd.device import get_context, ptr
+    rng = np.random.default_rng(2)
+    ngrid, n = 300 * 200, 31000
+    idx = torch.as_tensor(np.sort(rng.permutation(ngrid)[:n]).astype(np.int64), device="cuda")
+    src = torch.as_tensor(rng.standard_normal(n), device="cuda")
+    scale = torch.as_tensor(rng.standard_normal((300, 200)), device="cuda")
+    ref = torch.zeros(ngrid, dtype=torch.float64, device="cuda")
+    ref[idx] = src
+    assert torch.equal(gridops.scatter(idx, src, ngrid), ref)
+    assert torch.equal(gridops.scatter(idx, src, ngrid, scale=scale), ref * scale.reshape(-1))
+    g = torch.as_tensor(rng.standard_normal(ngrid), device="cuda")
+    want = g.clone()
+    want[idx] += src
+    assert gridops.add_at(idx, src, g) is g and torch.equal(g, want)
+    assert torch.equal(gridops.gather(idx, g), g[idx])
+    ctx = get_context()
+    e = torch.empty(0, dtype=torch.float64, device="cuda")
+    ei = torch.empty(0, dtype=torch.int64, device="cuda")
+    assert ctx.lib.ipde_grid_gather(ctx.handle, 0, ptr(ei), ptr(g), ptr(e)) == 0          # empty lists
+    assert ctx.lib.ipde_grid_add_at(ctx.handle, 0, ptr(ei), ptr(e), ptr(g)) == 0
+    assert ctx.lib.ipde_grid_scatter(ctx.handle, 8, 0, ptr(ei), ptr(e), None, ptr(g)) == 0
+    assert ctx.lib.ipde_grid_scatter(ctx.handle, 4, 8, ptr(idx), ptr(src), None, ptr(g)) == 1   # more entries than grid
+    assert ctx.lib.ipde_grid_gather(ctx.handle, 5, None, ptr(g), ptr(e)) == 1
+    assert ctx.lib.ipde_grid_add_at(None, 0, ptr(ei), ptr(e), ptr(g)) == 1
+    ctx.sync()
