@@ -186,6 +186,15 @@ extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
 extern "C" int ipde_ctx_sync(ipde_ctx* ctx) {
     if (!ctx) return IPDE_ERR_INVALID;
     IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // the persistent substitution's sticky time-out word (dense.hip) has arrived by now
+    if (ctx->d_lu_abort && ctx->h_pinned) {
+        volatile unsigned* seen = (volatile unsigned*)(ctx->h_pinned + ctx->h_pinned_bytes / sizeof(double) - 1);
+        if (*seen != 0) {
+            IPDE_SET_ERR(ctx, "a substitution workgroup of ipde_dense_lu_solve_batch timed out waiting for its "
+                              "predecessors: the results of that call are invalid");
+            return IPDE_ERR_HIP;
+        }
+    }
     return IPDE_OK;
 }
 
