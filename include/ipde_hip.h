@@ -306,6 +306,28 @@ int ipde_radial_to_grid(ipde_ctx* ctx, int loc, int64_t nfld, int64_t M, int64_t
                         const int64_t* idx, double* const* out);
 
 /*
+ * Stokes helper algebra around the annular solve (ipde/solvers/internals/vector.py:65-144), device
+ * arrays, asynchronous on the context's stream.  geom: DEVICE, 6 x n doubles — boundary normal x, y,
+ * boundary tangent x, y, interface normal x, y.
+ *   ipde_stokes_rotate           (u, v) -> (r, t) components (to_rt = 1; ipde/embedded_boundary.py:242-244)
+ *                                or back (0; :246-248) of two (M, n) fields; a, b at `loc`, outputs DEVICE
+ *   ipde_stokes_interface_jumps  from the annular solution (rr, tr, pr: (M, n)): its (u, v) components
+ *                                (ur, vr), its traction on the interface (get_interface_traction_uvp:
+ *                                radial derivative = D00 product, tangential derivative = batched FFT with
+ *                                the wavenumbers rk, rs / irs = radial speed and its inverse (M, n), est =
+ *                                interface estimator row (M)) and the jumps against the grid solution
+ *                                bdata = (u, v, T_xx, T_xy, T_yy) on the interface (5 x n):
+ *                                taus = sign [traction - T n], taud = sign [u, v], each 2 n doubles
+ *                                (sign: +1 interior, -1 exterior boundary)
+ */
+int ipde_stokes_rotate(ipde_ctx* ctx, int loc, int M, int n, const double* a, const double* b,
+                       const double* geom, int to_rt, double* o1, double* o2);
+int ipde_stokes_interface_jumps(ipde_ctx* ctx, int M, int n, const double* rr, const double* tr,
+                                const double* pr, const double* geom, const double* rs, const double* irs,
+                                const double* D00, const double* est, const double* rk, const double* bdata,
+                                double sign, double* ur, double* vr, double* taus, double* taud);
+
+/*
  * Grid <-> list moves of the multi-boundary solvers (ipde/embedded_function.py:105-113,135-138 and
  * ipde/solvers/multi_boundary/scalar.py:72-117 do them with numpy masks).  All arrays DEVICE; idx:
  * int64 positions in the flat grid, each at most once.

@@ -81,6 +81,8 @@ SIGNATURES = {
     "ipde_dense_lu_solve_batch": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "ipde_chebfourier_gather": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ipde_dense_lu_factor": (_int, [_vp, _i64, _vp, _vp]),
+    "ipde_stokes_rotate": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp, _int, _vp, _vp]),
+    "ipde_stokes_interface_jumps": (_int, [_vp, _int, _int] + [_vp] * 10 + [ctypes.c_double] + [_vp] * 4),
     "ipde_grid_scatter": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "ipde_grid_add_at": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "ipde_grid_gather": (_int, [_vp, _i64, _vp, _vp, _vp]),
@@ -137,7 +139,8 @@ def load():
 
 def _uses_fft(name):
     """entry points that may create or run rocFFT plans"""
-    return name.startswith(("ipde_fft", "ipde_fourier", "ipde_annular", "ipde_grid_interp", "ipde_radial_to_grid")) \
+    return name.startswith(("ipde_fft", "ipde_fourier", "ipde_annular", "ipde_grid_interp", "ipde_radial_to_grid",
+                            "ipde_stokes_interface")) \
         or name.endswith("_grid_solve")
 
 

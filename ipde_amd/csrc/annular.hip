@@ -1721,3 +1721,130 @@ extern "C" int ipde_annular_stokes_solve(ipde_annular_stokes* h, int loc, const 
                      *iters, *resid);
     return st_g;
 }
+
+// ===========================================================================
+// Stokes helper algebra between the annular solve and the QFS solves (reference
+// ipde/solvers/internals/vector.py:65-144: convert_rt_to_uv, get_interface_traction_uvp, the
+// traction / velocity jumps), on device arrays, one library call: the tangential derivative by
+// two batched 1-D transforms, everything else in two kernels.  In the multi-boundary solver this
+// replaces ~55 small tensor operations per boundary issued from a Python thread.
+namespace {
+
+// geom: bnx, bny, btx, bty (boundary normal / tangent), inx, iny (interface normal): 6 rows of n
+__global__ __launch_bounds__(256) void stokes_rotate_kernel(const double* __restrict__ a,
+                                                            const double* __restrict__ b,
+                                                            const double* __restrict__ geom, int M, int n,
+                                                            int to_rt, double* __restrict__ o1,
+                                                            double* __restrict__ o2) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * n) return;
+    const int j = (int)(idx % n);
+    const double nx = geom[j], ny = geom[n + j], tx = geom[2 * n + j], ty = geom[3 * n + j];
+    const double x = a[idx], y = b[idx];
+    if (to_rt) {                // (u, v) -> (r, t)   (embedded_boundary.py:242-244)
+        o1[idx] = x * nx + y * ny;
+        o2[idx] = x * tx + y * ty;
+    } else {                    // (r, t) -> (u, v)   (:246-248)
+        o1[idx] = x * nx + y * tx;
+        o2[idx] = x * ny + y * ty;
+    }
+}
+
+__global__ __launch_bounds__(256) void stokes_ik_kernel(cd* __restrict__ h, const double* __restrict__ rk,
+                                                        int M, int n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * n) return;
+    const double k = rk[idx % n];
+    const cd v = h[idx];
+    h[idx] = cd{-k * v.y, k * v.x};          // times i k
+}
+
+// a thread per interface node j: tractions of the annular solution on the interface, then the jumps
+__global__ __launch_bounds__(256) void stokes_jump_kernel(const double* __restrict__ rr,
+                                                          const double* __restrict__ tr,
+                                                          const double* __restrict__ pr,
+                                                          const cd* __restrict__ dth,     // ifft(i k fft(rr)), unscaled
+                                                          const double* __restrict__ geom,
+                                                          const double* __restrict__ rs,
+                                                          const double* __restrict__ irs,
+                                                          const double* __restrict__ D00,
+                                                          const double* __restrict__ est,
+                                                          const double* __restrict__ bdata, int M, int n,
+                                                          double sign, double* __restrict__ taus,
+                                                          double* __restrict__ taud) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const double invn = 1.0 / (double)n;
+    double e_rr = 0.0, e_p = 0.0, e_tr = 0.0, e_rt = 0.0;
+    for (int m = 0; m < M; ++m) {
+        double s_r = 0.0, s_t = 0.0;
+        const double* Dm = D00 + (size_t)m * M;
+#pragma unroll 4
+        for (int k = 0; k < M; ++k) {
+            const size_t kj = (size_t)k * n + j;
+            s_r = fma(Dm[k], rr[kj], s_r);                      // (D00 Ur)[m]
+            s_t = fma(Dm[k], tr[kj] * irs[kj], s_t);            // (D00 (Ut / speed))[m]
+        }
+        const size_t mj = (size_t)m * n + j;
+        const double e = est[m];
+        e_rr = fma(e, s_r, e_rr);
+        e_p = fma(e, pr[mj], e_p);
+        e_tr = fma(e, rs[mj] * s_t, e_tr);                       // Utr = speed * D00 (Ut / speed)
+        e_rt = fma(e, (dth[mj].x * invn) * irs[mj], e_rt);       // Urt = d_t Ur / speed
+    }
+    const double Tr = 2.0 * e_rr - e_p, Tt = e_tr + e_rt;
+    const double bnx = geom[j], bny = geom[n + j], btx = geom[2 * n + j], bty = geom[3 * n + j];
+    const double inx = geom[4 * n + j], iny = geom[5 * n + j];
+    const double rtx = Tr * bnx + Tt * btx, rty = Tr * bny + Tt * bty;
+    const double bu = bdata[j], bv = bdata[n + j], bxx = bdata[2 * n + j], bxy = bdata[3 * n + j],
+                 byy = bdata[4 * n + j];
+    const double gx = bxx * inx + bxy * iny, gy = bxy * inx + byy * iny;
+    taus[j] = sign * (rtx - gx);
+    taus[n + j] = sign * (rty - gy);
+    taud[j] = sign * bu;
+    taud[n + j] = sign * bv;
+}
+
+}  // namespace
+
+extern "C" int ipde_stokes_rotate(ipde_ctx* ctx, int loc, int M, int n, const double* a, const double* b,
+                                  const double* geom, int to_rt, double* o1, double* o2) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, (loc == IPDE_HOST || loc == IPDE_DEVICE) && M >= 1 && n >= 1 && a && b && geom && o1 && o2);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const double *da, *db;
+    IPDE_TRY(ipde_stage_in(ctx, loc, 0, a, (size_t)M * n, &da));
+    IPDE_TRY(ipde_stage_in(ctx, loc, 1, b, (size_t)M * n, &db));
+    hipLaunchKernelGGL(stokes_rotate_kernel, dim3(nb256((int64_t)M * n)), dim3(256), 0, ctx->stream, da, db, geom,
+                       M, n, to_rt, o1, o2);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
+extern "C" int ipde_stokes_interface_jumps(ipde_ctx* ctx, int M, int n, const double* rr, const double* tr,
+                                           const double* pr, const double* geom, const double* rs,
+                                           const double* irs, const double* D00, const double* est,
+                                           const double* rk, const double* bdata, double sign, double* ur,
+                                           double* vr, double* taus, double* taud) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, M >= 1 && n >= 1 && rr && tr && pr && geom && rs && irs && D00 && est && rk && bdata);
+    IPDE_CHECK_ARG(ctx, ur && vr && taus && taud && (sign == 1.0 || sign == -1.0));
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)M * n * sizeof(cd);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->r2g[0], bytes));
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->r2g[1], bytes));
+    cd* A = (cd*)ctx->r2g[0].p;
+    cd* B = (cd*)ctx->r2g[1].p;
+    hipStream_t st = ctx->stream;
+    const unsigned g = nb256((int64_t)M * n);
+    // d/dt of the radial component along the annulus' rows: ifft(i k fft(.))
+    hipLaunchKernelGGL(r2c_copy_kernel, dim3(g), dim3(256), 0, st, A, rr, (int64_t)M * n, 1.0);
+    IPDE_TRY(ipde_fft1_exec(ctx, M, n, -1, A, B));
+    hipLaunchKernelGGL(stokes_ik_kernel, dim3(g), dim3(256), 0, st, B, rk, M, n);
+    IPDE_TRY(ipde_fft1_exec(ctx, M, n, +1, B, A));
+    hipLaunchKernelGGL(stokes_jump_kernel, dim3(nb256(n)), dim3(256), 0, st, rr, tr, pr, (const cd*)A, geom, rs, irs,
+                       D00, est, bdata, M, n, sign, taus, taud);
+    hipLaunchKernelGGL(stokes_rotate_kernel, dim3(g), dim3(256), 0, st, rr, tr, geom, M, n, 0, ur, vr);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}

@@ -130,46 +130,39 @@ class VectorHelper(object):
             up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=float), device=dev)
             e, b, iface = self.ebdy, self.ebdy.bdy, self.ebdy.interface
             c = self._dev_const = dict(
-                inx=up(iface.normal_x), iny=up(iface.normal_y), iw=up(iface.weights),
-                bnx=up(b.normal_x), bny=up(b.normal_y), btx=up(b.tangent_x), bty=up(b.tangent_y),
-                D00=up(e.D00), ik=torch.as_tensor(1j * np.asarray(e.radial_k, dtype=float), device=dev),
-                rs=up(e.radial_speed), irs=up(e.inverse_radial_speed), iv_est=up(self._iv_estimator),
+                # boundary normal / tangent, interface normal: the `geom` block of the library calls
+                geom=up(np.stack([b.normal_x, b.normal_y, b.tangent_x, b.tangent_y, iface.normal_x, iface.normal_y])),
+                iw=up(iface.weights), D00=up(e.D00), rk=up(e.radial_k), rs=up(e.radial_speed),
+                irs=up(e.inverse_radial_speed), iv_est=up(self._iv_estimator),
                 zero=torch.zeros(b.N, dtype=torch.float64, device=dev))
         return c
 
-    def _interface_traction_uvp_device(self, u, v, p):
-        """get_interface_traction_uvp (:65-112) on device tensors"""
-        import torch
-        from ...spectral import fft1
-        c = self._device_constants()
-        ctx = getattr(self.annular_solver, 'ctx', None)
-        tder = lambda f: fft1(fft1(f, -1, ctx) * c['ik'], +1, ctx).real      # (fft1 scales the inverse)
-        est = lambda X: torch.mv(X.t(), c['iv_est'])
-        Ur, Ut = u * c['bnx'] + v * c['bny'], u * c['btx'] + v * c['bty']
-        Urr = c['D00'] @ Ur
-        Urt = tder(Ur) * c['irs']
-        Utr = c['rs'] * (c['D00'] @ (Ut * c['irs']))
-        Tr = 2 * est(Urr) - est(p)
-        Tt = est(Utr) + est(Urt)
-        return Tr * c['bnx'] + Tt * c['btx'], Tr * c['bny'] + Tt * c['bty']
-
     def _start_call_device(self, fur, fvr, bu, bv, btxx, btxy, btyy, **kwargs):
+        """start_call on device tensors: two library calls around the annular solve
+        (ipde_stokes_rotate, ipde_stokes_interface_jumps in csrc/annular.hip) on this helper's own
+        context — the forcing's (r, t) components; the solution's (u, v) components, its
+        interface traction and the jumps"""
         import torch
+        from ... import _lib
+        from ...device import get_context, ptr
         c = self._device_constants()
-        btx = btxx * c['inx'] + btxy * c['iny']
-        bty = btxy * c['inx'] + btyy * c['iny']
-        f2 = torch.as_tensor(np.ascontiguousarray(np.stack([fur, fvr]), dtype=float), device=bu.device)
-        fr, ft = f2[0] * c['bnx'] + f2[1] * c['bny'], f2[0] * c['btx'] + f2[1] * c['bty']
+        ctx = getattr(self.annular_solver, 'ctx', None) or get_context()
+        M, N = self.ebdy.radial_shape
+        dev = bu.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+        fr, ft = new(M, N), new(M, N)
+        fu, fv = (np.ascontiguousarray(a, dtype=float) for a in (fur, fvr))
+        ctx.check(ctx.lib.ipde_stokes_rotate(ctx.handle, _lib.IPDE_HOST, M, N, ptr(fu), ptr(fv), ptr(c['geom']), 1,
+                                             ptr(fr), ptr(ft)))
         z = c['zero']
         rr, tr, pr = self.annular_solver.solve(self.RAG, fr, ft, z, z, z, z, **kwargs)
         self.iterations_last_call = self.annular_solver.iterations_last_call
-        ur, vr = rr * c['bnx'] + tr * c['btx'], rr * c['bny'] + tr * c['bty']
-        rtx, rty = self._interface_traction_uvp_device(ur, vr, pr)
-        taus = torch.cat([rtx - btx, rty - bty])
-        taud = torch.cat([bu, bv])
-        if not self.interior:
-            taus = -taus
-            taud = -taud
+        bdata = torch.stack([bu, bv, btxx, btxy, btyy]).contiguous()
+        ur, vr, taus, taud = new(M, N), new(M, N), new(2 * N), new(2 * N)
+        ctx.check(ctx.lib.ipde_stokes_interface_jumps(
+            ctx.handle, M, N, ptr(rr), ptr(tr), ptr(pr), ptr(c['geom']), ptr(c['rs']), ptr(c['irs']), ptr(c['D00']),
+            ptr(c['iv_est']), ptr(c['rk']), ptr(bdata), 1.0 if self.interior else -1.0, ptr(ur), ptr(vr),
+            ptr(taus), ptr(taud)))
         self.ur, self.vr, self.pr = ur, vr, pr
         return [(self.interface_qfs_g, [taus, taud]), (self.interface_qfs_r, [taus, taud])]
 
