@@ -320,6 +320,12 @@ int ipde_radial_to_grid(ipde_ctx* ctx, int loc, int64_t nfld, int64_t M, int64_t
  *                                taus = sign [traction - T n], taud = sign [u, v], each 2 n doubles
  *                                (sign: +1 interior, -1 exterior boundary)
  */
+/*   ipde_scalar_interface_jumps  the scalar counterpart (ipde/solvers/internals/scalar.py:76-90):
+ *                                slp = sign [est . ur - (u_x n_x + u_y n_y)], dlp = sign u on the interface;
+ *                                ur (M, n), est (M), nrm (2 x n: interface normal), bdata (3 x n: u, u_x, u_y)
+ *                                of the grid solution); all DEVICE */
+int ipde_scalar_interface_jumps(ipde_ctx* ctx, int M, int n, const double* ur, const double* est,
+                                const double* nrm, const double* bdata, double sign, double* slp, double* dlp);
 int ipde_stokes_rotate(ipde_ctx* ctx, int loc, int M, int n, const double* a, const double* b,
                        const double* geom, int to_rt, double* o1, double* o2);
 int ipde_stokes_interface_jumps(ipde_ctx* ctx, int M, int n, const double* rr, const double* tr,

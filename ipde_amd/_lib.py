@@ -81,6 +81,7 @@ SIGNATURES = {
     "ipde_dense_lu_solve_batch": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "ipde_chebfourier_gather": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ipde_dense_lu_factor": (_int, [_vp, _i64, _vp, _vp]),
+    "ipde_scalar_interface_jumps": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp]),
     "ipde_stokes_rotate": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp, _int, _vp, _vp]),
     "ipde_stokes_interface_jumps": (_int, [_vp, _int, _int] + [_vp] * 10 + [ctypes.c_double] + [_vp] * 4),
     "ipde_grid_scatter": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),

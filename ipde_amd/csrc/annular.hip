@@ -1848,3 +1848,36 @@ extern "C" int ipde_stokes_interface_jumps(ipde_ctx* ctx, int M, int n, const do
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }
+
+// The scalar counterpart (reference ipde/solvers/internals/scalar.py:76-90): interface normal
+// derivative of the annular solution by the estimator row, jumps against the grid solution's value
+// and gradient.  nrm: DEVICE, 2 x n (interface normal x, y); bdata: DEVICE, 3 x n (u, u_x, u_y).
+namespace {
+__global__ __launch_bounds__(256) void scalar_jump_kernel(const double* __restrict__ ur,
+                                                          const double* __restrict__ est,
+                                                          const double* __restrict__ nrm,
+                                                          const double* __restrict__ bdata, int M, int n,
+                                                          double sign, double* __restrict__ slp,
+                                                          double* __restrict__ dlp) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double urn = 0.0;
+#pragma unroll 4
+    for (int m = 0; m < M; ++m) urn = fma(est[m], ur[(size_t)m * n + j], urn);
+    const double ucn = bdata[n + j] * nrm[j] + bdata[2 * n + j] * nrm[n + j];
+    slp[j] = sign * (urn - ucn);
+    dlp[j] = sign * bdata[j];
+}
+}  // namespace
+
+extern "C" int ipde_scalar_interface_jumps(ipde_ctx* ctx, int M, int n, const double* ur, const double* est,
+                                           const double* nrm, const double* bdata, double sign, double* slp,
+                                           double* dlp) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, M >= 1 && n >= 1 && ur && est && nrm && bdata && slp && dlp && (sign == 1.0 || sign == -1.0));
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(scalar_jump_kernel, dim3(nb256(n)), dim3(256), 0, ctx->stream, ur, est, nrm, bdata, M, n, sign,
+                       slp, dlp);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}

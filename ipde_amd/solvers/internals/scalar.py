@@ -111,25 +111,28 @@ class ScalarHelper(object):
             dev = self._interface_dev.x.device
             up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=float), device=dev)
             iface = self.ebdy.interface
-            c = self._dev_const = dict(nx=up(iface.normal_x), ny=up(iface.normal_y),
+            c = self._dev_const = dict(nrm=up(np.stack([iface.normal_x, iface.normal_y])),
                                        in_est=up(self._in_estimator),
                                        zero=torch.zeros(iface.N, dtype=torch.float64, device=dev))
         return c
 
     def _start_call_device(self, fr, bv, bx, by, **kwargs):
         import torch
+        from ...device import get_context, ptr
         c = self._device_constants()
-        ucn = bx * c['nx'] + by * c['ny']
         frd = fr if isinstance(fr, torch.Tensor) else \
             torch.as_tensor(np.ascontiguousarray(fr, dtype=float), device=bv.device)
         ur = self.annular_solver.solve(self.RAG, frd, c['zero'], c['zero'], **kwargs)
         self.iterations_last_call = self.annular_solver.iterations_last_call
-        urn = torch.mv(ur.t(), c['in_est'])          # interface normal derivative (:83)
-        slp = urn - ucn
-        dlp = bv.clone()
-        if not self.interior:
-            slp = -slp
-            dlp = -dlp
+        # interface normal derivative (:83) and the jumps (:84-90): one kernel on the annular
+        # solver's context (csrc/annular.hip: ipde_scalar_interface_jumps)
+        ctx = getattr(self.annular_solver, 'ctx', None) or get_context()
+        M, N = ur.shape
+        bdata = torch.stack([bv, bx, by]).contiguous()
+        slp = torch.empty(N, dtype=torch.float64, device=bv.device)
+        dlp = torch.empty(N, dtype=torch.float64, device=bv.device)
+        ctx.check(ctx.lib.ipde_scalar_interface_jumps(ctx.handle, M, N, ptr(ur), ptr(c['in_est']), ptr(c['nrm']),
+                                                      ptr(bdata), 1.0 if self.interior else -1.0, ptr(slp), ptr(dlp)))
         self.ur = ur
         return [(self.interface_qfs_g, [slp, dlp]), (self.interface_qfs_r, [slp, dlp])]
 
