@@ -4,6 +4,7 @@
  *     failure path goes through ipde_ctx_destroy; on success the context is destroyed again
  *   - every entry point with a NULL context / plan / handle returns IPDE_ERR_INVALID
  * Prints "ok" and exits 0; a sanitizer report aborts. */
+#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 #include "../../include/ipde_hip.h"
@@ -57,6 +58,21 @@ int main(void) {
     EXPECT_INVALID(ipde_annular_scalar_solve(NULL, IPDE_HOST, &x, &x, &x, 0, 1e-12, 10, 5, &x, &iters, &x));
     EXPECT_INVALID(ipde_ewald_destroy(NULL));
     EXPECT_INVALID(ipde_dense_lu_solve(NULL, 1, &x, NULL, &x, &x));
+    {
+        int perm = 0;
+        int64_t i64 = 0;
+        double* outs[1] = {&x};
+        EXPECT_INVALID(ipde_dense_lu_factor(NULL, 128, &x, &perm));
+        EXPECT_INVALID(ipde_dense_gemv(NULL, 1, 1, &x, &x, &x, 0));
+        EXPECT_INVALID(ipde_radial_to_grid(NULL, IPDE_HOST, 1, 4, 32, &x, &x, 1, &x, &x, NULL, outs));
+        EXPECT_INVALID(ipde_grid_scatter(NULL, 1, 1, &i64, &x, NULL, &x));
+        EXPECT_INVALID(ipde_grid_add_at(NULL, 1, &i64, &x, &x));
+        EXPECT_INVALID(ipde_grid_gather(NULL, 1, &i64, &x, &x));
+        EXPECT_INVALID(ipde_scalar_interface_jumps(NULL, 4, 8, &x, &x, &x, &x, 1.0, &x, &x));
+        EXPECT_INVALID(ipde_stokes_rotate(NULL, IPDE_HOST, 4, 8, &x, &x, &x, 1, &x, &x));
+        EXPECT_INVALID(ipde_stokes_interface_jumps(NULL, 4, 8, &x, &x, &x, &x, &x, &x, &x, &x, &x, &x, 1.0, &x, &x, &x,
+                                                   &x));
+    }
     puts("ok");
     return 0;
 }

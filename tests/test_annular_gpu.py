@@ -250,3 +250,72 @@ def test_gmres_graph_replay_is_bitwise_the_eager_solve(gs, scalar_geo, gst, stok
         V.ctx.set_option("gmres_graphs", 0)
     for x, y, z in zip(a, b, c):
         assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
+def test_helper_jump_kernels_match_the_numpy_statements():
+    """ipde_scalar_interface_jumps / ipde_stokes_rotate / ipde_stokes_interface_jumps (csrc/annular.hip)
+    against the numpy statements of the helpers they replace (reference internals/scalar.py:76-90,
+    internals/vector.py:65-144), on random data"""
+    import ctypes
+    import torch
+    from ipde_amd import _lib
+    from ipde_amd.device import get_context, ptr
+    ctx = get_context()
+    rng = np.random.default_rng(21)
+    M, N = 14, 600
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    new = lambda *s: torch.empty(s, dtype=torch.float64, device="cuda")
+    # (device copies are held in names: a temporary passed as ptr(up(x)) would be freed, and its
+    # memory handed to the next one, before the kernel runs)
+    # scalar
+    ur, est, nrm, bd = rng.standard_normal((M, N)), rng.standard_normal(M), rng.standard_normal((2, N)), \
+        rng.standard_normal((3, N))
+    d_ur, d_est, d_nrm, d_bd = up(ur), up(est), up(nrm), up(bd)
+    slp, dlp = new(N), new(N)
+    for sign in (1.0, -1.0):
+        ctx.check(ctx.lib.ipde_scalar_interface_jumps(ctx.handle, M, N, ptr(d_ur), ptr(d_est), ptr(d_nrm),
+                                                      ptr(d_bd), sign, ptr(slp), ptr(dlp)))
+        ref = sign * (est @ ur - (bd[1] * nrm[0] + bd[2] * nrm[1]))
+        assert np.abs(slp.cpu().numpy() - ref).max() < 1e-13 * np.abs(ref).max()
+        assert np.array_equal(dlp.cpu().numpy(), sign * bd[0])
+    # Stokes: rotation there and back, host and device inputs
+    th = rng.uniform(0, 2 * np.pi, N)
+    geom = np.stack([np.cos(th), np.sin(th), -np.sin(th), np.cos(th), np.cos(th + 0.1), np.sin(th + 0.1)])
+    d_geom = up(geom)
+    fu, fv = rng.standard_normal((M, N)), rng.standard_normal((M, N))
+    fr, ft, bu, bv = new(M, N), new(M, N), new(M, N), new(M, N)
+    ctx.check(ctx.lib.ipde_stokes_rotate(ctx.handle, _lib.IPDE_HOST, M, N, ptr(fu), ptr(fv), ptr(d_geom), 1,
+                                         ptr(fr), ptr(ft)))
+    assert np.allclose(fr.cpu().numpy(), fu * geom[0] + fv * geom[1], rtol=0, atol=1e-15)
+    assert np.allclose(ft.cpu().numpy(), fu * geom[2] + fv * geom[3], rtol=0, atol=1e-15)
+    ctx.check(ctx.lib.ipde_stokes_rotate(ctx.handle, _lib.IPDE_DEVICE, M, N, ptr(fr), ptr(ft), ptr(d_geom), 0,
+                                         ptr(bu), ptr(bv)))
+    assert np.abs(bu.cpu().numpy() - fu).max() < 1e-14 and np.abs(bv.cpu().numpy() - fv).max() < 1e-14
+    # Stokes: tractions and jumps
+    rr, tr, pr = (rng.standard_normal((M, N)) for _ in range(3))
+    rs = 1.0 + 0.3 * rng.uniform(size=(M, N))
+    irs = 1.0 / rs
+    D00, rk, bdata = rng.standard_normal((M, M)), np.fft.fftfreq(N, 1.0 / N) * 1.3, rng.standard_normal((5, N))
+    tder = lambda f: np.fft.ifft(np.fft.fft(f) * 1j * rk).real
+    Urr, Urt, Utr = D00 @ rr, tder(rr) * irs, rs * (D00 @ (tr * irs))
+    Tr, Tt = 2 * est @ Urr - est @ pr, est @ Utr + est @ Urt
+    rtx, rty = Tr * geom[0] + Tt * geom[2], Tr * geom[1] + Tt * geom[3]
+    gx, gy = bdata[2] * geom[4] + bdata[3] * geom[5], bdata[3] * geom[4] + bdata[4] * geom[5]
+    o_ur, o_vr, taus, taud = new(M, N), new(M, N), new(2 * N), new(2 * N)
+    dev = [up(a) for a in (rr, tr, pr, geom, rs, irs, D00, est, rk, bdata)]
+    ctx.check(ctx.lib.ipde_stokes_interface_jumps(ctx.handle, M, N, *[ptr(a) for a in dev], -1.0, ptr(o_ur),
+                                                  ptr(o_vr), ptr(taus), ptr(taud)))
+    ref_s = -np.concatenate([rtx - gx, rty - gy])
+    assert np.abs(taus.cpu().numpy() - ref_s).max() < 1e-12 * np.abs(ref_s).max()
+    assert np.array_equal(taud.cpu().numpy(), -np.concatenate([bdata[0], bdata[1]]))
+    assert np.allclose(o_ur.cpu().numpy(), rr * geom[0] + tr * geom[2], rtol=0, atol=1e-15)
+    assert np.allclose(o_vr.cpu().numpy(), rr * geom[1] + tr * geom[3], rtol=0, atol=1e-15)
+    # argument checks
+    assert ctx.lib.ipde_scalar_interface_jumps(ctx.handle, 0, N, ptr(slp), ptr(slp), ptr(slp), ptr(slp), 1.0,
+                                               ptr(slp), ptr(dlp)) == 1
+    assert ctx.lib.ipde_scalar_interface_jumps(ctx.handle, M, N, ptr(slp), ptr(slp), ptr(slp), ptr(slp), 0.5,
+                                               ptr(slp), ptr(dlp)) == 1
+    assert ctx.lib.ipde_stokes_rotate(ctx.handle, 7, M, N, ptr(fr), ptr(ft), ptr(fr), 1, ptr(fr), ptr(ft)) == 1
+    assert ctx.lib.ipde_stokes_rotate(ctx.handle, _lib.IPDE_DEVICE, M, N, None, ptr(ft), ptr(fr), 1, ptr(fr),
+                                      ptr(ft)) == 1
+    ctx.sync()
