@@ -70,7 +70,20 @@ int ipde_stage_finish(ipde_ctx* ctx, int loc, int slot, double* p, size_t n) {
 // entry holds R ~ 1/center(interval) and T = -log(R), so that
 //   log(x) = T + log1p(x*R - 1),  |x*R - 1| <= 2^-(B+1) (+ rounding).
 // Built on the host in long double and uploaded once.
+// One table per device and process, shared by every context of the device (read-only; never freed):
+// a context of its own per solver thread / factorisation stream would otherwise each pay the
+// synchronous upload — a blocking copy that waits for whatever the GPU is doing (30 ms apiece
+// inside a set-up).
+static std::mutex g_logtab_mutex;
+static std::map<int, LogTable> g_logtab;
+
 int ipde_build_log_table(ipde_ctx* ctx) {
+    std::lock_guard<std::mutex> guard(g_logtab_mutex);
+    auto it = g_logtab.find(ctx->device);
+    if (it != g_logtab.end()) {
+        ctx->logtab = it->second;
+        return IPDE_OK;
+    }
     LogTable& t = ctx->logtab;
     // 32 binades x 256 mantissa intervals = 8192 entries (128 KiB of LDS).  An entry
     // sits at position (key mod 8192): the kernels index with a shift and a mask
@@ -99,6 +112,7 @@ int ipde_build_log_table(ipde_ctx* ctx) {
     IPDE_HIP_CHECK(ctx, hipMalloc((void**)&t.d_tab, h.size() * sizeof(double)));
     IPDE_HIP_CHECK(ctx, hipMemcpy(t.d_tab, h.data(), h.size() * sizeof(double),
                                   hipMemcpyHostToDevice));
+    g_logtab[ctx->device] = t;
     return IPDE_OK;
 }
 
@@ -172,7 +186,7 @@ extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
     for (auto& kv : ctx->cheb_tab)
         if (kv.second) hipFree(kv.second);
     ctx->cheb_tab.clear();
-    if (ctx->logtab.d_tab) hipFree(ctx->logtab.d_tab);
+    // (the log table belongs to the device, see ipde_build_log_table)
     if (ctx->d_ktab) hipFree(ctx->d_ktab);
     if (ctx->d_lu_abort) hipFree(ctx->d_lu_abort);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);

@@ -115,12 +115,16 @@ def get_context(device=None):
         if not torch.cuda.is_available():
             raise _lib.IpdeHipError("no GPU visible: ipde_amd has no CPU fallback")
         device = torch.cuda.current_device()
+    created = False
     with _lock:
         ctx = _contexts.get(device)
         if ctx is None or not ctx.handle:
             ctx = Context(device)
             _contexts[device] = ctx
-        return ctx
+            created = True
+    if created and device == torch.cuda.current_device():
+        prewarm()            # the host BLAS's thread pool comes up beside whatever the caller does next
+    return ctx
 
 
 def private_context(device=None):
@@ -150,13 +154,17 @@ def _warm_worker():
 
 def prewarm(grid_shape=None, h=None, wait=False, fft1=()):
     """Pay the one-time library costs of a first solve in ONE background thread while the
-    host does geometry set-up: rocBLAS / rocSOLVER loads (first GEMM / LU call), the
-    rocFFT kernels of the batched 1-D transforms `fft1` = ((batch, n), ...) (annular solver,
-    radial interpolation) and, if the grid is given, of the 2-D grid solve (~1.6 s of
-    run-time compilation at 2048^2).  Jobs run strictly one after the other, and every
+    host does geometry set-up: the host BLAS's thread pool (numpy's first LAPACK call, ~0.1 s
+    on a many-core box), the rocFFT kernels of the batched 1-D transforms `fft1` =
+    ((batch, n), ...) (annular solver, radial interpolation) and, if the grid is given, of
+    the 2-D grid solve (~1.6 s of run-time compilation at 2048^2 without the shipped kernel
+    cache).  Jobs run strictly one after the other, and every
     FFT entry point of the package joins the thread first (`prewarm_wait`): rocFFT's plan
     creation / run-time compilation is never entered from two threads at once (doing so
-    crashed a two-rank rehearsal with SIGSEGV).  No-op without a GPU."""
+    crashed a two-rank rehearsal with SIGSEGV).  No-op without a GPU.
+    (rocBLAS / rocSOLVER are no longer loaded here: since the QFS systems are factored,
+    substituted and multiplied by the library's own kernels the scalar solvers never call
+    them, and every FFT entry point used to wait for their ~0.5 s cold load.)"""
     import queue
     import threading
     if not torch.cuda.is_available():
@@ -164,14 +172,8 @@ def prewarm(grid_shape=None, h=None, wait=False, fft1=()):
     dev = torch.cuda.current_device()
 
     def libs():
-        torch.cuda.set_device(dev)
-        d = get_context(dev).torch_device()
-        a = torch.ones((64, 64), dtype=torch.complex128, device=d)
-        (a @ a).sum().item()
-        b = torch.ones((64, 64), dtype=torch.float64, device=d) + torch.eye(64, dtype=torch.float64, device=d)
-        (b @ b).sum().item()
-        LU, piv = torch.linalg.lu_factor(b)
-        torch.linalg.lu_solve(LU, piv, b[:, :1]).sum().item()
+        e = np.eye(8)
+        np.linalg.inv(e + e @ e)
 
     def plans():
         torch.cuda.set_device(dev)
