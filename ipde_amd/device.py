@@ -174,6 +174,24 @@ def prewarm(grid_shape=None, h=None, wait=False, fft1=()):
     def libs():
         e = np.eye(8)
         np.linalg.inv(e + e @ e)
+        # torch loads the code object of every kernel type at its first launch (~10 ms apiece in a
+        # fresh process): a miniature of the QFS matrix assembly (dense_forms) touches the types
+        # the set-up uses, here instead of on the main thread
+        try:
+            from . import dense_forms as df
+            from .pybie2d_compat import Global_Smooth_Boundary, star
+            torch.cuda.set_device(dev)
+            d = torch.device("cuda", dev)
+            b = Global_Smooth_Boundary(c=star(32, a=0.2, f=5))
+            s2 = Global_Smooth_Boundary(c=1.1 * star(32, a=0.2, f=5))
+            m = df.laplace_form(s2, b, d, ifcharge=True, ifdipole=True) \
+                + df.laplace_singular_form(b, d, ifcharge=True, ifdipole=True)
+            m = m + torch.eye(32, dtype=torch.float64, device=d)
+            pad = torch.eye(128, dtype=torch.float64, device=d)
+            pad[:32, :32] = m
+            pad.view(2, 64, 2, 64).permute(0, 2, 3, 1).contiguous().sum().item()
+        except Exception:
+            pass
 
     def plans():
         torch.cuda.set_device(dev)
