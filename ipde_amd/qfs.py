@@ -629,8 +629,9 @@ class Stokes_QFS(_QFS):
                     up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=float), device=mu.device)
                     c = self._p_dev = ([up(r) for r in self._p_rows], up(self._p_src), up(self._n_src))
                 rows, p_src, n_src = c
-                p_true = sum(torch.dot(r, _on_device(d, mu.device)) for r, d in zip(rows, densities))
-                return mu + (p_true - torch.dot(p_src, mu)) / self._p_null * n_src
+                # (products and sums, not torch.dot: that would load rocBLAS for three dot products)
+                p_true = sum((r * _on_device(d, mu.device)).sum() for r, d in zip(rows, densities))
+                return mu + (p_true - (p_src * mu).sum()) / self._p_null * n_src
             p_true = sum(r @ np.asarray(d, dtype=float) for r, d in zip(self._p_rows, densities))
             mu = mu + (p_true - self._p_src @ mu) / self._p_null * self._n_src
         return mu
@@ -678,7 +679,7 @@ class QFS_Evaluator(object):
     def __call__(self, densities):
         if self._dev is not None:
             import torch
-            u = sum(B @ torch.as_tensor(np.ascontiguousarray(d, dtype=float), device=self._dev)
+            u = sum(_gemv(B.contiguous(), torch.as_tensor(np.ascontiguousarray(d, dtype=float), device=self._dev))
                     for B, d in zip(self.b2c_mats, densities))
             return self._fact.solve(self._A, u).cpu().numpy()
         u = sum(B @ np.asarray(d) for B, d in zip(self.b2c_mats, densities))
