@@ -4,6 +4,7 @@ Arrays may be numpy (host; the library stages them through its own device
 workspace) or torch CUDA tensors (device; zero-copy).  torch is used for device
 memory only — every computation on this path is a kernel of libipde_hip.so.
 """
+import atexit
 import ctypes
 import os
 import threading
@@ -218,6 +219,22 @@ def prewarm(grid_shape=None, h=None, wait=False, fft1=()):
                 _warm["queue"].put(fn)
     if wait:
         prewarm_wait()
+
+
+def _drain_at_exit():
+    """A process that ends while the warm-up thread is inside torch / HIP aborts during interpreter
+    shutdown (daemon threads are not joined): let the queue drain first — its jobs are fractions of
+    a second."""
+    q = _warm["queue"]
+    if q is None:
+        return
+    deadline = time.monotonic() + 30.0
+    with q.all_tasks_done:
+        while q.unfinished_tasks and time.monotonic() < deadline:
+            q.all_tasks_done.wait(0.05)
+
+
+atexit.register(_drain_at_exit)
 
 
 def prewarm_wait():

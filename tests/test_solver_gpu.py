@@ -321,3 +321,16 @@ def test_power_of_two_grid_paths_equal_the_general_ones(problem):
     print(problem, err / scale, err0 / scale0)
     assert err / scale < 1e-11 and err0 / scale0 < 1e-11
     assert np.abs(np.asarray(ue) - np.asarray(ue0)).max() < 1e-12 * scale
+
+
+def test_process_that_ends_during_the_warm_up_exits_cleanly():
+    """the warm-up thread (library loads, kernel-type warm-up) starts when the first context is
+    made; a process that ends right away — __graft_entry__.smoke() is such a process — must not
+    abort in interpreter shutdown with that thread inside torch / HIP"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from ipde_amd.device import get_context\n"
+            "get_context()\n") % ROOT
+    for _ in range(2):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-1500:]
