@@ -7,7 +7,7 @@ from ...grid_evaluators.modified_helmholtz_grid_evaluator import (
 
 
 class ModifiedHelmholtzSolver(ScalarSolver):
-    def __init__(self, ebdyc, k, solver_type='spectral', helpers=None, grid_backend='hip',
+    def __init__(self, ebdyc, k, solver_type='spectral', helpers=None, grid_backend=None,
                  source_upsample_factor=1.0):
         self.k = k
         self.source_upsample_factor = source_upsample_factor

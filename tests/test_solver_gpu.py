@@ -334,3 +334,24 @@ def test_process_that_ends_during_the_warm_up_exits_cleanly():
     for _ in range(2):
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-1500:]
+
+
+def test_grid_evaluator_is_chosen_by_problem_size():
+    """grid_backend None: the exact dense sum below ScalarSolver.AUTO_EWALD_MIN_PAIRS source-target
+    pairs (BASELINE configs[1-2]), the Ewald-type split above it (configs[3]); both reach the
+    manufactured solution"""
+    import interior_poisson
+    from ipde_amd.solvers.multi_boundary.scalar import ScalarSolver
+    err, scale, solver, _, _ = interior_poisson.run(nb=600, M=16)
+    assert solver.grid_backend == 'hip' and not solver.split_grid_evaluation
+    old = ScalarSolver.AUTO_EWALD_MIN_PAIRS
+    ScalarSolver.AUTO_EWALD_MIN_PAIRS = 0.0
+    try:
+        err_e, scale_e, solver_e, _, _ = interior_poisson.run(nb=600, M=16)
+    finally:
+        ScalarSolver.AUTO_EWALD_MIN_PAIRS = old
+    assert solver_e.split_grid_evaluation
+    assert err / scale < 1e-10 and err_e / scale_e < 1e-10
+    # an explicit choice is kept
+    _, _, solver_d, _, _ = interior_poisson.run(nb=600, M=16, grid_backend='hip')
+    assert solver_d.grid_backend == 'hip' and not solver_d.split_grid_evaluation
