@@ -13,6 +13,7 @@
 //                        in HBM, CGS2 orthogonalisation (2 fused multi-dots),
 //                        one host sync per iteration (the Hessenberg column).
 #include "ipde_common.h"
+#include "fft_core.h"
 
 int ipde_fft1_exec(ipde_ctx* ctx, int64_t batch, int64_t n, int direction, const void* in,
                    void* out);
@@ -590,7 +591,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     bool use_graphs = ctx->opt_gmres_graphs && st != nullptr && g.graph_failures < 3;
     {
         const long long sig = ((long long)restart << 8) ^ ((long long)(uintptr_t)st << 20) ^
-                              (ctx->opt_annular_grouped ? 1 : 0);
+                              (ctx->opt_annular_grouped ? 1 : 0) ^ (ctx->opt_annular_fused_fft ? 2 : 0);
         if (g.graph_sig != sig) {
             gmres_drop_graphs(g);
             g.graph_sig = sig;
@@ -787,6 +788,65 @@ int set_field(ipde_ctx* ctx, int loc, double* dst, const double* src, size_t n) 
 }  // namespace
 
 // ===========================================================================
+// A stage of the scalar operator is  rows -> inverse FFT -> times a metric field / n -> forward FFT.
+// For power-of-two n up to 4096 the three launches (two batched rocFFT transforms with a pointwise
+// kernel between them, each 5-10 us for 20-40 rows and a dependent kernel boundary apiece) are ONE
+// kernel: a workgroup takes a row, both transforms run in its registers and LDS (fft_core.h, the
+// Stockham passes of the 2-D pipeline), the field is applied in between, in place.
+template <int N>
+__global__ __launch_bounds__(fftcore::Cfg<N>::T) void fft_pair_kernel(cd* __restrict__ x,
+                                                                        const fftcore::cd* __restrict__ tw,
+                                                                        const double* __restrict__ F0,
+                                                                        const double* __restrict__ F1, int rows0,
+                                                                        double s) {
+    using G = fftcore::Cfg<N>;
+    constexpr int T = G::T, P = G::P;
+    extern __shared__ double2 pair_lds[];
+    fftcore::cd* buf = (fftcore::cd*)pair_lds;
+    const int t = threadIdx.x, row = blockIdx.x;
+    fftcore::cd* r = (fftcore::cd*)x + (size_t)row * N;
+    const double* F = row < rows0 ? F0 + (size_t)row * N : F1 + (size_t)(row - rows0) * N;
+    fftcore::cd v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) v[q] = r[t + T * q];
+    fftcore::fft_regs<N, +1, (T == 64)>(v, t, tw, buf);
+    fftcore::lds_sync<(T == 64)>();
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const double f = s * F[t + T * q];
+        v[q] = fftcore::cd{v[q].x * f, v[q].y * f};
+    }
+    fftcore::fft_regs<N, -1, (T == 64)>(v, t, tw, buf);
+#pragma unroll
+    for (int q = 0; q < P; ++q) r[t + T * q] = v[q];
+}
+
+template <int N>
+int launch_fft_pair(ipde_ctx* ctx, cd* x, const void* tw, int rows, const double* F0, const double* F1, int rows0,
+                    double s) {
+    const size_t lds = (size_t)fftcore::lds_slots<N>() * sizeof(fftcore::cd);
+    if (lds > 48 * 1024)
+        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fft_pair_kernel<N>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fft_pair_kernel<N>, dim3((unsigned)rows), dim3(fftcore::Cfg<N>::T), lds, ctx->stream, x,
+                       (const fftcore::cd*)tw, F0, F1, rows0, s);
+    return IPDE_OK;
+}
+
+inline bool fft_pair_supported(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096; }
+
+int fft_pair(ipde_ctx* ctx, int n, cd* x, const void* tw, int rows, const double* F0, const double* F1, int rows0,
+             double s) {
+    switch (n) {
+        case 512: return launch_fft_pair<512>(ctx, x, tw, rows, F0, F1, rows0, s);
+        case 1024: return launch_fft_pair<1024>(ctx, x, tw, rows, F0, F1, rows0, s);
+        case 2048: return launch_fft_pair<2048>(ctx, x, tw, rows, F0, F1, rows0, s);
+        case 4096: return launch_fft_pair<4096>(ctx, x, tw, rows, F0, F1, rows0, s);
+    }
+    return IPDE_ERR_INVALID;
+}
+
+// ===========================================================================
 // scalar (modified Helmholtz / Poisson) annular solver
 struct ipde_annular_scalar : public LinOp {
     int M = 0, n = 0;
@@ -802,10 +862,12 @@ struct ipde_annular_scalar : public LinOp {
     cd *hin = nullptr, *hout = nullptr;  // host-call staging
     GmresWork gw;
     bool have_geom = false;
+    void* tw = nullptr;      // exp(-2 pi i m / n), m < n: the fused transform pairs (power-of-two n <= 4096)
 
     int apply(const cd* uh, cd* out) override {
         hipStream_t st = ctx->stream;
         const int m1 = M - 1, m2 = M - 2;
+        const bool fused = tw != nullptr && ctx->opt_annular_fused_fft;
         dim3 b(256);
         // T1 = R01 (uh * iks), T2 = D01 uh
         {
@@ -814,10 +876,14 @@ struct ipde_annular_scalar : public LinOp {
             Bq.j[1] = MixcJob{T + (size_t)m1 * n, m1, 1, {MixcTerm{D01, uh, nullptr, M}, MixcTerm{}}, nullptr, 0};
             hipLaunchKernelGGL(mixc_fused_kernel, dim3(nb256(n), m1, 2), b, 0, st, Bq, n);
         }
-        IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, +1, T, U));
-        hipLaunchKernelGGL(cscale_field2_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, U, m1, m1, n,
-                           (const double*)ipsi1, (const double*)psi1, 1.0 / n);
-        IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, -1, U, T));
+        if (fused) {
+            IPDE_TRY(fft_pair(ctx, n, T, tw, 2 * m1, ipsi1, psi1, m1, 1.0 / n));
+        } else {
+            IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, +1, T, U));
+            hipLaunchKernelGGL(cscale_field2_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, U, m1, m1, n,
+                               (const double*)ipsi1, (const double*)psi1, 1.0 / n);
+            IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, -1, U, T));
+        }
         // S = R12 (T1 * iks) + D12 T2   -> U[0:m2]
         {
             MixcBatch Bq{};
@@ -825,10 +891,14 @@ struct ipde_annular_scalar : public LinOp {
                               nullptr, 0};
             hipLaunchKernelGGL(mixc_fused_kernel, dim3(nb256(n), m2, 1), b, 0, st, Bq, n);
         }
-        IPDE_TRY(ipde_fft1_exec(ctx, m2, n, +1, U, T));
-        hipLaunchKernelGGL(cscale_field_kernel, dim3(nb256((int64_t)m2 * n)), b, 0, st, T, m2, n,
-                           (const double*)ipsi2, 1.0 / n);
-        IPDE_TRY(ipde_fft1_exec(ctx, m2, n, -1, T, U));
+        if (fused) {
+            IPDE_TRY(fft_pair(ctx, n, U, tw, m2, ipsi2, ipsi2, m2, 1.0 / n));
+        } else {
+            IPDE_TRY(ipde_fft1_exec(ctx, m2, n, +1, U, T));
+            hipLaunchKernelGGL(cscale_field_kernel, dim3(nb256((int64_t)m2 * n)), b, 0, st, T, m2, n,
+                               (const double*)ipsi2, 1.0 / n);
+            IPDE_TRY(ipde_fft1_exec(ctx, m2, n, -1, T, U));
+        }
         // out = B uh ; out[0:m2] -= luh
         {
             MixcBatch Bq{};
@@ -849,6 +919,7 @@ struct ipde_annular_scalar : public LinOp {
             if (*p) hipFree(*p);
         for (cd** p : {&iks, &T, &U, &bvec, &hin, &hout})
             if (*p) hipFree(*p);
+        if (tw) hipFree(tw);
         gmres_free(gw);
     }
 };
@@ -893,6 +964,17 @@ extern "C" int ipde_annular_scalar_create(ipde_ctx* ctx, int M, int n, double he
                 for (int k = 0; k < M; ++k)
                     Kt[((size_t)j * M + k) * n + i] = kinv[((size_t)i * M + j) * M + k];
         up(&h->Kt, Kt.data(), Kt.size());
+    }
+    if (fft_pair_supported(n)) {   // twiddles of the fused transform pairs
+        std::vector<double> w(2 * (size_t)n);
+        for (int m = 0; m < n; ++m) {
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
+            w[2 * m] = (double)cosl(a);
+            w[2 * m + 1] = (double)sinl(a);
+        }
+        double* d = nullptr;
+        up(&d, w.data(), w.size());
+        h->tw = d;
     }
     {   // iks = 1j * fftfreq(n, 1/n)  (annular_full.py:67-71)
         std::vector<double> v(2 * (size_t)n);

@@ -319,3 +319,39 @@ def test_helper_jump_kernels_match_the_numpy_statements():
     assert ctx.lib.ipde_stokes_rotate(ctx.handle, _lib.IPDE_DEVICE, M, N, None, ptr(ft), ptr(fr), 1, ptr(fr),
                                       ptr(ft)) == 1
     ctx.sync()
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_fused_transform_pairs_equal_the_rocfft_stages(n):
+    """option "annular_fused_fft" (default on): for power-of-two n <= 4096 a stage of the scalar
+    operator — inverse FFT, metric field, forward FFT — is one kernel on the fft_core.h transforms
+    instead of two rocFFT calls around a pointwise kernel: the same operator to rounding, the same
+    solution, on a non-circular annulus"""
+    from ipde_amd.annular.annular_full import ApproximateAnnularGeometry, RealAnnularGeometry
+    from ipde_amd.annular.modified_helmholtz import AnnularModifiedHelmholtzSolver
+    M, width, R = 16, 0.12, 1.0
+    aag = ApproximateAnnularGeometry(n, M, width, R)
+    t = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    speed = R * (1.0 + 0.2 * np.cos(3 * t))
+    curv = (1.0 / R) * (1.0 + 0.3 * np.sin(2 * t))
+    rag = RealAnnularGeometry(speed, curv, aag)
+    S = AnnularModifiedHelmholtzSolver(aag, 2.0)
+    S._set_geometry(rag)
+    rng = np.random.default_rng(n)
+    uh = rng.standard_normal(M * n) + 1j * rng.standard_normal(M * n)
+    assert S.ctx.get_option("annular_fused_fft") == 1
+    a1 = np.asarray(S._apply(uh))
+    f = rng.standard_normal((M, n))
+    ig, og = rng.standard_normal(n), rng.standard_normal(n)
+    u1 = np.array(S.solve(rag, f, ig, og, tol=1e-12, maxiter=200, restart=60))
+    it1 = S.iterations_last_call
+    S.ctx.set_option("annular_fused_fft", 0)
+    try:
+        a0 = np.asarray(S._apply(uh))
+        u0 = np.array(S.solve(rag, f, ig, og, tol=1e-12, maxiter=200, restart=60))
+        it0 = S.iterations_last_call
+    finally:
+        S.ctx.set_option("annular_fused_fft", 1)
+    assert np.abs(a1 - a0).max() < 1e-13 * np.abs(a0).max()
+    assert abs(it1 - it0) <= 1
+    assert np.abs(u1 - u0).max() < 1e-9 * np.abs(u0).max()
