@@ -125,3 +125,18 @@ def test_lu_factor_argument_checks():
     assert call(ctx.handle, 128, ptr(T), None) == 1
     assert call(None, 128, ptr(T), ptr(p)) == 1
     ctx.sync()
+
+
+def test_factorisations_on_side_streams_equal_the_in_stream_one():
+    """qfs._OwnAsyncLU (private contexts bound to non-blocking torch streams, round robin): five
+    matrices factored back to back give the factors and pivots of the in-stream call"""
+    import torch
+    from ipde_amd import qfs
+    rng = np.random.default_rng(8)
+    mats = [torch.as_tensor(rng.standard_normal((n, n)), device="cuda") for n in (700, 1300, 200, 1300, 64)]
+    side = [qfs._OwnAsyncLU(A) for A in mats]          # all enqueued before any is used
+    for A, f in zip(mats, side):
+        g = qfs._own_lu(A)
+        assert torch.equal(f.perm, g.perm) and torch.equal(f.LU, g.LU)
+        b = torch.as_tensor(rng.standard_normal(A.shape[0]), device="cuda")
+        assert torch.equal(f._subst(b), g._subst(b))

@@ -350,3 +350,27 @@ def test_grid_list_moves():
     assert ctx.lib.ipde_grid_gather(ctx.handle, 5, None, ptr(g), ptr(e)) == 1
     assert ctx.lib.ipde_grid_add_at(None, 0, ptr(ei), ptr(e), ptr(g)) == 1
     ctx.sync()
+
+
+def test_host_io_staged_upload_and_pinned_result():
+    """ipde_amd/hostio.py: the forcing's chunked, thread-staged upload and the result container
+    built over pinned memory"""
+    import torch
+    from ipde_amd import hostio
+    rng = np.random.default_rng(4)
+    for n in (10, (1 << 18) - 3, 3 * (1 << 20) + 17):
+        src = rng.standard_normal(n)
+        pin = torch.empty(n, dtype=torch.float64, pin_memory=True)
+        dst = torch.empty(n, dtype=torch.float64, device="cuda")
+        hostio.upload(dst, src, pin)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), src)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples'))
+    import interior_poisson   # (an ebdyc to build a container on)
+    _, _, solver, ue, _ = interior_poisson.run(nb=400, M=12)
+    f, block = hostio.pinned_function(solver.ebdyc)
+    assert block.is_pinned() and f.shape == np.asarray(ue).shape
+    block.copy_(torch.as_tensor(np.asarray(ue), device="cuda"), non_blocking=False)
+    assert np.array_equal(np.asarray(f), np.asarray(ue))
+    assert np.array_equal(f[0], ue[0])        # the radial block of boundary 0 through the container
