@@ -95,6 +95,12 @@ class ScalarFreespaceGridEvaluator(object):
         raise NotImplementedError
 
     def __call__(self, src, ch, device_result=False):
+        if type(ch).__module__.startswith('torch'):
+            # device-resident sources and charges (the solvers' device flow): straight to the spread
+            if self._ewald is None:
+                raise ValueError("device charges need the Ewald method (method='ewald')")
+            out = self._ewald(src[0].contiguous(), src[1].contiguous(), ch.contiguous())
+            return out if device_result else out.cpu().numpy()
         src = np.asarray(src, dtype=float)
         ch = np.asarray(ch, dtype=float)
         if self._ewald is not None:

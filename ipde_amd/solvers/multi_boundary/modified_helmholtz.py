@@ -64,6 +64,12 @@ class ModifiedHelmholtzSolver(ScalarSolver):
                 self.ewald_evaluator = self.grid_backend
 
             def evaluator(ch):
+                if type(ch).__module__.startswith('torch'):      # device flow: sources resident too
+                    from ...layer_potentials import _device_source
+                    from ...device import get_context
+                    import torch
+                    d = _device_source(self.grid_sources, get_context())
+                    return self.ewald_evaluator(torch.stack([d.x, d.y]), ch * d.weights, device_result=True)
                 return self.ewald_evaluator(self.grid_sources.get_stacked_boundary(),
                                             ch * self.grid_sources.weights, device_result=True)
             self.Grid_Evaluator = evaluator

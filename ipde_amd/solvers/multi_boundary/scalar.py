@@ -207,8 +207,13 @@ class ScalarSolver(object):
             grid_out = self.Grid_Evaluator(sigmag)
             grid_out = grid_out if isinstance(grid_out, torch.Tensor) \
                 else torch.as_tensor(grid_out, device=self._dev)
-            grid_pna = grid_out.reshape(-1)[self._pna_idx]
-            interface_out = self.Layer_Apply(self.grid_sources, self.ebdyc.all_iv, sigmag)
+            grid_pna = gridops.gather(self._pna_idx, grid_out.reshape(-1).contiguous())
+            if isinstance(sigmag, torch.Tensor):     # device flow: the interface nodes resident too
+                if getattr(self, '_all_iv_dev', None) is None:
+                    self._all_iv_dev = DeviceTargets(self.ebdyc.all_iv)
+                interface_out = self.Layer_Apply(self.grid_sources, self._all_iv_dev, sigmag)
+            else:
+                interface_out = self.Layer_Apply(self.grid_sources, self.ebdyc.all_iv, sigmag)
             return torch.cat([grid_pna, torch.as_tensor(interface_out, device=self._dev)])
         return self.Grid_Evaluator(sigmag)
 
@@ -239,7 +244,7 @@ class ScalarSolver(object):
         # In one process the per-boundary vectors now stay in HBM through all the stages below
         # (helpers' device forms, qfs.call_many / u2s_many and the layer applies pass device
         # tensors through); the torch.distributed path keeps the host vectors its exchanges take.
-        device_flow = self.DEVICE_FLOW and not is_distributed() and not self.split_grid_evaluation
+        device_flow = self.DEVICE_FLOW and not is_distributed()
         if not device_flow:
             all_bvs = all_bvs.cpu().numpy()
         bvl, bxl, byl = e.v2l(all_bvs[0]), e.v2l(all_bvs[1]), e.v2l(all_bvs[2])
