@@ -35,6 +35,9 @@ VALU_INSTR_PER_PAIR = 11.0     # ISA count of the row-run table kernel: 8.5 fp64
                                # + 2.5 int32 (v_bfe, v_lshl_add, one v_min3_u32 per two pairs for the
                                # lower table bound; the upper one is guaranteed by the scaling); every VALU
                                # instruction, fp64 or int32, occupies the SIMD for one quad-cycle here
+VALU_INSTR_PER_PAIR_PATCH = 10.4   # ISA count of laplace_patch_kernel: 8.06 fp64 (eight subs and squares per
+                                   # source and 16 targets, d2 = one fma, y, 4 fma, accumulate) + 2 int32 +
+                                   # 0.34 for the table bound (min of dx^2 + min of dy^2 per patch)
 PEAK_VALU_LANE_INSTR = 256 * 4 * 16 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz
 PEAK_FP64_VECTOR_TFLOPS = 78.6  # MI355X fp64 vector (= 256 CU*4 SIMD*32 flop/clk*2.4 GHz)
 PEAK_HBM_GBS = 8000.0
@@ -169,6 +172,8 @@ def main():
                     help="strong (default): one 2048^2 target list split over the ranks; "
                          "weak: one 2048^2 grid per rank")
     ap.add_argument("--no-fft", action="store_true", help="skip the spectral-path measurement")
+    ap.add_argument("--no-patches", action="store_true",
+                    help="the list kernel (laplace_rowrun_kernel) instead of the 4 x 4 patch kernel")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="all ranks on cuda:0, collectives over gloo through host memory: exercises the "
                          "N > 1 code path on a one-GPU box (a rehearsal, not a measurement)")
@@ -201,7 +206,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ipde_amd.device import get_context
-    from ipde_amd import layer_potentials as lp
+    from ipde_amd import layer_potentials as lp, target_plan
 
     ctx = get_context(local_rank)
     if args.variant is not None:
@@ -211,7 +216,10 @@ def main():
     from ipde_amd.sharding import target_slice
     strong = args.scaling == "strong"
     sl = target_slice(trg.N, rank, world) if strong else slice(0, trg.N)
-    dt = lp.DeviceTargets(trg.x[sl], trg.y[sl], ctx=ctx)
+    # the list resident in HBM and cut into 4 x 4 patches, as the Poisson solver holds grid_pnai
+    # (set-up, not timed: ipde_amd/target_plan.py); --no-patches: the list kernel
+    dt = lp.DeviceTargets(trg.x[sl], trg.y[sl], ctx=ctx, plan=not args.no_patches)
+    plan = dt.plan()
     sx = torch.as_tensor(c.x, device=dev)
     sy = torch.as_tensor(c.y, device=dev)
     w = torch.as_tensor(c.weights, device=dev)
@@ -238,7 +246,10 @@ def main():
             dens = gathered
         else:
             dens = sig_full
-        lp.laplace_apply(sx, sy, dt.x, dt.y, w_sigma=dens * w, ctx=ctx, out=out)
+        if plan is not None:
+            target_plan.laplace_apply(plan, sx, sy, w_sigma=dens * w, ctx=ctx, out=out)
+        else:
+            lp.laplace_apply(sx, sy, dt.x, dt.y, w_sigma=dens * w, ctx=ctx, out=out)
 
     for _ in range(args.warmup):
         step()
@@ -298,7 +309,10 @@ def main():
         parity = allreduce_max(parity)
     result = None
     if rank == 0:
-        kpairs = float(NBDY) * float(dt.N) / (kernel_ms_avg * 1e-3)
+        # pairs the timed kernel evaluates FOR targets (the unstored points of cut tiles do not count;
+        # a plan's remainder, if any, is a second, small launch of the list kernel)
+        kpairs = float(NBDY) * float(dt.N - (plan.nrest if plan is not None else 0)) / (kernel_ms_avg * 1e-3)
+        vipp = VALU_INSTR_PER_PAIR_PATCH if plan is not None else VALU_INSTR_PER_PAIR
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside
         # this process; the number is the rocprofv3 FETCH_SIZE / WRITE_SIZE measurement of this
         # same command (tools/collect_traffic.py), stamped with the commit it was taken at
@@ -330,6 +344,9 @@ def main():
                                    if rehearse else "density all-gather over RCCL each step") if use_dist
                                   else "single process, no collective"),
                 "kernel_variant": args.variant,
+                "target_patches": None if plan is None else
+                    {"patches": plan.np, "targets_in_patches": int(dt.N - plan.nrest),
+                     "unstored_points": int(16 * plan.np - (dt.N - plan.nrest)), "remainder": plan.nrest},
             },
             "collective_ms_per_step": collective_ms,
             "parity_max_rel_err_vs_oracle": parity,
@@ -340,8 +357,9 @@ def main():
                 "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": kpairs * FLOPS_PER_PAIR_ALGO / 1e12 / PEAK_FP64_VECTOR_TFLOPS,
                 "flops_per_pair_algorithmic": FLOPS_PER_PAIR_ALGO,
-                "frac_of_valu_issue_rate": kpairs * VALU_INSTR_PER_PAIR / PEAK_VALU_LANE_INSTR,
-                "valu_instr_per_pair": VALU_INSTR_PER_PAIR,
+                "kernel": "laplace_patch_kernel<SLP>" if plan is not None else "laplace_rowrun_kernel<SLP, 4>",
+                "frac_of_valu_issue_rate": kpairs * vipp / PEAK_VALU_LANE_INSTR,
+                "valu_instr_per_pair": vipp,
                 "kernel_ms": kernel_ms_avg,
                 "kernel_pairs_per_s": kpairs,
                 "hbm": {

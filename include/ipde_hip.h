@@ -112,6 +112,25 @@ int ipde_laplace_apply(ipde_ctx* ctx, int loc,
                        double* out, int flags);
 
 /*
+ * The same sums for targets handed over as 4 x 4 tensor patches (device pointers only):
+ * patch p holds the sixteen targets (xs[a], ys[b]), a, b = 0..3, with
+ *   pxy[a * np + p] = xs[a], pxy[(4 + a) * np + p] = ys[a]       (8 rows of np doubles)
+ *   pout[(4 a + b) * np + p] = position of target (a, b) in `out` (16 rows of np int32)
+ * A C-ordered grid list with a band removed — the reference's grid_pnai targets,
+ * ipde/solvers/multi_boundary/scalar.py:63-71 — splits into its full 4 x 4 tiles plus a
+ * remainder (ipde_amd/target_plan.py); the tiles come here (one add per pair for d^2), the
+ * remainder goes through ipde_laplace_apply.  A negative pout entry marks a point of the
+ * patch that is not a target (a tile the band cut into): computed, not stored.  Entries of
+ * `out` no patch names are not touched.  Same values as ipde_laplace_apply to a rounding of d^2.
+ */
+int ipde_laplace_apply_patches(ipde_ctx* ctx,
+                               int64_t ns, const double* sx, const double* sy,
+                               const double* w_sigma,
+                               const double* nx, const double* ny, const double* w_tau,
+                               int64_t np, const double* pxy, const int32_t* pout,
+                               double* out);
+
+/*
  * Modified Helmholtz (k^2 - Lap) single+double layer:
  *   out_i = sum_j [ (1/2pi) K0(k r) w_sigma_j + (k/2pi) K1(k r) (n_j.d)/r w_tau_j ]
  * Replaces pybie2d Modified_Helmholtz_Layer_Apply(src, trg, charge=, k=) as

@@ -61,6 +61,7 @@ SIGNATURES = {
     "ipde_ctx_last_kernel_ms": (_int, [_vp, _c_double_p]),
     "ipde_laplace_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                   _vp, _int]),
+    "ipde_laplace_apply_patches": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ipde_modhelm_apply": (_int, [_vp, _int, _dbl, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
                                   _vp, _vp, _int]),
     "ipde_stokes_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,

@@ -126,6 +126,12 @@ struct TabAddr {
         asm("v_bfe_u32 %0, %1, 12, 13" : "=v"(idx) : "v"(hi));
         return ltab[idx];
     }
+    // the same read without the range tracking (callers that bound x themselves)
+    __device__ __forceinline__ double2 lookup_untracked(const double2* ltab, double x) const {
+        unsigned idx;
+        asm("v_bfe_u32 %0, %1, 12, 13" : "=v"(idx) : "v"((unsigned)__double2hiint(x)));
+        return ltab[idx];
+    }
     // every x seen so far was at or above the lowest covered binade?  (NaN / Inf inputs give
     // NaN / Inf results through the arithmetic itself; the 13-bit index keeps any read
     // inside the table)

@@ -291,6 +291,179 @@ __global__ __launch_bounds__(NT) void laplace_rowrun_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Patch variant (ipde_laplace_apply_patches): a lane owns a 4 x 4 TENSOR patch of targets,
+// (xs[a], ys[b]).  Then d2 = dx2[a] + dy2[b]: the eight squares are formed once per source and
+// lane (a sub and a mul each: 1.0 instruction per pair) and a pair's d2 is ONE more instruction
+// (row-run: 2.5 in all) — 10.4 VALU instructions per pair against 11.15.  The solver's target
+// lists are grids in C order with a band around the curve removed; the host cuts them into 4 x 4
+// tiles (ipde_amd/target_plan.py).  A tile the band cut into still runs as a patch: its missing
+// points are computed and not stored (pout < 0; ~1 % of the pairs of a grid_pnai list).
+// Table range: min over the patch of d2 = min_a dx2 + min_b dy2, tracked through the high
+// words (two v_min3/v_min per axis, an add, a min: 6 per 16 pairs).
+// Layout: pxy[8][np] (rows 0-3 the xs, 4-7 the ys), pout[16][np] the positions in `out` of
+// target (a, b) at row 4a + b: every load and the partial stores are coalesced.
+template <int MODE>
+__device__ __forceinline__ void laplace_patch_loop(const double* __restrict__ rec, int j0, int j1,
+                                                   const double2* ltab, TabAddr& ta,
+                                                   const double (&xs)[4], const double (&ys)[4],
+                                                   double (&acc)[16]) {
+    for (int b = j0 / IPDE_SRC_PAD; b < j1 / IPDE_SRC_PAD; ++b) {
+        SrcRow sx, sy, sq, sax, say;
+        sx.load(rec, b, 0);
+        sy.load(rec, b, 1);
+        if (MODE & MODE_SLP) sq.load(rec, b, 2);
+        if (MODE & MODE_DLP) {
+            sax.load(rec, b, 3);
+            say.load(rec, b, 4);
+        }
+#pragma unroll
+        for (int u = 0; u < IPDE_SRC_PAD; ++u) {
+            double dx2[4], dy2[4], axdx[4], aydy[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const double dx = xs[a] - sx.v[u];
+                const double dy = ys[a] - sy.v[u];
+                dx2[a] = dx * dx;
+                dy2[a] = dy * dy;
+                if (MODE & MODE_DLP) {
+                    axdx[a] = sax.v[u] * dx;
+                    aydy[a] = say.v[u] * dy;
+                }
+            }
+            {
+                const unsigned hx = min(min((unsigned)__double2hiint(dx2[0]), (unsigned)__double2hiint(dx2[1])),
+                                        min((unsigned)__double2hiint(dx2[2]), (unsigned)__double2hiint(dx2[3])));
+                const unsigned hy = min(min((unsigned)__double2hiint(dy2[0]), (unsigned)__double2hiint(dy2[1])),
+                                        min((unsigned)__double2hiint(dy2[2]), (unsigned)__double2hiint(dy2[3])));
+                const double lo = __hiloint2double((int)hx, 0) + __hiloint2double((int)hy, 0);
+                ta.hmin = min(ta.hmin, (unsigned)__double2hiint(lo));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double d2[4], z[4];
+                double2 e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d2[r] = dx2[a] + dy2[r];
+                    e[r] = ta.lookup_untracked(ltab, d2[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[r] = tab_y(d2[r], e[r].x);
+                if (MODE & MODE_SLP) {
+                    double p[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] = fma(z[r], -4.0, IPDE_LOG_K3);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] = fma(z[r], p[r], -2.0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] = fma(z[r], p[r], IPDE_LOG_K1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] = fma(z[r], p[r], e[r].y);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[4 * a + r] = fma(sq.v[u], p[r], acc[4 * a + r]);
+                }
+                if (MODE & MODE_DLP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[4 * a + r] = fma(axdx[a] + aydy[r], rcp_from_y_fast(e[r].x, z[r]), acc[4 * a + r]);
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void laplace_patch_kernel(
+    const double* __restrict__ rec, int ns_pad, int chunk, const double* __restrict__ pxy, int64_t np,
+    const int* __restrict__ pout, double* __restrict__ out, double* __restrict__ partial,
+    const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab, unsigned key_lo,
+    unsigned nkeys) {
+    extern __shared__ double2 ltab[];
+    for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
+    __syncthreads();
+    TabAddr ta;
+    const int j0 = blockIdx.y * chunk;
+    const int j1 = min(ns_pad, j0 + chunk);
+    const double s1 = ldexp(1.0, prm->sh);
+    const int64_t lane = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t t = min(lane, np - 1);
+    double xs[4], ys[4], acc[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        xs[a] = pxy[(int64_t)a * np + t] * s1;
+        ys[a] = pxy[(int64_t)(4 + a) * np + t] * s1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+    laplace_patch_loop<MODE>(rec, j0, j1, ltab, ta, xs, ys, acc);
+    if (!ta.all_inside(key_lo) || prm->pad) {
+        // a pair of this patch may have left the table: its rows again with the generic math
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double xa[4] = {xs[a], xs[a], xs[a], xs[a]};
+            double g[4] = {0.0, 0.0, 0.0, 0.0};
+            laplace_generic_loop<MODE, false, 4>(rec, j0, j1, xa, ys, g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[4 * a + r] = g[r];
+        }
+    }
+    if (lane >= np) return;
+    const double corr = (blockIdx.y == 0) ? prm->corr : 0.0;
+    if (partial) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) partial[((int64_t)blockIdx.y * 16 + r) * np + t] = acc[r] + corr;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = pout[(int64_t)r * np + t];
+            if (i >= 0) out[i] = acc[r] + corr;
+        }
+    }
+}
+
+// out[pout[i]] = sum over the source chunks, in chunk order
+__global__ __launch_bounds__(256) void laplace_patch_reduce(const double* __restrict__ partial, int nchunk,
+                                                            int64_t n16, const int* __restrict__ pout,
+                                                            double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    double s = partial[i];
+    for (int c = 1; c < nchunk; ++c) s += partial[(int64_t)c * n16 + i];
+    if (pout[i] >= 0) out[pout[i]] = s;
+}
+
+template <int MODE>
+int launch_laplace_patches(ipde_ctx* ctx, const double* rec, int64_t ns, const double* pxy, int64_t np,
+                           const int* pout, double* out, const ApplyParams* prm) {
+    constexpr int NT = 1024;
+    const LogTable& lt = ctx->logtab;
+    const LayerGeom g = ipde_layer_geom(ns, 16 * np, 16 * NT, ctx->num_cu);
+    double* partial = nullptr;
+    if (g.nchunk > 1) {
+        IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, (size_t)g.nchunk * 16 * np * sizeof(double)));
+        partial = (double*)ctx->partial.p;
+    }
+    const size_t lds = (size_t)lt.nkeys * sizeof(double2);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_patch_kernel<MODE, NT>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ctx->timing) hipEventRecord(ctx->ev0, ctx->stream);
+    hipLaunchKernelGGL((laplace_patch_kernel<MODE, NT>), dim3((unsigned)g.gx, (unsigned)g.nchunk), dim3(NT), lds,
+                       ctx->stream, rec, g.ns_pad, g.chunk, pxy, np, pout, out, partial, prm,
+                       (const double2*)lt.d_tab, (unsigned)lt.key_lo, (unsigned)lt.nkeys);
+    if (ctx->timing) {
+        hipEventRecord(ctx->ev1, ctx->stream);
+        ctx->last_kernel_ms = -1.0;
+    }
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    if (partial) {
+        hipLaunchKernelGGL(laplace_patch_reduce, dim3((unsigned)ceil_div64(16 * np, 256)), dim3(256), 0,
+                           ctx->stream, (const double*)partial, g.nchunk, 16 * np, pout, out);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return IPDE_OK;
+}
+
 template <int MODE, int R, int NT>
 int launch_rowrun_variant(ipde_ctx* ctx, dim3 grid, const double* rec, const LayerGeom& g,
                           const double* tx, const double* ty, int64_t nt, double* dst,
@@ -456,4 +629,44 @@ extern "C" int ipde_laplace_apply(ipde_ctx* ctx, int loc, int64_t ns, const doub
         st = launch_laplace<MODE_BOTH>(ctx, rec, ns, d_tx, d_ty, nt, d_out, prm, flags);
     IPDE_TRY(st);
     return ipde_stage_finish(ctx, loc, 7, out, nt);
+}
+
+extern "C" int ipde_laplace_apply_patches(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                          const double* w_sigma, const double* nx, const double* ny,
+                                          const double* w_tau, int64_t np, const double* pxy,
+                                          const int32_t* pout, double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ns >= 0 && np >= 0 && ns < (1LL << 30) && np < (1LL << 27));
+    IPDE_CHECK_ARG(ctx, w_sigma != nullptr || w_tau != nullptr);
+    IPDE_CHECK_ARG(ctx, w_tau == nullptr || (nx != nullptr && ny != nullptr));
+    if (np == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, pxy && pout && out);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    PackArgs pa{};
+    pa.sx = sx;
+    pa.sy = sy;
+    pa.ch[0] = w_sigma;
+    pa.mul[0] = -0.25 / M_PI;
+    pa.ch[1] = w_tau ? nx : nullptr;
+    pa.mulby[1] = w_tau;
+    pa.mul[1] = 0.5 / M_PI;
+    pa.pw[1] = 1;
+    pa.ch[2] = w_tau ? ny : nullptr;
+    pa.mulby[2] = w_tau;
+    pa.mul[2] = 0.5 / M_PI;
+    pa.pw[2] = 1;
+    pa.corr_ch = 0;
+    pa.corr2_ch = -1;
+    pa.use_scale = 1;
+    pa.exp_hi = ctx->logtab.exp_hi;
+    const double* rec;
+    const ApplyParams* prm;
+    // the patches' xs and ys are rows 0-3 and 4-7 of pxy: the bounding box of the 4 np + 4 np
+    // coordinates is the bounding box of the targets
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, pxy, pxy + 4 * np, 4 * np, &rec, &prm));
+    const int mode = (w_sigma ? MODE_SLP : 0) | (w_tau ? MODE_DLP : 0);
+    if (mode == MODE_SLP) return launch_laplace_patches<MODE_SLP>(ctx, rec, ns, pxy, np, pout, out, prm);
+    if (mode == MODE_DLP) return launch_laplace_patches<MODE_DLP>(ctx, rec, ns, pxy, np, pout, out, prm);
+    return launch_laplace_patches<MODE_BOTH>(ctx, rec, ns, pxy, np, pout, out, prm);
 }

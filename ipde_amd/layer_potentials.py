@@ -26,12 +26,28 @@ __all__ = [
 ]
 
 
+_plan_threads = []
+
+
+def _join_plan_threads():
+    # a process must not end while a daemon thread is inside torch / HIP (see device._drain_at_exit)
+    for t in _plan_threads:
+        t.join(30.0)
+
+
+import atexit
+atexit.register(_join_plan_threads)
+
+
 class DeviceTargets:
     """A target point set kept resident in HBM (the solver evaluates onto the same
     `grid_pnai` / `radial_targ` / `grid_and_radial_pts` sets in every solve;
     reference ipde/ebdy_collection.py:426-429,488-491)."""
 
-    def __init__(self, x, y=None, ctx=None):
+    def __init__(self, x, y=None, ctx=None, plan=False):
+        """plan=True: the list is also cut into 4 x 4 tensor patches for the Laplace patch kernel
+        (ipde_amd/target_plan.py) — in a background thread; the first Laplace apply onto the set
+        joins it.  For the big grid lists (grid_pnai); lists under 2^18 points keep the list kernel."""
         if y is None:  # a PointSet-like object
             x, y = x.x, x.y
         self.ctx = ctx or get_context()
@@ -40,6 +56,37 @@ class DeviceTargets:
         self.y = to_device(np.asarray(y, dtype=np.float64).ravel(), self.ctx) \
             if not isinstance(y, torch.Tensor) else y.to(torch.float64).contiguous().view(-1)
         self.N = int(self.x.shape[0])
+        self._plan, self._plan_thread, self._plan_error = None, None, None
+        if plan:
+            self.request_plan()
+
+    def request_plan(self):
+        from . import target_plan
+        if self._plan_thread is not None or not self.x.is_cuda or self.N < 16 * target_plan.MIN_PATCHES:
+            return
+        import threading
+        dev = self.x.device
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                side = torch.cuda.Stream(dev)       # not in the way of the set-up's own launches
+                with torch.cuda.stream(side):
+                    plan = target_plan.build(self.x, self.y, min_patches=target_plan.MIN_PATCHES)
+                side.synchronize()
+                self._plan = plan if plan.np else None
+            except Exception as e:                  # the list kernel needs no plan
+                self._plan_error = e
+        self._plan_thread = threading.Thread(target=work, name="ipde-target-plan", daemon=True)
+        self._plan_thread.start()
+        _plan_threads.append(self._plan_thread)
+
+    def plan(self):
+        """the patch plan if one was requested (waits for the thread that builds it), else None"""
+        if self._plan_thread is None:
+            return None
+        self._plan_thread.join()
+        return self._plan
 
 
 class ShardedTargets:
@@ -211,6 +258,14 @@ def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=N
     if charge is None and dipstr is None:
         raise ValueError("need a charge and/or a dipstr density")
     src = _source_side(source, trg)
+    plan = target.plan() if isinstance(target, DeviceTargets) else None
+    if plan is not None:
+        from . import target_plan
+        return target_plan.laplace_apply(plan, src.x, src.y,
+                                         w_sigma=_weighted(charge, src.weights),
+                                         nx=None if dipstr is None else src.normal_x,
+                                         ny=None if dipstr is None else src.normal_y,
+                                         w_tau=_weighted(dipstr, src.weights), ctx=target.ctx)
     return laplace_apply(src.x, src.y, tx, ty,
                          w_sigma=_weighted(charge, src.weights),
                          nx=None if dipstr is None else src.normal_x,

@@ -197,21 +197,29 @@ def make_sharded_evaluator(layer_apply, targets, wrap_targets, dist=None, group=
         return state["all"]
 
     if world == 1:
-        return lambda sources, density: layer_apply(sources, resident(), density)
+        single = lambda sources, density: layer_apply(sources, resident(), density)
+        single.prepare = lambda n_sources=None: resident()
+        return single
     sl = target_slice(nt, rank, world)
+
+    def local():
+        if "local" not in state:
+            state["local"] = wrap_targets(targets.x[sl], targets.y[sl])
+        return state["local"]
 
     def evaluator(sources, density):
         if nt * float(sources.N) < min_pairs:
             return layer_apply(sources, resident(), density)
-        if "local" not in state:
-            state["local"] = wrap_targets(targets.x[sl], targets.y[sl])
-        out = layer_apply(sources, state["local"], density)
+        out = layer_apply(sources, local(), density)
         parts = out if isinstance(out, tuple) else (out,)
         g = state.get(len(parts))
         if g is None:
             g = state[len(parts)] = ResultGather(nt, len(parts), dist, group)
         full = g(parts)
         return full if isinstance(out, tuple) else full[0]
+    # make the target set resident ahead of the first evaluation (the solvers' set-up)
+    evaluator.prepare = lambda n_sources=None: (resident() if n_sources is not None and nt * float(n_sources) < min_pairs
+                                                else local())
     return evaluator
 
 
@@ -219,7 +227,9 @@ def make_pnai_evaluator(layer_apply, sources, targets, wrap_targets, dist=None, 
     """The solvers' `Grid_Evaluator(density)` onto grid_pnai: `make_sharded_evaluator`
     bound to the solver's grid sources (BASELINE configs 4 and 5)."""
     ev = make_sharded_evaluator(layer_apply, targets, wrap_targets, dist, group)
-    return lambda density: ev(sources, density)
+    on_pnai = lambda density: ev(sources, density)
+    on_pnai.prepare = lambda: ev.prepare(sources.N)
+    return on_pnai
 
 
 # -- per-boundary work distributed over ranks ------------------------------------------------

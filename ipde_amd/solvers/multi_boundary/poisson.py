@@ -8,6 +8,8 @@ from ...grid_evaluators.laplace_grid_evaluator import (LaplaceFreespaceGridEvalu
 
 
 class PoissonSolver(ScalarSolver):
+    PATCH_TARGETS = True      # ipde_laplace_apply_patches for the sum onto grid_pnai
+
     def __init__(self, ebdyc, solver_type='spectral', AS_list=None, grid_backend=None):
         super().__init__(ebdyc, solver_type, AS_list, grid_backend)
 

@@ -8,6 +8,8 @@ up once (pinned), the masks / cut-offs / index sets are resident, every grid upd
 a device gather/scatter, and only the physical values of the answer come back.  Small
 per-boundary vectors (N or M*N doubles) travel as numpy, as in the reference.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -113,6 +115,15 @@ class ScalarSolver(object):
         self._make_device_state()
         self._resolve_grid_backend()
         self._define_grid_evaluator()
+        if os.environ.get("IPDE_PATCH_TARGETS", "1") == "0":
+            self.PATCH_TARGETS = False      # A/B switch: the list kernel
+        if self.PATCH_TARGETS and hasattr(self.Grid_Evaluator, "prepare"):
+            # the grid_pnai list into HBM and into patches now, in the background of the set-up,
+            # instead of inside the first solve
+            self.Grid_Evaluator.prepare()
+
+    # the dense sum onto grid_pnai through the 4 x 4 patch kernel (kernels that have one: Laplace)
+    PATCH_TARGETS = False
 
     # grid_backend None / 'auto': the package's choice — the exact dense sum up to this many
     # source-target pairs per solve (BASELINE configs[1-2]: 1e10), beyond it, in a single process, the
@@ -172,7 +183,7 @@ class ScalarSolver(object):
         from ...pybie2d_compat import PointSet
         return make_pnai_evaluator(lambda src, trg, ch: self.Layer_Apply(src, trg, ch),
                                    self.grid_sources, self.ebdyc.grid_pnai,
-                                   lambda x, y: DeviceTargets(PointSet(x=x, y=y)))
+                                   lambda x, y: DeviceTargets(PointSet(x=x, y=y), plan=self.PATCH_TARGETS))
 
     def _get_helper(self, ebdy, helper):
         raise NotImplementedError

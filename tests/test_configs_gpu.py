@@ -36,7 +36,13 @@ def test_config2_full_interior_poisson_2048():
     print(err / scale, T)
     assert list(T['grid']) == [2048, 2048]
     assert err / scale < 1e-12
-    del solver, ue
+    # the sum onto grid_pnai went through the 4 x 4 patch kernel (ipde_amd/target_plan.py)
+    dt = solver.Grid_Evaluator.prepare()
+    plan = dt.plan()
+    assert dt._plan_error is None, repr(dt._plan_error)
+    # (the list ends with the 4096 interface nodes, which are on no grid line: the remainder)
+    assert plan is not None and plan.np > 0.98 * solver.ebdyc.grid_pnai.N / 16 and 4096 <= plan.nrest < 4200
+    del solver, ue, plan, dt
     _free()
 
 

@@ -462,3 +462,125 @@ def test_table_kernels_at_extreme_coordinate_scales(lp, scale):
     assert np.abs(u1 - (u0 + shift * q.sum())).max() < 2e-13 * max(np.abs(u1).max(), 1.0)
     assert np.abs(v1 - (v0 + shift * q.sum())).max() < 2e-13 * max(np.abs(v1).max(), 1.0)
     assert np.abs(p1 * scale - p0).max() < 1e-12 * np.abs(p0).max()
+
+
+# ---------------------------------------------------------------------------
+# 4 x 4 patch kernel (ipde_laplace_apply_patches, ipde_amd/target_plan.py)
+def _patch_kw(c, mode, sig, tau):
+    kw = {}
+    if mode in ("slp", "both"):
+        kw["w_sigma"] = sig * c.weights
+    if mode in ("dlp", "both"):
+        kw.update(nx=c.normal_x, ny=c.normal_y, w_tau=tau * c.weights)
+    return kw
+
+
+@pytest.mark.parametrize("mode", ["slp", "dlp", "both"])
+@pytest.mark.parametrize("ngrid,nb", [(157, 192), (640, 512)])
+def test_laplace_patches_against_oracle_and_list_kernel(lp, mode, ngrid, nb):
+    """The band list cut into patches (tiles the band cut into included: unstored points) against
+    the C oracle and the list kernel; the small case splits the sources over blockIdx.y (partial
+    sums + the reduce-and-scatter kernel), the larger one is a single chunk."""
+    import torch
+    from ipde_amd import target_plan
+    from ipde_amd.device import to_device
+    c = Curve(nb, a=0.2, f=5)
+    trg, h = grid_targets(c, ngrid, clearance=2.0)
+    rng = np.random.default_rng(ngrid)
+    kw = _patch_kw(c, mode, rng.standard_normal(c.N), rng.standard_normal(c.N))
+    x, y = to_device(trg.x), to_device(trg.y)
+    plan = target_plan.build(x, y)
+    assert plan.np > 0 and plan.nrest == 0 and bool((plan.pout < 0).any())
+    got = target_plan.laplace_apply(plan, c.x, c.y, **kw).cpu().numpy()
+    lst = lp.laplace_apply(c.x, c.y, trg.x, trg.y, **kw)
+    idx = rng.choice(trg.N, min(trg.N, 6000), replace=False)
+    ref = oracle.c_laplace_apply(c.x, c.y, trg.x[idx], trg.y[idx], **kw)
+    assert rel_err(got[idx], ref) < TOL
+    assert rel_err(got, lst) < 1e-13
+    # full tiles + a remainder through the list kernel (the split a ragged list gets)
+    old, target_plan.PARTIAL_MIN_FILL = target_plan.PARTIAL_MIN_FILL, 2.0
+    try:
+        plan2 = target_plan.build(x, y)
+    finally:
+        target_plan.PARTIAL_MIN_FILL = old
+    assert plan2.nrest > 0 and bool((plan2.pout >= 0).all())
+    out = torch.full((trg.N,), float("nan"), dtype=torch.float64, device=x.device)
+    got2 = target_plan.laplace_apply(plan2, c.x, c.y, out=out, **kw)
+    assert got2 is out and rel_err(got2.cpu().numpy(), lst) < 1e-13
+
+
+@pytest.mark.parametrize("mode", ["slp", "both"])
+def test_laplace_patches_table_miss_and_unstored_point_on_a_source(lp, mode):
+    """Patches whose pairs leave the LDS table: sources 1e-9 and 1e-13 away from grid targets (the
+    patch's rows are redone with the generic math), and sources sitting EXACTLY on points of cut
+    tiles that are not targets (log 0 in a value nobody stores must not leak into the
+    neighbours).  Against the C oracle, target by target."""
+    from ipde_amd import target_plan
+    from ipde_amd.device import to_device
+    c = Curve(160, a=0.2, f=5)
+    trg, h = grid_targets(c, 128, clearance=2.0)
+    rng = np.random.default_rng(5)
+    sx, sy = c.x.copy(), c.y.copy()
+    v = np.linspace(-1.5, 1.5, 128, endpoint=False)
+    present = set(zip(trg.x.tolist(), trg.y.tolist()))
+    hit = rng.choice(trg.N, 12, replace=False)
+    sx[:12] = trg.x[hit] + np.where(np.arange(12) % 2 == 0, 1e-9, 1e-13)
+    sy[:12] = trg.y[hit] - np.where(np.arange(12) % 3 == 0, 1e-9, 3e-13)
+    holes = [(a, b) for a in v for b in v if (a, b) not in present]
+    holes = [holes[i] for i in rng.choice(len(holes), 10, replace=False)]
+    sx[12:22], sy[12:22] = [p[0] for p in holes], [p[1] for p in holes]
+    kw = _patch_kw(c, mode, rng.standard_normal(c.N), rng.standard_normal(c.N))
+    plan = target_plan.build(to_device(trg.x), to_device(trg.y))
+    assert plan.np > 0 and plan.nrest == 0
+    got = target_plan.laplace_apply(plan, sx, sy, **kw).cpu().numpy()
+    ref = oracle.c_laplace_apply(sx, sy, trg.x, trg.y, **kw)
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - ref) <= TOL * np.maximum(np.abs(ref), np.abs(ref[np.abs(ref) < 1e3]).max()))
+
+
+def test_laplace_patches_full_size_through_the_high_level_call(lp):
+    """BASELINE configs[1] through the route the Poisson solver takes: DeviceTargets(plan=True),
+    Laplace_Layer_Apply -> patch kernel.  Linearity on the whole 2048^2 list, 4096 random targets
+    against the C oracle, 1e-13 from the list kernel, and the argument checks of the entry point."""
+    import torch
+    c = Curve(4096, a=0.2, f=5)
+    trg, h = grid_targets(c, 2048)
+    dt = lp.DeviceTargets(trg, plan=True)
+    plain = lp.DeviceTargets(trg)
+    plan = dt.plan()
+    assert plan is not None and plan.nrest == 0 and plain.plan() is None
+    assert 16 * plan.np < 1.01 * trg.N
+    rng = np.random.default_rng(3)
+    s1, s2 = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    u1 = lp.Laplace_Layer_Apply(c, dt, charge=s1)
+    u2 = lp.Laplace_Layer_Apply(c, dt, charge=s2)
+    u3 = lp.Laplace_Layer_Apply(c, dt, charge=2.0 * s1 - 0.5 * s2)
+    scale = float(torch.max(torch.abs(u3)))
+    assert float(torch.max(torch.abs(u3 - (2.0 * u1 - 0.5 * u2)))) < 1e-12 * scale
+    idx = rng.choice(trg.N, 4096, replace=False)
+    ref = oracle.c_laplace_apply(c.x, c.y, trg.x[idx], trg.y[idx], w_sigma=s1 * c.weights)
+    assert np.max(np.abs(u1.cpu().numpy()[idx] - ref)) < 1e-12 * float(torch.max(torch.abs(u1)))
+    lst = lp.Laplace_Layer_Apply(c, plain, charge=s1)
+    assert float(torch.max(torch.abs(u1 - lst))) < 1e-13 * float(torch.max(torch.abs(lst)))
+    both = lp.Laplace_Layer_Apply(c, dt, charge=s1, dipstr=s2)
+    both_l = lp.Laplace_Layer_Apply(c, plain, charge=s1, dipstr=s2)
+    assert float(torch.max(torch.abs(both - both_l))) < 1e-13 * float(torch.max(torch.abs(both_l)))
+    # a list under 2^18 points keeps the list kernel
+    small, _ = grid_targets(c, 256)
+    assert lp.DeviceTargets(small, plan=True).plan() is None
+    # argument checks
+    ctx, P = dt.ctx, lp.ptr
+    from ipde_amd._lib import IpdeHipError
+    src = lp._source_side(c, dt)
+    w = src.weights
+    with pytest.raises(IpdeHipError):
+        ctx.check(ctx.lib.ipde_laplace_apply_patches(ctx.handle, c.N, P(src.x), P(src.y), None, None, None, None,
+                                                     plan.np, P(plan.pxy), P(plan.pout), P(u1)))
+    with pytest.raises(IpdeHipError):
+        ctx.check(ctx.lib.ipde_laplace_apply_patches(ctx.handle, c.N, P(src.x), P(src.y), P(w), None, None, None,
+                                                     plan.np, None, P(plan.pout), P(u1)))
+    with pytest.raises(IpdeHipError):
+        ctx.check(ctx.lib.ipde_laplace_apply_patches(ctx.handle, c.N, P(src.x), P(src.y), None, None, None, P(w),
+                                                     plan.np, P(plan.pxy), P(plan.pout), P(u1)))
+    ctx.check(ctx.lib.ipde_laplace_apply_patches(ctx.handle, c.N, P(src.x), P(src.y), P(w), None, None, None,
+                                                 0, None, None, None))

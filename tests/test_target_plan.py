@@ -1,0 +1,106 @@
+"""ipde_amd/target_plan.py: the split of a target list into 4 x 4 tensor patches and a remainder
+(host logic, torch on the CPU here; the kernel it feeds is tested in tests/test_layer_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from ipde_amd import target_plan
+
+
+def _check_partition(x, y, plan):
+    n = x.shape[0]
+    pout = plan.pout.numpy()
+    pxy = plan.pxy.numpy()
+    seen = np.zeros(n, dtype=int)
+    np.add.at(seen, pout[pout >= 0], 1)
+    np.add.at(seen, plan.rest.numpy(), 1)
+    assert np.array_equal(seen, np.ones(n, dtype=int))          # every target exactly once
+    for a in range(4):
+        for b in range(4):
+            idx = pout[4 * a + b]
+            m = idx >= 0
+            assert np.array_equal(x[idx[m]], pxy[a][m]) and np.array_equal(y[idx[m]], pxy[4 + b][m])
+    assert np.array_equal(plan.rest_x.numpy(), x[plan.rest.numpy()])
+    assert np.array_equal(plan.rest_y.numpy(), y[plan.rest.numpy()])
+
+
+def _band_list(ngrid=96, lim=1.5, clearance=4.0):
+    v = np.linspace(-lim, lim, ngrid, endpoint=False)
+    X, Y = np.meshgrid(v, v, indexing="ij")
+    x, y = X.ravel(), Y.ravel()
+    r = np.hypot(x, y)
+    rb = 1.0 + 0.2 * np.cos(5 * np.arctan2(y, x))
+    keep = np.abs(r - rb) > clearance * (v[1] - v[0])
+    return x[keep], y[keep]
+
+
+@pytest.mark.parametrize("block", [(1, 1 << 20), (8, 8), (4, 4)])
+def test_grid_with_a_band_removed_splits_into_tiles_and_remainder(block):
+    x, y = _band_list(160, clearance=2.5)
+    plan = target_plan.build(torch.from_numpy(x), torch.from_numpy(y), block=block)
+    _check_partition(x, y, plan)
+    assert plan.nrest == 0 and x.shape[0] / 16 < plan.np < 1.25 * x.shape[0] / 16
+    assert (plan.pout.numpy() < 0).any()                # tiles the band cut into
+    # the same patches whatever the hand-out order
+    ref = target_plan.build(torch.from_numpy(x), torch.from_numpy(y), block=(1, 1 << 20))
+    key = lambda p: np.sort(p.pout.numpy().max(axis=0))
+    assert np.array_equal(key(plan), key(ref))
+    # a list too ragged for that keeps its full tiles and a remainder
+    old, target_plan.PARTIAL_MIN_FILL = target_plan.PARTIAL_MIN_FILL, 0.999
+    try:
+        plan = target_plan.build(torch.from_numpy(x), torch.from_numpy(y), block=block)
+    finally:
+        target_plan.PARTIAL_MIN_FILL = old
+    _check_partition(x, y, plan)
+    assert plan.np > 0.6 * x.shape[0] / 16 and 0 < plan.nrest < 0.4 * x.shape[0]
+    assert (plan.pout.numpy() >= 0).all()
+
+
+def test_full_grid_has_no_remainder_and_odd_sizes_keep_their_edges():
+    v = np.linspace(0.0, 1.0, 32)
+    X, Y = np.meshgrid(v, v * 2.0, indexing="ij")
+    plan = target_plan.build(torch.from_numpy(X.ravel()), torch.from_numpy(Y.ravel()))
+    assert plan.np == 64 and plan.nrest == 0
+    _check_partition(X.ravel(), Y.ravel(), plan)
+    w = np.linspace(0.0, 1.0, 30)
+    X, Y = np.meshgrid(v[:27], w, indexing="ij")
+    plan = target_plan.build(torch.from_numpy(X.ravel()), torch.from_numpy(Y.ravel()))
+    assert plan.np == 7 * 8 and plan.nrest == 0         # 27 x 30: edge tiles with unstored points
+    _check_partition(X.ravel(), Y.ravel(), plan)
+
+
+def test_lists_that_are_no_grid_and_repeated_points():
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(500), rng.standard_normal(500)
+    plan = target_plan.build(torch.from_numpy(x), torch.from_numpy(y))
+    assert plan.np == 0 and plan.nrest == 500
+    _check_partition(x, y, plan)
+    # a grid list in which some points occur twice: one copy sits in a tile, the other in the remainder
+    gx, gy = _band_list(48)
+    x, y = np.concatenate([gx, gx[100:140]]), np.concatenate([gy, gy[100:140]])
+    plan = target_plan.build(torch.from_numpy(x), torch.from_numpy(y))
+    _check_partition(x, y, plan)
+    assert plan.np > 0
+    # too few tiles for the patch kernel to be worth a launch: everything stays in the list
+    plan = target_plan.build(torch.from_numpy(gx), torch.from_numpy(gy), min_patches=10 ** 6)
+    assert plan.np == 0 and plan.nrest == gx.shape[0]
+    # an unordered grid list (any order of a tensor-product set qualifies)
+    perm = rng.permutation(gx.shape[0])
+    plan = target_plan.build(torch.from_numpy(gx[perm]), torch.from_numpy(gy[perm]))
+    _check_partition(gx[perm], gy[perm], plan)
+    assert plan.np > 0
+
+
+def test_grid_list_followed_by_off_lattice_points():
+    """grid_pnai = the grid points outside the annuli FOLLOWED BY the interface nodes (reference
+    ipde/ebdy_collection.py:426-429): the curve's nodes are on no grid line and stay in the list"""
+    gx, gy = _band_list(160, clearance=2.5)
+    t = np.linspace(0, 2 * np.pi, 300, endpoint=False)
+    cx, cy = 0.8 * np.cos(t) + 1e-3, 0.8 * np.sin(t) - 2e-3
+    cx[:3], cy[:3] = gx[[5, 900, 4000]], cy[:3]              # on a grid line in x only
+    x, y = np.concatenate([gx, cx]), np.concatenate([gy, cy])
+    plan = target_plan.build(torch.from_numpy(x), torch.from_numpy(y))
+    _check_partition(x, y, plan)
+    assert plan.nrest == 300 and np.array_equal(np.sort(plan.rest.numpy()), gx.shape[0] + np.arange(300))
+    ref = target_plan.build(torch.from_numpy(gx), torch.from_numpy(gy))
+    assert plan.np == ref.np
