@@ -5,8 +5,9 @@
 
 One "step" = one Laplace single-layer evaluation of a 4096-node star boundary
 onto a 2048^2 grid (points within 7.5 h of the curve removed, as the solver never
-evaluates on-surface) through the C ABI (ipde_laplace_apply), inputs
-resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU)
+evaluates on-surface) through the C ABI, inputs resident in HBM: the list, cut once
+into 4 x 4 patches as the Poisson solver keeps grid_pnai (ipde_amd/target_plan.py, set-up), goes
+through ipde_laplace_apply_patches; --no-patches times ipde_laplace_apply on the plain list.  With N > 1 (launched by torch.distributed.run, one rank per GPU)
 the ONE 2048^2 target list is split into N contiguous slices (strong scaling, the
 north_star's "2048^2 grid / 4096-node boundary at 1, 2, 4 and 8 GPUs"); every rank owns
 1/N of the boundary density, which is all-gathered over RCCL each step — the one real
@@ -42,6 +43,7 @@ PEAK_VALU_LANE_INSTR = 256 * 4 * 16 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz
 PEAK_FP64_VECTOR_TFLOPS = 78.6  # MI355X fp64 vector (= 256 CU*4 SIMD*32 flop/clk*2.4 GHz)
 PEAK_HBM_GBS = 8000.0
 ALGO_BYTES_PER_TARGET = 24     # read x, y; write u
+ALGO_BYTES_PER_PATCH = 8 * 8 + 16 * 4 + 16 * 8   # patch kernel: 4 xs + 4 ys, 16 int32 positions, 16 values
 
 
 def make_workload():
@@ -313,6 +315,8 @@ def main():
         # a plan's remainder, if any, is a second, small launch of the list kernel)
         kpairs = float(NBDY) * float(dt.N - (plan.nrest if plan is not None else 0)) / (kernel_ms_avg * 1e-3)
         vipp = VALU_INSTR_PER_PAIR_PATCH if plan is not None else VALU_INSTR_PER_PAIR
+        # list kernel: x, y in, u out per target; patch kernel: 8 coordinates + 16 positions in, 16 values out per patch
+        algo_bytes = float(ALGO_BYTES_PER_PATCH * plan.np if plan is not None else ALGO_BYTES_PER_TARGET * dt.N)
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside
         # this process; the number is the rocprofv3 FETCH_SIZE / WRITE_SIZE measurement of this
         # same command (tools/collect_traffic.py), stamped with the commit it was taken at
@@ -363,10 +367,10 @@ def main():
                 "kernel_ms": kernel_ms_avg,
                 "kernel_pairs_per_s": kpairs,
                 "hbm": {
-                    "achieved": ALGO_BYTES_PER_TARGET * dt.N / (kernel_ms_avg * 1e-3) / 1e9,
+                    "achieved": algo_bytes / (kernel_ms_avg * 1e-3) / 1e9,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": ALGO_BYTES_PER_TARGET * dt.N / (kernel_ms_avg * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                    "algorithmic_bytes_per_launch": ALGO_BYTES_PER_TARGET * dt.N,
+                    "frac": algo_bytes / (kernel_ms_avg * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "algorithmic_bytes_per_launch": algo_bytes,
                 },
                 "traffic": traffic,
                 "traffic_source": traffic_src,

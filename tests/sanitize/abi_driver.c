@@ -40,6 +40,8 @@ int main(void) {
     EXPECT_INVALID(ipde_ctx_enable_timing(NULL, 1));
     EXPECT_INVALID(ipde_ctx_last_kernel_ms(NULL, &x));
     EXPECT_INVALID(ipde_laplace_apply(NULL, IPDE_HOST, 1, &x, &x, &x, NULL, NULL, NULL, 1, &x, &x, &x, 0));
+    { int32_t pi = 0;
+      EXPECT_INVALID(ipde_laplace_apply_patches(NULL, 1, &x, &x, &x, NULL, NULL, NULL, 1, &x, &pi, &x)); }
     EXPECT_INVALID(ipde_modhelm_apply(NULL, IPDE_HOST, 1.0, 1, &x, &x, &x, NULL, NULL, NULL, 1, &x, &x, &x, 0));
     EXPECT_INVALID(ipde_stokes_apply(NULL, IPDE_HOST, 1, &x, &x, &x, &x, NULL, NULL, NULL, NULL, 1, &x, &x,
                                      &x, &x, &x, 0));

@@ -76,6 +76,13 @@ def main():
     rec("laplace_slp", lambda: lp.Laplace_Layer_Apply(c, dt, charge=sig), 8)
     rec("laplace_dlp", lambda: lp.Laplace_Layer_Apply(c, dt, dipstr=tau), 12)
     rec("laplace_slp_dlp", lambda: lp.Laplace_Layer_Apply(c, dt, charge=sig, dipstr=tau), 15)
+    # the same three sums through the 4 x 4 patch kernel (the route of the Poisson solver and bench.py)
+    dtp = lp.DeviceTargets(trg, plan=True)
+    if dtp.plan() is not None:
+        rec("laplace_slp_patches", lambda: lp.Laplace_Layer_Apply(c, dtp, charge=sig), 8)
+        rec("laplace_dlp_patches", lambda: lp.Laplace_Layer_Apply(c, dtp, dipstr=tau), 12)
+        rec("laplace_slp_dlp_patches", lambda: lp.Laplace_Layer_Apply(c, dtp, charge=sig, dipstr=tau), 15)
+    del dtp
     rec("modhelm_slp_k10", lambda: lp.Modified_Helmholtz_Layer_Apply(c, dt, k=10.0, charge=sig), 10)
     rec("modhelm_dlp_k10", lambda: lp.Modified_Helmholtz_Layer_Apply(c, dt, k=10.0, dipstr=tau), 15)
     rec("stokes_slp", lambda: lp.Stokes_Layer_Apply(c, dt, forces=f2), 20)

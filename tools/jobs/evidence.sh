@@ -29,6 +29,12 @@ timeout -k 10 60 /tmp/lu_probe 4096 1 > $O/lu_subst_probe.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIPDE_LU_STAMPS tools/lu_panel_probe.hip -o /tmp/lu_panel_probe 2>/dev/null
 timeout -k 10 60 /tmp/lu_panel_probe 4096 0 > $O/lu_panel_probe.txt
 timeout -k 10 60 /tmp/lu_panel_probe 4096 60 >> $O/lu_panel_probe.txt
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_a -- python3 tools/profile_dense.py 2 patches,laplace > $O/pmc_sq_a.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_b -- python3 tools/profile_dense.py 2 patches,laplace > $O/pmc_sq_b.log 2>&1
+python3 tools/summarize_pmc.py $O/pmc_sq_a $O/pmc_sq_laplace_a.json laplace_ > /dev/null
+python3 tools/summarize_pmc.py $O/pmc_sq_b $O/pmc_sq_laplace_b.json laplace_ > /dev/null
+timeout -k 10 120 python3 tools/power_probe.py 2>&1 | grep -v amdgpu.ids > $O/power_probe.txt
+timeout -k 10 300 python3 tools/ab_patches.py 2>&1 | grep -v amdgpu.ids > $O/patches_ab.txt
 find $O -name "*_kernel_trace.csv" -size +20M -delete
 cat $O/smoke.txt $O/gputest.txt $O/poisson_warm_unprofiled.txt $O/stokes_warm_unprofiled.txt
 python3 -c "

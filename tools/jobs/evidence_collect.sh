@@ -15,7 +15,11 @@ cp $O/stokes_solve_budget.json $P/r02_stokes_3body_solve_budget.json
 cp $O/lu_subst_probe.txt $P/r02_lu_subst_probe.txt
 cp $O/lu_panel_probe.txt $P/r02_lu_panel_probe.txt
 cat $O/poisson_warm_unprofiled.txt $O/stokes_warm_unprofiled.txt > $P/r02_warm_solves_unprofiled.txt
-python3 tools/collect_traffic.py $O/pmc_fetch $O/pmc_write laplace_rowrun_kernel r02
+python3 tools/collect_traffic.py $O/pmc_fetch $O/pmc_write laplace_patch_kernel r02
 cp $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $P/r02_pmc_fetch_laplace.csv
 cp $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $P/r02_pmc_write_laplace.csv
+cp $O/pmc_sq_laplace_a.json $P/r02_pmc_sq_laplace_patch_a.json
+cp $O/pmc_sq_laplace_b.json $P/r02_pmc_sq_laplace_patch_b.json
+cp $O/power_probe.txt $P/r02_power_clock_probe.txt
+cp $O/patches_ab.txt $P/r02_patches_ab.txt
 echo collected

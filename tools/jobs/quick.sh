@@ -1,9 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02
-python bench.py > gpurun_out/r02/bench_cold_patches.json 2> gpurun_out/r02/bench_cold.err
+timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 2 --steps 5 --warmup 2 --rehearse-shared-gpu > gpurun_out/bench_rehearse2.json 2> gpurun_out/bench_rehearse2.err
 python3 -c "
-import json; b=json.load(open('gpurun_out/r02/bench_cold_patches.json')); print(b['value'], b['ms_per_step'], b['roofline']['frac'], b['roofline']['kernel_ms']); f=b['full_poisson_solve']; print({k:f[k] for k in ('setup_s','first_inhomogeneous_solve_s','homogeneous_correction_s','end_to_end_s','warm_inhomogeneous_solve_ms')})"
-for v in 0 1 0 1; do IPDE_PATCH_TARGETS=$v timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | tail -1; done
-timeout -k 10 1000 python3 -m pytest tests/test_layer_gpu.py tests/test_solver_gpu.py tests/test_configs_gpu.py -m gpu -x -q 2>&1 | grep -v "^  File\|^Extension" | tail -8
+import json; d=json.load(open('gpurun_out/bench_rehearse2.json')); print(d['n_gpus'], d['ms_per_step'], d['parity_max_rel_err_vs_oracle'], d['config']['target_patches'], d['config']['n_targets_per_gpu'])"
+timeout -k 10 900 python3 -m pytest tests/test_sharding.py tests/test_spectral_gpu.py tests/test_ewald_gpu.py -m gpu -x -q 2>&1 | grep -v "^  File\|^Extension" | tail -5

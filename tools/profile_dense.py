@@ -2,7 +2,7 @@
 """Profiling driver: the dense layer-potential kernels at BASELINE configs[1]
 (2048^2 grid x 4096 nodes), device resident.  Run directly after `rocprofv3 ... --`.
 
-    python3 tools/profile_dense.py [reps] [families: laplace,modhelm,stokes]
+    python3 tools/profile_dense.py [reps] [families: laplace,patches,modhelm,stokes]
 """
 import os
 import sys
@@ -26,7 +26,11 @@ def main():
     rng = np.random.default_rng(0)
     sig, tau = rng.standard_normal(c.N), rng.standard_normal(c.N)
     f2 = rng.standard_normal((2, c.N))
+    dtp = lp.DeviceTargets(trg, plan=True) if "patches" in fam else None
     for _ in range(reps):
+        if "patches" in fam:         # the 4 x 4 patch kernel (laplace_patch_kernel)
+            lp.Laplace_Layer_Apply(c, dtp, charge=sig)
+            lp.Laplace_Layer_Apply(c, dtp, dipstr=tau)
         if "laplace" in fam:
             lp.Laplace_Layer_Apply(c, dt, charge=sig)
             lp.Laplace_Layer_Apply(c, dt, dipstr=tau)
