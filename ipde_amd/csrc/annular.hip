@@ -499,6 +499,10 @@ struct GmresWork {
     // default-stream kernel — fails with "would make the legacy stream depend on a capturing
     // blocking stream".  The graph is then launched on the context's stream.
     hipStream_t cap_stream = nullptr;
+    // look-ahead (option "gmres_lookahead"): the Hessenberg column of inner iteration j reaches the
+    // host through pinned area j & 1, signalled by col_ev[j & 1], while iteration j + 1 is
+    // already in the stream
+    hipEvent_t col_ev[2] = {nullptr, nullptr};
 };
 
 void gmres_drop_graphs(GmresWork& g) {
@@ -538,6 +542,10 @@ void gmres_free(GmresWork& g) {
     gmres_drop_graphs(g);
     if (g.cap_stream) hipStreamDestroy(g.cap_stream);
     g.cap_stream = nullptr;
+    for (hipEvent_t& e : g.col_ev) {
+        if (e) hipEventDestroy(e);
+        e = nullptr;
+    }
     for (cd** p : {&g.V, &g.w, &g.z, &g.x, &g.t, &g.hdev, &g.mdpart})
         if (*p) {
             hipFree(*p);
@@ -589,6 +597,17 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     // graphs of the inner iterations: valid for one (restart, stream, option set); the legacy
     // default stream cannot be captured
     bool use_graphs = ctx->opt_gmres_graphs && st != nullptr && g.graph_failures < 3;
+    // look-ahead of one inner iteration (default): three pinned areas — columns of even / odd
+    // iterations, the cycle's y — and an event per area
+    const size_t hstride = (size_t)(2 * restart + 4);
+    bool lookahead = ctx->opt_gmres_lookahead && !use_graphs &&
+                     (3 * hstride * sizeof(cd) + 16 <= ctx->h_pinned_bytes);
+    for (int i = 0; lookahead && i < 2; ++i)
+        if (!g.col_ev[i] && hipEventCreateWithFlags(&g.col_ev[i], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            g.col_ev[i] = nullptr;
+            lookahead = false;
+        }
     {
         const long long sig = ((long long)restart << 8) ^ ((long long)(uintptr_t)st << 20) ^
                               (ctx->opt_annular_grouped ? 1 : 0) ^ (ctx->opt_annular_fused_fft ? 2 : 0);
@@ -629,6 +648,8 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
         for (auto& v : gv) v = hc{0.0, 0.0};
         gv[0] = hc{beta, 0.0};
         int j = 0;
+        int enq = 0;                                   // inner iterations of this cycle already in the stream
+        double r_prev = beta / bnorm, r_prev2 = 0.0;   // residual history for the look-ahead's guess
         for (; j < restart && iters < maxiter; ++j) {
             // Inner iteration j, everything up to the host's look at the new Hessenberg column:
             // preconditioner, operator, CGS2, the column's way to pinned memory, and the
@@ -638,7 +659,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
             // 8.75 / 9.11 ms eager vs 9.02 / 8.94 replayed, 3-body Stokes 20.4 / 21.7 vs 20.4 / 20.7;
             // the critical stream is bound by its own chain of 5-25 us kernels (the outer Stokes body:
             // 21 kernels, 255 us per iteration), not by the host's launch rate.  Off by default.
-            auto enqueue = [&](hipStream_t st) -> int {
+            auto enqueue = [&](hipStream_t st, int j, cd* hpj, hipEvent_t done) -> int {
                 cd* vj = g.V + (size_t)j * NB;
                 IPDE_TRY(op.precond(vj, g.z));
                 IPDE_TRY(op.apply(g.z, g.w));
@@ -655,13 +676,33 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
                                    (const cd*)h2, j + 1, NB, g.nrmpart, g.mdticket + (restart + 2),
                                    h1 + (j + 1));
                 IPDE_HIP_CHECK(ctx, hipGetLastError());
-                IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, g.hdev, (size_t)(2 * restart + 4) * sizeof(cd),
+                IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hpj, g.hdev, (size_t)(2 * restart + 4) * sizeof(cd),
                                                    hipMemcpyDeviceToHost, st));
+                if (done) IPDE_HIP_CHECK(ctx, hipEventRecord(done, st));
                 hipLaunchKernelGGL(cscale_copy_rnorm_kernel, dim3(nb256(NB)), dim3(256), 0, st,
                                    g.V + (size_t)(j + 1) * NB, (const cd*)g.w, NB, (const cd*)(h1 + (j + 1)));
                 IPDE_HIP_CHECK(ctx, hipGetLastError());
                 return IPDE_OK;
             };
+            const cd* hpj = hp;
+            if (lookahead) {
+                // Iteration j is in the stream already if the previous pass put it there.  Then
+                // iteration j + 1 goes in BEFORE the host waits for column j — unless the residual
+                // history says column j will end the solve (an iteration enqueued in vain costs more
+                // than the wait it hides; either way the results are the same bits: a surplus
+                // iteration writes only buffers the solution update does not read).
+                if (enq <= j) {
+                    IPDE_TRY(enqueue(st, j, hp + (size_t)(j & 1) * hstride, g.col_ev[j & 1]));
+                    enq = j + 1;
+                }
+                const double rho = (r_prev2 > 0.0) ? fmin(1.0, r_prev / r_prev2) : 1.0;
+                if (j + 1 < restart && iters + 1 < maxiter && r_prev * rho > 10.0 * tol) {
+                    IPDE_TRY(enqueue(st, j + 1, hp + (size_t)((j + 1) & 1) * hstride, g.col_ev[(j + 1) & 1]));
+                    enq = j + 2;
+                }
+                IPDE_HIP_CHECK(ctx, hipEventSynchronize(g.col_ev[j & 1]));
+                hpj = hp + (size_t)(j & 1) * hstride;
+            } else {
             bool replayed = false;
             if (use_graphs) {
                 if ((int)g.iter_graph.size() <= j) g.iter_graph.resize(j + 1, nullptr);
@@ -672,7 +713,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
                     if (ok) ok = hipStreamBeginCapture(g.cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                     if (ok) {
                         ctx->stream = g.cap_stream;        // the operator's launches follow the context
-                        const int s_enq = enqueue(g.cap_stream);
+                        const int s_enq = enqueue(g.cap_stream, j, hp, nullptr);
                         ctx->stream = st;
                         hipGraph_t graph = nullptr;
                         ok = hipStreamEndCapture(g.cap_stream, &graph) == hipSuccess && s_enq == IPDE_OK &&
@@ -694,12 +735,13 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
                     replayed = true;
                 }
             }
-            if (!replayed) IPDE_TRY(enqueue(st));
+            if (!replayed) IPDE_TRY(enqueue(st, j, hp, nullptr));
             IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            }
             hc* col = &H[(size_t)j * (restart + 1)];
             for (int i = 0; i <= j; ++i)
-                col[i] = hc{hp[i].x + hp[restart + 2 + i].x, hp[i].y + hp[restart + 2 + i].y};
-            double hn = sqrt(fmax(hp[j + 1].x, 0.0));
+                col[i] = hc{hpj[i].x + hpj[restart + 2 + i].x, hpj[i].y + hpj[restart + 2 + i].y};
+            double hn = sqrt(fmax(hpj[j + 1].x, 0.0));
             col[j + 1] = hc{hn, 0.0};
             // Givens
             for (int i = 0; i < j; ++i) {
@@ -728,6 +770,8 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
             }
             ++iters;
             resid = habs(gv[j + 1]) / bnorm;
+            r_prev2 = r_prev;
+            r_prev = resid;
             if (resid <= tol || hn == 0.0) {
                 converged = resid <= tol || hn == 0.0;
                 ++j;
@@ -752,8 +796,10 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
                 y[i] = hc{(s.re * d.re + s.im * d.im) / dd, (s.im * d.re - s.re * d.im) / dd};
             }
         }
-        for (int i = 0; i < m; ++i) hp[i] = cd{y[i].re, y[i].im};
-        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(g.hdev, hp, (size_t)m * sizeof(cd),
+        // (look-ahead: a surplus iteration's column may still be on its way into areas 0 / 1)
+        cd* hy = lookahead ? hp + 2 * hstride : hp;
+        for (int i = 0; i < m; ++i) hy[i] = cd{y[i].re, y[i].im};
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(g.hdev, hy, (size_t)m * sizeof(cd),
                                            hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(lincomb_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.t, (const cd*)g.V, NB,
                            (const cd*)g.hdev, m, NB);

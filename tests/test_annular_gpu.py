@@ -252,6 +252,48 @@ def test_gmres_graph_replay_is_bitwise_the_eager_solve(gs, scalar_geo, gst, stok
         assert np.array_equal(x, y) and np.array_equal(x, z)
 
 
+def test_gmres_lookahead_is_bitwise_the_wait_per_iteration_solve(gs, scalar_geo, gst, stokes_geo):
+    """option "gmres_lookahead" (default on; csrc/annular.hip): inner iteration j + 1 is enqueued
+    before the host has read the Hessenberg column of iteration j (two pinned areas, an event
+    each; no look-ahead when the residual history predicts the last iteration).  Same bits and
+    iteration counts as enqueue-wait-enqueue: full cycles, restarts shorter than the solve, a
+    maxiter that stops it early (status NOCONV either way), tolerances that end on different
+    iterations."""
+    from ipde_amd.annular.modified_helmholtz import AnnularModifiedHelmholtzSolver
+    from ipde_amd.annular.stokes import AnnularStokesSolver
+    aag, rag = scalar_geo
+    S = AnnularModifiedHelmholtzSolver(aag, float(gs["mh_k"][0]))
+    assert S.ctx.get_option("gmres_lookahead") == 1
+    args = (rag, gs["mh_force"], gs["mh_ig"], gs["mh_og"])
+
+    def both(solver, call):
+        on = call()
+        it_on = solver.iterations_last_call
+        solver.ctx.set_option("gmres_lookahead", 0)
+        try:
+            off = call()
+        finally:
+            solver.ctx.set_option("gmres_lookahead", 1)
+        assert solver.iterations_last_call == it_on
+        return on, off
+
+    for kw in (dict(tol=1e-13, maxiter=200, restart=100), dict(tol=1e-13, maxiter=200, restart=4),
+               dict(tol=1e-13, maxiter=200, restart=3), dict(tol=1e-6, maxiter=200, restart=100),
+               dict(tol=1e-3, maxiter=200, restart=100), dict(tol=1e-9, maxiter=200, restart=2)):
+        on, off = both(S, lambda: np.array(S.solve(*args, **kw)))
+        assert np.array_equal(on, off)
+    # maxiter reached (the solvers return the unconverged iterate): same iterate after the same 3 iterations
+    on, off = both(S, lambda: np.array(S.solve(*args, tol=1e-13, maxiter=3, restart=100)))
+    assert np.array_equal(on, off) and S.iterations_last_call == 3
+    aag, rag = stokes_geo
+    V = AnnularStokesSolver(aag, 1.0)
+    sargs = (rag, gst["fr"], gst["ft"], gst["irg"], gst["itg"], gst["org"], gst["otg"])
+    for kw in (dict(tol=1e-12, maxiter=300, restart=100), dict(tol=1e-12, maxiter=300, restart=5)):
+        on, off = both(V, lambda: [np.array(x) for x in V.solve(*sargs, **kw)])
+        for x, y in zip(on, off):
+            assert np.array_equal(x, y)
+
+
 def test_helper_jump_kernels_match_the_numpy_statements():
     """ipde_scalar_interface_jumps / ipde_stokes_rotate / ipde_stokes_interface_jumps (csrc/annular.hip)
     against the numpy statements of the helpers they replace (reference internals/scalar.py:76-90,
