@@ -133,6 +133,28 @@ int ipde_laplace_apply_patches(ipde_ctx* ctx,
                                double* out);
 
 /*
+ * The cut of a target list (HOST arrays x, y of nt points) into those patches, on the host — no
+ * GPU work, callable from any thread.  Grid lines are the coordinate values at least
+ * line_min_points points share (exact comparisons); tiles of the lattice of lines that hold a
+ * point become patches — all of them if the list fills at least partial_min_fill of their 16
+ * points on average (missing points: pout = -1), else the full tiles only; patches are ordered in
+ * blocks of block_i x block_j tiles (consecutive lanes take consecutive patches); fewer than
+ * min_patches patches, or a list that is no grid: np = 0.  The remainder (list positions in
+ * increasing order) is everything no patch holds.  ipde_amd/target_plan.py calls this for the
+ * reference's grid_pnai lists (ipde/ebdy_collection.py:426-429).
+ * build -> sizes -> export into caller-allocated HOST buffers (pxy: 8 np doubles, pout: 16 np
+ * int32, rest: nrest int64) -> destroy.
+ */
+typedef struct ipde_target_plan ipde_target_plan;
+int ipde_target_plan_build(int64_t nt, const double* x, const double* y,
+                           int block_i, int block_j, double partial_min_fill,
+                           int64_t min_patches, int line_min_points,
+                           ipde_target_plan** plan);
+int ipde_target_plan_sizes(const ipde_target_plan* plan, int64_t* np, int64_t* nrest);
+int ipde_target_plan_export(const ipde_target_plan* plan, double* pxy, int32_t* pout, int64_t* rest);
+int ipde_target_plan_destroy(ipde_target_plan* plan);
+
+/*
  * Modified Helmholtz (k^2 - Lap) single+double layer:
  *   out_i = sum_j [ (1/2pi) K0(k r) w_sigma_j + (k/2pi) K1(k r) (n_j.d)/r w_tau_j ]
  * Replaces pybie2d Modified_Helmholtz_Layer_Apply(src, trg, charge=, k=) as
@@ -219,6 +241,8 @@ int ipde_fourier_deriv(ipde_fft_plan* plan, int loc, const double* f, int axis, 
  * physical units.  Oversampled (2x .. 4x: the fine grid is a power of two) inverse transform +
  * 16 x 16 window gather, ~1e-14. */
 int ipde_fft_plan2d_keep_spectrum(ipde_fft_plan* plan, int on, int* supported);
+/* Optional: build the interpolation state of this plan now (else at the first call below). */
+int ipde_grid_interp_prepare(ipde_fft_plan* plan);
 int ipde_grid_interp(ipde_fft_plan* plan, int loc, int64_t np, const double* x, const double* y,
                      double* out3);
 /* The same for linear combinations of real grid fields and their first derivatives — the Stokes

@@ -19,6 +19,7 @@ IPDE_HOST = 0
 IPDE_DEVICE = 1
 
 IPDE_OK = 0
+IPDE_ERR_INVALID = 1
 IPDE_ERR_NOCONV = 6
 FLAG_NONE = 0
 FLAG_SKIP_COINCIDENT = 1
@@ -62,6 +63,10 @@ SIGNATURES = {
     "ipde_laplace_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                   _vp, _int]),
     "ipde_laplace_apply_patches": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "ipde_target_plan_build": (_int, [_i64, _vp, _vp, _int, _int, _dbl, _i64, _int, _c_void_pp]),
+    "ipde_target_plan_sizes": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "ipde_target_plan_export": (_int, [_vp, _vp, _vp, _vp]),
+    "ipde_target_plan_destroy": (_int, [_vp]),
     "ipde_modhelm_apply": (_int, [_vp, _int, _dbl, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
                                   _vp, _vp, _int]),
     "ipde_stokes_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
@@ -76,6 +81,7 @@ SIGNATURES = {
     "ipde_fourier_deriv": (_int, [_vp, _int, _vp, _int, _vp]),
     "ipde_fourier_multiply": (_int, [_vp, _int, _vp, _vp, _vp]),
     "ipde_fft_plan2d_keep_spectrum": (_int, [_vp, _int, ctypes.POINTER(_int)]),
+    "ipde_grid_interp_prepare": (_int, [_vp]),
     "ipde_grid_interp": (_int, [_vp, _int, _i64, _vp, _vp, _vp]),
     "ipde_grid_interp_fields": (_int, [_vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ipde_dense_lu_solve": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),

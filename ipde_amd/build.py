@@ -34,6 +34,7 @@ SOURCES = [
     "dense.hip",
     "lu_factor.hip",
     "geometry.hip",
+    "target_plan.hip",
 ]
 
 CXXFLAGS = [

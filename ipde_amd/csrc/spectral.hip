@@ -451,6 +451,25 @@ extern "C" int ipde_fft_plan2d_keep_spectrum(ipde_fft_plan* p, int on, int* supp
     return IPDE_OK;
 }
 
+// The interpolation state (fine-grid plan, window factors, work grids: ~60 ms of allocation
+// and host quadrature at 2048^2) ahead of the first ipde_grid_interp / ipde_grid_interp_fields —
+// the path a scalar grid solve on this plan will leave its spectrum for.
+extern "C" int ipde_grid_interp_prepare(ipde_fft_plan* p) {
+    if (!p) return IPDE_ERR_INVALID;
+    ipde_ctx* ctx = p->ctx;
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (p->fast.ready && ctx->opt_fft2d && grid_interp_supported(p->nx, p->ny)) {
+        if (!p->interp) {
+            grid_interp_force_shifted(ctx->opt_interp_shifted != 0);
+            IPDE_TRY(grid_interp_create(ctx, p->nx, p->ny, p->hx, p->hy, &p->interp));
+        }
+    } else if (grid_interp_general_supported(p->nx, p->ny)) {
+        if (!p->interp_general)
+            IPDE_TRY(grid_interp_create(ctx, p->nx, p->ny, p->hx, p->hy, &p->interp_general, true));
+    }
+    return IPDE_OK;
+}
+
 extern "C" int ipde_grid_interp(ipde_fft_plan* p, int loc, int64_t np, const double* x, const double* y,
                                 double* out3) {
     if (!p) return IPDE_ERR_INVALID;

@@ -51,6 +51,11 @@ class DeviceTargets:
         if y is None:  # a PointSet-like object
             x, y = x.x, x.y
         self.ctx = ctx or get_context()
+        # (host copies kept for the plan builder only while it runs)
+        self._host_xy = None
+        if plan and not isinstance(x, torch.Tensor) and not isinstance(y, torch.Tensor):
+            self._host_xy = (np.ascontiguousarray(x, dtype=np.float64).ravel(),
+                             np.ascontiguousarray(y, dtype=np.float64).ravel())
         self.x = to_device(np.asarray(x, dtype=np.float64).ravel(), self.ctx) \
             if not isinstance(x, torch.Tensor) else x.to(torch.float64).contiguous().view(-1)
         self.y = to_device(np.asarray(y, dtype=np.float64).ravel(), self.ctx) \
@@ -72,11 +77,17 @@ class DeviceTargets:
                 torch.cuda.set_device(dev)
                 side = torch.cuda.Stream(dev)       # not in the way of the set-up's own launches
                 with torch.cuda.stream(side):
-                    plan = target_plan.build(self.x, self.y, min_patches=target_plan.MIN_PATCHES)
+                    if self._host_xy is not None:   # the library's host routine, then four uploads
+                        plan = target_plan.build_host(*self._host_xy, device=dev,
+                                                      min_patches=target_plan.MIN_PATCHES)
+                    else:                           # a list that only exists on the device: torch sorts
+                        plan = target_plan.build(self.x, self.y, min_patches=target_plan.MIN_PATCHES)
                 side.synchronize()
                 self._plan = plan if plan.np else None
             except Exception as e:                  # the list kernel needs no plan
                 self._plan_error = e
+            finally:
+                self._host_xy = None
         self._plan_thread = threading.Thread(target=work, name="ipde-target-plan", daemon=True)
         self._plan_thread.start()
         _plan_threads.append(self._plan_thread)

@@ -19,7 +19,7 @@ from ...interp import periodic_interp2d, periodic_interp2d_gradient, radial_to_g
 from ...qfs import call_many, u2s_many
 from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
-from ...device import prewarm_wait
+from ...device import prewarm_wait, prewarm_submit
 from ... import hostio, gridops
 from ...sharding import make_pnai_evaluator, exchange_owned, owner_of, is_distributed, _dist_state
 from ...spectral import get_plan
@@ -109,6 +109,8 @@ class ScalarSolver(object):
         # full spectrum by the dense Fourier sums of ipde_amd.interp
         self._fast_interp = self.USE_FAST_INTERP and self.interpolation_order == np.inf \
             and self.plan.keep_spectrum(True)
+        if self._fast_interp:      # its one-time state in the background of the set-up, not in the first solve
+            prewarm_submit(("interp", self.grid.Nx, self.grid.Ny), self.plan.prepare_interp)
         self.grid_step = self.ebdyc.grid_step
         self._define_layer_apply()
         self._collect_grid_sources()

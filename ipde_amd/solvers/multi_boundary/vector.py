@@ -15,7 +15,7 @@ from ...layer_potentials import DeviceTargets
 from ...pybie2d_compat import BoundaryCollection
 from ...qfs import call_many, u2s_many
 from .scalar import _finish_all, _concurrent_helpers, _owned, _run_owned
-from ...device import prewarm_wait
+from ...device import prewarm_wait, prewarm_submit
 from ... import hostio, gridops
 from ...sharding import make_pnai_evaluator, exchange_owned, is_distributed
 from ...spectral import get_plan
@@ -43,6 +43,8 @@ class VectorSolver(object):
         # oversampled-FFT interpolation where the plan has it (power-of-two grids)
         self._fast_interp = self.USE_FAST_INTERP and self.interpolation_order == np.inf \
             and self.plan.keep_spectrum(False)
+        if self._fast_interp:
+            prewarm_submit(("interp", self.grid.Nx, self.grid.Ny), self.plan.prepare_interp)
         self.grid_step = self.ebdyc.grid_step
         self._define_layer_apply()
         self._collect_grid_sources()

@@ -46,6 +46,12 @@ class GridPlan:
                                                                   ctypes.byref(ok)))
         return bool(ok.value)
 
+    def prepare_interp(self):
+        """Build the interpolation state now (fine-grid plan, window factors, work grids) instead
+        of inside the first interp_gradient / interp_fields (the solvers run it on the warm-up
+        thread: device.prewarm_submit)."""
+        self.ctx.check(self.ctx.lib.ipde_grid_interp_prepare(self.handle))
+
     def interp_gradient(self, x, y):
         """(3, P): the last kept grid solution, its x and its y derivative at the points
         (x, y) given in box units [0, 2 pi) (reference multi_boundary/scalar.py:80-88)"""

@@ -97,6 +97,37 @@ def build(x, y, block=DEFAULT_BLOCK, min_patches=0):
     return TargetPlan(n, pxy, pout, rest, x[rest].contiguous(), y[rest].contiguous())
 
 
+def build_host(x, y, device=None, block=DEFAULT_BLOCK, min_patches=0):
+    """The same cut by the library's host routine (ipde_target_plan_build, csrc/target_plan.hip):
+    x, y numpy arrays; the plan's arrays are uploaded to `device` (None: they stay on the host).
+    What the solvers use — no GPU library is touched, so it runs beside a cold set-up for free
+    (torch's first sort loads ~0.6 s of code objects)."""
+    import ctypes
+    import numpy as np
+    from . import _lib
+    lib = _lib.load()
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+    y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+    n = int(x.shape[0])
+    assert y.shape[0] == n
+    handle = ctypes.c_void_p()
+    _lib.check(lib.ipde_target_plan_build(n, ptr(x), ptr(y), int(block[0]), int(min(block[1], 2 ** 30)),
+                                          float(PARTIAL_MIN_FILL), int(min_patches), int(LINE_MIN_POINTS),
+                                          ctypes.byref(handle)))
+    try:
+        np_, nrest = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.ipde_target_plan_sizes(handle, ctypes.byref(np_), ctypes.byref(nrest)))
+        pxy = np.empty((8, np_.value), dtype=np.float64)
+        pout = np.empty((16, np_.value), dtype=np.int32)
+        rest = np.empty(nrest.value, dtype=np.int64)
+        _lib.check(lib.ipde_target_plan_export(handle, ptr(pxy), ptr(pout), ptr(rest)))
+    finally:
+        lib.ipde_target_plan_destroy(handle)
+    up = (lambda a: torch.from_numpy(a)) if device is None else (lambda a: torch.as_tensor(a, device=device))
+    return TargetPlan(n, up(pxy), up(pout), up(rest), up(np.ascontiguousarray(x[rest])),
+                      up(np.ascontiguousarray(y[rest])))
+
+
 def laplace_apply(plan, sx, sy, w_sigma=None, nx=None, ny=None, w_tau=None, ctx=None, out=None):
     """ipde_laplace_apply over a planned list (device tensors; densities weight-multiplied as in
     layer_potentials.laplace_apply): the patches through ipde_laplace_apply_patches, the

@@ -104,3 +104,74 @@ def test_grid_list_followed_by_off_lattice_points():
     assert plan.nrest == 300 and np.array_equal(np.sort(plan.rest.numpy()), gx.shape[0] + np.arange(300))
     ref = target_plan.build(torch.from_numpy(gx), torch.from_numpy(gy))
     assert plan.np == ref.np
+
+
+def _lists():
+    rng = np.random.default_rng(7)
+    gx, gy = _band_list(160, clearance=2.5)
+    t = np.linspace(0, 2 * np.pi, 300, endpoint=False)
+    yield "band", gx, gy
+    yield "band + curve nodes", np.concatenate([gx, 0.8 * np.cos(t) + 1e-3]), np.concatenate([gy, 0.8 * np.sin(t)])
+    perm = rng.permutation(gx.shape[0])
+    yield "unordered", gx[perm], gy[perm]
+    v = np.linspace(0.0, 1.0, 27)
+    X, Y = np.meshgrid(v, np.linspace(-2.0, 0.0, 30), indexing="ij")
+    yield "27 x 30 full", X.ravel(), Y.ravel()
+    yield "scattered", rng.standard_normal(500), rng.standard_normal(500)
+    yield "coarse ragged", *_band_list(40, clearance=1.0)
+    bad = gx.copy()
+    bad[[3, 77]] = [np.nan, np.inf]
+    yield "non-finite entries", bad, gy
+    yield "signed zeros", np.where(gx == 0.0, -0.0, gx), gy
+    yield "tiny", gx[:9], gy[:9]
+
+
+def test_host_builder_of_the_library_equals_the_torch_builder():
+    """ipde_target_plan_build (csrc/target_plan.hip, plain C++ behind the C ABI: the builder the
+    solvers use) against the torch statement of the same algorithm: identical patches in identical
+    order, identical remainder — lists without repeated points (for those the choice of the copy
+    that sits on the lattice is free: partition checked instead)."""
+    for block in ((8, 8), (1, 1 << 20), (4, 4)):
+        for name, x, y in _lists():
+            a = target_plan.build_host(x, y, block=block)
+            b = target_plan.build(torch.from_numpy(x), torch.from_numpy(y), block=block)
+            assert (a.np, a.nrest) == (b.np, b.nrest), name
+            assert np.array_equal(a.pxy.numpy(), b.pxy.numpy(), equal_nan=True), name
+            assert np.array_equal(a.pout.numpy(), b.pout.numpy()), name
+            assert np.array_equal(a.rest.numpy(), b.rest.numpy()), name
+            assert np.array_equal(a.rest_x.numpy(), b.rest_x.numpy(), equal_nan=True), name
+            if np.isfinite(x).all():
+                _check_partition(x, y, a)
+    gx, gy = _band_list(48)
+    x, y = np.concatenate([gx, gx[100:140]]), np.concatenate([gy, gy[100:140]])
+    a = target_plan.build_host(x, y)
+    _check_partition(x, y, a)
+    assert a.np > 0 and a.nrest >= 40
+    assert target_plan.build_host(gx, gy, min_patches=10 ** 6).np == 0
+    old, target_plan.PARTIAL_MIN_FILL = target_plan.PARTIAL_MIN_FILL, 2.0
+    try:
+        a = target_plan.build_host(gx, gy)
+        b = target_plan.build(torch.from_numpy(gx), torch.from_numpy(gy))
+    finally:
+        target_plan.PARTIAL_MIN_FILL = old
+    assert a.np == b.np and a.nrest == b.nrest > 0 and np.array_equal(a.pout.numpy(), b.pout.numpy())
+
+
+def test_host_builder_argument_checks():
+    import ctypes
+    from ipde_amd import _lib
+    lib = _lib.load()
+    x = np.zeros(32)
+    h = ctypes.c_void_p()
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)
+    assert lib.ipde_target_plan_build(32, P(x), None, 8, 8, 0.9, 0, 4, ctypes.byref(h)) == _lib.IPDE_ERR_INVALID
+    assert lib.ipde_target_plan_build(-1, P(x), P(x), 8, 8, 0.9, 0, 4, ctypes.byref(h)) == _lib.IPDE_ERR_INVALID
+    assert lib.ipde_target_plan_build(32, P(x), P(x), 0, 8, 0.9, 0, 4, ctypes.byref(h)) == _lib.IPDE_ERR_INVALID
+    assert lib.ipde_target_plan_build(32, P(x), P(x), 8, 8, 0.9, 0, 4, None) == _lib.IPDE_ERR_INVALID
+    assert lib.ipde_target_plan_build(0, None, None, 8, 8, 0.9, 0, 4, ctypes.byref(h)) == _lib.IPDE_OK
+    n1, n2 = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    assert lib.ipde_target_plan_sizes(h, ctypes.byref(n1), ctypes.byref(n2)) == _lib.IPDE_OK and (n1.value, n2.value) == (0, 0)
+    assert lib.ipde_target_plan_export(h, None, None, None) == _lib.IPDE_OK
+    assert lib.ipde_target_plan_sizes(None, ctypes.byref(n1), ctypes.byref(n2)) == _lib.IPDE_ERR_INVALID
+    assert lib.ipde_target_plan_destroy(h) == _lib.IPDE_OK
+    assert lib.ipde_target_plan_destroy(None) == _lib.IPDE_OK

@@ -35,6 +35,7 @@ python3 tools/summarize_pmc.py $O/pmc_sq_a $O/pmc_sq_laplace_a.json laplace_ > /
 python3 tools/summarize_pmc.py $O/pmc_sq_b $O/pmc_sq_laplace_b.json laplace_ > /dev/null
 timeout -k 10 120 python3 tools/power_probe.py 2>&1 | grep -v amdgpu.ids > $O/power_probe.txt
 timeout -k 10 300 python3 tools/ab_patches.py 2>&1 | grep -v amdgpu.ids > $O/patches_ab.txt
+for i in 1 2 3; do timeout -k 10 200 python3 tools/cold_solve.py 2>/dev/null | tail -1 >> $O/cold_process.jsonl; done
 find $O -name "*_kernel_trace.csv" -size +20M -delete
 cat $O/smoke.txt $O/gputest.txt $O/poisson_warm_unprofiled.txt $O/stokes_warm_unprofiled.txt
 python3 -c "

@@ -23,4 +23,5 @@ cp $O/pmc_sq_laplace_a.json $P/r02_pmc_sq_laplace_patch_a.json
 cp $O/pmc_sq_laplace_b.json $P/r02_pmc_sq_laplace_patch_b.json
 cp $O/power_probe.txt $P/r02_power_clock_probe.txt
 cp $O/patches_ab.txt $P/r02_patches_ab.txt
+cp $O/cold_process.jsonl $P/r02_poisson_2048_cold_process.jsonl
 echo collected
