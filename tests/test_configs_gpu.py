@@ -85,6 +85,15 @@ def _run_sharded(problem, extra, port):
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
 
+def test_config2_two_rank_rehearsal_patch_kernel_on_the_halves():
+    """interior Poisson, 2048^2 grid, 4096 nodes, grid_pnai split over two ranks: each rank cuts ITS
+    half of the list into 4 x 4 patches (the halves are big enough for the patch kernel, which then
+    splits the sources over blockIdx.y) — the N > 1 form of configs[2]"""
+    res = _run_sharded("poisson", ["--nb", "4096", "--M", "20", "--ng", "2048"], 29567)
+    print(res)
+    assert res["world"] == 2 and res["error"] < 1e-12
+
+
 def test_config3_two_rank_rehearsal_mid_size():
     """modified Helmholtz k = 10, 2048^2 grid, 4096 nodes, targets split over two ranks"""
     res = _run_sharded("modhelm", ["--nb", "4096", "--M", "20", "--k", "10", "--ng", "2048"], 29561)
