@@ -187,7 +187,7 @@ extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
         if (kv.second) hipFree(kv.second);
     ctx->cheb_tab.clear();
     // (the log table belongs to the device, see ipde_build_log_table)
-    if (ctx->d_ktab) hipFree(ctx->d_ktab);
+    // (d_ktab belongs to the device, not to the context: layer_modhelm.hip)
     if (ctx->d_lu_abort) hipFree(ctx->d_lu_abort);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -229,6 +229,7 @@ static int* option_slot(ipde_ctx* ctx, const char* name) {
     if (!strcmp(name, "dense_pairs")) return &ctx->opt_dense_pairs;
     if (!strcmp(name, "dense_persistent")) return &ctx->opt_dense_persistent;
     if (!strcmp(name, "gmres_graphs")) return &ctx->opt_gmres_graphs;
+    if (!strcmp(name, "modhelm_variant")) return &ctx->opt_modhelm_variant;
     if (!strcmp(name, "gmres_lookahead")) return &ctx->opt_gmres_lookahead;
     if (!strcmp(name, "annular_fused_fft")) return &ctx->opt_annular_fused_fft;
     if (!strcmp(name, "annular_grouped")) return &ctx->opt_annular_grouped;

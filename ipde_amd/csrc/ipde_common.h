@@ -62,6 +62,7 @@ struct ipde_ctx {
     int opt_dense_pairs = 1;      // substitution: two 64-row blocks per launch (0: one)
     int opt_dense_persistent = 1; // substitution: one launch per triangular pass, in-launch hand-off (0: a launch per step)
     unsigned* d_lu_abort = nullptr;   // sticky time-out word of the persistent substitution (last 8 bytes of h_pinned mirror it)
+    int opt_modhelm_variant = 0;  // table kernel geometry: 0: 2 targets per lane, 1: 4, 2: 2 x two sources in flight, 3: 3
     int opt_stokes_variant = 1;   // 1: row-run stokeslet kernel (single layer), 0: strided table kernel
     int opt_interp_shifted = 0;   // 1: ipde_grid_interp always through four shifted coarse transforms (testing)
     int opt_fft2d = 1;            // 1: hand-written 2-D FFT pipeline on power-of-two grids (fft2d.hip), 0: rocFFT

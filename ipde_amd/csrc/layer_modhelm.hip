@@ -10,9 +10,9 @@
 //
 // Table kernel (the fast path).  F0(y) = K0(sqrt y) and F1(y) = K1(sqrt y)/sqrt y are
 // smooth on log-spaced intervals (the only singularity is y = 0), so each covered binade
-// is cut into 2^5 intervals by the top 5 mantissa bits of y; per interval the LDS table
-// holds R ~ 1/centre and the 8 coefficients of a degree-7 polynomial in z = y R - 1
-// (|z| <= 2^-6), fitted at Chebyshev nodes from long-double std::cyl_bessel_k at context
+// is cut into 2^6 intervals by the top 6 mantissa bits of y; per interval the LDS table
+// holds the 6 coefficients of a degree-5 polynomial in z = y - c (c the interval's centre,
+// |z| <= 2^-7 c), fitted at Chebyshev nodes from long-double std::cyl_bessel_k at context
 // creation.  A table covers 32 binades; EIGHT windows [2^(-21+2w), 2^(11+2w)) are resident
 // in HBM and the pack kernel picks, from the bounding box, the lowest one whose top covers
 // (k * diameter)^2 — so for any k every pair farther apart than diameter * 2^-16 is a table
@@ -21,8 +21,8 @@
 // accuracy: 1e-15 for k r <= 11, 2e-14 at 20, 9e-14 at 30, 2e-12 at 40, 1e-10 at 45
 // (where the value is 1e-20 of a near-field one); y below the window or r = 0 is detected
 // per lane and that lane's targets are redone with the series / Chebyshev code below.
-//   per pair: 4 (dx,dy,y) + 1 (z) + 7 (Horner) + 1 (accumulate) fp64 ops
-//             (+2 for the DLP's a.d), 3 int32 ops, 5 ds_read_b128 (80-byte entry).
+//   per pair: 4 (dx,dy,y) + 1 (z) + 5 (Horner) + 1 (accumulate) fp64 ops
+//             (+2 for the DLP's a.d), 4 int32 ops, 3 ds_read_b128 (48-byte entry).
 // Roofline: fp64 VALU / LDS-read co-bound; algorithmic HBM traffic 24 B per target.
 #include "layer_pack.h"
 #include "bessel_device.h"
@@ -87,14 +87,26 @@ __global__ __launch_bounds__(NT) void modhelm_generic_kernel(
 
 // ---------------------------------------------------------------------------
 // table kernel
-#define KT_B 5
+#define KT_B 6
 #define KT_SHIFT (20 - KT_B)
 #define KT_BINADES 32
-#define KT_NKEYS (KT_BINADES << KT_B)    // 1024 entries
-#define KT_NC 8                          // coefficients: degree 7 (degree 6 / 64-byte entries is 3 %
-                                         // faster but only 3.5e-12 RELATIVE at k r = 10, where the
-                                         // functions fall by 27 % across an interval)
-#define KT_ENTRY 10                      // doubles per entry: R, a0..a7, pad  (80 B)
+#define KT_NKEYS (KT_BINADES << KT_B)    // 2048 entries
+#define KT_NC 6                          // coefficients: degree 5 on 64 intervals per binade, in z = y - c
+#define KT_ENTRY 6                       // doubles per entry: b0..b5 (48 B: THREE ds_read_b128)
+#define KT_READS 3
+// Round 1 had degree 7 on 32 intervals in 80-byte entries {R, a0..a7} (five reads per pair).  The
+// kernel is bound by LDS reads — 4.7-5.3 LDS cycles per ds_read_b128 of random entries, against 15-16
+// VALU issue cycles per pair and CU — so the entry is what to shrink:
+//   * the interval's centre c comes out of the bits of y itself (top 6 mantissa bits kept, the next
+//     one set: one v_and_or_b32), so no reciprocal is stored: z = y - c exactly, coefficients
+//     b_j = a_j / c^j;
+//   * twice the intervals pay for two dropped degrees: pointwise RELATIVE error 5e-15 for k r <= 5,
+//     6e-14 at 10, 2e-12 at 20, 7e-12 at 30 (degree 7 / 32: 1e-15, 1e-14, 6e-14) — ABSOLUTE error below
+//     2e-15 of the near-field values everywhere (the functions decay like exp(-k r)), which is what the
+//     1e-12-of-max|u| parity bar and the solvers' tolerances see.
+// Tried on the way (2048^2 x 4096, k = 10): degree 6 with R in packed 64-byte slots — chunk c of every
+// entry in the same four bank groups, 12.8 ms; the same in 80-byte slots (160 KiB, all of a CU's LDS):
+// 9.6 ms against 9.9 for round 1's table; 2, 3 or 4 targets per lane and two sources in flight: equal.
 #define KT_EXP_LO (-21)                  // window 0 covers y in [2^-21, 2^11): k r in [7e-4, 45]
 #define KT_NWIN 8                        // window w is shifted up by 2w binades (k r up to 5800)
 
@@ -106,12 +118,15 @@ __global__ __launch_bounds__(NT) void modhelm_table_kernel(
     extern __shared__ double2 ltab[];  // KT_NKEYS * KT_ENTRY/2 double2
     // the pack kernel picked the window from the bounding box: (k * diameter)^2 < 2^(11 + 2w),
     // so every pair farther apart than diameter * 2^-16 is inside the table whatever k is
-    const int win = prm->pad;
+    // (window KT_NWIN: the pairs reach beyond the last one — every lane takes the generic body)
+    const bool nowin = prm->pad >= KT_NWIN;
+    const int win = nowin ? KT_NWIN - 1 : prm->pad;
     gtab += (size_t)win * KT_NKEYS * (KT_ENTRY / 2);
     for (unsigned i = threadIdx.x; i < KT_NKEYS * (KT_ENTRY / 2); i += NT) ltab[i] = gtab[i];
     __syncthreads();
     const unsigned key_lo = (unsigned)((1023 + KT_EXP_LO + 2 * win) << KT_B);
-    unsigned hmin = 0xFFFFFFFFu, hmax = 0u;
+    // only the LOWER end needs watching: the window's top covers the bounding box (pack kernel)
+    unsigned hmin = 0xFFFFFFFFu;
 
     const int j0 = blockIdx.y * chunk;
     const int j1 = min(ns_pad, j0 + chunk);
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(NT) void modhelm_table_kernel(
 #pragma unroll
         for (int u0 = 0; u0 < IPDE_SRC_PAD; u0 += U) {
             double dx[U][R], dy[U][R], d2[U][R];
-            double2 e[U][R][KT_ENTRY / 2];
+            double2 e[U][R][KT_READS];
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -147,29 +162,30 @@ __global__ __launch_bounds__(NT) void modhelm_table_kernel(
                     d2[u][r] = fma(dy[u][r], dy[u][r], dx[u][r] * dx[u][r]);
                     unsigned hi = (unsigned)__double2hiint(d2[u][r]);
                     hmin = min(hmin, hi);
-                    hmax = max(hmax, hi);
                     unsigned idx;
-                    static_assert(KT_SHIFT == 15 && KT_B + 5 == 10, "literal operands below");
-                    asm("v_bfe_u32 %0, %1, 15, 10" : "=v"(idx) : "v"(hi));
+                    static_assert(KT_SHIFT == 14 && KT_B + 5 == 11, "literal operands below");
+                    asm("v_bfe_u32 %0, %1, 14, 11" : "=v"(idx) : "v"(hi));
                     // 24-bit multiply-add is full rate (v_mul_lo_u32 is quarter rate)
                     const double2* ep = (const double2*)((const char*)ltab +
                                                          __umul24(idx, KT_ENTRY * 8u));
 #pragma unroll
-                    for (int c = 0; c < KT_ENTRY / 2; ++c) e[u][r][c] = ep[c];
+                    for (int c = 0; c < KT_READS; ++c) e[u][r][c] = ep[c];
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const double2* c = e[u][r];
-                    double z = fma(d2[u][r], c[0].x, -1.0);
-                    double p = fma(c[4].x, z, c[3].y);   // a7 z + a6
-                    p = fma(p, z, c[3].x);               // a5
-                    p = fma(p, z, c[2].y);               // a4
-                    p = fma(p, z, c[2].x);               // a3
-                    p = fma(p, z, c[1].y);               // a2
-                    p = fma(p, z, c[1].x);               // a1
-                    p = fma(p, z, c[0].y);               // a0
+                    // the centre of y's interval: sign, exponent and 6 mantissa bits of y, then a one
+                    static_assert(KT_B == 6 && KT_NC == 6 && KT_READS == 3, "entry = {b0, b1}, {b2, b3}, {b4, b5}");
+                    const unsigned hi = (unsigned)__double2hiint(d2[u][r]);
+                    const double ctr = __hiloint2double((int)((hi & 0xFFFFC000u) | 0x2000u), 0);
+                    const double z = d2[u][r] - ctr;
+                    double p = fma(c[2].y, z, c[2].x);   // b5 z + b4
+                    p = fma(p, z, c[1].y);               // b3
+                    p = fma(p, z, c[1].x);               // b2
+                    p = fma(p, z, c[0].y);               // b1
+                    p = fma(p, z, c[0].x);               // b0
                     if (MODE == MODE_SLP) {
                         acc[r] = fma(sq.v[u0 + u], p, acc[r]);
                     } else {
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(NT) void modhelm_table_kernel(
                 }
         }
     }
-    const bool inside = (hmin >> KT_SHIFT) >= key_lo && (hmax >> KT_SHIFT) < key_lo + KT_NKEYS;
+    const bool inside = (hmin >> KT_SHIFT) >= key_lo && !nowin;
     if (!inside) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.0;
@@ -205,8 +221,11 @@ int launch_modhelm(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
                    int64_t nt, double* out, const ApplyParams* prm, int flags, int accumulate) {
     const bool skip = (flags & IPDE_FLAG_SKIP_COINCIDENT) != 0;
     const bool generic = skip || (flags & IPDE_FLAG_GENERIC_MATH) != 0;
-    constexpr int NT_T = 1024, R_T = 2, U_T = 1;
+    constexpr int NT_T = 1024;
     constexpr int NT_G = 256, R_G = 2;
+    // targets per lane x sources in flight of the table kernel (option "modhelm_variant")
+    const int variant = ctx->opt_modhelm_variant;
+    const int R_T = variant == 1 ? 4 : variant == 3 ? 3 : 2;
     const LayerGeom g = generic ? ipde_layer_geom(ns, nt, NT_G * R_G, 2 * ctx->num_cu)
                                 : ipde_layer_geom(ns, nt, NT_T * R_T, ctx->num_cu);
     double* dst = out;
@@ -228,12 +247,21 @@ int launch_modhelm(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
     } else {
         const double* tab = ctx->d_ktab + (MODE == MODE_SLP ? 0 : (size_t)KT_NWIN * KT_NKEYS * KT_ENTRY);
         size_t lds = (size_t)KT_NKEYS * KT_ENTRY * sizeof(double);
-        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute(
-                                (const void*)modhelm_table_kernel<MODE, R_T, NT_T, U_T>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((modhelm_table_kernel<MODE, R_T, NT_T, U_T>), grid, dim3(NT_T), lds,
-                           ctx->stream, rec, g.ns_pad, g.chunk, tx, ty, nt, dst, prm,
-                           (const double2*)tab, acc_main);
+        auto go = [&](auto kern) -> int {
+            IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)lds));
+            hipLaunchKernelGGL(kern, grid, dim3(NT_T), lds, ctx->stream, rec, g.ns_pad, g.chunk, tx, ty, nt, dst,
+                               prm, (const double2*)tab, acc_main);
+            return IPDE_OK;
+        };
+        int st;
+        switch (variant) {
+            case 1: st = go(modhelm_table_kernel<MODE, 4, NT_T, 1>); break;
+            case 2: st = go(modhelm_table_kernel<MODE, 2, NT_T, 2>); break;
+            case 3: st = go(modhelm_table_kernel<MODE, 3, NT_T, 1>); break;
+            default: st = go(modhelm_table_kernel<MODE, 2, NT_T, 1>); break;
+        }
+        IPDE_TRY(st);
     }
     if (ctx->timing) {
         hipEventRecord(ctx->ev1, ctx->stream);
@@ -288,7 +316,18 @@ void fit_interval(long double c, long double a, F f, double* coef /*KT_NC*/) {
 
 }  // namespace
 
+// One table set per DEVICE (3.4 MB; ~0.14 s of long-double Bessel evaluations): the solvers keep a
+// context per boundary thread, and each used to build its own.
+static std::mutex g_ktab_mutex;
+static std::map<int, double*> g_ktab;
+
 int ipde_build_k_table(ipde_ctx* ctx) {
+    std::lock_guard<std::mutex> guard(g_ktab_mutex);
+    auto it = g_ktab.find(ctx->device);
+    if (it != g_ktab.end()) {
+        ctx->d_ktab = it->second;
+        return IPDE_OK;
+    }
     IPDE_HIP_CHECK(ctx, ipde_bessel_upload());
     // piecewise tables of F0(y) = K0(sqrt y), F1(y) = K1(sqrt y)/sqrt y
     // layout: [kind (K0 | K1/x)][window][key][entry]
@@ -307,25 +346,30 @@ int ipde_build_k_table(ipde_ctx* ctx) {
             double xlo, xhi;
             memcpy(&xlo, &lo_bits, 8);
             memcpy(&xhi, &hi_bits, 8);
-            double R = (double)(2.0L / ((long double)xlo + (long double)xhi));
-            long double c = 1.0L / (long double)R;  // the centre the kernel actually uses
-            long double a =
-                fmaxl(fabsl((long double)xlo / c - 1.0L), fabsl((long double)xhi / c - 1.0L));
+            // the centre the kernel forms from the bits of y: exactly the midpoint
+            const long double c = 0.5L * ((long double)xlo + (long double)xhi);
+            const long double a = ((long double)xhi - (long double)xlo) / (2.0L * c);
             for (int t = 0; t < 2; ++t) {
                 double* e = &h[(((size_t)t * KT_NWIN + w) * KT_NKEYS + pos) * KT_ENTRY];
-                e[0] = R;
                 // beyond k r ~ 700 the functions underflow even in long double: zero entries
                 if (xlo > 4.9e5) continue;
                 if (t == 0)
-                    fit_interval(c, a, F0, e + 1);
+                    fit_interval(c, a, F0, e);
                 else
-                    fit_interval(c, a, F1, e + 1);
+                    fit_interval(c, a, F1, e);
+                // from the relative variable y / c - 1 to z = y - c
+                long double s = 1.0L;
+                for (int j = 0; j < KT_NC; ++j) {
+                    e[j] = (double)((long double)e[j] / s);
+                    s *= c;
+                }
             }
         }
     }
     IPDE_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_ktab, h.size() * sizeof(double)));
     IPDE_HIP_CHECK(ctx, hipMemcpy(ctx->d_ktab, h.data(), h.size() * sizeof(double),
                                   hipMemcpyHostToDevice));
+    g_ktab[ctx->device] = ctx->d_ktab;
     return IPDE_OK;
 }
 

@@ -123,10 +123,12 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
             // binade 2^(11 + 2w) covers y_max = (k * diameter)^2
             int wv = 0;
             if (a.fixed_scale != 0.0 && D2 > 0.0 && D2 < INFINITY) {
-                int ey = ilogb(D2 * a.fixed_scale * a.fixed_scale) + 1;   // y_max < 2^ey
+                // (margin: D2 and every pair's y carry a few roundings; the kernel does not watch the
+                // upper end of the table)
+                int ey = ilogb(D2 * a.fixed_scale * a.fixed_scale * (1.0 + 0x1p-30)) + 1;   // y_max < 2^ey
                 wv = (ey - 11 + 1) / 2;
                 if (ey <= 11) wv = 0;
-                if (wv > 7) wv = 7;
+                if (wv > 7) wv = 8;      // beyond the last window (k * diameter > 5800): no table, generic body
             }
             s_win = wv;
         }
