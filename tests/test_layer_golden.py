@@ -72,6 +72,32 @@ def lp():
 
 
 @pytest.mark.gpu
+def test_hip_laplace_patch_kernel_against_reference_numbers():
+    """ipde_laplace_apply_patches on the fixture's 160 (scattered) targets: patch p holds
+    xs = tx[4p : 4p+4], ys = ty[4p : 4p+4], so its DIAGONAL points are targets 4p .. 4p+3 and the
+    twelve others are computed and not stored (pout = -1) — the patch kernel's arithmetic against
+    the numbers of the reference's own Laplace_Eval / gf."""
+    import torch
+    from ipde_amd import target_plan
+    from ipde_amd.device import to_device
+    g = G
+    n = g["tx"].shape[0]
+    assert n % 4 == 0
+    npatch = n // 4
+    pxy = np.concatenate([g["tx"].reshape(npatch, 4).T, g["ty"].reshape(npatch, 4).T], axis=0)
+    pout = np.full((16, npatch), -1, dtype=np.int32)
+    for a in range(4):
+        pout[5 * a] = 4 * np.arange(npatch) + a
+    dev = to_device(g["tx"]).device
+    plan = target_plan.TargetPlan(n, torch.as_tensor(np.ascontiguousarray(pxy), device=dev),
+                                  torch.as_tensor(pout, device=dev), torch.empty(0, dtype=torch.int64, device=dev),
+                                  torch.empty(0, dtype=torch.float64, device=dev),
+                                  torch.empty(0, dtype=torch.float64, device=dev))
+    u = target_plan.laplace_apply(plan, g["sx"], g["sy"], w_sigma=g["sigma"] * g["w"]).cpu().numpy()
+    assert rel(u, g["laplace_slp_eval"]) < TOL and rel(u, g["laplace_slp_gf"]) < TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("generic", [False, True])
 def test_hip_laplace_slp_against_reference_numbers(lp, generic):
     g = G
