@@ -22,7 +22,13 @@ class LaplaceFreespaceGridEvaluator(ScalarFreespaceGridEvaluator):
     def __init__(self, backend, xv, yv, allow_rectangular=False):
         super().__init__(backend, xv, yv, allow_rectangular)
 
+    PATCH_TARGETS = True     # the full grid is all full tiles: ipde_laplace_apply_patches
+
     def _apply(self, sx, sy, ch):
+        plan = self.targets.plan()
+        if plan is not None:
+            from .. import target_plan
+            return target_plan.laplace_apply(plan, sx, sy, w_sigma=ch)
         return laplace_apply(sx, sy, self.targets.x, self.targets.y, w_sigma=ch)
 
 

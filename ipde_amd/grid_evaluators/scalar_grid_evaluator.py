@@ -89,7 +89,10 @@ class ScalarFreespaceGridEvaluator(object):
         else:
             self._ewald = None
             xg, yg = np.meshgrid(self.xv, self.yv, indexing='ij')
-            self.targets = DeviceTargets(xg.ravel(), yg.ravel())   # resident across calls
+            # resident across calls; for a kernel with a patch variant also cut into 4 x 4 patches
+            self.targets = DeviceTargets(xg.ravel(), yg.ravel(), plan=self.PATCH_TARGETS)
+
+    PATCH_TARGETS = False
 
     def _apply(self, sx, sy, ch):
         raise NotImplementedError

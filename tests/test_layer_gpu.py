@@ -362,6 +362,16 @@ def test_grid_evaluator_class_api():
     ref = olp.modified_helmholtz_layer_apply(c.x, c.y, xg.ravel(), yg.ravel(), 10.0,
                                              charge=ch).reshape(n, n)
     assert rel_err(got, ref) < TOL
+    # a grid big enough for the patch kernel (>= 2^18 points): the same class, the full grid as patches
+    n2 = 640
+    xv2 = np.linspace(-1.5, 1.5, n2, endpoint=False) + 0.0123
+    ev2 = LaplaceFreespaceGridEvaluator(LaplaceGridBackend(xv2[1] - xv2[0], 20), xv2, xv2)
+    assert ev2.targets.plan() is not None and ev2.targets.plan().nrest == 0
+    got2 = ev2(c.get_stacked_boundary(), ch)
+    idx = rng.choice(n2 * n2, 4000, replace=False)
+    xg2, yg2 = np.meshgrid(xv2, xv2, indexing="ij")
+    ref2 = oracle.c_laplace_apply(c.x, c.y, xg2.ravel()[idx], yg2.ravel()[idx], w_sigma=ch)
+    assert got2.shape == (n2, n2) and rel_err(got2.ravel()[idx], ref2) < TOL
     with pytest.raises(Exception):
         LaplaceFreespaceGridEvaluator(LaplaceGridBackend(h * 1.01, 20), xv, xv)
     with pytest.raises(Exception):

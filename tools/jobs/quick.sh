@@ -1,4 +1,4 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for v in 0 0; do timeout -k 10 300 python3 tools/ab_modhelm.py 2>&1 | tail -1; done
+timeout -k 10 900 python3 -m pytest tests/test_layer_gpu.py tests/test_layer_golden.py tests/test_ewald_gpu.py -m gpu -q 2>&1 | grep -v "^  File\|^Extension" | tail -5
