@@ -278,6 +278,18 @@ def main():
         step()
         kms.append(ctx.last_kernel_ms())
     kernel_ms_avg = float(np.mean(kms))
+    # the list kernel (ipde_laplace_apply on the plain list) beside it: what any target list gets
+    list_kernel_ms = None
+    if plan is not None:
+        lk = []
+        for _ in range(4):
+            lp.laplace_apply(sx, sy, dt.x, dt.y, w_sigma=sig_full * w, ctx=ctx, out=out)
+            ctx.sync()
+            lk.append(ctx.last_kernel_ms())
+        list_kernel_ms = float(np.mean(lk[1:]))
+        # `out` again from the timed route (parity check below; no collective here)
+        target_plan.laplace_apply(plan, sx, sy, w_sigma=sig_full * w, ctx=ctx, out=out)
+        ctx.sync()
     ctx.enable_timing(False)
 
     def allreduce_max(x):
@@ -366,6 +378,11 @@ def main():
                 "valu_instr_per_pair": vipp,
                 "kernel_ms": kernel_ms_avg,
                 "kernel_pairs_per_s": kpairs,
+                "list_kernel": None if list_kernel_ms is None else
+                    {"kernel": "laplace_rowrun_kernel<SLP, 4> (ipde_laplace_apply, any target list)",
+                     "kernel_ms": list_kernel_ms,
+                     "pairs_per_s": float(NBDY) * float(dt.N) / (list_kernel_ms * 1e-3),
+                     "valu_instr_per_pair": VALU_INSTR_PER_PAIR},
                 "hbm": {
                     "achieved": algo_bytes / (kernel_ms_avg * 1e-3) / 1e9,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
