@@ -35,6 +35,10 @@ def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False
     ebdy = EmbeddedBoundary(bdy, True, M, bh, pad_zone=0, heaviside=MOL.step, qfs_tolerance=1e-14)
     ebdyc = EmbeddedBoundaryCollection([ebdy, ])
     grid = ebdyc.generate_grid(bh, Ns=Ns)
+    # set-up bracket as in the reference's examples/poisson_for_paper.py:60-64: geometry, grid, solver
+    solver = ModifiedHelmholtzSolver(ebdyc, k=helmholtz_k, grid_backend=grid_backend)
+    T['setup_s'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     kk = 2 * np.pi / 3
     solution_func = lambda x, y: np.exp(np.sin(kk * x)) * np.sin(kk * y)
     force_func = lambda x, y: helmholtz_k ** 2 * solution_func(x, y) \
@@ -45,8 +49,7 @@ def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False
     ua.define_via_function(solution_func)
     bc = BoundaryFunction(ebdyc)
     bc.define_via_function(solution_func)
-    solver = ModifiedHelmholtzSolver(ebdyc, k=helmholtz_k, grid_backend=grid_backend)
-    T['setup_s'] = time.perf_counter() - t0
+    T['problem_definition_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     ue = solver(f, tol=solver_tol, verbose=verbose, maxiter=100, restart=20)
     T['inhomogeneous_solve_s'] = time.perf_counter() - t0

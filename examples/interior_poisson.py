@@ -50,6 +50,11 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
     grid = ebdyc.generate_grid(bh / grid_upsample, Ns=Ns)
     ebdyc.ready_bump(MOL.bump, (grid.x_bounds[1] - ebdy.radial_width, grid.y_bounds[1] - ebdy.radial_width),
                      ebdyc[0].radial_width)
+    # the reference's set-up bracket (examples/poisson_for_paper.py:60-64) ends with the solver's
+    # construction: geometry, grid registration, solver.  The manufactured problem is defined after it.
+    solver = PoissonSolver(ebdyc, solver_type=solver_type, grid_backend=grid_backend)
+    T['setup_s'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     if problem == 'easy':
         solution_func = lambda x, y: -np.cos(x) * np.exp(np.sin(x)) * np.sin(y)
         force_func = lambda x, y: (2.0 * np.cos(x) + 3.0 * np.cos(x) * np.sin(x) - np.cos(x) ** 3) \
@@ -65,9 +70,7 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
     ua.define_via_function(solution_func)
     bc = BoundaryFunction(ebdyc)
     bc.define_via_function(solution_func)
-    # grid_backend='ewald': the Ewald-split grid evaluator instead of the dense sum
-    solver = PoissonSolver(ebdyc, solver_type=solver_type, grid_backend=grid_backend)
-    T['setup_s'] = time.perf_counter() - t0
+    T['problem_definition_s'] = time.perf_counter() - t0     # f, u_exact, boundary data on 2.2 M points (numpy)
 
     t0 = time.perf_counter()
     ue = solver(f, tol=solver_tol, verbose=verbose, maxiter=100, restart=20)
