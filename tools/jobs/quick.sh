@@ -1,5 +1,5 @@
+# scratch job: edit for the experiment at hand (gpurun -- 'bash tools/jobs/quick.sh')
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout -k 10 300 python3 tools/hostprof_ewald_setup.py 2>&1 | grep -v amdgpu.ids | cut -c1-180 > gpurun_out/ewald_setup_prof.txt
-head -50 gpurun_out/ewald_setup_prof.txt
+python -c "import __graft_entry__ as g; g.smoke()"
