@@ -82,7 +82,9 @@ const char* ipde_last_error(ipde_ctx* ctx);
    "fft2d" (1: hand-written 2-D FFT pipeline on power-of-two grids, 0: rocFFT),
    "interp_shifted" (1: ipde_grid_interp through four shifted coarse transforms at any size),
    "dense_persistent", "annular_fused_fft", "gmres_graphs", "gmres_lookahead" (1: inner iteration
-   j + 1 of the annular GMRES enters the stream before the host has read column j; same bits). */
+   j + 1 of the annular GMRES enters the stream before the host has read column j; same bits),
+   "gmres_fused_scale" (1: the Arnoldi normalisation inside the preconditioner's kernel; same bits),
+   "modhelm_variant" (targets per lane of the modified Helmholtz table kernel). */
 int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value);
 /* Current value of a knob (so that a caller can restore what it found). */
 int ipde_ctx_get_option(ipde_ctx* ctx, const char* name, int* value);

@@ -276,6 +276,58 @@ __global__ __launch_bounds__(256) void prec_cplx_kernel(cd* __restrict__ out,
     out[(size_t)j * ns + i] = cd{sr, si};
 }
 
+// The same two products with the Arnoldi normalisation folded in (option "gmres_fused_scale"): the
+// input is w, x = w / sqrt(nrm2) is formed on the fly — rounded to a double before it enters the
+// product, so x and the product are the bits the separate normalisation kernel gave — and thread
+// (i, j) also stores x[j, i] as the new basis vector.  A vanished norm (breakdown) leaves the basis
+// vector alone, as cscale_copy_rnorm_kernel does.
+__global__ __launch_bounds__(256) void prec_scalar_scaled_kernel(cd* __restrict__ out, const double* __restrict__ Kt,
+                                                                 const cd* __restrict__ w, int M, int n,
+                                                                 const cd* __restrict__ nrm2, cd* __restrict__ vout) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= n) return;
+    const double hn = sqrt(fmax(nrm2->x, 0.0));
+    const bool ok = hn > 0.0;
+    const double s = ok ? 1.0 / hn : 0.0;
+    const double* K = Kt + (size_t)j * M * n + i;
+    double sr = 0.0, si = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < M; ++k) {
+        double kw = K[(size_t)k * n];
+        cd v = w[(size_t)k * n + i];
+        const double vx = s * v.x, vy = s * v.y;
+        if (k == j && ok) vout[(size_t)k * n + i] = cd{vx, vy};
+        sr = fma(kw, vx, sr);
+        si = fma(kw, vy, si);
+    }
+    out[(size_t)j * n + i] = cd{sr, si};
+}
+__global__ __launch_bounds__(256) void prec_cplx_scaled_kernel(cd* __restrict__ out, const cd* __restrict__ Kt,
+                                                               const cd* __restrict__ w, int B, int ns,
+                                                               const cd* __restrict__ nrm2, cd* __restrict__ vout) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= ns) return;
+    const double hn = sqrt(fmax(nrm2->x, 0.0));
+    const bool ok = hn > 0.0;
+    const double s = ok ? 1.0 / hn : 0.0;
+    const cd* K = Kt + (size_t)j * B * ns + i;
+    double sr = 0.0, si = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < B; ++k) {
+        cd kw = K[(size_t)k * ns];
+        cd v = w[(size_t)k * ns + i];
+        const double vx = s * v.x, vy = s * v.y;
+        if (k == j && ok) vout[(size_t)k * ns + i] = cd{vx, vy};
+        sr = fma(kw.x, vx, sr);
+        sr = fma(-kw.y, vy, sr);
+        si = fma(kw.x, vy, si);
+        si = fma(kw.y, vx, si);
+    }
+    out[(size_t)j * ns + i] = cd{sr, si};
+}
+
 // ---- GMRES vector kernels --------------------------------------------------
 // h[i] = <V_i, w> = sum conj(V_i) * w, i = blockIdx.x < nv.  Every vector is split over
 // MD_SPLIT blocks (one block per vector read 2 x 2 MB through a single CU: 27 us); each
@@ -473,8 +525,16 @@ struct LinOp {
     int64_t NB = 0;
     virtual int apply(const cd* in, cd* out) = 0;
     virtual int precond(const cd* in, cd* out) = 0;
+    // vout = w / sqrt(nrm2->x), out = M^{-1} vout (the solvers override it with one kernel)
+    virtual int precond_scaled(const cd* w, const cd* nrm2, cd* vout, cd* out);
     virtual ~LinOp() {}
 };
+
+int LinOp::precond_scaled(const cd* w, const cd* nrm2, cd* vout, cd* out) {
+    hipLaunchKernelGGL(cscale_copy_rnorm_kernel, dim3(nb256(NB)), dim3(256), 0, ctx->stream, vout, w, NB, nrm2);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return precond(vout, out);
+}
 
 struct GmresWork {
     cd* V = nullptr;   // (restart+1, NB)
@@ -599,6 +659,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     bool use_graphs = ctx->opt_gmres_graphs && st != nullptr && g.graph_failures < 3;
     // look-ahead of one inner iteration (default): three pinned areas — columns of even / odd
     // iterations, the cycle's y — and an event per area
+    const bool fused = ctx->opt_gmres_fused_scale != 0;
     const size_t hstride = (size_t)(2 * restart + 4);
     bool lookahead = ctx->opt_gmres_lookahead && !use_graphs &&
                      (3 * hstride * sizeof(cd) + 16 <= ctx->h_pinned_bytes);
@@ -610,7 +671,8 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
         }
     {
         const long long sig = ((long long)restart << 8) ^ ((long long)(uintptr_t)st << 20) ^
-                              (ctx->opt_annular_grouped ? 1 : 0) ^ (ctx->opt_annular_fused_fft ? 2 : 0);
+                              (ctx->opt_annular_grouped ? 1 : 0) ^ (ctx->opt_annular_fused_fft ? 2 : 0) ^
+                              (ctx->opt_gmres_fused_scale ? 8 : 0);
         if (g.graph_sig != sig) {
             gmres_drop_graphs(g);
             g.graph_sig = sig;
@@ -661,7 +723,13 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
             // 21 kernels, 255 us per iteration), not by the host's launch rate.  Off by default.
             auto enqueue = [&](hipStream_t st, int j, cd* hpj, hipEvent_t done) -> int {
                 cd* vj = g.V + (size_t)j * NB;
-                IPDE_TRY(op.precond(vj, g.z));
+                // v_j = w / ||w|| of the previous iteration is formed INSIDE the preconditioner's
+                // kernel (fused: no normalisation launch at the end of an iteration); v_0 is the
+                // cycle's scaled residual
+                if (fused && j > 0)
+                    IPDE_TRY(op.precond_scaled(g.w, g.hdev + j, vj, g.z));
+                else
+                    IPDE_TRY(op.precond(vj, g.z));
                 IPDE_TRY(op.apply(g.z, g.w));
                 // CGS2
                 cd* h1 = g.hdev;
@@ -679,9 +747,11 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
                 IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hpj, g.hdev, (size_t)(2 * restart + 4) * sizeof(cd),
                                                    hipMemcpyDeviceToHost, st));
                 if (done) IPDE_HIP_CHECK(ctx, hipEventRecord(done, st));
-                hipLaunchKernelGGL(cscale_copy_rnorm_kernel, dim3(nb256(NB)), dim3(256), 0, st,
-                                   g.V + (size_t)(j + 1) * NB, (const cd*)g.w, NB, (const cd*)(h1 + (j + 1)));
-                IPDE_HIP_CHECK(ctx, hipGetLastError());
+                if (!fused) {
+                    hipLaunchKernelGGL(cscale_copy_rnorm_kernel, dim3(nb256(NB)), dim3(256), 0, st,
+                                       g.V + (size_t)(j + 1) * NB, (const cd*)g.w, NB, (const cd*)(h1 + (j + 1)));
+                    IPDE_HIP_CHECK(ctx, hipGetLastError());
+                }
                 return IPDE_OK;
             };
             const cd* hpj = hp;
@@ -960,6 +1030,12 @@ struct ipde_annular_scalar : public LinOp {
         IPDE_HIP_CHECK(ctx, hipGetLastError());
         return IPDE_OK;
     }
+    int precond_scaled(const cd* w, const cd* nrm2, cd* vout, cd* out) override {
+        hipLaunchKernelGGL(prec_scalar_scaled_kernel, dim3(nb256(n), M), dim3(256), 0, ctx->stream, out,
+                           (const double*)Kt, w, M, n, nrm2, vout);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+        return IPDE_OK;
+    }
     ~ipde_annular_scalar() override {
         for (double** p : {&R01, &R12, &D01, &D12, &R02, &Bmat, &Kt, &psi1, &ipsi1, &ipsi2, &rwork})
             if (*p) hipFree(*p);
@@ -1194,6 +1270,13 @@ struct ipde_annular_stokes : public LinOp {
         const int B = 3 * M - 1;
         hipLaunchKernelGGL(prec_cplx_kernel, dim3(nb256(ns), B), dim3(256), 0, ctx->stream, out,
                            (const cd*)Kt, in, B, ns);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+        return IPDE_OK;
+    }
+    int precond_scaled(const cd* w, const cd* nrm2, cd* vout, cd* out) override {
+        const int B = 3 * M - 1;
+        hipLaunchKernelGGL(prec_cplx_scaled_kernel, dim3(nb256(ns), B), dim3(256), 0, ctx->stream, out,
+                           (const cd*)Kt, w, B, ns, nrm2, vout);
         IPDE_HIP_CHECK(ctx, hipGetLastError());
         return IPDE_OK;
     }

@@ -231,6 +231,7 @@ static int* option_slot(ipde_ctx* ctx, const char* name) {
     if (!strcmp(name, "gmres_graphs")) return &ctx->opt_gmres_graphs;
     if (!strcmp(name, "modhelm_variant")) return &ctx->opt_modhelm_variant;
     if (!strcmp(name, "gmres_lookahead")) return &ctx->opt_gmres_lookahead;
+    if (!strcmp(name, "gmres_fused_scale")) return &ctx->opt_gmres_fused_scale;
     if (!strcmp(name, "annular_fused_fft")) return &ctx->opt_annular_fused_fft;
     if (!strcmp(name, "annular_grouped")) return &ctx->opt_annular_grouped;
     if (!strcmp(name, "fft2d")) return &ctx->opt_fft2d;

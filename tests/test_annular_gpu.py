@@ -294,6 +294,41 @@ def test_gmres_lookahead_is_bitwise_the_wait_per_iteration_solve(gs, scalar_geo,
             assert np.array_equal(x, y)
 
 
+def test_gmres_normalisation_inside_the_preconditioner_kernel_is_bitwise(gs, scalar_geo, gst, stokes_geo):
+    """option "gmres_fused_scale" (default on): v_j = w / ||w|| is formed inside the preconditioner's
+    kernel of iteration j instead of by a launch of its own at the end of iteration j - 1 — same
+    bits, with and without the look-ahead, across restarts"""
+    from ipde_amd.annular.modified_helmholtz import AnnularModifiedHelmholtzSolver
+    from ipde_amd.annular.stokes import AnnularStokesSolver
+    aag, rag = scalar_geo
+    S = AnnularModifiedHelmholtzSolver(aag, float(gs["mh_k"][0]))
+    assert S.ctx.get_option("gmres_fused_scale") == 1
+    args = (rag, gs["mh_force"], gs["mh_ig"], gs["mh_og"])
+    aag2, rag2 = stokes_geo
+    V = AnnularStokesSolver(aag2, 1.0)
+    sargs = (rag2, gst["fr"], gst["ft"], gst["irg"], gst["itg"], gst["org"], gst["otg"])
+    for solver, call, kws in (
+            (S, lambda kw: [np.array(S.solve(*args, **kw))],
+             (dict(tol=1e-13, maxiter=200, restart=100), dict(tol=1e-13, maxiter=200, restart=3),
+              dict(tol=1e-5, maxiter=200, restart=100), dict(tol=1e-13, maxiter=4, restart=100))),
+            (V, lambda kw: [np.array(x) for x in V.solve(*sargs, **kw)],
+             (dict(tol=1e-12, maxiter=300, restart=100), dict(tol=1e-12, maxiter=300, restart=5)))):
+        for kw in kws:
+            ref = call(kw)
+            it = solver.iterations_last_call
+            for look in (1, 0):
+                solver.ctx.set_option("gmres_fused_scale", 0)
+                solver.ctx.set_option("gmres_lookahead", look)
+                try:
+                    got = call(kw)
+                finally:
+                    solver.ctx.set_option("gmres_fused_scale", 1)
+                    solver.ctx.set_option("gmres_lookahead", 1)
+                assert solver.iterations_last_call == it
+                for x, y in zip(ref, got):
+                    assert np.array_equal(x, y)
+
+
 def test_helper_jump_kernels_match_the_numpy_statements():
     """ipde_scalar_interface_jumps / ipde_stokes_rotate / ipde_stokes_interface_jumps (csrc/annular.hip)
     against the numpy statements of the helpers they replace (reference internals/scalar.py:76-90,

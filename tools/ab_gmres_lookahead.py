@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the annular GMRES with and without the one-iteration look-ahead (option
-"gmres_lookahead"): single-body annular Poisson (n = 4096) and Stokes (n = 4096 and 3200) solves,
+"gmres_lookahead") and the normalisation folded into the preconditioner kernel ("gmres_fused_scale"): single-body annular Poisson (n = 4096) and Stokes (n = 4096 and 3200) solves,
 median wall time of 30 solves each, the two settings alternating."""
 import os, sys, time
 import numpy as np
@@ -23,15 +23,18 @@ def geometry(nb, M, full):
 
 
 def ab(name, solver, call):
-    res = {0: [], 1: []}
+    res = {}
     call()
+    settings = ((1, 1), (1, 0), (0, 1), (0, 0))      # (gmres_lookahead, gmres_fused_scale)
     for rep in range(30):
-        for v in (1, 0):
-            solver.ctx.set_option("gmres_lookahead", v)
-            t0 = time.perf_counter(); call(); res[v].append((time.perf_counter() - t0) * 1e3)
+        for look, fused in settings:
+            solver.ctx.set_option("gmres_lookahead", look)
+            solver.ctx.set_option("gmres_fused_scale", fused)
+            t0 = time.perf_counter(); call(); res.setdefault((look, fused), []).append((time.perf_counter() - t0) * 1e3)
     solver.ctx.set_option("gmres_lookahead", 1)
-    print(f"{name}: {solver.iterations_last_call} iterations; look-ahead {np.median(res[1]):.3f} ms, "
-          f"wait per iteration {np.median(res[0]):.3f} ms", flush=True)
+    solver.ctx.set_option("gmres_fused_scale", 1)
+    print(f"{name}: {solver.iterations_last_call} iterations; " + ", ".join(
+        f"look-ahead {l} fused scale {f}: {np.median(res[(l, f)]):.3f} ms" for l, f in settings), flush=True)
 
 
 c, aag, rag = geometry(4096, 20, True)
