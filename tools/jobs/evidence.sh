@@ -8,8 +8,9 @@ O=gpurun_out/r02/final
 rm -rf $O
 mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
-timeout -k 10 1000 python3 -m pytest tests -m gpu -q 2>&1 | grep -v '^  File\|^Extension' | tail -4 > $O/gputest.txt
+# (the bench line first, as the driver takes it: on a box that has not just run 95 s of tests)
 python bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 1000 python3 -m pytest tests -m gpu -q 2>&1 | grep -v '^  File\|^Extension' | tail -4 > $O/gputest.txt
 python tools/bench_kernels.py > $O/kernels.json 2> $O/kernels.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-full-solve > $O/bench_under_rocprof.json 2> $O/bench_trace.err
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-full-solve --no-fft > $O/pmc_fetch.log 2>&1
