@@ -123,6 +123,15 @@ def _worker_pnai(rank, world, port, q):
         got = make_pnai_evaluator(la, c, trg, wrap)(sigma).numpy()
         ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=sigma, weights=c.weights)
         ok = got.shape == ref.shape and np.allclose(got, ref, rtol=0, atol=1e-13)
+        # prepare(): the rank's slice is wrapped ahead of the first evaluation (the solvers' set-up makes
+        # the list resident — and cut into patches — there), exactly once, and is what the evaluation uses
+        from ipde_amd.sharding import target_slice
+        wrapped = []
+        ev = make_pnai_evaluator(la, c, trg, lambda x, y: wrapped.append(Points(x, y)) or wrapped[-1])
+        mine = ev.prepare()
+        sl = target_slice(trg.N, rank, world)
+        ok = ok and len(wrapped) == 1 and mine is wrapped[0] and np.array_equal(mine.x, trg.x[sl])
+        ok = ok and np.allclose(ev(sigma).numpy(), ref, rtol=0, atol=1e-13) and len(wrapped) == 1
         got3 = make_pnai_evaluator(la3, c, trg, wrap)(f)
         ref3 = olp.stokes_layer_apply(c.x, c.y, trg.x, trg.y, force=f, weights=c.weights)
         ok = ok and all(np.allclose(g.numpy(), r, rtol=0, atol=1e-13) for g, r in zip(got3, ref3))
