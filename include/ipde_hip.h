@@ -75,8 +75,6 @@ int ipde_ctx_sync(ipde_ctx* ctx);
 int ipde_ctx_set_stream(ipde_ctx* ctx, void* hip_stream);
 void* ipde_ctx_get_stream(ipde_ctx* ctx);
 const char* ipde_last_error(ipde_ctx* ctx);
-/* Average duration in ms of the dominant kernel of the LAST layer-potential
-   apply, measured with hipEvents on the context's stream (0 if timing is off). */
 /* Tuning knobs (kernel geometry variants); never changes results beyond rounding.
    Names: "laplace_variant", "stokes_variant", "dense_pairs", "annular_grouped",
    "fft2d" (1: hand-written 2-D FFT pipeline on power-of-two grids, 0: rocFFT),
@@ -88,8 +86,16 @@ const char* ipde_last_error(ipde_ctx* ctx);
 int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value);
 /* Current value of a knob (so that a caller can restore what it found). */
 int ipde_ctx_get_option(ipde_ctx* ctx, const char* name, int* value);
+/* Duration in ms of the dominant kernel of the LAST layer-potential apply, measured with
+   hipEvents on the context's stream (0 if timing is off).  Switching timing on starts a new
+   measurement (the history below is emptied). */
 int ipde_ctx_enable_timing(ipde_ctx* ctx, int on);
 int ipde_ctx_last_kernel_ms(ipde_ctx* ctx, double* ms);
+/* Durations (ms) of the dominant kernel of the applies issued since ipde_ctx_enable_timing(ctx, 1),
+   oldest first, at most the last 256 and at most `cap`: every apply records its own event pair
+   on the context's stream, so a timed loop needs no host synchronisation inside and is resolved
+   here afterwards (waits for the last pair).  *n = number written. */
+int ipde_ctx_kernel_ms_history(ipde_ctx* ctx, double* ms, int cap, int* n);
 
 /* ------------------------------------------------------------------------- */
 /* layer potentials                                        */

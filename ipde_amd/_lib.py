@@ -60,6 +60,7 @@ SIGNATURES = {
     "ipde_ctx_get_option": (_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_int)]),
     "ipde_ctx_enable_timing": (_int, [_vp, _int]),
     "ipde_ctx_last_kernel_ms": (_int, [_vp, _c_double_p]),
+    "ipde_ctx_kernel_ms_history": (_int, [_vp, _c_double_p, _int, ctypes.POINTER(_int)]),
     "ipde_laplace_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                   _vp, _int]),
     "ipde_laplace_apply_patches": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),

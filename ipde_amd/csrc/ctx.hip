@@ -143,8 +143,6 @@ extern "C" int ipde_ctx_create(int device_id, ipde_ctx** out) {
     int s = IPDE_OK;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamDefault) != hipSuccess) s = IPDE_ERR_HIP;
     ctx->stream = ctx->own_stream;
-    if (s == IPDE_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess))
-        s = IPDE_ERR_HIP;
     ctx->h_pinned_bytes = 1 << 16;
     if (s == IPDE_OK && hipHostMalloc((void**)&ctx->h_pinned, ctx->h_pinned_bytes) != hipSuccess) {
         ctx->h_pinned = nullptr;
@@ -190,8 +188,10 @@ extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
     // (d_ktab belongs to the device, not to the context: layer_modhelm.hip)
     if (ctx->d_lu_abort) hipFree(ctx->d_lu_abort);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
-    if (ctx->ev0) hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < ipde_ctx::TIMING_RING; ++i) {
+        if (ctx->ring_ev0[i]) hipEventDestroy(ctx->ring_ev0[i]);
+        if (ctx->ring_ev1[i]) hipEventDestroy(ctx->ring_ev1[i]);
+    }
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return IPDE_OK;
@@ -263,18 +263,37 @@ extern "C" int ipde_ctx_get_option(ipde_ctx* ctx, const char* name, int* value) 
 
 extern "C" int ipde_ctx_enable_timing(ipde_ctx* ctx, int on) {
     if (!ctx) return IPDE_ERR_INVALID;
+    if (on && !ctx->timing) {   // a new measurement: forget the pairs of the previous one
+        ctx->ring_n = 0;
+        ctx->ring_open = -1;
+        ctx->last_kernel_ms = 0.0;
+    }
     ctx->timing = on;
+    return IPDE_OK;
+}
+
+static int ring_slot_ms(ipde_ctx* ctx, int slot, double* ms) {
+    IPDE_HIP_CHECK(ctx, hipEventSynchronize(ctx->ring_ev1[slot]));
+    float f = 0.f;
+    IPDE_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ring_ev0[slot], ctx->ring_ev1[slot]));
+    *ms = (double)f;
     return IPDE_OK;
 }
 
 extern "C" int ipde_ctx_last_kernel_ms(ipde_ctx* ctx, double* ms) {
     if (!ctx || !ms) return IPDE_ERR_INVALID;
-    if (ctx->timing && ctx->last_kernel_ms < 0.0) {
-        IPDE_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
-        float f = 0.f;
-        IPDE_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
-        ctx->last_kernel_ms = (double)f;
-    }
+    if (ctx->timing && ctx->last_kernel_ms < 0.0 && ctx->ring_n > 0)
+        IPDE_TRY(ring_slot_ms(ctx, (int)((ctx->ring_n - 1) % ipde_ctx::TIMING_RING), &ctx->last_kernel_ms));
     *ms = ctx->last_kernel_ms;
+    return IPDE_OK;
+}
+
+extern "C" int ipde_ctx_kernel_ms_history(ipde_ctx* ctx, double* ms, int cap, int* n) {
+    if (!ctx || !ms || !n || cap < 0) return IPDE_ERR_INVALID;
+    int64_t have = ctx->ring_n < ipde_ctx::TIMING_RING ? ctx->ring_n : ipde_ctx::TIMING_RING;
+    if (have > cap) have = cap;
+    for (int64_t i = 0; i < have; ++i)   // oldest of the kept ones first
+        IPDE_TRY(ring_slot_ms(ctx, (int)((ctx->ring_n - have + i) % ipde_ctx::TIMING_RING), &ms[i]));
+    *n = (int)have;
     return IPDE_OK;
 }

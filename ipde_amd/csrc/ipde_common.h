@@ -47,7 +47,13 @@ struct ipde_ctx {
     double* d_ktab = nullptr;
     // timing
     int timing = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // ring of event pairs around the dominant kernel of every layer-potential apply since timing
+    // was switched on: a timed loop records without a host sync and resolves the ring afterwards
+    // (ipde_ctx_kernel_ms_history); pairs are created at first use
+    static constexpr int TIMING_RING = 256;
+    hipEvent_t ring_ev0[TIMING_RING] = {}, ring_ev1[TIMING_RING] = {};
+    int64_t ring_n = 0;          // pairs recorded since ipde_ctx_enable_timing(1)
+    int ring_open = -1;          // slot whose start event is recorded and whose stop is not
     double last_kernel_ms = 0.0;
     // 1-D batched fft plan cache: key (batch, n)
     std::map<std::pair<int64_t, int64_t>, void*> fft1_plans;
@@ -115,5 +121,29 @@ int ipde_stage_finish(ipde_ctx* ctx, int loc, int slot, double* p, size_t n_doub
 
 int ipde_build_log_table(ipde_ctx* ctx);
 int ipde_build_k_table(ipde_ctx* ctx);
+
+// Bracket the dominant kernel of an apply (no-ops when timing is off).
+static inline void ipde_time_begin(ipde_ctx* ctx) {
+    if (!ctx->timing) return;
+    const int slot = (int)(ctx->ring_n % ipde_ctx::TIMING_RING);
+    if (!ctx->ring_ev0[slot] &&
+        (hipEventCreate(&ctx->ring_ev0[slot]) != hipSuccess || hipEventCreate(&ctx->ring_ev1[slot]) != hipSuccess))
+        return;
+    if (hipEventRecord(ctx->ring_ev0[slot], ctx->stream) == hipSuccess) ctx->ring_open = slot;
+}
+// The next kernel belongs to the pair recorded last (an accumulating second launch of one apply):
+// its stop event is recorded again behind it.
+static inline void ipde_time_continue(ipde_ctx* ctx) {
+    if (!ctx->timing || ctx->ring_n == 0) return;
+    ctx->ring_n -= 1;
+    ctx->ring_open = (int)(ctx->ring_n % ipde_ctx::TIMING_RING);
+}
+static inline void ipde_time_end(ipde_ctx* ctx) {
+    if (!ctx->timing || ctx->ring_open < 0) return;
+    hipEventRecord(ctx->ring_ev1[ctx->ring_open], ctx->stream);
+    ctx->ring_open = -1;
+    ctx->ring_n += 1;
+    ctx->last_kernel_ms = -1.0;  // resolved lazily in ipde_ctx_last_kernel_ms
+}
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

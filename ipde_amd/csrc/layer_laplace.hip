@@ -447,14 +447,11 @@ int launch_laplace_patches(ipde_ctx* ctx, const double* rec, int64_t ns, const d
     const size_t lds = (size_t)lt.nkeys * sizeof(double2);
     IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_patch_kernel<MODE, NT>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (ctx->timing) hipEventRecord(ctx->ev0, ctx->stream);
+    ipde_time_begin(ctx);
     hipLaunchKernelGGL((laplace_patch_kernel<MODE, NT>), dim3((unsigned)g.gx, (unsigned)g.nchunk), dim3(NT), lds,
                        ctx->stream, rec, g.ns_pad, g.chunk, pxy, np, pout, out, partial, prm,
                        (const double2*)lt.d_tab, (unsigned)lt.key_lo, (unsigned)lt.nkeys);
-    if (ctx->timing) {
-        hipEventRecord(ctx->ev1, ctx->stream);
-        ctx->last_kernel_ms = -1.0;
-    }
+    ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     if (partial) {
         hipLaunchKernelGGL(laplace_patch_reduce, dim3((unsigned)ceil_div64(16 * np, 256)), dim3(256), 0,
@@ -525,7 +522,7 @@ int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
         dst = (double*)ctx->partial.p;
     }
     dim3 grid((unsigned)g.gx, (unsigned)g.nchunk);
-    if (ctx->timing) hipEventRecord(ctx->ev0, ctx->stream);
+    ipde_time_begin(ctx);
     if (generic) {
         if (skip)
             hipLaunchKernelGGL((laplace_generic_kernel<MODE, true, 2, 256>), grid, dim3(256), 0,
@@ -555,10 +552,7 @@ int launch_laplace(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
         }
         IPDE_TRY(st);
     }
-    if (ctx->timing) {
-        hipEventRecord(ctx->ev1, ctx->stream);
-        ctx->last_kernel_ms = -1.0;  // resolved lazily in ipde_ctx_last_kernel_ms
-    }
+    ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     if (g.nchunk > 1) {
         hipLaunchKernelGGL(ipde_reduce_partials, dim3((unsigned)ceil_div64(nt, 256)), dim3(256), 0,

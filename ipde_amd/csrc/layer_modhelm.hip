@@ -236,7 +236,8 @@ int launch_modhelm(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
         acc_main = 0;
     }
     dim3 grid((unsigned)g.gx, (unsigned)g.nchunk);
-    if (ctx->timing && !accumulate) hipEventRecord(ctx->ev0, ctx->stream);
+    if (accumulate) ipde_time_continue(ctx);
+    else ipde_time_begin(ctx);
     if (generic) {
         if (skip)
             hipLaunchKernelGGL((modhelm_generic_kernel<MODE, true, R_G, NT_G>), grid, dim3(NT_G), 0,
@@ -263,10 +264,7 @@ int launch_modhelm(ipde_ctx* ctx, const double* rec, int64_t ns, const double* t
         }
         IPDE_TRY(st);
     }
-    if (ctx->timing) {
-        hipEventRecord(ctx->ev1, ctx->stream);
-        ctx->last_kernel_ms = -1.0;
-    }
+    ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     if (g.nchunk > 1) {
         hipLaunchKernelGGL(reduce_partials_acc, dim3((unsigned)ceil_div64(nt, 256)), dim3(256), 0,

@@ -354,7 +354,7 @@ int launch_stokes(ipde_ctx* ctx, const double* rec, int64_t ns, const double* tx
         dp = op ? dv + per : nullptr;
     }
     dim3 grid((unsigned)g.gx, (unsigned)g.nchunk);
-    if (ctx->timing) hipEventRecord(ctx->ev0, ctx->stream);
+    ipde_time_begin(ctx);
     if (generic) {
         if (skip)
             hipLaunchKernelGGL((stokes_generic_kernel<MODE, true, R_GEN, NT_GEN>), grid, dim3(NT_GEN), 0,
@@ -382,10 +382,7 @@ int launch_stokes(ipde_ctx* ctx, const double* rec, int64_t ns, const double* tx
                            (const double2*)lt.d_tab, (unsigned)lt.key_lo, (unsigned)lt.nkeys,
                            20 - lt.mant_bits);
     }
-    if (ctx->timing) {
-        hipEventRecord(ctx->ev1, ctx->stream);
-        ctx->last_kernel_ms = -1.0;
-    }
+    ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     if (g.nchunk > 1) {
         dim3 g2((unsigned)ceil_div64(nt, 256));

@@ -97,6 +97,14 @@ class Context:
         self.check(self.lib.ipde_ctx_last_kernel_ms(self.handle, ctypes.byref(ms)))
         return ms.value
 
+    def kernel_ms_history(self, cap=256):
+        """Durations (ms) of the dominant kernel of every apply since enable_timing(True), oldest
+        first (at most the last 256): recorded without a host sync, resolved here."""
+        buf = (ctypes.c_double * cap)()
+        n = ctypes.c_int()
+        self.check(self.lib.ipde_ctx_kernel_ms_history(self.handle, buf, cap, ctypes.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
     def torch_device(self):
         return torch.device("cuda", self.device)
 
@@ -259,6 +267,19 @@ def _drain_at_exit():
     with q.all_tasks_done:
         while q.unfinished_tasks and time.monotonic() < deadline:
             q.all_tasks_done.wait(0.05)
+        stuck = q.unfinished_tasks
+    if stuck:
+        # carrying on would run the interpreter's teardown under a thread that is still inside
+        # torch / HIP: the abort this hook exists to prevent.  End the process here, visibly.
+        import sys
+        sys.stderr.write("ipde_amd: %d warm-up job(s) still running 30 s after exit was requested; "
+                         "ending the process without interpreter teardown (exit status 70)\n" % stuck)
+        sys.stderr.flush()
+        try:
+            sys.stdout.flush()
+        except Exception:
+            pass
+        os._exit(70)
 
 
 atexit.register(_drain_at_exit)

@@ -4,8 +4,11 @@
  * oracle/layer_potentials.py (see its header for the reference citations:
  * ipde/grid_evaluators/laplace_grid_evaluator.py:8-12,
  * ipde/solvers/internals/poisson.py:27-36,
- * ipde/solvers/internals/stokes_save.py:29-81).  PARITY UNPINNED upstream
- * (pybie2d / pyfmmlib2d are not in the reference tree).
+ * ipde/solvers/internals/stokes_save.py:29-81).  Parity status as in that header:
+ * Laplace SLP and the Stokes pressures are PINNED by reference-computed fixtures
+ * (tests/golden/layer_kernels.npz), Laplace DLP and the Stokes velocities are UNPINNED
+ * upstream (pybie2d / pyfmmlib2d are not in the reference tree) and held by analytic
+ * identities and derivative relations to the pinned kernels.
  *
  * This is the "port" CPU baseline timed by bench.py and the checker for the
  * larger parity tests.  The product never links or calls it.

@@ -2,10 +2,23 @@
 sums on ipde's hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import this; the product (ipde_amd/) never does.
 
-PARITY UNPINNED for this file: the arithmetic lives in third-party packages that
-are neither under the reference tree nor installed (pybie2d `*_Layer_Apply`,
-pyfmmlib2d `SFMM`, fmm2dpy; no version pinned anywhere, reference setup.py:26).
-What the reference tree itself pins, and what this file follows:
+PARITY STATUS, kernel by kernel (tests/test_oracle_golden.py, tests/golden/layer_kernels.npz,
+made by tests/golden/make_golden.py from the imported reference):
+  PINNED   Laplace SLP             against sums formed with the reference's own `Laplace_Eval`
+                                   (ipde/solvers/multi_boundary/poisson.py:10-17) and `gf`
+                                   (ipde/grid_evaluators/laplace_grid_evaluator.py:8-12)
+  PINNED   modified-Helmholtz SLP  against the reference's `gf`
+                                   (ipde/grid_evaluators/modified_helmholtz_grid_evaluator.py:8-9)
+  PINNED   Stokes SLP/DLP pressure against the last rows of the reference's PSLP / PDLP and
+                                   `eval_p1` (ipde/solvers/internals/stokes_save.py:29-81)
+  UNPINNED Laplace DLP, modified-Helmholtz DLP, Stokes SLP/DLP velocities: that arithmetic lives
+           in third-party packages that are neither under the reference tree nor installed
+           (pybie2d `*_Layer_Apply`, pyfmmlib2d `SFMM`, fmm2dpy; no version pinned anywhere,
+           reference setup.py:26); nothing in the reference computes them.  They are held by
+           analytic identities (tests/test_oracle_layer_kat.py) and by derivative relations to the
+           pinned kernels (tests/test_oracle_layer_relations.py: DLP = -n.grad_s SLP, stokeslet from
+           the pinned log kernel, -grad p + lap u = 0).
+What the reference tree itself states, and what this file follows:
 
   Laplace SLP   -log(r)/(2 pi)            ipde/grid_evaluators/laplace_grid_evaluator.py:8-12,
                                           ipde/solvers/multi_boundary/poisson.py:12-17,

@@ -614,3 +614,69 @@ def test_laplace_patches_full_size_through_the_high_level_call(lp):
                                                      plan.np, P(plan.pxy), P(plan.pout), P(u1)))
     ctx.check(ctx.lib.ipde_laplace_apply_patches(ctx.handle, c.N, P(src.x), P(src.y), P(w), None, None, None,
                                                  0, None, None, None))
+
+
+# -- the kernels no reference code computes, tied to the pinned ones through derivative relations
+#    (tests/test_oracle_layer_relations.py has the same checks for the oracle; here every
+#    evaluation is a HIP kernel call and nothing goes through the oracle's closed formulas) -------
+def _relations_setup():
+    import test_oracle_layer_relations as rel
+    S = rel._setup(ns=60, nt=40, seed=3)
+    return rel, S
+
+
+def test_hip_laplace_and_modhelm_dlp_are_normal_derivatives_of_the_hip_slp(lp):
+    rel, S = _relations_setup()
+    tau = S["rng"].standard_normal(S["sx"].size)
+    w = S["w"]
+    slp = lambda sx, sy, q: lp.laplace_apply(sx, sy, S["tx"], S["ty"], w_sigma=q * w)
+    ref = rel.dlp_from_slp(slp, S, tau, 0.01)
+    got = lp.laplace_apply(S["sx"], S["sy"], S["tx"], S["ty"], nx=S["nx"], ny=S["ny"], w_tau=tau * w)
+    assert rel_err(got, ref) < 1e-9
+    for k in (0.7, 10.0):
+        slp = lambda sx, sy, q: lp.modified_helmholtz_apply(sx, sy, S["tx"], S["ty"], k, w_sigma=q * w)
+        ref = rel.dlp_from_slp(slp, S, tau, 0.004 if k > 5 else 0.01)
+        got = lp.modified_helmholtz_apply(S["sx"], S["sy"], S["tx"], S["ty"], k, nx=S["nx"], ny=S["ny"],
+                                          w_tau=tau * w)
+        assert rel_err(got, ref) < 1e-9
+
+
+def test_hip_stokes_velocities_from_the_pinned_laplace_slp_and_pressures(lp):
+    rel, S = _relations_setup()
+    w = S["w"]
+    f = S["rng"].standard_normal((2, S["sx"].size))
+    g = S["rng"].standard_normal((2, S["sx"].size))
+    # stokeslet from HIP Laplace single layers (pinned by tests/golden/layer_kernels.npz)
+    lap = lambda q, x, y: lp.laplace_apply(S["sx"], S["sy"], x, y, w_sigma=q * w)
+    u_ref, v_ref = rel.stokeslet_from_laplace(S, f, S["tx"], S["ty"], lap_slp=lap)
+    u, v, _ = lp.stokes_apply(S["sx"], S["sy"], S["tx"], S["ty"], wfx=f[0] * w, wfy=f[1] * w)
+    scale = max(np.max(np.abs(u_ref)), np.max(np.abs(v_ref)))
+    assert max(np.max(np.abs(u - u_ref)), np.max(np.abs(v - v_ref))) < 1e-9 * scale
+    # stresslet = -(stress of the stokeslet).n: HIP stokeslet velocities (just checked) and pressures (pinned)
+    sto = lambda ff, x, y: lp.stokes_apply(S["sx"], S["sy"], x, y, wfx=ff[0] * w, wfy=ff[1] * w)
+    u_ref, v_ref = rel.stresslet_from_stokeslet(S, g, S["tx"], S["ty"], sto)
+    u, v, _ = lp.stokes_apply(S["sx"], S["sy"], S["tx"], S["ty"], nx=S["nx"], ny=S["ny"],
+                              wdx=g[0] * w, wdy=g[1] * w)
+    scale = max(np.max(np.abs(u_ref)), np.max(np.abs(v_ref)))
+    assert max(np.max(np.abs(u - u_ref)), np.max(np.abs(v - v_ref))) < 1e-9 * scale
+
+
+@pytest.mark.parametrize("layer", ["slp", "dlp"])
+def test_hip_stokes_outputs_satisfy_momentum_and_mass(lp, layer):
+    rel, S = _relations_setup()
+    w = S["w"]
+    d = S["rng"].standard_normal((2, S["sx"].size))
+    if layer == "slp":
+        fn = lambda x, y: lp.stokes_apply(S["sx"], S["sy"], x, y, wfx=d[0] * w, wfy=d[1] * w)
+    else:
+        fn = lambda x, y: lp.stokes_apply(S["sx"], S["sy"], x, y, nx=S["nx"], ny=S["ny"],
+                                          wdx=d[0] * w, wdy=d[1] * w)
+    eps, tx, ty = 0.02, S["tx"], S["ty"]
+    px = rel.d_target(lambda x, y: fn(x, y)[2], tx, ty, 0, eps)
+    py = rel.d_target(lambda x, y: fn(x, y)[2], tx, ty, 1, eps)
+    lu = rel.lap_target(lambda x, y: fn(x, y)[0], tx, ty, eps)
+    lv = rel.lap_target(lambda x, y: fn(x, y)[1], tx, ty, eps)
+    div = rel.d_target(lambda x, y: fn(x, y)[0], tx, ty, 0, eps) + rel.d_target(lambda x, y: fn(x, y)[1], tx, ty, 1, eps)
+    scale = max(np.max(np.abs(px)), np.max(np.abs(py)))
+    assert max(np.max(np.abs(lu - px)), np.max(np.abs(lv - py))) < 1e-6 * scale
+    assert np.max(np.abs(div)) < 1e-8 * scale
