@@ -27,6 +27,11 @@ _PREFIX = "ipde"
 _TARGET = "ipde_amd"
 
 
+# module names the reference's scripts import that its tree no longer has under that name
+# (examples/poisson_for_paper.py:9 imports ipde.embedded_boundary_standalone)
+_RENAMED = {".embedded_boundary_standalone": ".embedded_boundary"}
+
+
 class _AliasLoader(importlib.abc.Loader):
     def __init__(self, target):
         self.target = target
@@ -48,7 +53,7 @@ class _IpdeAliasFinder(importlib.abc.MetaPathFinder):
     def find_spec(self, name, path=None, target=None):
         if name != _PREFIX and not name.startswith(_PREFIX + "."):
             return None
-        real = _TARGET + name[len(_PREFIX):]
+        real = _TARGET + _RENAMED.get(name[len(_PREFIX):], name[len(_PREFIX):])
         try:
             mod = importlib.import_module(real)
         except ImportError:

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(NT) void modhelm_table_kernel(
     extern __shared__ double2 ltab[];  // KT_NKEYS * KT_ENTRY/2 double2
     // the pack kernel picked the window from the bounding box: (k * diameter)^2 < 2^(11 + 2w),
     // so every pair farther apart than diameter * 2^-16 is inside the table whatever k is
-    // (window KT_NWIN: the pairs reach beyond the last one — every lane takes the generic body)
+    // (window KT_NWIN: the pairs reach beyond the last one, or every pair is at k r >= 18 where the
+    // table's relative error would show (layer_pack.h) — every lane takes the generic body)
     const bool nowin = prm->pad >= KT_NWIN;
     const int win = nowin ? KT_NWIN - 1 : prm->pad;
     gtab += (size_t)win * KT_NKEYS * (KT_ENTRY / 2);
@@ -140,7 +141,9 @@ __global__ __launch_bounds__(NT) void modhelm_table_kernel(
         y[r] = ty[i] * s1;
         acc[r] = 0.0;
     }
-    for (int b = j0 / IPDE_SRC_PAD; b < j1 / IPDE_SRC_PAD; ++b) {
+    // (no window: the table pass is skipped, every lane goes to the generic body below)
+    const int b_end = nowin ? j0 / IPDE_SRC_PAD : j1 / IPDE_SRC_PAD;
+    for (int b = j0 / IPDE_SRC_PAD; b < b_end; ++b) {
         SrcRow sx, sy, sq, sax, say;
         sx.load(rec, b, 0);
         sy.load(rec, b, 1);

@@ -55,6 +55,9 @@ struct PackArgs {
     double fixed_scale;      // != 0: scale coordinates by this factor instead of 2^sh
 };
 
+// (k r)^2 from which a launch whose pairs are ALL that far apart leaves the table kernel
+#define IPDE_MODHELM_FAR_KR2 64.0
+
 // single block of 1024 threads; ns_alloc = whole batches (multiple of 8) >= ns
 __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int64_t ns,
                                                                  int64_t ns_alloc,
@@ -62,44 +65,62 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
                                                                  int nbbox,
                                                                  double* __restrict__ rec,
                                                                  ApplyParams* __restrict__ prm) {
-    __shared__ double red[16][4];
+    __shared__ double red[16][8];
     __shared__ int s_sh, s_win, s_force;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     int sh = 0, win = 0, force_generic = 0;
     if (a.use_scale) {
-        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        // bounding boxes of the targets (t: from the partials of the bounding-box kernel) and of the
+        // sources (s) kept apart: their union scales the tables, their GAP bounds the smallest distance
+        double t[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+        double b[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
         for (int i = tid; i < nbbox; i += 1024) {
-            xmin = fmin(xmin, bbox_part[4 * i + 0]);
-            xmax = fmax(xmax, bbox_part[4 * i + 1]);
-            ymin = fmin(ymin, bbox_part[4 * i + 2]);
-            ymax = fmax(ymax, bbox_part[4 * i + 3]);
+            t[0] = fmin(t[0], bbox_part[4 * i + 0]);
+            t[1] = fmax(t[1], bbox_part[4 * i + 1]);
+            t[2] = fmin(t[2], bbox_part[4 * i + 2]);
+            t[3] = fmax(t[3], bbox_part[4 * i + 3]);
         }
         for (int64_t i = tid; i < ns; i += 1024) {
             double x = a.sx[i], y = a.sy[i];
-            xmin = fmin(xmin, x);
-            xmax = fmax(xmax, x);
-            ymin = fmin(ymin, y);
-            ymax = fmax(ymax, y);
+            b[0] = fmin(b[0], x);
+            b[1] = fmax(b[1], x);
+            b[2] = fmin(b[2], y);
+            b[3] = fmax(b[3], y);
         }
-        xmin = wave_min(xmin);
-        xmax = wave_max(xmax);
-        ymin = wave_min(ymin);
-        ymax = wave_max(ymax);
+        t[0] = wave_min(t[0]);
+        t[1] = wave_max(t[1]);
+        t[2] = wave_min(t[2]);
+        t[3] = wave_max(t[3]);
+        b[0] = wave_min(b[0]);
+        b[1] = wave_max(b[1]);
+        b[2] = wave_min(b[2]);
+        b[3] = wave_max(b[3]);
         if (lane == 0) {
-            red[w][0] = xmin;
-            red[w][1] = xmax;
-            red[w][2] = ymin;
-            red[w][3] = ymax;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[w][c] = t[c];
+                red[w][4 + c] = b[c];
+            }
         }
         __syncthreads();
         if (tid == 0) {
             for (int i = 1; i < 16; ++i) {
-                xmin = fmin(xmin, red[i][0]);
-                xmax = fmax(xmax, red[i][1]);
-                ymin = fmin(ymin, red[i][2]);
-                ymax = fmax(ymax, red[i][3]);
+                t[0] = fmin(t[0], red[i][0]);
+                t[1] = fmax(t[1], red[i][1]);
+                t[2] = fmin(t[2], red[i][2]);
+                t[3] = fmax(t[3], red[i][3]);
+                b[0] = fmin(b[0], red[i][4]);
+                b[1] = fmax(b[1], red[i][5]);
+                b[2] = fmin(b[2], red[i][6]);
+                b[3] = fmax(b[3], red[i][7]);
             }
+            const double xmin = fmin(t[0], b[0]), xmax = fmax(t[1], b[1]);
+            const double ymin = fmin(t[2], b[2]), ymax = fmax(t[3], b[3]);
+            // distance between the two boxes (0 when they overlap or one side is empty)
+            const double gx = fmax(0.0, fmax(t[0] - b[1], b[0] - t[1]));
+            const double gy = fmax(0.0, fmax(t[2] - b[3], b[2] - t[3]));
+            const double gap2 = (gx < INFINITY && gy < INFINITY) ? gx * gx + gy * gy : 0.0;
             double ddx = xmax - xmin, ddy = ymax - ymin;
             double D2 = ddx * ddx + ddy * ddy;
             int shv = 0, force = 0;
@@ -129,6 +150,11 @@ __global__ __launch_bounds__(1024) static void ipde_pack_kernel(PackArgs a, int6
                 wv = (ey - 11 + 1) / 2;
                 if (ey <= 11) wv = 0;
                 if (wv > 7) wv = 8;      // beyond the last window (k * diameter > 5800): no table, generic body
+                // every pair at k r >= 8: the whole result is of the size e^(-k r) at which the
+                // degree-5 table's RELATIVE error (K1 part: 1.5e-12 measured on a set with k r >= 12;
+                // 2e-12 at k r = 20, 7e-12 at 30) is no longer hidden under near-field values —
+                // full-precision body (IPDE_MODHELM_FAR_KR2)
+                if (gap2 * a.fixed_scale * a.fixed_scale >= IPDE_MODHELM_FAR_KR2) wv = 8;
             }
             s_win = wv;
         }

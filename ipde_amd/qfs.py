@@ -285,8 +285,8 @@ class _OwnAsyncLU(object):
     torch stream): most of a factorisation is its single-workgroup panel kernel, so the two QFS
     systems of every interface and the example's integral equation factor side by side, under the
     host's geometry work and the default stream's kernels (on the context's own blocking stream
-    every default-stream operation of the set-up waited for them: +0.08 s).  The first use makes
-    the consumer's stream wait for the factorisation's event."""
+    every default-stream operation of the set-up waited for them: +0.08 s).  Every use before
+    the factorisation has finished makes the consumer's stream wait for its event."""
 
     def __init__(self, A):
         import torch
@@ -312,14 +312,24 @@ class _OwnAsyncLU(object):
         self._done = torch.cuda.Event()
         self._done.record(side)
         self._obj = _DeviceLU.from_tiled(T, perm, int(A.shape[0]), get_context(dev))
-        self._waited = False
+        self._complete = False
 
     def _get(self):
-        if not self._waited:
-            import torch
-            torch.cuda.current_stream().wait_event(self._done)
-            # (the library's own stream is a blocking one: it runs behind the default stream)
-            self._waited = True
+        # every use before the factorisation has FINISHED orders the consumer behind it: the
+        # current torch stream (which may be a non-blocking one inside `with torch.cuda.stream`)
+        # and the legacy default stream, which the library's own blocking streams run behind.
+        # (A one-time flag set by the first consumer would leave later consumers on other
+        # streams unordered.)  Once the event has completed nothing is enqueued any more.
+        if not self._complete:
+            if self._done.query():
+                self._complete = True
+            else:
+                import torch
+                cur = torch.cuda.current_stream()
+                cur.wait_event(self._done)
+                dflt = torch.cuda.default_stream()
+                if dflt != cur:
+                    dflt.wait_event(self._done)
         return self._obj
 
     def __getattr__(self, name):

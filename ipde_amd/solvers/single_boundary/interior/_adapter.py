@@ -17,6 +17,26 @@ from ....embedded_function import EmbeddedFunction
 from ....pybie2d_compat import PointSet
 
 
+class _AnnularSolverHolder(object):
+    """what the multi-boundary helpers take as `helper`: an object carrying .annular_solver"""
+    def __init__(self, annular_solver):
+        self.annular_solver = annular_solver
+
+
+def annular_solver_holder(AS, ebdy, name):
+    """The reference's optional pre-built annular solver argument (APS / AMHS; reference
+    single_boundary/interior/poisson.py:30-34): reused when it fits the boundary, refused otherwise."""
+    if AS is None:
+        return None
+    AAG = getattr(AS, 'AAG', None)
+    if AAG is None or not callable(getattr(AS, 'solve', None)):
+        raise TypeError('%s must be an annular solver of this package (has .AAG and .solve)' % name)
+    if (AAG.n, AAG.M) != (ebdy.bdy.N, ebdy.M):
+        raise ValueError('%s was built for n = %d, M = %d; the boundary has n = %d, M = %d'
+                         % (name, AAG.n, AAG.M, ebdy.bdy.N, ebdy.M))
+    return _AnnularSolverHolder(AS)
+
+
 class SingleBoundaryAdapter(object):
     def __init__(self, ebdy, solver_type='spectral'):
         if getattr(ebdy, 'grid', None) is None:

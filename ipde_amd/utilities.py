@@ -36,7 +36,8 @@ def ifft2(a):
 
 
 def concat(*args):
-    return np.concatenate([np.array(arg).ravel() for arg in args])
+    """All arguments (scalars, lists, arrays) flattened into one vector (ipde/utilities.py:14-15)."""
+    return np.hstack([np.ravel(np.asarray(arg)) for arg in args])
 
 
 def affine_transformation(xin, min_in, max_in, min_out, max_out, return_ratio=False,
@@ -47,22 +48,28 @@ def affine_transformation(xin, min_in, max_in, min_out, max_out, return_ratio=Fa
 
 
 def get_chebyshev_nodes(lb, ub, order):
-    """Chebyshev-Gauss nodes, lowest first, scaled to [lb, ub]
-    (ipde/utilities.py:36-49): returns (unscaled, scaled, ratio)."""
-    xc, _ = np.polynomial.chebyshev.chebgauss(order)
-    x, rat = affine_transformation(xc[::-1], -1, 1, lb, ub, return_ratio=True)
-    return xc[::-1], x, rat
+    """Chebyshev-Gauss nodes in ascending order, on [-1, 1] and mapped to [lb, ub]
+    (ipde/utilities.py:36-49): returns (unscaled, scaled, d scaled / d unscaled)."""
+    ascending = np.polynomial.chebyshev.chebgauss(order)[0][::-1]
+    scaled, rat = affine_transformation(ascending, -1, 1, lb, ub, return_ratio=True)
+    return ascending, scaled, rat
+
+
+# (ndim of M1, ndim of M2) -> product with 1-D operands read as diagonal matrices
+_FAST_DOT = {
+    (1, 1): lambda a, b: a * b,
+    (2, 1): lambda a, b: a * b,            # columns scaled: A diag(b)
+    (1, 2): lambda a, b: a[:, None] * b,   # rows scaled: diag(a) B
+    (2, 2): lambda a, b: a.dot(b),
+}
 
 
 def fast_dot(M1, M2):
-    """1-D operands stand for diagonal matrices (ipde/utilities.py:51-66)."""
-    if len(M1.shape) in [1, 2] and len(M2.shape) == 1:
-        return M1 * M2
-    elif len(M1.shape) == 1 and len(M2.shape) == 2:
-        return M1[:, None] * M2
-    elif len(M1.shape) == 2 and len(M2.shape) == 2:
-        return M1.dot(M2)
-    raise Exception('fast_dot requires shapes to be 1 or 2')
+    """Matrix product in which a 1-D operand stands for a diagonal matrix (ipde/utilities.py:51-66)."""
+    rule = _FAST_DOT.get((M1.ndim, M2.ndim))
+    if rule is None:
+        raise Exception('fast_dot requires shapes to be 1 or 2')
+    return rule(M1, M2)
 
 
 # Nyquist-dropping transforms (ipde/utilities.py:78-101)
@@ -96,31 +103,27 @@ def ffourier_multiply(fh, m):
 
 
 # Transforms that zero entry N//2 + 1 instead of dropping the Nyquist column (ipde/utilities.py
-# :103-121; imported by ipde/annular/stokes.py).  Like the reference's, they zero that entry of
-# their INPUT in place.
-def pfourier_multiply(fh, m):
-    pos = int(fh.shape[1] // 2 + 1)
-    fh[:, pos] = 0.0
-    oh = fft(m * ifft(fh))
-    oh[:, pos] = 0.0
-    return oh
-
-
-def pfft(f):
-    pos = int(f.shape[1] // 2 + 1)
-    fh = fft(f)
-    fh[:, pos] = 0.0
+# :103-121; imported by ipde/annular/stokes.py).  Like the reference's, the ones that take a
+# spectrum zero that entry of their INPUT in place.
+def _blank(fh):
+    fh[:, fh.shape[1] // 2 + 1] = 0.0
     return fh
 
 
+def pfft(f):
+    return _blank(fft(f))
+
+
 def pifft(fh):
-    pos = int(fh.shape[1] // 2 + 1)
-    fh[:, pos] = 0.0
-    return ifft(fh)
+    return ifft(_blank(fh))
 
 
 def pifftr(fh):
     return pifft(fh).real
+
+
+def pfourier_multiply(fh, m):
+    return pfft(m * pifft(fh))
 
 
 def fast_LU_solve(LU, b):
@@ -130,30 +133,29 @@ def fast_LU_solve(LU, b):
 
 
 class SimpleFourierFilter(object):
-    """Fourier filter of a periodic vector (ipde/utilities.py:126-162); tiny 1-D
-    boundary data, host side."""
+    """Fourier filter of a periodic vector (ipde/utilities.py:126-162): `modes` are the wavenumbers
+    in np.fft order; 'fraction' keeps |k| <= fraction max|k|, 'rule 36' multiplies by
+    exp(-p (|k| / max|k|)^p), p = `power` (36).  Tiny 1-D boundary data, host side."""
 
     def __init__(self, modes, filter_type, **kwargs):
-        self.n = modes.shape[0]
         self.modes = modes
+        self.n = modes.shape[0]
         self.filter_type = filter_type
-        max_k = np.abs(self.modes).max()
+        top = np.abs(modes).max()
+        rel = np.abs(modes) / top
         if filter_type == 'fraction':
-            self.filter = np.ones(self.n, dtype=float)
-            self.filter[np.abs(self.modes) > max_k * kwargs['fraction']] = 0.0
+            self.filter = np.where(np.abs(modes) > top * kwargs['fraction'], 0.0, 1.0)
         elif filter_type == 'rule 36':
-            p = kwargs.get('power', 36)
-            self.filter = np.exp(-p * (np.abs(self.modes) / max_k) ** p)
+            power = kwargs.get('power', 36)
+            self.filter = np.exp(-power * rel ** power)
         else:
             raise Exception('Filter type not defined.')
 
     def __call__(self, fin, input_type='space', output_type='space'):
-        input_is_real = fin.dtype == float and input_type == 'space'
-        if input_type == 'space':
-            fin = np.fft.fft(fin)
-        fout = fin * self.filter
-        if output_type == 'space':
-            fout = np.fft.ifft(fout)
-            if input_is_real:
-                fout = fout.real
-        return fout
+        from_space, to_space = input_type == 'space', output_type == 'space'
+        spectrum = (np.fft.fft(fin) if from_space else fin) * self.filter
+        if not to_space:
+            return spectrum
+        out = np.fft.ifft(spectrum)
+        # real samples in, real samples out
+        return out.real if (from_space and fin.dtype == float) else out

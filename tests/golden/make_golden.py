@@ -474,16 +474,44 @@ def golden_utilities():
     print("utilities.npz", len(out))
 
 
+def golden_fourier_filter():
+    """ipde/utilities.py:126-162 SimpleFourierFilter: both filter types, real / complex samples and
+    the spectrum-in / spectrum-out call forms."""
+    import ipde.utilities as U
+    rng = np.random.default_rng(606)
+    out = {}
+    n = 48
+    modes = np.fft.fftfreq(n, 1.0 / n)
+    fr = rng.standard_normal(n)
+    fc = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    out["modes"], out["fr"], out["fc"] = modes, fr, fc
+    F = U.SimpleFourierFilter(modes, 'fraction', fraction=2.0 / 3.0)
+    out["fraction_filter"] = F.filter
+    out["fraction_real"], out["fraction_cplx"] = F(fr), F(fc)
+    out["fraction_spec_in"] = F(np.fft.fft(fr), input_type='fourier')
+    out["fraction_spec_out"] = F(fr, output_type='fourier')
+    R = U.SimpleFourierFilter(modes, 'rule 36')
+    out["rule36_filter"], out["rule36_real"] = R.filter, R(fr)
+    R8 = U.SimpleFourierFilter(modes, 'rule 36', power=8)
+    out["rule8_filter"], out["rule8_cplx"] = R8.filter, R8(fc)
+    np.savez(os.path.join(OUT, "fourier_filter.npz"), **out)
+    print("fourier_filter.npz", len(out))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be regenerated where it is")
     _install_standins()
     sys.path.insert(0, REF)
+    if sys.argv[1:] == ["fourier_filter"]:      # one fixture alone (the others are unchanged)
+        golden_fourier_filter()
+        raise SystemExit(0)
     golden_derivatives()
     golden_annular_scalar()
     golden_annular_stokes()
     golden_slepian()
     golden_grid_evaluator_kernels()
     golden_utilities()
+    golden_fourier_filter()
     _install_absent_package_finder()
     golden_layer_kernels()

@@ -274,6 +274,31 @@ def test_modhelm_beyond_the_last_table_window(lp):
         assert np.max(np.abs(ref)) > 1e-3 and rel_err(got, ref) < 1e-10, k
 
 
+@pytest.mark.parametrize("krmin", [5.0, 7.9, 8.1, 12.0, 19.0, 25.0, 40.0])
+def test_modhelm_far_only_target_set(lp, krmin):
+    """Every pair at k r >= krmin (targets in a box beside the curve): max|u| itself is of the size
+    e^(-k r), so the 1e-12-of-max bar asks for RELATIVE accuracy of the far kernel values — the
+    degree-5 table has 2e-12 at k r = 20, 7e-12 at 30 (1.5e-12 measured for the double layer on a set
+    with k r >= 12), so from k r_min = 8 on (bounding-box gap, pack kernel) such launches take the
+    full-precision body; below that the near end of the set dominates and the table holds the bar."""
+    c = Curve(256, a=0.2, f=5)
+    k = 10.0
+    rng = np.random.default_rng(23)
+    x0 = c.x.max() + krmin / k
+    tx = x0 + rng.uniform(0.0, 0.5, 1500)
+    ty = rng.uniform(-1.0, 1.0, 1500)
+    sig, tau = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    w = c.weights
+    for ch, dp in ((sig, None), (None, tau), (sig, tau)):
+        ref = olp.modified_helmholtz_layer_apply(c.x, c.y, tx, ty, k, charge=ch, dipstr=dp, weights=w,
+                                                 nx=c.normal_x, ny=c.normal_y)
+        got = lp.modified_helmholtz_apply(c.x, c.y, tx, ty, k, w_sigma=None if ch is None else ch * w,
+                                          nx=None if dp is None else c.normal_x,
+                                          ny=None if dp is None else c.normal_y,
+                                          w_tau=None if dp is None else dp * w)
+        assert rel_err(got, ref) < TOL, (krmin, ch is not None, dp is not None, rel_err(got, ref))
+
+
 def test_modhelm_closure_and_self(lp, setup):
     c, trg, sig, _, _, _ = setup
     f = lp.make_modified_helmholtz_layer_apply(3.0)

@@ -47,3 +47,24 @@ def test_fft_backed_functions_against_reference_outputs():
     b = a.copy()
     U.pifft(b)
     assert np.all(b[:, b.shape[1] // 2 + 1] == 0)       # like the reference: input zeroed in place
+
+
+def test_simple_fourier_filter_against_reference_outputs():
+    """SimpleFourierFilter (ipde/utilities.py:126-162) against the reference class's own outputs
+    (tests/golden/fourier_filter.npz)."""
+    from ipde_amd.utilities import SimpleFourierFilter
+    F = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fourier_filter.npz"))
+    modes, fr, fc = F["modes"], F["fr"], F["fc"]
+    f = SimpleFourierFilter(modes, 'fraction', fraction=2.0 / 3.0)
+    assert np.array_equal(f.filter, F["fraction_filter"])
+    got = f(fr)
+    assert got.dtype == F["fraction_real"].dtype and close(got, F["fraction_real"], 1e-15)
+    assert close(f(fc), F["fraction_cplx"], 1e-15)
+    assert close(f(np.fft.fft(fr), input_type='fourier'), F["fraction_spec_in"], 1e-15)
+    assert close(f(fr, output_type='fourier'), F["fraction_spec_out"], 1e-15)
+    r = SimpleFourierFilter(modes, 'rule 36')
+    assert close(r.filter, F["rule36_filter"], 1e-15) and close(r(fr), F["rule36_real"], 1e-15)
+    r8 = SimpleFourierFilter(modes, 'rule 36', power=8)
+    assert close(r8.filter, F["rule8_filter"], 1e-15) and close(r8(fc), F["rule8_cplx"], 1e-15)
+    with pytest.raises(Exception):
+        SimpleFourierFilter(modes, 'no such filter')
