@@ -162,6 +162,19 @@ def fft_block(n=NGRID, reps=40):
         gbs = 16 * N / (ms * 1e-3) / 1e9
         out[name] = {"ms": ms, "GB/s": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
                      "GFLOP/s": flops / (ms * 1e-3) / 1e9}
+    # HBM-side bytes of one Poisson grid solve (its three kernels): rocprofv3 FETCH_SIZE / WRITE_SIZE
+    # passes over tools/profile_fft.py (tools/fft_traffic.py), stamped with the commit they were taken at
+    tf = os.path.join(ROOT, "profiles", "traffic_fft_latest.json")
+    out["traffic"], out["traffic_source"] = None, None
+    if n == NGRID and os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            if tj.get("grid") == [n, n]:
+                out["traffic"] = tj.get("poisson_solve_hbm_bytes")
+                out["traffic_source"] = {k: tj.get(k) for k in ("poisson_solve_kernels", "measured_at_commit",
+                                                                 "measured_on", "command")}
+        except Exception:
+            pass
     return out
 
 

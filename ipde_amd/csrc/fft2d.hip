@@ -88,13 +88,16 @@ __global__ __launch_bounds__(256) void row_r2c_kernel(const double* __restrict__
     const int64_t row = (int64_t)blockIdx.x * RPW + sub;
     cd* buf = lds + sub * lds_slots<H>();
     const double2* src = (const double2*)(f + row * NY);
+    // every table entry the thread will need, requested before the data (one latency for all)
+    const PassTw<H> pw = load_pass_twiddles<H>(t, tw_h);
+    const cd wt = tw_ny[t];   // exp(-2 pi i t / NY)
     cd v[P];
 #pragma unroll
     for (int q = 0; q < P; ++q) {
         double2 a = src[t + T * q];
         v[q] = cd{a.x, a.y};
     }
-    fft_regs<H, -1, (T == 64)>(v, t, tw_h, buf);
+    fft_regs<H, -1, (T == 64)>(v, t, pw, buf);
     cd m[P];   // Z[(H - k) mod H]
     gather_mirror<H, (T == 64)>(v, m, t, buf);
     cd* dst = W + row * H;
@@ -104,7 +107,9 @@ __global__ __launch_bounds__(256) void row_r2c_kernel(const double* __restrict__
         cd zk = v[q], zm = cconj(m[q]);
         cd e = cd{0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y)};
         cd d = cd{0.5 * (zk.x - zm.x), 0.5 * (zk.y - zm.y)};
-        cd w = tw_ny[k];   // exp(-2 pi i k / NY)
+        // exp(-2 pi i k / NY) = exp(-2 pi i t / NY) exp(-2 pi i T q / NY): the second factor sits at
+        // a wave-uniform address (scalar load)
+        cd w = q == 0 ? wt : cmul(wt, tw_ny[T * q]);
         cd wd = cmul(w, d);
         cd X = cd{e.x + wd.y, e.y - wd.x};   // e - i w d
         if (k == 0) X = cd{zk.x + zk.y, zk.x - zk.y};   // {X[0], X[ny/2]}, both real
@@ -127,6 +132,8 @@ __global__ __launch_bounds__(256) void row_c2r_kernel(const cd* __restrict__ W, 
     const int64_t row = (int64_t)blockIdx.x * RPW + sub;
     cd* buf = lds + sub * lds_slots<H>();
     const cd* src = W + row * H;
+    const PassTw<H> pw = load_pass_twiddles<H>(t, tw_h);
+    const cd wt = cconj(tw_ny[t]);   // exp(+2 pi i t / NY)
     cd v[P];
 #pragma unroll
     for (int q = 0; q < P; ++q) v[q] = src[t + T * q];
@@ -142,11 +149,11 @@ __global__ __launch_bounds__(256) void row_c2r_kernel(const cd* __restrict__ W, 
         }
         cd e = cd{0.5 * (xk.x + xm.x), 0.5 * (xk.y + xm.y)};
         cd d = cd{0.5 * (xk.x - xm.x), 0.5 * (xk.y - xm.y)};
-        cd w = cconj(tw_ny[k]);   // exp(+2 pi i k / NY)
+        cd w = q == 0 ? wt : cmul(wt, cconj(tw_ny[T * q]));   // exp(+2 pi i k / NY), k = t + T q
         cd wd = cmul(w, d);
         v[q] = cd{e.x - wd.y, e.y + wd.x};   // e + i w d
     }
-    fft_regs<H, +1, (T == 64)>(v, t, tw_h, buf);
+    fft_regs<H, +1, (T == 64)>(v, t, pw, buf);
     double2* dst = (double2*)(out + row * NY);
 #pragma unroll
     for (int q = 0; q < P; ++q) dst[t + T * q] = double2{v[q].x, v[q].y};
@@ -184,11 +191,12 @@ __global__ __launch_bounds__(C* Cfg<NX>::T) void col_kernel(cd* __restrict__ W, 
     const int col = tid % C, t = tid / C;
     const int j0 = blk * C;
     cd* base = W + j0 + col;
+    const PassTw<NX> pw = load_pass_twiddles<NX>(t, tw_x);   // (both transforms; before the data)
     cd v[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) v[i] = base[(int64_t)(t + T * i) * pitch];
     cd* buf = lds + col * NPC;
-    if (MODE != 2) fft_regs<NX, -1, false>(v, t, tw_x, buf);
+    if (MODE != 2) fft_regs<NX, -1, false>(v, t, pw, buf);
     if (MODE == 0) {
         const int j = j0 + col;
         if (blk == 0) {   // (uniform over the workgroup)
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(C* Cfg<NX>::T) void col_kernel(cd* __restrict__ W, 
 #pragma unroll
         for (int q = 0; q < P; ++q) so[(int64_t)(t + T * q) * pitch] = v[q];
     }
-    if (MODE != 1) fft_regs<NX, +1, false>(v, t, tw_x, buf);
+    if (MODE != 1) fft_regs<NX, +1, false>(v, t, pw, buf);
 #pragma unroll
     for (int i = 0; i < P; ++i) base[(int64_t)(t + T * i) * pitch] = v[i];
 }

@@ -162,23 +162,39 @@ constexpr int lds_slots() {
     return N + N / 16;
 }
 
+// The twiddles a thread needs for passes two and three.  Butterfly i of a pass with stride NS takes
+// w = exp(-2 pi i k / (NS R)), k = (t + T i) mod NS; every configuration above has NS | T, so k = t mod NS
+// whatever i is: ONE table entry per pass and thread.  Loaded at the top of a kernel, next to the
+// data, they cost no latency of their own (read where the pass needs them, each was a dependent
+// global load: two exposed L2 round trips per transform at two waves per SIMD).
+template <int N>
+struct PassTw {
+    cd w2, w3;
+};
+template <int N>
+__device__ __forceinline__ PassTw<N> load_pass_twiddles(int t, const cd* __restrict__ tw) {
+    using G = Cfg<N>;
+    static_assert(G::T % G::R1 == 0 && G::T % (G::R1 * G::R2) == 0, "k = t mod NS needs NS | T");
+    static_assert(G::R1 * G::R2 * G::R3 == N, "three passes");
+    PassTw<N> p;
+    p.w2 = tw[(t & (G::R1 - 1)) * (N / (G::R1 * G::R2))];   // exp(-2 pi i k / (R1 R2))
+    p.w3 = tw[t & (G::R1 * G::R2 - 1)];                       // exp(-2 pi i k / N)
+    return p;
+}
+
 // One Stockham pass on the thread's registers.  Slot convention: butterfly i (of P/R) takes
-// slots {i + (P/R) r}; its output r goes back to the same slot.
+// slots {i + (P/R) r}; its output r goes back to the same slot.  w1: the pass twiddle of this
+// thread (forward sign; unused in the first pass, NS = 1).
 template <int N, int T, int P, int R, int NS, int SIGN>
-__device__ __forceinline__ void pass_compute(cd (&v)[P], int t, const cd* __restrict__ tw) {
+__device__ __forceinline__ void pass_compute(cd (&v)[P], cd w1) {
     constexpr int nb = P / R;
+    if (SIGN > 0) w1.y = -w1.y;
 #pragma unroll
     for (int i = 0; i < nb; ++i) {
         cd u[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) u[r] = v[i + nb * r];
-        if (NS > 1) {
-            const int j = t + T * i;
-            const int k = j & (NS - 1);
-            cd w1 = tw[k * (N / (NS * R))];   // exp(-2 pi i k / (NS R))
-            if (SIGN > 0) w1.y = -w1.y;
-            twiddle<R>(u, w1);
-        }
+        if (NS > 1) twiddle<R>(u, w1);
         Dft<R, SIGN>::run(u);
 #pragma unroll
         for (int r = 0; r < R; ++r) v[i + nb * r] = u[r];
@@ -219,20 +235,27 @@ __device__ __forceinline__ void lds_permute(const cd (&in)[P], cd (&out)[P], cd*
 // result in the same layout, natural order, unnormalised.  tw[m] = exp(-2 pi i m / N);
 // buf: this transform's lds_slots<N>() complex slots.
 template <int N, int SIGN, bool WAVE>
-__device__ __forceinline__ void fft_regs(cd (&v)[Cfg<N>::P], int t, const cd* __restrict__ tw,
+__device__ __forceinline__ void fft_regs(cd (&v)[Cfg<N>::P], int t, const PassTw<N>& pw,
                                          cd* __restrict__ buf) {
     using G = Cfg<N>;
     constexpr int T = G::T, P = G::P;
     auto natural = [&](int q) { return padpos(t + T * q); };
-    pass_compute<N, T, P, G::R1, 1, SIGN>(v, t, tw);
+    pass_compute<N, T, P, G::R1, 1, SIGN>(v, cd{1.0, 0.0});
     lds_permute<P, WAVE>(v, v, buf,
                          [&](int s) { return padpos(outpos<T, G::R1, 1>(t, s % (P / G::R1), s / (P / G::R1))); },
                          natural);
-    pass_compute<N, T, P, G::R2, G::R1, SIGN>(v, t, tw);
+    pass_compute<N, T, P, G::R2, G::R1, SIGN>(v, pw.w2);
     lds_permute<P, WAVE>(v, v, buf,
                          [&](int s) { return padpos(outpos<T, G::R2, G::R1>(t, s % (P / G::R2), s / (P / G::R2))); },
                          natural);
-    pass_compute<N, T, P, G::R3, G::R1 * G::R2, SIGN>(v, t, tw);
+    pass_compute<N, T, P, G::R3, G::R1 * G::R2, SIGN>(v, pw.w3);
+}
+// (the same with the twiddles read here: tw[m] = exp(-2 pi i m / N))
+template <int N, int SIGN, bool WAVE>
+__device__ __forceinline__ void fft_regs(cd (&v)[Cfg<N>::P], int t, const cd* __restrict__ tw,
+                                         cd* __restrict__ buf) {
+    const PassTw<N> pw = load_pass_twiddles<N>(t, tw);
+    fft_regs<N, SIGN, WAVE>(v, t, pw, buf);
 }
 
 // value at the mirrored natural index (N - k) mod N for every k the thread holds

@@ -1,8 +1,12 @@
-# the whole GPU test-suite and the two warm-solve timings (one MI355X)
+# the whole GPU test-suite (the driver's literal command), smoke, bench (one MI355X)
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02
-timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q 2>&1 | grep -v "^  File\|^Extension" | tail -6
-timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | tail -1
-timeout -k 10 300 python3 tools/profile_stokes_solve.py 2>&1 | tail -1
+O=gpurun_out/r03
+mkdir -p $O
+python3 -m pytest tests -m gpu -x -q > $O/gputest.txt 2>&1 || { tail -60 $O/gputest.txt; exit 1; }
+tail -4 $O/gputest.txt
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python3 bench.py --steps 20 --warmup 5 > $O/bench_b.json 2> $O/bench_b.err || { tail -20 $O/bench_b.err; exit 1; }
+python3 -c "
+import json; r=json.load(open('$O/bench_b.json')); print(r['value'], r['ms_per_step'], {k:v for k,v in r['roofline'].items() if k in ('kernel_ms','kernel_ms_isolated','frac','traffic')}, r['fft']['poisson_grid_solve'], r['fft']['traffic'], r['full_poisson_solve']['warm_inhomogeneous_solve_ms'], r['full_poisson_solve']['setup_s'])"

@@ -2,7 +2,7 @@
 """Profiling driver: the dense layer-potential kernels at BASELINE configs[1]
 (2048^2 grid x 4096 nodes), device resident.  Run directly after `rocprofv3 ... --`.
 
-    python3 tools/profile_dense.py [reps] [families: laplace,patches,modhelm,stokes]
+    python3 tools/profile_dense.py [reps] [families: laplace,patches,modhelm,stokes,stokes_dlp]
 """
 import os
 import sys
@@ -39,6 +39,8 @@ def main():
             lp.Modified_Helmholtz_Layer_Apply(c, dt, k=10.0, dipstr=tau)
         if "stokes" in fam:
             lp.Stokes_Layer_Apply(c, dt, forces=f2)
+        if "stokes_dlp" in fam:
+            lp.Stokes_Layer_Apply(c, dt, dipstr=f2)
     torch.cuda.synchronize()
 
 
