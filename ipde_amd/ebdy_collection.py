@@ -24,6 +24,20 @@ def merge_sources(src_list):
     return p
 
 
+def LoadEmbeddedBoundaryCollection(d):
+    """Collection (with its grid registered and its bump, when it had them) from the dictionary
+    `EmbeddedBoundaryCollection.save` made (reference ipde/ebdy_collection.py:220-228)."""
+    from .embedded_boundary import LoadEmbeddedBoundary
+    from .pybie2d_compat import Grid
+    ebdyc = EmbeddedBoundaryCollection([LoadEmbeddedBoundary(e) for e in d['ebdy_list']])
+    if d['grid'] is not None:
+        ebdyc.register_grid(Grid(**d['grid']), danger_zone_distance=d['ddd'])
+    if d['bumpy'] is not None:
+        ebdyc.bumpy = np.array(d['bumpy'])
+        ebdyc.bumpy_readied = True
+    return ebdyc
+
+
 class EmbeddedBoundaryCollection(object):
     def __init__(self, ebdy_list):
         self.ebdys = list(ebdy_list)
@@ -43,6 +57,19 @@ class EmbeddedBoundaryCollection(object):
         return self.ebdys[ind]
 
     # -- grid generation (reference :279-339) ------------------------------------
+    def save(self):
+        """Dictionary sufficient for LoadEmbeddedBoundaryCollection (reference
+        ipde/ebdy_collection.py:255-278): the boundaries, the grid's constructor arguments, the bump."""
+        grid = getattr(self, 'grid', None)
+        return {
+            'ebdy_list': [ebdy.save() for ebdy in self.ebdys],
+            'grid': None if grid is None else {
+                'x_bounds': list(grid.x_bounds), 'y_bounds': list(grid.y_bounds), 'Nx': grid.Nx, 'Ny': grid.Ny,
+                'mask': grid.mask, 'x_endpoints': list(grid.x_endpoints), 'y_endpoints': list(grid.y_endpoints)},
+            'bumpy': np.array(self.bumpy) if getattr(self, 'bumpy_readied', False) else None,
+            'ddd': getattr(self, 'danger_zone_distance', None) if grid is not None else None,
+        }
+
     def generate_grid(self, h=None, Ns=None, force_square=False, danger_zone_distance=None):
         iebdy = self[0]
         if not iebdy.interior:
@@ -78,6 +105,7 @@ class EmbeddedBoundaryCollection(object):
     # -- registration (reference :352-526) ------------------------------------------
     def register_grid(self, grid, danger_zone_distance=None, verbose=False):
         self.grid = grid
+        self.danger_zone_distance = danger_zone_distance
         prewarm(grid.shape, (grid.xh, grid.yh))   # rocFFT plans compile while the host classifies points
         phys = np.zeros(grid.shape, dtype=bool) if self.ebdys[0].interior \
             else np.ones(grid.shape, dtype=bool)

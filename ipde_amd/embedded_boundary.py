@@ -20,6 +20,14 @@ def setit(n, dictionary, default):
     return dictionary[n] if n in dictionary else default
 
 
+def LoadEmbeddedBoundary(d):
+    """EmbeddedBoundary from the dictionary its `save` method made (reference
+    ipde/embedded_boundary.py:38-43).  The heaviside function is not stored (`save` drops it, as the
+    reference's does): the loaded boundary gets the default one unless d['kwargs'] is given one."""
+    bdy = GSB(x=np.array(d['bx'], dtype=float), y=np.array(d['by'], dtype=float))
+    return EmbeddedBoundary(bdy, d['interior'], d['M'], d['h'], **d['kwargs'])
+
+
 class EmbeddedBoundary(object):
     def __init__(self, bdy, interior, M, h, *legacy, **kwargs):
         # library loads and the length-N 1-D FFT kernels (annular solver, radial
@@ -121,6 +129,15 @@ class EmbeddedBoundary(object):
         else:
             w1, w2 = r >= 0, r <= self.radial_width
         return np.logical_and(w1, w2), np.logical_not(w2), np.logical_not(w1)
+
+    def save(self):
+        """Dictionary sufficient for recreating the object with LoadEmbeddedBoundary (reference
+        ipde/embedded_boundary.py:160-176; the heaviside callable is left out, as there)."""
+        return {
+            'bx': np.array(self.bdy.x), 'by': np.array(self.bdy.y),
+            'interior': self.interior, 'M': self.M, 'h': self.h,
+            'kwargs': {k: v for k, v in self.kwargs.items() if k != 'heaviside'},
+        }
 
     def register_grid(self, grid, verbose=False):
         """Find the grid points in the annulus, their (r, t) coordinates and the

@@ -9,6 +9,19 @@ import weakref
 import numpy as np
 
 
+def LoadEmbeddedFunction(d, ebdyc=None):
+    """(EmbeddedFunction, its collection) from a `save` dictionary and a collection, or from a
+    `full_save` dictionary alone (reference ipde/embedded_function.py:6-14)."""
+    if ebdyc is None:
+        if 'ebdyc_dict' not in d:
+            raise Exception('Need ebdyc provided unless save was generated with full_save method.')
+        from .ebdy_collection import LoadEmbeddedBoundaryCollection
+        ebdyc = LoadEmbeddedBoundaryCollection(d['ebdyc_dict'])
+    ef = EmbeddedFunction(ebdyc)
+    ef.load_linear_data(d['linear_data'])
+    return ef, ebdyc
+
+
 class EmbeddedFunction(np.ndarray):
     def __new__(cls, ebdyc, dtype=float, array=None, function=None, grid_value=None,
                 radial_value_list=None, linear_data=None, zero=False):
@@ -171,6 +184,11 @@ class EmbeddedFunction(np.ndarray):
 
     def save(self):
         return {'linear_data': np.array(self.view(np.ndarray))}
+
+    def full_save(self):
+        """`save` plus the collection's own dictionary: LoadEmbeddedFunction then needs nothing
+        else (reference ipde/embedded_function.py:56-61)."""
+        return {'ebdyc_dict': self._ebdyc_test().save(), 'linear_data': np.array(self.view(np.ndarray))}
 
 
 class BoundaryFunction(np.ndarray):

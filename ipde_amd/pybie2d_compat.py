@@ -181,6 +181,7 @@ class Grid(object):
         self.shape = (self.Nx, self.Ny)
         self.N = self.Nx * self.Ny
         self.mask = mask
+        self.x_endpoints, self.y_endpoints = list(x_endpoints), list(y_endpoints)
 
     @staticmethod
     def _axis(b, n, ends):

@@ -15,7 +15,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FROM_IMPORTS = [
-    ("ipde.embedded_boundary", "EmbeddedBoundary"),
+    ("ipde.embedded_boundary", "EmbeddedBoundary"), ("ipde.embedded_boundary", "LoadEmbeddedBoundary"),
+    ("ipde.embedded_boundary_standalone", "EmbeddedBoundary"),
+    ("ipde.ebdy_collection", "LoadEmbeddedBoundaryCollection"),
+    ("ipde.embedded_function", "LoadEmbeddedFunction"),
     ("ipde.ebdy_collection", "EmbeddedBoundaryCollection"),
     ("ipde.ebdy_collection", "BoundaryFunction"),
     ("ipde.embedded_function", "EmbeddedFunction"),
