@@ -38,7 +38,7 @@ def _forms():
 
 
 def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, grid_upsample=1,
-        Ns=None, verbose=False, timings=None, grid_backend=None, h=None):
+        Ns=None, verbose=False, timings=None, grid_backend=None, h=None, sharded_result=False):
     T = {} if timings is None else timings
     t0 = time.perf_counter()
     MOL = SlepianMollifier(1.5 * M)
@@ -73,7 +73,9 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
     T['problem_definition_s'] = time.perf_counter() - t0     # f, u_exact, boundary data on 2.2 M points (numpy)
 
     t0 = time.perf_counter()
-    ue = solver(f, tol=solver_tol, verbose=verbose, maxiter=100, restart=20)
+    # sharded_result (torch.distributed): the answer stays sharded through the solve and the correction
+    # below, `ue.owned` marks the entries complete on this rank (ipde_amd/solvers/multi_boundary/scalar.py)
+    ue = solver(f, tol=solver_tol, verbose=verbose, maxiter=100, restart=20, sharded_result=sharded_result)
     T['inhomogeneous_solve_s'] = time.perf_counter() - t0
 
     # homogeneous correction: double-layer density on the boundary, evaluated through QFS
@@ -82,7 +84,7 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
     A = Singular_DLP(bdy, bdy)
     qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [lambda src, trg: A, ], Naive_SLP, on_surface=True, form_b2c=False)
     Alu = DenseSolver(A)
-    targets = ShardedTargets(ebdyc.grid_and_radial_pts)
+    targets = ShardedTargets(ebdyc.grid_and_radial_pts, owned=getattr(ue, 'owned', None))
     T['homogeneous_form_s'] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
@@ -96,6 +98,9 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
     T['homogeneous_apply_s'] = time.perf_counter() - t0
 
     err = np.abs(np.asarray(ue) - np.asarray(ua))
+    if getattr(ue, 'owned', None) is not None:      # a sharded answer: this rank's entries, then the max over the ranks
+        from ipde_amd.sharding import global_max
+        err = np.array([global_max(err[ue.owned].max())])
     T['dof'] = int(ebdyc.dof)
     T['grid'] = list(grid.shape)
     T['gmres_iterations'] = solver.iteration_counts

@@ -98,6 +98,41 @@ int ipde_ctx_last_kernel_ms(ipde_ctx* ctx, double* ms);
 int ipde_ctx_kernel_ms_history(ipde_ctx* ctx, double* ms, int cap, int* n);
 
 /* ------------------------------------------------------------------------- */
+/* One host process, several GPUs ("ipde_ctx_create(ndev, dev_ids, &ctx) owns   */
+/* streams, rocFFT plans, RCCL comm"; §8(e): targets split over the devices)                  */
+
+typedef struct ipde_multi ipde_multi;
+#define IPDE_MULTI_FORCE_COMM 1   /* ipde_multi_create: build the RCCL communicator for one device too */
+
+/* One context (stream, plans, tables) per device of dev_ids and, for ndev > 1 (or with
+   IPDE_MULTI_FORCE_COMM), an RCCL communicator over them (ncclCommInitAll; librccl is loaded at run
+   time, here).  The devices must be distinct gfx950 devices. */
+int ipde_multi_create(int ndev, const int* dev_ids, int flags, ipde_multi** m);
+int ipde_multi_destroy(ipde_multi* m);
+int ipde_multi_ndev(ipde_multi* m, int* ndev);
+int ipde_multi_ctx(ipde_multi* m, int i, ipde_ctx** ctx);       /* the context of device i (borrowed) */
+int ipde_multi_has_comm(ipde_multi* m, int* yes);
+const char* ipde_multi_last_error(ipde_multi* m);
+/* A fixed target set (host arrays) split into ndev contiguous, balanced slices, slice i resident on
+   device i: what the reference's solvers evaluate onto (grid_pnai, radial_targ). */
+int ipde_multi_set_targets(ipde_multi* m, int64_t nt, const double* tx, const double* ty);
+int ipde_multi_target_slice(ipde_multi* m, int i, int64_t* start, int64_t* stop);
+/* ipde_laplace_apply / ipde_modhelm_apply / ipde_stokes_apply onto the resident targets, all arrays
+   in host memory: the sources go up once and reach the other devices by ncclBroadcast over xGMI, the
+   devices sum their slices side by side on their own streams, the slices come back into `out`
+   (nt doubles; Stokes: out_u, out_v and, unless NULL, out_p).  No collective on targets or results. */
+int ipde_multi_laplace_apply(ipde_multi* m, int64_t ns, const double* sx, const double* sy,
+                             const double* w_sigma, const double* nx, const double* ny, const double* w_tau,
+                             double* out, int flags);
+int ipde_multi_modhelm_apply(ipde_multi* m, double k, int64_t ns, const double* sx, const double* sy,
+                             const double* w_sigma, const double* nx, const double* ny, const double* w_tau,
+                             double* out, int flags);
+int ipde_multi_stokes_apply(ipde_multi* m, int64_t ns, const double* sx, const double* sy,
+                            const double* wfx, const double* wfy, const double* nx, const double* ny,
+                            const double* wdx, const double* wdy, double* out_u, double* out_v, double* out_p,
+                            int flags);
+
+/* ------------------------------------------------------------------------- */
 /* layer potentials                                        */
 
 /*

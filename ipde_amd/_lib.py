@@ -61,6 +61,17 @@ SIGNATURES = {
     "ipde_ctx_enable_timing": (_int, [_vp, _int]),
     "ipde_ctx_last_kernel_ms": (_int, [_vp, _c_double_p]),
     "ipde_ctx_kernel_ms_history": (_int, [_vp, _c_double_p, _int, ctypes.POINTER(_int)]),
+    "ipde_multi_create": (_int, [_int, ctypes.POINTER(_int), _int, _c_void_pp]),
+    "ipde_multi_destroy": (_int, [_vp]),
+    "ipde_multi_ndev": (_int, [_vp, ctypes.POINTER(_int)]),
+    "ipde_multi_ctx": (_int, [_vp, _int, _c_void_pp]),
+    "ipde_multi_has_comm": (_int, [_vp, ctypes.POINTER(_int)]),
+    "ipde_multi_last_error": (ctypes.c_char_p, [_vp]),
+    "ipde_multi_set_targets": (_int, [_vp, _i64, _vp, _vp]),
+    "ipde_multi_target_slice": (_int, [_vp, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "ipde_multi_laplace_apply": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
+    "ipde_multi_modhelm_apply": (_int, [_vp, _dbl, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
+    "ipde_multi_stokes_apply": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
     "ipde_laplace_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                   _vp, _int]),
     "ipde_laplace_apply_patches": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -35,6 +35,7 @@ SOURCES = [
     "lu_factor.hip",
     "geometry.hip",
     "target_plan.hip",
+    "multi.hip",
 ]
 
 CXXFLAGS = [

@@ -46,6 +46,10 @@ class EmbeddedFunction(np.ndarray):
         if obj is None:
             return
         self.ebdyc = getattr(obj, 'ebdyc', None)
+        # (set by a solver's sharded result: which entries are complete on this rank)
+        own = getattr(obj, 'owned', None)
+        if own is not None and getattr(own, 'shape', None) == self.shape:
+            self.owned = own
         if self.ebdyc is not None and self.ebdyc() is not None and self.ndim == 1:
             try:
                 self._generate()

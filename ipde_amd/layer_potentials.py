@@ -108,7 +108,10 @@ class ShardedTargets:
     `DeviceTargets`.  For the big one-off sums of the example scripts (homogeneous
     correction onto grid_and_radial_pts, reference examples/interior_poisson.py:84-92)."""
 
-    def __init__(self, x, y=None, ctx=None):
+    def __init__(self, x, y=None, ctx=None, owned=None):
+        """owned: boolean mask over the points — evaluate only there and leave the result sharded:
+        full-length tensors with zeros at the other points, no collective (the form a solver's
+        `sharded_result` answer takes: its `owned` mask partitions the points over the ranks)."""
         from . import sharding
         if y is None:
             x, y = x.x, x.y
@@ -116,13 +119,27 @@ class ShardedTargets:
         self.N = int(x.shape[0])
         _, rank, world = sharding._dist_state()
         self.world = world
-        sl = sharding.target_slice(self.N, rank, world)
-        self.local = DeviceTargets(x[sl], y[sl], ctx=ctx)
+        self._owned_idx = None
+        if owned is not None:
+            idx = np.nonzero(np.asarray(owned, dtype=bool).ravel())[0]
+            self.local = DeviceTargets(x[idx], y[idx], ctx=ctx)
+            self._owned_idx = to_device(idx.astype(np.int64), self.local.ctx)
+        else:
+            sl = sharding.target_slice(self.N, rank, world)
+            self.local = DeviceTargets(x[sl], y[sl], ctx=ctx)
         self._gathers = {}
 
     def evaluate(self, apply_local):
         """apply_local(DeviceTargets) -> tensor or tuple of tensors on the local slice"""
         out = apply_local(self.local)
+        if self._owned_idx is not None:
+            parts = out if isinstance(out, tuple) else (out,)
+            full = []
+            for p in parts:
+                z = torch.zeros(self.N, dtype=p.dtype, device=p.device)
+                z[self._owned_idx] = p
+                full.append(z)
+            return tuple(full) if isinstance(out, tuple) else full[0]
         if self.world == 1:
             return out
         from . import sharding

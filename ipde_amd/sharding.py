@@ -20,6 +20,21 @@ production passes `ipde_amd.layer_potentials.laplace_apply` & friends).
 """
 import numpy as np
 
+# logical payload of the collectives issued through this module (bytes this rank receives),
+# so that a solve's exchange volume can be printed (tools/run_sharded_solve.py)
+STATS = {"collectives": 0, "bytes": 0}
+
+
+def reset_stats():
+    STATS["collectives"] = 0
+    STATS["bytes"] = 0
+
+
+def _count(nbytes):
+    STATS["collectives"] += 1
+    STATS["bytes"] += int(nbytes)
+
+
 # sums smaller than this many source-target pairs are evaluated by every rank itself (a
 # collective costs ~50 us; 2.5e8 pairs is ~0.15 ms of kernel time)
 MIN_PAIRS_TO_SHARD = 2.5e8
@@ -97,6 +112,7 @@ class ResultGather:
         for c, p in enumerate(parts):
             send[c, :n].copy_(p)
         self.dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+        _count(recv.numel() * recv.element_size())
         even = self.nt == self.m * self.world
         out = []
         for c in range(self.ncomp):
@@ -173,6 +189,71 @@ class ShardedLayerApply:
         return full if isinstance(local, tuple) else full[0]
 
 
+def gather_tail(parts, sl, nt, n_tail, dist=None, group=None):
+    """The last `n_tail` entries of full-length results of which this rank holds the slice `sl`
+    (`parts`: tuple of 1-D tensors, the local slice of each component) — on every rank.
+
+    One all-reduce(SUM) of a zero-filled (ncomp, n_tail) buffer: every position is written by the
+    one rank whose slice holds it, and x + 0 + ... + 0 == x exactly.  This is all a solve has to
+    exchange of a sum onto grid_pnai when its grid part stays sharded (the tail of that list is
+    the interface nodes, reference ebdy_collection.py:488-491): n_tail * 8 bytes per component
+    instead of the whole list."""
+    import torch
+    dist, rank, world = _dist_state(dist, group)
+    t0 = parts[0]
+    lo = nt - n_tail                       # first list position of the tail
+    a, b = max(sl.start, lo), max(sl.stop, lo)
+    if world == 1:
+        return tuple(p[lo - sl.start:] for p in parts)
+    via_host = t0.is_cuda and dist.get_backend(group) == "gloo"
+    dev = torch.device("cpu") if via_host else t0.device
+    buf = torch.zeros((len(parts), n_tail), dtype=t0.dtype, device=dev)
+    if b > a:
+        for c, p in enumerate(parts):
+            buf[c, a - lo:b - lo].copy_(p[a - sl.start:b - sl.start])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    _count(buf.numel() * buf.element_size())
+    if via_host:
+        buf = buf.to(t0.device)
+    return tuple(buf[c] for c in range(len(parts)))
+
+
+def gather_owned(values, owned, dist=None, group=None):
+    """Replicate a vector of which every rank holds some entries complete (`owned`, a boolean mask;
+    the masks of the ranks partition the index range): all-reduce(SUM) of the vector with the
+    entries of other ranks zeroed — exact, one collective.  numpy in, numpy out."""
+    import torch
+    dist, rank, world = _dist_state(dist, group)
+    v = np.where(owned, np.asarray(values, dtype=np.float64), 0.0)
+    if world == 1:
+        return v
+    t = torch.from_numpy(np.ascontiguousarray(v))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    _count(t.numel() * 8)
+    return t.numpy()
+
+
+def global_max(x, dist=None, group=None):
+    """max over the ranks of a host scalar (error norms of sharded results)"""
+    import torch
+    dist, rank, world = _dist_state(dist, group)
+    if world == 1:
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+class ShardedOut:
+    """Result of a sharded evaluation that stays sharded: `local` (tensor or tuple of tensors) are
+    the entries `slice` of the full-length result, `tail` the last `n_tail` entries of it, complete
+    on every rank."""
+    __slots__ = ("local", "slice", "tail", "nt")
+
+    def __init__(self, local, sl, tail, nt):
+        self.local, self.slice, self.tail, self.nt = local, sl, tail, nt
+
+
 def make_sharded_evaluator(layer_apply, targets, wrap_targets, dist=None, group=None,
                            min_pairs=0.0):
     """`evaluate(sources, density)` onto a FIXED target set, every rank holding the full
@@ -196,9 +277,16 @@ def make_sharded_evaluator(layer_apply, targets, wrap_targets, dist=None, group=
             state["all"] = wrap_targets(targets.x, targets.y)
         return state["all"]
 
+    def _sharded_single(sources, density, n_tail):
+        out = layer_apply(sources, resident(), density)
+        parts = out if isinstance(out, tuple) else (out,)
+        tail = tuple(p[nt - n_tail:] for p in parts)
+        return ShardedOut(out, slice(0, nt), tail if isinstance(out, tuple) else tail[0], nt)
+
     if world == 1:
         single = lambda sources, density: layer_apply(sources, resident(), density)
         single.prepare = lambda n_sources=None: resident()
+        single.sharded = _sharded_single
         return single
     sl = target_slice(nt, rank, world)
 
@@ -217,6 +305,15 @@ def make_sharded_evaluator(layer_apply, targets, wrap_targets, dist=None, group=
             g = state[len(parts)] = ResultGather(nt, len(parts), dist, group)
         full = g(parts)
         return full if isinstance(out, tuple) else full[0]
+    def sharded(sources, density, n_tail):
+        """the same sum, the result left sharded: this rank's slice and the gathered tail"""
+        if nt * float(sources.N) < min_pairs:
+            return _sharded_single(sources, density, n_tail)
+        out = layer_apply(sources, local(), density)
+        parts = out if isinstance(out, tuple) else (out,)
+        tail = gather_tail(parts, sl, nt, n_tail, dist, group)
+        return ShardedOut(out, sl, tail if isinstance(out, tuple) else tail[0], nt)
+    evaluator.sharded = sharded
     # make the target set resident ahead of the first evaluation (the solvers' set-up)
     evaluator.prepare = lambda n_sources=None: (resident() if n_sources is not None and nt * float(n_sources) < min_pairs
                                                 else local())
@@ -229,6 +326,8 @@ def make_pnai_evaluator(layer_apply, sources, targets, wrap_targets, dist=None, 
     ev = make_sharded_evaluator(layer_apply, targets, wrap_targets, dist, group)
     on_pnai = lambda density: ev(sources, density)
     on_pnai.prepare = lambda: ev.prepare(sources.N)
+    # the sum with its grid part left sharded: n_tail = number of interface nodes at the list's end
+    on_pnai.sharded = lambda density, n_tail: ev.sharded(sources, density, n_tail)
     return on_pnai
 
 
@@ -245,17 +344,43 @@ def exchange_owned(values, shapes, dist=None, group=None, device=None, extra=Non
     One all-reduce(SUM) of a zero-filled flat buffer: each position is written by exactly
     one rank, and x + 0 + ... + 0 == x exactly, so this is a gather with no per-boundary
     collectives and no ragged bookkeeping.  `extra`: an optional small vector with one entry
-    per boundary (zero for the boundaries of other ranks) that rides along.  Returns the
-    list of numpy arrays (and the summed `extra` when given).  `device`: where the
-    collective runs (a CUDA device for the nccl backend; gloo uses host memory)."""
+    per boundary (zero for the boundaries of other ranks) that rides along.
+
+    Owned values that are torch tensors (the solvers' device-resident flow) are packed into a
+    flat buffer ON THEIR DEVICE and come back as device tensors: with the nccl backend nothing
+    passes through host memory; gloo (CPU tests, one-GPU rehearsals) moves the flat buffer through
+    the host.  numpy values take the host path and come back as numpy arrays.  `device`: where the
+    collective of the numpy path runs (a CUDA device for nccl).  Returns the list of arrays (and
+    the summed `extra`, as numpy, when given)."""
     import torch
     dist, rank, world = _dist_state(dist, group)
+    as_tensors = any(isinstance(v, torch.Tensor) for v in values if v is not None)
     if world == 1:
-        vals = [np.asarray(v, dtype=np.float64).reshape(s) for v, s in zip(values, shapes)]
+        if as_tensors:
+            vals = [v.reshape(s) for v, s in zip(values, shapes)]
+        else:
+            vals = [np.asarray(v, dtype=np.float64).reshape(s) for v, s in zip(values, shapes)]
         return vals if extra is None else (vals, np.asarray(extra, dtype=np.float64))
     sizes = [int(np.prod(s)) for s in shapes]
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n_extra = 0 if extra is None else len(extra)
+    if as_tensors:
+        tdev = next(v.device for v in values if isinstance(v, torch.Tensor))
+        flat = torch.zeros(int(off[-1]) + n_extra, dtype=torch.float64, device=tdev)
+        for i, (v, s) in enumerate(zip(values, shapes)):
+            if owner_of(i, world) == rank:
+                flat[off[i]:off[i + 1]].copy_(torch.as_tensor(v, device=tdev).reshape(-1))
+        if n_extra:
+            flat[off[-1]:].copy_(torch.as_tensor(np.asarray(extra, dtype=np.float64)))
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        _count(flat.numel() * 8)
+        vals = [flat[off[i]:off[i + 1]].reshape(s) for i, s in enumerate(shapes)]
+        return vals if extra is None else (vals, flat[off[-1]:].cpu().numpy())
     flat = np.zeros(int(off[-1]) + n_extra)
     for i, (v, s) in enumerate(zip(values, shapes)):
         if owner_of(i, world) == rank:
@@ -265,6 +390,7 @@ def exchange_owned(values, shapes, dist=None, group=None, device=None, extra=Non
     on_dev = dist.get_backend(group) != "gloo" and device is not None
     t = torch.as_tensor(flat, device=device) if on_dev else torch.from_numpy(flat)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    _count(flat.size * 8)
     flat = t.cpu().numpy() if on_dev else flat
     vals = [flat[off[i]:off[i + 1]].reshape(s).copy() for i, s in enumerate(shapes)]
     return vals if extra is None else (vals, flat[off[-1]:].copy())

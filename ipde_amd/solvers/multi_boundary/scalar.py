@@ -230,8 +230,14 @@ class ScalarSolver(object):
             return torch.cat([grid_pna, torch.as_tensor(interface_out, device=self._dev)])
         return self.Grid_Evaluator(sigmag)
 
-    def __call__(self, f, **kwargs):
-        """f: EmbeddedFunction -> EmbeddedFunction (reference :72-117)."""
+    def __call__(self, f, sharded_result=False, **kwargs):
+        """f: EmbeddedFunction -> EmbeddedFunction (reference :72-117).
+
+        sharded_result (under torch.distributed): the dense sum onto grid_pnai is left sharded through
+        the masked add — every rank returns an answer whose grid values outside the annuli are
+        complete only on its own slice of grid_pnai, flagged by the boolean `owned` attribute of the
+        result (everything else is complete everywhere); the per-solve exchange of that sum drops from
+        the whole list to the interface values.  Default: the answer replicated on every rank."""
         prewarm_wait()      # FFT plans below: never concurrently with the warm-up thread
         e = self.ebdyc
         Nx, Ny = self.grid.shape
@@ -254,10 +260,11 @@ class ScalarSolver(object):
             # (the library's own D2Z plan: one rocFFT in the process, no torch.fft)
             stack = torch.stack([self.plan.fft2(g.contiguous()) for g in (uc, self.dx(uc), self.dy(uc))])
             all_bvs = periodic_interp2d(stack, self._ifx_d, self._ify_d, real_part=True)
-        # In one process the per-boundary vectors now stay in HBM through all the stages below
-        # (helpers' device forms, qfs.call_many / u2s_many and the layer applies pass device
-        # tensors through); the torch.distributed path keeps the host vectors its exchanges take.
-        device_flow = self.DEVICE_FLOW and not is_distributed()
+        # The per-boundary vectors stay in HBM through all the stages below (helpers' device forms,
+        # qfs.call_many / u2s_many and the layer applies pass device tensors through); under
+        # torch.distributed the exchanges of the owned boundaries' vectors take the tensors as they
+        # are (sharding.exchange_owned: a flat device buffer, nothing through the host with nccl).
+        device_flow = self.DEVICE_FLOW
         if not device_flow:
             all_bvs = all_bvs.cpu().numpy()
         bvl, bxl, byl = e.v2l(all_bvs[0]), e.v2l(all_bvs[1]), e.v2l(all_bvs[2])
@@ -273,11 +280,25 @@ class ScalarSolver(object):
                                               device=self._dev, extra=its)
         self.iteration_counts = [int(i) for i in its]
         sigmag = torch.cat(list(sigmag_list)) if device_flow else np.concatenate(sigmag_list)
-        out = self.evaluate_to_grid_pnai(sigmag)                 # device, len(grid_pnai)
         n_pna = e.grid_pna.N
         ucf = uc.view(-1)
-        gridops.add_at(self._pna_idx, out[:n_pna].contiguous(), ucf)
-        bus = e.v2l(out[n_pna:] if device_flow else out[n_pna:].cpu().numpy())
+        owned = None
+        if sharded_result and hasattr(self.Grid_Evaluator, "sharded") and not self.split_grid_evaluation:
+            # the sum onto grid_pnai with its grid part LEFT sharded ("outputs stay
+            # sharded for the subsequent masked add"): this rank adds its slice of the list onto its
+            # copy of the grid; only the tail of the list, the values on the interface nodes every
+            # boundary's correction needs, is exchanged (n_interface numbers instead of the list)
+            so = self.Grid_Evaluator.sharded(sigmag, int(e.grid_pnai.N - n_pna))
+            a, b = so.slice.start, min(so.slice.stop, n_pna)
+            if b > a:
+                gridops.add_at(self._pna_idx[a:b], so.local[:b - a].contiguous(), ucf)
+            tail = so.tail
+            owned = (a, max(a, b))
+        else:
+            out = self.evaluate_to_grid_pnai(sigmag)                 # device, len(grid_pnai)
+            gridops.add_at(self._pna_idx, out[:n_pna].contiguous(), ucf)
+            tail = out[n_pna:]
+        bus = e.v2l(tail if device_flow else tail.cpu().numpy())
         urs = _run_owned(self, mine, 'start_correct', 'finish_correct', [(bu,) for bu in bus], u2s_many)
         if distributed:
             urs = exchange_owned(urs, [h.ebdy.radial_shape for h in self.helpers], device=self._dev)
@@ -295,7 +316,30 @@ class ScalarSolver(object):
             else:
                 ue[i] = ur                       # (numpy copy: no torch CPU op, see VectorSolver)
         block[:e.grid_phys.N].copy_(gridops.gather(self._phys_idx, ucf), non_blocking=False)   # (in stream order: the last)
+        if owned is not None:
+            # which entries of the answer are complete on THIS rank: the radial parts and the grid
+            # points inside the annuli everywhere, a grid point outside the annuli on the rank whose
+            # slice of grid_pnai holds it
+            ue.owned = self._owned_mask(ue, owned)
         return ue
+
+    def _owned_mask(self, ue, owned):
+        """A PARTITION of the answer's entries over the ranks: a grid point outside the annuli belongs
+        to the rank whose slice of grid_pnai holds it (only there is its value complete); the grid
+        points inside the annuli and the radial values, complete on every rank, are split into
+        contiguous runs so that sums over the answer (corrections, norms) count each entry once."""
+        from ...sharding import target_slice
+        e = self.ebdyc
+        _, rank, world = _dist_state()
+        if getattr(self, "_pna_in_phys", None) is None:
+            in_pna = np.zeros(ue.shape[0], dtype=bool)
+            in_pna[np.nonzero(e.phys_not_in_annulus[e.phys])[0]] = True
+            self._pna_in_phys = np.nonzero(in_pna)[0]
+            self._not_pna = np.nonzero(~in_pna)[0]
+        m = np.zeros(ue.shape[0], dtype=bool)
+        m[self._pna_in_phys[owned[0]:owned[1]]] = True
+        m[self._not_pna[target_slice(self._not_pna.shape[0], rank, world)]] = True
+        return m
 
     def _define_layer_apply(self):
         self.Layer_Apply = self.helpers[0].Layer_Apply

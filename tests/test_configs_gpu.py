@@ -99,6 +99,23 @@ def test_config2_two_rank_rehearsal_patch_kernel_on_the_halves():
     assert res["world"] == 2 and res["error"] < 1e-12
 
 
+def test_sharded_result_two_rank_rehearsal_outputs_stay_sharded():
+    """SURVEY 8e "outputs stay sharded for the subsequent masked add": two ranks, the dense sum onto
+    grid_pnai left sharded through the solve and the example's correction.  Each rank's entries are
+    bitwise those of the replicated solve, the ownership masks partition the answer, and the sum's
+    exchange is the interface values (n_b doubles) instead of the list."""
+    res = _run_sharded("poisson", ["--nb", "2000", "--M", "16", "--sharded-result"], 29573)
+    print(res)
+    assert res["world"] == 2 and res["error"] < 1e-12
+    assert res["sharded_result_bitwise_equal_on_owned"] and res["owned_masks_partition_the_answer"]
+    assert res["gathered_sharded_result_equals_replicated"]
+    full, part = res["collectives_per_solve"], res["collectives_per_solve_sharded_result"]
+    assert part["bytes"] < full["bytes"] / 50 and part["bytes"] <= 4 * 8 * 2000
+    res = _run_sharded("modhelm", ["--nb", "1200", "--M", "16", "--k", "10", "--sharded-result"], 29575)
+    assert res["error"] < 1e-11 and res["sharded_result_bitwise_equal_on_owned"]
+    assert res["gathered_sharded_result_equals_replicated"]
+
+
 def test_config3_two_rank_rehearsal_mid_size():
     """modified Helmholtz k = 10, 2048^2 grid, 4096 nodes, targets split over two ranks"""
     res = _run_sharded("modhelm", ["--nb", "4096", "--M", "20", "--k", "10", "--ng", "2048"], 29561)

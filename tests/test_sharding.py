@@ -261,3 +261,99 @@ def test_gather_exchange_and_ownership_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(r, True) for r in range(world)], results
+
+
+def _worker_sharded_through(rank, world, port, q):
+    """The sum onto grid_pnai with its grid part LEFT sharded (sharding.gather_tail, the evaluators'
+    .sharded form): local slice + gathered tail reproduce the full sum, scalar and tuple results,
+    tails shorter and longer than the last rank's slice; the exchange is n_tail numbers, not the list;
+    exchange_owned on tensors returns tensors (the device-resident flow's form)."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import layer_potentials as olp
+        from util import Curve, Points
+        from ipde_amd import sharding
+        from ipde_amd.sharding import make_pnai_evaluator, target_slice, exchange_owned, owner_of
+        c = Curve(64, a=0.2, f=5)
+        rng = np.random.default_rng(0)
+        nt = 1001
+        trg = Points(rng.uniform(-0.5, 0.5, nt), rng.uniform(-0.5, 0.5, nt))
+        sigma = rng.standard_normal(c.N)
+        f = rng.standard_normal((2, c.N))
+        wrap = lambda x, y: Points(x, y)
+
+        def la(src, t, d):
+            return torch.as_tensor(olp.laplace_layer_apply(src.x, src.y, t.x, t.y, charge=d,
+                                                           weights=src.weights))
+
+        def la3(src, t, d):
+            return tuple(torch.as_tensor(a) for a in
+                         olp.stokes_layer_apply(src.x, src.y, t.x, t.y, force=d, weights=src.weights))
+        ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=sigma, weights=c.weights)
+        ref3 = olp.stokes_layer_apply(c.x, c.y, trg.x, trg.y, force=f, weights=c.weights)
+        sl = target_slice(nt, rank, world)
+        ok = True
+        for n_tail in (0, 37, 400, 700):       # 700 > a slice at world 2 and 3: the tail spans ranks
+            sharding.reset_stats()
+            so = make_pnai_evaluator(la, c, trg, wrap).sharded(sigma, n_tail)
+            ok = ok and (so.slice.start, so.slice.stop, so.nt) == (sl.start, sl.stop, nt)
+            ok = ok and np.allclose(so.local.numpy(), ref[sl], rtol=0, atol=1e-13)
+            ok = ok and so.tail.shape[0] == n_tail and np.allclose(so.tail.numpy(), ref[nt - n_tail:], rtol=0, atol=1e-13)
+            ok = ok and sharding.STATS == {"collectives": 1, "bytes": 8 * n_tail}
+            sharding.reset_stats()
+            so3 = make_pnai_evaluator(la3, c, trg, wrap).sharded(f, n_tail)
+            ok = ok and all(np.allclose(l.numpy(), r[sl], rtol=0, atol=1e-13) for l, r in zip(so3.local, ref3))
+            ok = ok and all(np.allclose(t.numpy(), r[nt - n_tail:], rtol=0, atol=1e-13) for t, r in zip(so3.tail, ref3))
+            ok = ok and sharding.STATS == {"collectives": 1, "bytes": 3 * 8 * n_tail}   # one collective per tuple
+        # the gathered form of the same evaluator moves the whole (padded) list
+        sharding.reset_stats()
+        make_pnai_evaluator(la, c, trg, wrap)(sigma)
+        ok = ok and sharding.STATS["bytes"] >= 8 * nt
+        # exchange_owned with tensors in, tensors out (every position written by its owner only)
+        nb = 4
+        shapes = [(3, 5), (7,), (2, 2), (6,)]
+        vals = [torch.full(s, float(i + 1), dtype=torch.float64) if owner_of(i, world) == rank else None
+                for i, s in enumerate(shapes)]
+        its = [float(10 + i) if owner_of(i, world) == rank else 0.0 for i in range(nb)]
+        full, its_all = exchange_owned(vals, shapes, extra=its)
+        ok = ok and all(isinstance(v, torch.Tensor) and tuple(v.shape) == s and bool((v == i + 1).all())
+                        for i, (v, s) in enumerate(zip(full, shapes)))
+        ok = ok and np.array_equal(its_all, [10.0, 11.0, 12.0, 13.0])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bool(ok)))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_through_evaluation_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded_through, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, True) for r in range(world)], results
+
+
+def test_sharded_form_in_a_single_process():
+    from oracle import layer_potentials as olp
+    from util import Curve, Points
+    from ipde_amd.sharding import make_pnai_evaluator
+    c = Curve(32, a=0.2, f=5)
+    rng = np.random.default_rng(1)
+    trg = Points(rng.uniform(-0.5, 0.5, 200), rng.uniform(-0.5, 0.5, 200))
+    sigma = rng.standard_normal(c.N)
+    la = lambda src, t, d: torch.as_tensor(olp.laplace_layer_apply(src.x, src.y, t.x, t.y, charge=d,
+                                                                   weights=src.weights))
+    so = make_pnai_evaluator(la, c, trg, lambda x, y: Points(x, y)).sharded(sigma, 30)
+    ref = olp.laplace_layer_apply(c.x, c.y, trg.x, trg.y, charge=sigma, weights=c.weights)
+    assert (so.slice.start, so.slice.stop) == (0, 200)
+    assert np.allclose(so.local.numpy(), ref, rtol=0, atol=1e-13) and np.array_equal(so.tail.numpy(), so.local.numpy()[170:])

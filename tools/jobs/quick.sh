@@ -4,5 +4,5 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r03
 mkdir -p $O
-timeout -k 10 900 python3 tools/paper_table.py > $O/paper_table.jsonl 2> $O/paper_table.err || { tail -20 $O/paper_table.err; exit 1; }
-cut -c1-400 $O/paper_table.jsonl
+timeout -k 10 900 python3 -m pytest tests/test_configs_gpu.py tests/test_solver_gpu.py -m gpu -x -q -k "rank or sharded or two_ranks" > $O/quick_tests.txt 2>&1 || { tail -60 $O/quick_tests.txt; exit 1; }
+tail -5 $O/quick_tests.txt

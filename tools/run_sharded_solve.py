@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--grid-backend", default=None, help="'ewald' for the split grid evaluator")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (one-GPU rehearsal)")
+    ap.add_argument("--sharded-result", action="store_true",
+                    help="scalar problems: the answer stays sharded through the solve and the correction "
+                         "(only the interface values of the sum onto grid_pnai are exchanged)")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -47,11 +50,13 @@ def main():
     t0 = time.perf_counter()
     if a.problem == "poisson":
         import interior_poisson
-        err, scale, solver, ue, T = interior_poisson.run(nb=a.nb, M=a.M, Ns=Ns, grid_backend=a.grid_backend)
+        err, scale, solver, ue, T = interior_poisson.run(nb=a.nb, M=a.M, Ns=Ns, grid_backend=a.grid_backend,
+                                                         sharded_result=a.sharded_result)
         res = {"error": err / scale}
     elif a.problem == "modhelm":
         import interior_modified_helmholtz as imh
-        err, scale, solver, ue, T = imh.run(nb=a.nb, M=a.M, helmholtz_k=a.k, Ns=Ns, grid_backend=a.grid_backend)
+        err, scale, solver, ue, T = imh.run(nb=a.nb, M=a.M, helmholtz_k=a.k, Ns=Ns, grid_backend=a.grid_backend,
+                                            sharded_result=a.sharded_result)
         res = {"error": err / scale}
     else:
         import multi_stokes
@@ -63,11 +68,30 @@ def main():
         from ipde_amd.embedded_function import EmbeddedFunction
         f = EmbeddedFunction(solver.ebdyc)
         f.define_via_function(lambda x, y: np.sin(x) * np.cos(y))
+        from ipde_amd import sharding
         torch.cuda.synchronize()
+        sharding.reset_stats()
         t1 = time.perf_counter()
-        solver(f, tol=1e-12, maxiter=100, restart=20)
+        full = solver(f, tol=1e-12, maxiter=100, restart=20)
         torch.cuda.synchronize()
         res["warm_inhomogeneous_solve_s"] = time.perf_counter() - t1
+        # logical payload this rank received in the solve's collectives (ipde_amd/sharding.py STATS)
+        res["collectives_per_solve"] = dict(sharding.STATS)
+        if a.sharded_result:
+            sharding.reset_stats()
+            t1 = time.perf_counter()
+            part = solver(f, tol=1e-12, maxiter=100, restart=20, sharded_result=True)
+            torch.cuda.synchronize()
+            res["warm_inhomogeneous_solve_sharded_result_s"] = time.perf_counter() - t1
+            res["collectives_per_solve_sharded_result"] = dict(sharding.STATS)
+            own = part.owned
+            # this rank's entries are BITWISE those of the replicated answer, and the masks partition
+            same = bool(np.array_equal(np.asarray(part)[own], np.asarray(full)[own]))
+            counts = sharding.gather_owned(np.ones(own.shape[0]), own)
+            whole = sharding.gather_owned(np.asarray(part), own)
+            res["sharded_result_bitwise_equal_on_owned"] = same
+            res["owned_masks_partition_the_answer"] = bool(np.all(counts == 1.0))
+            res["gathered_sharded_result_equals_replicated"] = bool(np.array_equal(whole, np.asarray(full)))
     res.update({"problem": a.problem, "world": world, "nb": a.nb, "M": a.M,
                 "grid_backend": a.grid_backend, "wall_s": time.perf_counter() - t0,
                 "timings": {k: v for k, v in T.items() if isinstance(v, (int, float, list))}})
