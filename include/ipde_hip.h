@@ -82,6 +82,8 @@ const char* ipde_last_error(ipde_ctx* ctx);
    "dense_persistent", "annular_fused_fft", "gmres_graphs", "gmres_lookahead" (1: inner iteration
    j + 1 of the annular GMRES enters the stream before the host has read column j; same bits),
    "gmres_fused_scale" (1: the Arnoldi normalisation inside the preconditioner's kernel; same bits),
+   "gmres_persistent" (1: the scalar annular GMRES runs its first cycle in ONE launch with the Arnoldi
+   bookkeeping on the device; inner products summed in another order: last-bit differences),
    "modhelm_variant" (targets per lane of the modified Helmholtz table kernel). */
 int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value);
 /* Current value of a knob (so that a caller can restore what it found). */

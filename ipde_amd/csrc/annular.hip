@@ -12,6 +12,9 @@
 //   * GMRES            : right preconditioned, restarted, Krylov basis resident
 //                        in HBM, CGS2 orthogonalisation (2 fused multi-dots),
 //                        one host sync per iteration (the Hessenberg column).
+#include <algorithm>
+#include <atomic>
+
 #include "ipde_common.h"
 #include "fft_core.h"
 
@@ -626,8 +629,10 @@ inline double habs(hc a) { return hypot(a.re, a.im); }
 
 // Right-preconditioned restarted GMRES for A x = b (x0 = 0).  The result is left
 // in g.x.  Stops when ||r|| <= tol*||b||.  iters = total inner iterations.
+// iters_done > 0: g.x holds the estimate a first cycle left (the device-side cycle) — the solve
+// continues with the next restart cycle from it.
 int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, int restart,
-                int* iters_out, double* resid_out) {
+                int* iters_out, double* resid_out, int iters_done = 0) {
     ipde_ctx* ctx = op.ctx;
     const int64_t NB = op.NB;
     hipStream_t st = ctx->stream;
@@ -638,7 +643,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     IPDE_CHECK_ARG(ctx, (size_t)(2 * restart + 4) * sizeof(cd) + 16 <= ctx->h_pinned_bytes);   // (last 8 bytes: dense.hip)
     IPDE_CHECK_ARG(ctx, tol > 0.0);
     IPDE_TRY(gmres_reserve(ctx, g, NB, restart));
-    IPDE_HIP_CHECK(ctx, hipMemsetAsync(g.x, 0, NB * sizeof(cd), st));
+    if (iters_done == 0) IPDE_HIP_CHECK(ctx, hipMemsetAsync(g.x, 0, NB * sizeof(cd), st));
     cd* hp = (cd*)ctx->h_pinned;  // pinned: [restart+2] entries used per transfer
     // ||b||
     hipLaunchKernelGGL(multidot_kernel, dim3(1, MD_SPLIT), dim3(256), 0, st, b, NB, b, NB, g.hdev, g.mdpart,
@@ -646,7 +651,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, g.hdev, sizeof(cd), hipMemcpyDeviceToHost, st));
     IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
     const double bnorm = sqrt(hp[0].x);
-    int iters = 0;
+    int iters = iters_done;
     double resid = 0.0;
     int status = IPDE_OK;
     if (!(bnorm > 0.0)) {
@@ -680,7 +685,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     }
     std::vector<hc> H((size_t)(restart + 1) * restart), cs(restart), sn(restart), gv(restart + 1);
     bool converged = false;
-    bool first_cycle = true;
+    bool first_cycle = iters_done == 0;
     while (!converged && iters < maxiter) {
         // r = b - A x   (x = 0 in the first cycle)
         double beta;
@@ -962,6 +967,14 @@ int fft_pair(ipde_ctx* ctx, int n, cd* x, const void* tw, int rows, const double
     return IPDE_ERR_INVALID;
 }
 
+#include "annular_gmres_persist.h"
+
+// persistent cycles in flight on this process's devices: a grid whose workgroups are only partly
+// resident next to other partly resident ones would wait for ever (until its time-out), so at most
+// PG_MAX_IN_FLIGHT run side by side (64 workgroups of one per CU each: 192 of the 256 CUs)
+std::atomic<int> g_pg_in_flight{0};
+constexpr int PG_MAX_IN_FLIGHT = 3;
+
 // ===========================================================================
 // scalar (modified Helmholtz / Poisson) annular solver
 struct ipde_annular_scalar : public LinOp {
@@ -979,6 +992,13 @@ struct ipde_annular_scalar : public LinOp {
     GmresWork gw;
     bool have_geom = false;
     void* tw = nullptr;      // exp(-2 pi i m / n), m < n: the fused transform pairs (power-of-two n <= 4096)
+    // device-side GMRES cycle (annular_gmres_persist.h): [counter, time-out word, pad | result (4) |
+    // partial norms (G) | partial inner products (G, PG_RMAX + 2)]
+    void* pg_ws = nullptr;
+    int pg_G = 0;
+    bool pg_disabled = false;
+    int persistent_cycle(const cd* b, double tol, int maxiter, int restart, int* iters, double* resid,
+                         int* converged);
 
     int apply(const cd* uh, cd* out) override {
         hipStream_t st = ctx->stream;
@@ -1042,9 +1062,108 @@ struct ipde_annular_scalar : public LinOp {
         for (cd** p : {&iks, &T, &U, &bvec, &hin, &hout})
             if (*p) hipFree(*p);
         if (tw) hipFree(tw);
+        if (pg_ws) hipFree(pg_ws);
         gmres_free(gw);
     }
 };
+
+template <int N>
+int launch_gmres_persistent(ipde_ctx* ctx, const PgArgs& A) {
+    const size_t lds = (size_t)A.lds_cd * sizeof(cd);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gmres_scalar_persistent<N>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gmres_scalar_persistent<N>, dim3((unsigned)A.G), dim3(fftcore::Cfg<N>::T), lds, ctx->stream, A);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
+// One GMRES cycle (x0 = 0, at most `restart` inner iterations) in one launch; the solution estimate
+// is left in gw.x.  *converged = 0: the cycle ran out (the caller goes on with the launch-per-stage
+// cycles from gw.x); returns IPDE_ERR_INVALID when the configuration is not eligible or the kernel
+// timed out (the caller then runs the whole solve the launch-per-stage way).
+int ipde_annular_scalar::persistent_cycle(const cd* b, double tol, int maxiter, int restart, int* iters,
+                                          double* resid, int* converged) {
+    if (pg_disabled || !tw || !ctx->opt_gmres_persistent || !fft_pair_supported(n) || M < 3 ||
+        M > PG_RS * PG_MR || restart < 1 || restart > PG_RMAX)
+        return IPDE_ERR_INVALID;
+    const int TT = n >= 4096 ? 256 : n >= 2048 ? 128 : 64, CPB = TT / PG_RS, NW = (TT + 63) / 64;
+    const int m1 = M - 1;
+    const int G = std::max((n + CPB - 1) / CPB, 2 * m1);
+    const int fslots = n + n / 16;
+    PgArgs A{};
+    A.off_colA = std::max(fslots, 2 * m1 * CPB);
+    A.off_red = A.off_colA + M * CPB;
+    A.off_hs = A.off_red + NW * (PG_RMAX + 2);
+    A.off_H = A.off_hs + 2 * (PG_RMAX + 2);
+    A.off_g = A.off_H + (PG_RMAX + 1) * PG_RMAX;
+    A.lds_cd = A.off_g + 4 * (PG_RMAX + 1) + 4;
+    if ((size_t)A.lds_cd * sizeof(cd) > 160 * 1024) return IPDE_ERR_INVALID;
+    if (g_pg_in_flight.fetch_add(1) >= PG_MAX_IN_FLIGHT) {
+        g_pg_in_flight.fetch_sub(1);
+        return IPDE_ERR_INVALID;
+    }
+    struct Release {
+        ~Release() { g_pg_in_flight.fetch_sub(1); }
+    } release;
+    hipStream_t st = ctx->stream;
+    IPDE_TRY(gmres_reserve(ctx, gw, NB, restart));
+    const size_t ws_bytes = 64 + (size_t)G * sizeof(double) + (size_t)G * (PG_RMAX + 2) * sizeof(cd);
+    if (!pg_ws || pg_G != G) {
+        if (pg_ws) IPDE_HIP_CHECK(ctx, hipFree(pg_ws));
+        pg_ws = nullptr;
+        IPDE_HIP_CHECK(ctx, hipMalloc(&pg_ws, ws_bytes));
+        pg_G = G;
+    }
+    IPDE_HIP_CHECK(ctx, hipMemsetAsync(pg_ws, 0, 64, st));     // counter, time-out word, result
+    A.M = M;
+    A.restart = restart;
+    A.maxiter = maxiter;
+    A.G = G;
+    A.tol = tol;
+    A.R01 = R01;
+    A.R12 = R12;
+    A.D01 = D01;
+    A.D12 = D12;
+    A.Bmat = Bmat;
+    A.Kt = Kt;
+    A.iks = iks;
+    A.psi1 = psi1;
+    A.ipsi1 = ipsi1;
+    A.ipsi2 = ipsi2;
+    A.tw = (const fftcore::cd*)tw;
+    A.T = this->T;
+    A.U = U;
+    A.V = gw.V;
+    A.b = b;
+    A.x = gw.x;
+    A.counter = (unsigned*)pg_ws;
+    A.result = (double*)((char*)pg_ws + 16);
+    A.partn = (double*)((char*)pg_ws + 64);
+    A.part = (cd*)((char*)pg_ws + 64 + (size_t)((G * sizeof(double) + 15) / 16) * 16);
+    int s;
+    switch (n) {
+        case 512: s = launch_gmres_persistent<512>(ctx, A); break;
+        case 1024: s = launch_gmres_persistent<1024>(ctx, A); break;
+        case 2048: s = launch_gmres_persistent<2048>(ctx, A); break;
+        default: s = launch_gmres_persistent<4096>(ctx, A); break;
+    }
+    IPDE_TRY(s);
+    // the result record (and the time-out word in front of it) through the context's pinned buffer
+    double* hp = ctx->h_pinned;
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, pg_ws, 48, hipMemcpyDeviceToHost, st));
+    IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const unsigned timed_out = ((const unsigned*)hp)[1];
+    if (timed_out) {
+        fprintf(stderr, "ipde_hip: the device-side GMRES cycle timed out at a grid barrier (its %d workgroups were "
+                        "not resident together); this solver goes back to the launch-per-stage cycle\n", G);
+        pg_disabled = true;
+        return IPDE_ERR_INVALID;
+    }
+    *iters = (int)hp[2];
+    *resid = hp[3];
+    *converged = hp[4] != 0.0;
+    return IPDE_OK;
+}
 
 extern "C" int ipde_annular_scalar_create(ipde_ctx* ctx, int M, int n, double helmholtz_k,
                                           const double* R01, const double* R12, const double* R02,
@@ -1220,7 +1339,22 @@ extern "C" int ipde_annular_scalar_solve(ipde_annular_scalar* h, int loc, const 
     hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256((int64_t)M * n)), dim3(256), 0, st, h->T,
                        (const double*)ffr, (int64_t)M * n, 1.0);
     IPDE_TRY(ipde_fft1_exec(ctx, M, n, -1, h->T, h->bvec));
-    int st_g = gmres_solve(*h, h->gw, h->bvec, tol, maxiter, restart, iters, resid);
+    // the first cycle in one launch (annular_gmres_persist.h) when the configuration allows; a cycle
+    // that runs out, and every other case, through the launch-per-stage cycles
+    int st_g, conv = 0, it0 = 0;
+    double r0 = 0.0;
+    const int rs_eff = restart < 1 ? 1 : (restart > maxiter ? std::max(1, maxiter) : restart);
+    if (h->persistent_cycle(h->bvec, tol, std::max(1, maxiter), rs_eff, &it0, &r0, &conv) == IPDE_OK) {
+        if (conv || it0 >= maxiter) {
+            *iters = it0;
+            *resid = r0;
+            st_g = conv ? IPDE_OK : IPDE_ERR_NOCONV;
+        } else {
+            st_g = gmres_solve(*h, h->gw, h->bvec, tol, maxiter, restart, iters, resid, it0);
+        }
+    } else {
+        st_g = gmres_solve(*h, h->gw, h->bvec, tol, maxiter, restart, iters, resid);
+    }
     if (st_g != IPDE_OK && st_g != IPDE_ERR_NOCONV) return st_g;
     // out = ifft(x).real
     IPDE_TRY(ipde_fft1_exec(ctx, M, n, +1, h->gw.x, h->T));

@@ -229,6 +229,7 @@ static int* option_slot(ipde_ctx* ctx, const char* name) {
     if (!strcmp(name, "dense_pairs")) return &ctx->opt_dense_pairs;
     if (!strcmp(name, "dense_persistent")) return &ctx->opt_dense_persistent;
     if (!strcmp(name, "gmres_graphs")) return &ctx->opt_gmres_graphs;
+    if (!strcmp(name, "gmres_persistent")) return &ctx->opt_gmres_persistent;
     if (!strcmp(name, "modhelm_variant")) return &ctx->opt_modhelm_variant;
     if (!strcmp(name, "gmres_lookahead")) return &ctx->opt_gmres_lookahead;
     if (!strcmp(name, "gmres_fused_scale")) return &ctx->opt_gmres_fused_scale;

@@ -432,3 +432,57 @@ def test_fused_transform_pairs_equal_the_rocfft_stages(n):
     assert np.abs(a1 - a0).max() < 1e-13 * np.abs(a0).max()
     assert abs(it1 - it0) <= 1
     assert np.abs(u1 - u0).max() < 1e-9 * np.abs(u0).max()
+
+
+@pytest.mark.parametrize("n,M", [(512, 8), (1024, 12), (2048, 16), (4096, 20), (4096, 31)])
+def test_device_side_gmres_cycle_against_the_launch_per_stage_cycle(n, M):
+    """option "gmres_persistent" (default on; csrc/annular_gmres_persist.h): the first GMRES cycle of
+    the scalar annular solve in ONE launch, Arnoldi / Givens bookkeeping on the device.  Same operator
+    and preconditioner bits; the inner products are summed in another order, so: same iteration counts
+    (to one), solutions equal to 1e-12 of max|u|, residuals under the tolerance — for a cycle that
+    converges, one that runs out (restart shorter than the solve: the launch-per-stage cycles take
+    over from its estimate), a maxiter that stops the solve early, and a zero right-hand side."""
+    from ipde_amd.annular.annular_full import ApproximateAnnularGeometry, RealAnnularGeometry
+    from ipde_amd.annular.modified_helmholtz import AnnularModifiedHelmholtzSolver
+    from ipde_amd.annular.poisson import AnnularPoissonSolver
+    t = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    rad = 1.0 + 0.2 * np.cos(5 * t)
+    drad, d2rad = -np.sin(5 * t), -5.0 * np.cos(5 * t)
+    speed = np.sqrt(rad ** 2 + drad ** 2)
+    curv = (rad ** 2 + 2 * drad ** 2 - rad * d2rad) / speed ** 3
+    width = M * (2 * np.pi / n) * speed.min()
+    aag = ApproximateAnnularGeometry(n, M, width, 1.0)
+    rag = RealAnnularGeometry(speed, curv, aag)
+    rng = np.random.default_rng(n + M)
+    f = rng.standard_normal((M, n))
+    ig, og = rng.standard_normal(n), rng.standard_normal(n)
+    for S in (AnnularPoissonSolver(aag), AnnularModifiedHelmholtzSolver(aag, 7.0)):
+        assert S.ctx.get_option("gmres_persistent") == 1
+
+        def both(**kw):
+            on = np.array(S.solve(rag, f, ig, og, **kw))
+            it_on, r_on = S.iterations_last_call, S.residual_last_call
+            S.ctx.set_option("gmres_persistent", 0)
+            try:
+                off = np.array(S.solve(rag, f, ig, og, **kw))
+            finally:
+                S.ctx.set_option("gmres_persistent", 1)
+            return on, off, it_on, S.iterations_last_call, r_on
+
+        on, off, it_on, it_off, r_on = both(tol=1e-12, maxiter=100, restart=30)
+        assert it_on >= 4 and abs(it_on - it_off) <= 1 and r_on <= 1e-12
+        assert rel_err(on, off) < 1e-11
+        full = it_on
+        # the first cycle runs out (a restart a little over half the solve): launch-per-stage cycles take over
+        on, off, it_on, it_off, r_on = both(tol=1e-12, maxiter=200, restart=full // 2 + 2)
+        assert it_on > full // 2 + 2 and abs(it_on - it_off) <= 2 and r_on <= 1e-12 and rel_err(on, off) < 1e-10
+        on, off, it_on, it_off, _ = both(tol=1e-13, maxiter=3, restart=30)         # stopped early
+        assert it_on == it_off == 3 and rel_err(on, off) < 1e-7    # (an unconverged iterate of an ill-conditioned system: the last bits of h are amplified, 1.6e-9 at n = 4096)
+        on, off, it_on, it_off, _ = both(tol=1e-6, maxiter=100, restart=30)
+        assert abs(it_on - it_off) <= 1 and rel_err(on, off) < 1e-5
+        z = np.array(S.solve(rag, np.zeros((M, n)), np.zeros(n), np.zeros(n), tol=1e-12, maxiter=50, restart=20))
+        assert S.iterations_last_call == 0 and not np.any(z)
+        # repeated solves are bitwise reproducible (partials are summed in index order)
+        a = np.array(S.solve(rag, f, ig, og, tol=1e-12, maxiter=100, restart=30))
+        b = np.array(S.solve(rag, f, ig, og, tol=1e-12, maxiter=100, restart=30))
+        assert np.array_equal(a, b)
