@@ -83,7 +83,8 @@ const char* ipde_last_error(ipde_ctx* ctx);
    j + 1 of the annular GMRES enters the stream before the host has read column j; same bits),
    "gmres_fused_scale" (1: the Arnoldi normalisation inside the preconditioner's kernel; same bits),
    "gmres_persistent" (1: the scalar annular GMRES runs its first cycle in ONE launch with the Arnoldi
-   bookkeeping on the device; inner products summed in another order: last-bit differences),
+   bookkeeping on the device; inner products summed in another order: last-bit differences; default 0 —
+   measured slower than the launch-per-stage cycle),
    "modhelm_variant" (targets per lane of the modified Helmholtz table kernel). */
 int ipde_ctx_set_option(ipde_ctx* ctx, const char* name, int value);
 /* Current value of a knob (so that a caller can restore what it found). */

@@ -1067,14 +1067,21 @@ struct ipde_annular_scalar : public LinOp {
     }
 };
 
-template <int N>
-int launch_gmres_persistent(ipde_ctx* ctx, const PgArgs& A) {
+template <int N, int MR>
+int launch_gmres_persistent_mr(ipde_ctx* ctx, const PgArgs& A) {
     const size_t lds = (size_t)A.lds_cd * sizeof(cd);
-    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gmres_scalar_persistent<N>,
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gmres_scalar_persistent<N, MR>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(gmres_scalar_persistent<N>, dim3((unsigned)A.G), dim3(fftcore::Cfg<N>::T), lds, ctx->stream, A);
+    hipLaunchKernelGGL((gmres_scalar_persistent<N, MR>), dim3((unsigned)A.G), dim3(fftcore::Cfg<N>::T), lds,
+                       ctx->stream, A);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
+}
+template <int N>
+int launch_gmres_persistent(ipde_ctx* ctx, const PgArgs& A) {
+    if (A.M <= 4 * PG_RS) return launch_gmres_persistent_mr<N, 4>(ctx, A);
+    if (A.M <= 5 * PG_RS) return launch_gmres_persistent_mr<N, 5>(ctx, A);
+    return launch_gmres_persistent_mr<N, PG_MR_MAX>(ctx, A);
 }
 
 // One GMRES cycle (x0 = 0, at most `restart` inner iterations) in one launch; the solution estimate
@@ -1084,7 +1091,7 @@ int launch_gmres_persistent(ipde_ctx* ctx, const PgArgs& A) {
 int ipde_annular_scalar::persistent_cycle(const cd* b, double tol, int maxiter, int restart, int* iters,
                                           double* resid, int* converged) {
     if (pg_disabled || !tw || !ctx->opt_gmres_persistent || !fft_pair_supported(n) || M < 3 ||
-        M > PG_RS * PG_MR || restart < 1 || restart > PG_RMAX)
+        M > PG_RS * PG_MR_MAX || restart < 1 || restart > PG_RMAX)
         return IPDE_ERR_INVALID;
     const int TT = n >= 4096 ? 256 : n >= 2048 ? 128 : 64, CPB = TT / PG_RS, NW = (TT + 63) / 64;
     const int m1 = M - 1;
@@ -1096,8 +1103,9 @@ int ipde_annular_scalar::persistent_cycle(const cd* b, double tol, int maxiter, 
     A.off_hs = A.off_red + NW * (PG_RMAX + 2);
     A.off_H = A.off_hs + 2 * (PG_RMAX + 2);
     A.off_g = A.off_H + (PG_RMAX + 1) * PG_RMAX;
-    A.lds_cd = A.off_g + 4 * (PG_RMAX + 1) + 4;
-    if ((size_t)A.lds_cd * sizeof(cd) > 160 * 1024) return IPDE_ERR_INVALID;
+    A.off_mat = A.off_g + 4 * (PG_RMAX + 1) + 4;
+    A.lds_cd = A.off_mat + (2 * m1 * M + 2 * (M - 2) * m1 + M * M + 1) / 2;
+    if ((size_t)A.lds_cd * sizeof(cd) > 160 * 1024 || G > 64) return IPDE_ERR_INVALID;
     if (g_pg_in_flight.fetch_add(1) >= PG_MAX_IN_FLIGHT) {
         g_pg_in_flight.fetch_sub(1);
         return IPDE_ERR_INVALID;
@@ -1107,14 +1115,14 @@ int ipde_annular_scalar::persistent_cycle(const cd* b, double tol, int maxiter, 
     } release;
     hipStream_t st = ctx->stream;
     IPDE_TRY(gmres_reserve(ctx, gw, NB, restart));
-    const size_t ws_bytes = 64 + (size_t)G * sizeof(double) + (size_t)G * (PG_RMAX + 2) * sizeof(cd);
+    const size_t ws_bytes = 256 + (size_t)G * sizeof(double) + 16 + (size_t)G * (PG_RMAX + 2) * sizeof(cd);
     if (!pg_ws || pg_G != G) {
         if (pg_ws) IPDE_HIP_CHECK(ctx, hipFree(pg_ws));
         pg_ws = nullptr;
         IPDE_HIP_CHECK(ctx, hipMalloc(&pg_ws, ws_bytes));
         pg_G = G;
     }
-    IPDE_HIP_CHECK(ctx, hipMemsetAsync(pg_ws, 0, 64, st));     // counter, time-out word, result
+    IPDE_HIP_CHECK(ctx, hipMemsetAsync(pg_ws, 0, 256, st));    // counter, time-out word, result, stage profile
     A.M = M;
     A.restart = restart;
     A.maxiter = maxiter;
@@ -1138,8 +1146,8 @@ int ipde_annular_scalar::persistent_cycle(const cd* b, double tol, int maxiter, 
     A.x = gw.x;
     A.counter = (unsigned*)pg_ws;
     A.result = (double*)((char*)pg_ws + 16);
-    A.partn = (double*)((char*)pg_ws + 64);
-    A.part = (cd*)((char*)pg_ws + 64 + (size_t)((G * sizeof(double) + 15) / 16) * 16);
+    A.partn = (double*)((char*)pg_ws + 256);
+    A.part = (cd*)((char*)pg_ws + 256 + (size_t)((G * sizeof(double) + 15) / 16) * 16);
     int s;
     switch (n) {
         case 512: s = launch_gmres_persistent<512>(ctx, A); break;
@@ -1150,8 +1158,16 @@ int ipde_annular_scalar::persistent_cycle(const cd* b, double tol, int maxiter, 
     IPDE_TRY(s);
     // the result record (and the time-out word in front of it) through the context's pinned buffer
     double* hp = ctx->h_pinned;
-    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, pg_ws, 48, hipMemcpyDeviceToHost, st));
+    static const bool profile = getenv("IPDE_PG_PROFILE") != nullptr;
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, pg_ws, profile ? 16 + 16 * 8 : 48, hipMemcpyDeviceToHost, st));
     IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (profile) {      // 100 MHz ticks of workgroup 0 per stage kind, summed over the cycle's iterations
+        const double* tk = hp + 2 + 8;
+        fprintf(stderr, "ipde_hip: device-side GMRES cycle, %d iterations, us per iteration: prec+mix %.1f, pairs(T) %.1f, "
+                        "mix %.1f, pairs(U) %.1f, w+dots %.1f, axpy+dots %.1f, axpy+norm %.1f, barriers %.1f\n",
+                (int)hp[2], tk[0] / 100 / hp[2], tk[1] / 100 / hp[2], tk[2] / 100 / hp[2], tk[3] / 100 / hp[2],
+                tk[4] / 100 / hp[2], tk[5] / 100 / hp[2], tk[6] / 100 / hp[2], tk[7] / 100 / hp[2]);
+    }
     const unsigned timed_out = ((const unsigned*)hp)[1];
     if (timed_out) {
         fprintf(stderr, "ipde_hip: the device-side GMRES cycle timed out at a grid barrier (its %d workgroups were "

@@ -32,7 +32,7 @@
 #pragma once
 
 constexpr int PG_RS = 4;          // row groups per column
-constexpr int PG_MR = 8;          // rows per thread at most: M <= 32
+constexpr int PG_MR_MAX = 8;      // rows of a column per thread at most: M <= 32
 constexpr int PG_RMAX = 32;       // longest cycle kept on the device
 constexpr unsigned PG_SPIN_LIMIT = 1u << 24;
 
@@ -52,7 +52,7 @@ struct PgArgs {
     unsigned* counter;  // barrier counter (zeroed per launch), [1]: sticky time-out word
     double* result;     // [iterations, relative residual, converged (1) / cycle exhausted (0), bnorm]
     // LDS carve (in cd units from the base)
-    int off_colA, off_red, off_hs, off_H, off_g, lds_cd;
+    int off_colA, off_red, off_hs, off_H, off_g, off_mat, lds_cd;
 };
 
 struct PgSync {
@@ -101,8 +101,9 @@ __device__ __forceinline__ cd ld_cd_agent(const cd* p) {
 }
 
 // rows -> inverse FFT -> field / n -> forward FFT of ONE handed-over row (fft_pair_kernel's arithmetic)
+// (not inlined: the transform's ~200 registers stay out of the cycle kernel's own allocation)
 template <int N>
-__device__ __forceinline__ void pg_fft_pair_row(cd* row, const double* __restrict__ F, double s,
+__device__ __attribute__((noinline)) void pg_fft_pair_row(cd* row, const double* __restrict__ F, double s,
                                                 const fftcore::cd* __restrict__ tw, fftcore::cd* buf, int t) {
     using G = fftcore::Cfg<N>;
     constexpr int T = G::T, P = G::P;
@@ -125,8 +126,11 @@ __device__ __forceinline__ void pg_fft_pair_row(cd* row, const double* __restric
     for (int q = 0; q < P; ++q) st_cd_agent(row + t + T * q, cd{v[q].x, v[q].y});
 }
 
-template <int N>
-__global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(PgArgs A) {
+// (one workgroup per CU by its LDS: a wave may take the whole 512-entry register file of its SIMD)
+template <int N, int MR>
+__global__ __launch_bounds__(fftcore::Cfg<N>::T) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gmres_scalar_persistent(PgArgs A) {
+    constexpr int PG_MR = MR;         // rows of a column per thread: M <= PG_RS * MR
     using FG = fftcore::Cfg<N>;
     constexpr int T = FG::T, RS = PG_RS, CPB = T / RS, NW = (T + 63) / 64;
     constexpr int n = N;
@@ -142,7 +146,9 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
     cd* ggv = gsn + (PG_RMAX + 1);
     cd* gy = ggv + (PG_RMAX + 1);
     double* sc = (double*)(gy + (PG_RMAX + 1));   // [0] norm^2 / hn, [1] residual, [2] stop flag
-    volatile int* bflag = (volatile int*)(sc + 4);
+    volatile int* bflag = (volatile int*)(sc + 6);
+    // the radial matrices, once per launch: R01, D01 (M - 1, M), R12, D12 (M - 2, M - 1), B (M, M)
+    double* mR01 = (double*)((cd*)pg_lds + A.off_mat);
     const int tid = threadIdx.x, blk = blockIdx.x, lane = tid & 63, wv = tid >> 6;
     const int M = A.M, m1 = M - 1, m2 = M - 2;
     const int64_t NB = (int64_t)M * n;
@@ -151,6 +157,20 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
     const bool has_col = c < n;
     const int R = A.restart < A.maxiter ? A.restart : A.maxiter;
     constexpr int PS = PG_RMAX + 2;
+    double* mD01 = mR01 + m1 * M;
+    double* mR12 = mD01 + m1 * M;
+    double* mD12 = mR12 + m2 * m1;
+    double* mB = mD12 + m2 * m1;
+    for (int i = tid; i < m1 * M; i += T) {
+        mR01[i] = A.R01[i];
+        mD01[i] = A.D01[i];
+    }
+    for (int i = tid; i < m2 * m1; i += T) {
+        mR12[i] = A.R12[i];
+        mD12[i] = A.D12[i];
+    }
+    for (int i = tid; i < M * M; i += T) mB[i] = A.Bmat[i];
+    __syncthreads();
     PgSync sy{(ann_gu32*)A.counter, (ann_gu32*)(A.counter + 1), (unsigned)A.G, 0u};
 
     auto wave_sum = [&](double v) {
@@ -171,25 +191,35 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
     // inner products <V_i, w> over this workgroup's columns, i <= j, into part[blk][i]
     cd wcol[PG_MR];
     auto dots_to_partials = [&](int j) {
-        for (int i = 0; i <= j; ++i) {
-            double sr = 0.0, si = 0.0;
-            if (has_col) {
-                const cd* Vi = A.V + (size_t)i * NB + c;
+        for (int i0 = 0; i0 <= j; i0 += 4) {
+            cd va[4][PG_MR];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int q = 0; q < PG_MR; ++q) {
                     const int r = part + RS * q;
-                    if (r < M) {
-                        const cd a = Vi[(size_t)r * n], b = wcol[q];
+                    va[u][q] = (has_col && i0 + u <= j && r < M) ? A.V[(size_t)(i0 + u) * NB + (size_t)r * n + c]
+                                                                 : cd{0.0, 0.0};
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u > j) break;
+                double sr = 0.0, si = 0.0;
+#pragma unroll
+                for (int q = 0; q < PG_MR; ++q) {
+                    const int r = part + RS * q;
+                    if (has_col && r < M) {
+                        const cd a = va[u][q], b = wcol[q];
                         sr = fma(a.x, b.x, sr);
                         sr = fma(a.y, b.y, sr);
                         si = fma(a.x, b.y, si);
                         si = fma(-a.y, b.x, si);
                     }
                 }
+                sr = wave_sum(sr);
+                si = wave_sum(si);
+                if (lane == 0) red[wv * PS + i0 + u] = cd{sr, si};
             }
-            sr = wave_sum(sr);
-            si = wave_sum(si);
-            if (lane == 0) red[wv * PS + i] = cd{sr, si};
         }
         __syncthreads();
         if (tid <= j) {
@@ -201,32 +231,41 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
             st_cd_agent(A.part + (size_t)blk * PS + tid, s);
         }
     };
-    // h_i = sum over the workgroups (index order) of the partials -> dst[i], i <= j
+    // h_i = sum over the workgroups of the partials -> dst[i], i <= j: wave w takes i = w, w + NW, ...,
+    // lane g the partial of workgroup g (G <= 64), a fixed shuffle tree adds them
     auto gather_h = [&](int j, cd* dst) {
-        if (tid <= j) {
-            cd s{0.0, 0.0};
-            for (int g = 0; g < A.G; ++g) {
-                const cd p = ld_cd_agent(A.part + (size_t)g * PS + tid);
-                s.x += p.x;
-                s.y += p.y;
-            }
-            dst[tid] = s;
+        for (int i = wv; i <= j; i += NW) {
+            cd p{0.0, 0.0};
+            if (lane < A.G) p = ld_cd_agent(A.part + (size_t)lane * PS + i);
+            const double sr = wave_sum(p.x), si = wave_sum(p.y);
+            if (lane == 0) dst[i] = cd{sr, si};
         }
         __syncthreads();
     };
     // w -= sum_i h_i V_i
     auto subtract = [&](int j, const cd* h) {
         if (!has_col) return;
-        for (int i = 0; i <= j; ++i) {
-            const cd ci = h[i];
-            const cd* Vi = A.V + (size_t)i * NB + c;
+        for (int i0 = 0; i0 <= j; i0 += 4) {
+            cd va[4][PG_MR];
 #pragma unroll
-            for (int q = 0; q < PG_MR; ++q) {
-                const int r = part + RS * q;
-                if (r < M) {
-                    const cd v = Vi[(size_t)r * n];
-                    wcol[q].x -= ci.x * v.x - ci.y * v.y;
-                    wcol[q].y -= ci.x * v.y + ci.y * v.x;
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < PG_MR; ++q) {
+                    const int r = part + RS * q;
+                    va[u][q] = (i0 + u <= j && r < M) ? A.V[(size_t)(i0 + u) * NB + (size_t)r * n + c] : cd{0.0, 0.0};
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u > j) break;
+                const cd ci = h[i0 + u];
+#pragma unroll
+                for (int q = 0; q < PG_MR; ++q) {
+                    const int r = part + RS * q;
+                    if (r < M) {
+                        const cd v = va[u][q];
+                        wcol[q].x -= ci.x * v.x - ci.y * v.y;
+                        wcol[q].y -= ci.x * v.y + ci.y * v.x;
+                    }
                 }
             }
         }
@@ -244,16 +283,24 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
         __syncthreads();
         if (has_col) {
 #pragma unroll
-            for (int q = 0; q < PG_MR; ++q) {
+            for (int q = 0; q < PG_MR; ++q) {      // (row by row: one row's table entries in registers at a time)
                 const int r = part + RS * q;
+                __builtin_amdgcn_sched_barrier(0);
                 if (r < M) {
+                    // (one wave per SIMD: the row's M table entries are requested together, then summed
+                    // in index order as prec_scalar_kernel does)
                     const double* K = A.Kt + (size_t)r * M * n + c;
+                    double kw[PG_RS * PG_MR];
+#pragma unroll
+                    for (int k = 0; k < PG_RS * PG_MR; ++k) kw[k] = k < M ? K[(size_t)k * n] : 0.0;
                     double sr = 0.0, si = 0.0;
-                    for (int k = 0; k < M; ++k) {
-                        const double kw = K[(size_t)k * n];
-                        const cd v = colA[k * CPB + cl];
-                        sr = fma(kw, v.x, sr);
-                        si = fma(kw, v.y, si);
+#pragma unroll
+                    for (int k = 0; k < PG_RS * PG_MR; ++k) {
+                        if (k < M) {
+                            const cd v = colA[k * CPB + cl];
+                            sr = fma(kw[k], v.x, sr);
+                            si = fma(kw[k], v.y, si);
+                        }
                     }
                     out[q] = cd{sr, si};
                 }
@@ -280,10 +327,9 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
         if (tid == 0) st_agent(A.partn + blk, bs);
     }
     if (!pg_grid_sync(sy, bflag)) return;
-    if (tid == 0) {
-        double t = 0.0;
-        for (int g = 0; g < A.G; ++g) t += ld_agent(A.partn + g);
-        sc[0] = t;
+    if (wv == 0) {
+        const double t = wave_sum(lane < A.G ? ld_agent(A.partn + lane) : 0.0);
+        if (lane == 0) sc[0] = t;
     }
     __syncthreads();
     const double bnorm = sqrt(sc[0]);
@@ -314,6 +360,14 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
     int iters = 0;
     double resid = 1.0;
     bool converged = false;
+    // (workgroup 0 keeps a stage profile of the cycle in result[8 ..]: 100 MHz ticks per stage kind)
+    unsigned long long stamp_t = wall_clock64();
+    double stage_ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int k) {
+        const unsigned long long now = wall_clock64();
+        stage_ticks[k] += (double)(now - stamp_t);
+        stamp_t = now;
+    };
     for (int j = 0; j < R; ++j) {
         // ---- column stage 0: V_j, z = Kinv v_j, T1 = R01 (z iks), T2 = D01 z --------------------
         if (has_col) {
@@ -336,9 +390,10 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
         if (has_col) {
             const cd ik = A.iks[c];
             for (int ro = part; ro < m1; ro += RS) {
-                const double* a1 = A.R01 + (size_t)ro * M;
-                const double* a2 = A.D01 + (size_t)ro * M;
+                const double* a1 = mR01 + ro * M;
+                const double* a2 = mD01 + ro * M;
                 double s1r = 0.0, s1i = 0.0, s2r = 0.0, s2i = 0.0;
+#pragma unroll 4
                 for (int k = 0; k < M; ++k) {
                     const cd v = colA[k * CPB + cl];
                     s1r = fma(a1[k], v.x, s1r);
@@ -350,24 +405,40 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
                 st_cd_agent(A.T + (size_t)(m1 + ro) * n + c, cd{s2r, s2i});
             }
         }
+        stamp(0);
         if (!pg_grid_sync(sy, bflag)) return;
+        stamp(7);
         // ---- row stage 1: transform pairs of the 2 (M - 1) rows of T -----------------------------
         if (blk < 2 * m1)
             pg_fft_pair_row<N>(A.T + (size_t)blk * n,
                                blk < m1 ? A.ipsi1 + (size_t)blk * n : A.psi1 + (size_t)(blk - m1) * n, 1.0 / n,
                                A.tw, fbuf, tid);
+        stamp(1);
         if (!pg_grid_sync(sy, bflag)) return;
+        stamp(7);
         // ---- column stage 1: S = R12 (T1 iks) + D12 T2 --------------------------------------------
         if (has_col) {
-            for (int k = part; k < 2 * m1; k += RS) colB[k * CPB + cl] = ld_cd_agent(A.T + (size_t)k * n + c);
+            // (up to 2 PG_MR x 2 handed-over rows per thread, requested together)
+            cd tv[2 * PG_MR];
+#pragma unroll
+            for (int u = 0; u < 2 * PG_MR; ++u) {
+                const int k = part + RS * u;
+                tv[u] = k < 2 * m1 ? ld_cd_agent(A.T + (size_t)k * n + c) : cd{0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * PG_MR; ++u) {
+                const int k = part + RS * u;
+                if (k < 2 * m1) colB[k * CPB + cl] = tv[u];
+            }
         }
         __syncthreads();
         if (has_col) {
             const cd ik = A.iks[c];
             for (int ro = part; ro < m2; ro += RS) {
-                const double* a1 = A.R12 + (size_t)ro * m1;
-                const double* a2 = A.D12 + (size_t)ro * m1;
+                const double* a1 = mR12 + ro * m1;
+                const double* a2 = mD12 + ro * m1;
                 double s1r = 0.0, s1i = 0.0, s2r = 0.0, s2i = 0.0;
+#pragma unroll 4
                 for (int k = 0; k < m1; ++k) {
                     const cd v1 = colB[k * CPB + cl], v2 = colB[(m1 + k) * CPB + cl];
                     s1r = fma(a1[k], v1.x, s1r);
@@ -379,18 +450,23 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
                 st_cd_agent(A.U + (size_t)ro * n + c, cd{fma(1.0, t0.x, s2r), fma(1.0, t0.y, s2i)});
             }
         }
+        stamp(2);
         if (!pg_grid_sync(sy, bflag)) return;
+        stamp(7);
         // ---- row stage 2: transform pairs of the M - 2 rows of U ----------------------------------
         if (blk < m2) pg_fft_pair_row<N>(A.U + (size_t)blk * n, A.ipsi2 + (size_t)blk * n, 1.0 / n, A.tw, fbuf, tid);
+        stamp(3);
         if (!pg_grid_sync(sy, bflag)) return;
+        stamp(7);
         // ---- column stage 2: w = B z - [luh]; first Gram-Schmidt pass ------------------------------
         if (has_col) {
 #pragma unroll
             for (int q = 0; q < PG_MR; ++q) {
                 const int r = part + RS * q;
                 if (r < M) {
-                    const double* a = A.Bmat + (size_t)r * M;
+                    const double* a = mB + r * M;
                     double sr = 0.0, si = 0.0;
+#pragma unroll 4
                     for (int k = 0; k < M; ++k) {
                         const cd v = colA[k * CPB + cl];
                         sr = fma(a[k], v.x, sr);
@@ -407,12 +483,16 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
         }
         __syncthreads();
         dots_to_partials(j);
+        stamp(4);
         if (!pg_grid_sync(sy, bflag)) return;
+        stamp(7);
         gather_h(j, hs);
         subtract(j, hs);
         // ---- second pass --------------------------------------------------------------------------
         dots_to_partials(j);
+        stamp(5);
         if (!pg_grid_sync(sy, bflag)) return;
+        stamp(7);
         gather_h(j, hs + PS);
         subtract(j, hs + PS);
         {
@@ -426,12 +506,17 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
             const double bs = block_sum(s);
             if (tid == 0) st_agent(A.partn + blk, bs);
         }
+        stamp(6);
         if (!pg_grid_sync(sy, bflag)) return;
+        stamp(7);
         // ---- Hessenberg column j, Givens, residual: the same few operations in every workgroup -----
+        if (wv == 0) {
+            const double t = wave_sum(lane < A.G ? ld_agent(A.partn + lane) : 0.0);
+            if (lane == 0) sc[3] = t;
+        }
+        __syncthreads();
         if (tid == 0) {
-            double t = 0.0;
-            for (int g = 0; g < A.G; ++g) t += ld_agent(A.partn + g);
-            const double hn = sqrt(fmax(t, 0.0));
+            const double hn = sqrt(fmax(sc[3], 0.0));
             cd* col = Hm + (size_t)j * (PG_RMAX + 1);
             for (int i = 0; i <= j; ++i) col[i] = cd{hs[i].x + hs[PS + i].x, hs[i].y + hs[PS + i].y};
             col[j + 1] = cd{hn, 0.0};
@@ -522,5 +607,6 @@ __global__ __launch_bounds__(fftcore::Cfg<N>::T) void gmres_scalar_persistent(Pg
         A.result[1] = resid;
         A.result[2] = converged ? 1.0 : 0.0;
         A.result[3] = bnorm;
+        for (int k = 0; k < 8; ++k) A.result[8 + k] = stage_ticks[k];
     }
 }

@@ -65,7 +65,7 @@ struct ipde_ctx {
     int opt_annular_fused_fft = 1; // scalar annular operator: transform pairs as one kernel for power-of-two n <= 4096 (0: rocFFT + pointwise)
     int opt_gmres_lookahead = 1;  // annular GMRES: inner iteration j + 1 enters the stream before the host has read column j (0: enqueue, wait, enqueue)
     int opt_gmres_fused_scale = 1; // annular GMRES: v_j = w / ||w|| formed inside the preconditioner's kernel (0: a launch of its own)
-    int opt_gmres_persistent = 1; // scalar annular GMRES: the first cycle in ONE launch, Arnoldi bookkeeping on the device (annular_gmres_persist.h; 0: launch per stage)
+    int opt_gmres_persistent = 0; // scalar annular GMRES: 1 = the first cycle in ONE launch, Arnoldi bookkeeping on the device (annular_gmres_persist.h). Measured 8-14 % SLOWER than the launch-per-stage cycle with its look-ahead (profiles/r03_gmres_persistent_ab.txt): off
     int opt_gmres_graphs = 0;     // annular GMRES: 1 = inner iterations replayed from hipGraphs (no gain measured: profiles/r02_gmres_graph_ab.txt)
     int opt_dense_pairs = 1;      // substitution: two 64-row blocks per launch (0: one)
     int opt_dense_persistent = 1; // substitution: one launch per triangular pass, in-launch hand-off (0: a launch per step)
