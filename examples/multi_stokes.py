@@ -169,12 +169,11 @@ if __name__ == "__main__":
     ap.add_argument("--a", type=float, default=4.0)
     ap.add_argument("--b", type=float, default=3.0)
     ap.add_argument("--single", action="store_true", help="outer boundary only")
-    ap.add_argument("--ewald", action="store_true", help="Ewald-split grid evaluator instead of the dense sum")
     ap.add_argument("--warm", action="store_true", help="time a second (warm) inhomogeneous solve")
     ap.add_argument("--simple", action="store_true", help="one 5-arm star of radius 1 in [-1.5, 1.5]^2")
     a_ = ap.parse_args()
     ue, ve, pe, scale, T = run(a_.nb, a_.M, a_.a, a_.b, verbose=True, holes=not a_.single, simple=a_.simple, warm=a_.warm,
-                               grid_backend='ewald' if a_.ewald else None)
+                               grid_backend=None)
     print('Error, u {:0.2e}'.format(ue))
     print('Error, v {:0.2e}'.format(ve))
     print('Error, p {:0.2e} (mean removed)'.format(pe), ' (|u|max %.3f)' % scale)

@@ -88,29 +88,21 @@ class VectorSolver(object):
             self._ia.append((idx, torch.as_tensor(ebdy.grid_ia_xi, device=dev),
                              torch.as_tensor(ebdy.grid_ia_t, device=dev)))
         from ...pybie2d_compat import PointSet
-        if self.grid_backend == 'ewald':
-            # whole-grid evaluation through the Laplace-split (grid_evaluators/ewald.py) +
-            # the interface nodes by the dense kernel (the scalar solvers'
-            # split_grid_evaluation branch, reference multi_boundary/scalar.py:63-71)
-            from ...grid_evaluators.stokes_grid_evaluator import (StokesGridBackend,
-                                                                  StokesFreespaceGridEvaluator)
-            ev = StokesFreespaceGridEvaluator(StokesGridBackend(self.grid.xh, 24), self.grid.xv,
-                                              self.grid.yv)
-            iv = DeviceTargets(e.all_iv)
-            src = self.grid_sources
-
-            def evaluator(f):
-                fw = np.asarray(f, dtype=float).reshape(2, -1) * src.weights
-                g = ev(src.get_stacked_boundary(), fw, device_result=True)
-                b = self.Layer_Apply(src, iv, f)
-                return tuple(torch.cat([gg.reshape(-1)[self._pna_idx], bb]) for gg, bb in zip(g, b))
-            self.Grid_Evaluator = evaluator
-            self.split_grid_evaluation = True
-        else:
-            self.Grid_Evaluator = make_pnai_evaluator(
-                lambda src, trg, f: self.Layer_Apply(src, trg, f), self.grid_sources, e.grid_pnai,
-                lambda x, y: DeviceTargets(PointSet(x=x, y=y)))
-            self.split_grid_evaluation = False
+        if self.grid_backend not in (None, 'auto', 'hip'):
+            # The dense sum is the ONLY evaluator of this solver.  The Ewald-type split exists for the
+            # stokeslet too (grid_evaluators/stokes_grid_evaluator.py) and was selectable here until
+            # round 3, but its error grows with the grid (3.6e-11 of max|u| at 2048^2, n^1.6: the far
+            # field of the gradient potentials peaks like 1/R near the sources) and is multiplied by QFS
+            # densities of size 1e3-1e4: 1.5e-9 in the solution at BASELINE configs[4] scale against
+            # 9e-12 with the dense sum — outside north_star's 1e-10 for Stokes.  The
+            # reference's own sub-quadratic path here is an FMM (internals/stokes.py:25-35).
+            raise ValueError("StokesSolver evaluates onto the grid by the dense sum only (grid_backend=None or "
+                             "'hip'): the split evaluator does not hold 1e-10 at scale; "
+                             "ipde_amd.grid_evaluators.stokes_grid_evaluator stays available on its own")
+        self.Grid_Evaluator = make_pnai_evaluator(
+            lambda src, trg, f: self.Layer_Apply(src, trg, f), self.grid_sources, e.grid_pnai,
+            lambda x, y: DeviceTargets(PointSet(x=x, y=y)))
+        self.split_grid_evaluation = False
         self._pin_in = torch.empty((2, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
 
     def _extract_extra_kwargs(self, **kwargs):

@@ -151,12 +151,15 @@ def test_stokes_ewald_matches_dense_kernel():
         assert np.abs(a.ravel() - b)[~near].max() < 3e-12 * np.abs(b[~near]).max()
 
 
-def test_stokes_solver_with_ewald_backend():
+def test_stokes_solver_refuses_the_split_evaluator():
+    """the Stokes SOLVER evaluates onto the grid by the dense sum only (the split
+    evaluator's error, 3.6e-11 at 2048^2 and growing like n^1.6, times QFS densities of 1e3-1e4, is
+    1.5e-9 at configs[4] scale: outside north_star's 1e-10); the evaluator class itself stays"""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
     import multi_stokes
-    ue, ve, pe, scale, T = multi_stokes.run(nb=400, M=12, simple=True, grid_backend='ewald')
-    ud, vd, pd, scale, T = multi_stokes.run(nb=400, M=12, simple=True)
-    assert max(ue, ve) / scale < 2e-8
-    assert abs(ue - ud) < 1e-9 and abs(pe - pd) < 1e-6
+    with pytest.raises(ValueError, match="dense sum only"):
+        multi_stokes.run(nb=400, M=12, simple=True, grid_backend='ewald')
+    ud, vd, pd, scale, T = multi_stokes.run(nb=400, M=12, simple=True, grid_backend='hip')
+    assert max(ud, vd) / scale < 2e-8
