@@ -26,6 +26,8 @@
 //
 // Sizes: nx in {512, 1024, 2048, 4096}, ny in {1024, 2048, 4096, 8192}; everything else
 // stays on the rocFFT path (spectral.hip).
+#include <atomic>
+
 #include "ipde_common.h"
 #include "fft2d.h"
 #include "fft_core.h"
@@ -327,11 +329,16 @@ __global__ __launch_bounds__(256) void stokes_packed_symbol_kernel(cd* __restric
     Pb[idx] = p;
 }
 
+// (once per kernel and device: the attribute call is ~2 us of host time, a third of a launch;
+// `done` is the caller's static flag word for that kernel instantiation, one bit per device)
 template <typename K>
-int allow_lds(ipde_ctx* ctx, K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
-        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kernel,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+int allow_lds(ipde_ctx* ctx, K kernel, size_t bytes, std::atomic<unsigned long long>& done) {
+    if (bytes <= 48 * 1024) return IPDE_OK;
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return IPDE_OK;
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)bytes));
+    done.fetch_or(bit, std::memory_order_relaxed);
     return IPDE_OK;
 }
 
@@ -340,12 +347,13 @@ int launch_rows(ipde_ctx* ctx, const Fft2dPlan& p, bool forward, const double* f
     constexpr int H = NY / 2, T = Cfg<H>::T, RPW = 256 / T;
     const size_t lds = (size_t)RPW * lds_slots<H>() * sizeof(cd);
     const dim3 grid((unsigned)(p.nx / RPW));
+    static std::atomic<unsigned long long> done_f{0}, done_b{0};
     if (forward) {
-        IPDE_TRY(allow_lds(ctx, row_r2c_kernel<NY>, lds));
+        IPDE_TRY(allow_lds(ctx, row_r2c_kernel<NY>, lds, done_f));
         hipLaunchKernelGGL(row_r2c_kernel<NY>, grid, dim3(256), lds, ctx->stream, f, W,
                            (const cd*)p.tw_h, (const cd*)p.tw_ny);
     } else {
-        IPDE_TRY(allow_lds(ctx, row_c2r_kernel<NY>, lds));
+        IPDE_TRY(allow_lds(ctx, row_c2r_kernel<NY>, lds, done_b));
         hipLaunchKernelGGL(row_c2r_kernel<NY>, grid, dim3(256), lds, ctx->stream, (const cd*)W,
                            out, (const cd*)p.tw_h, (const cd*)p.tw_ny);
     }
@@ -369,7 +377,8 @@ int launch_cols_t(ipde_ctx* ctx, const Fft2dPlan& p, cd* W, double k2h, double s
     const int nblocks = (int)((ncols + C - 1) / C);
     const unsigned grid = (unsigned)(((nblocks + 7) / 8) * 8);
     auto k = col_kernel<NX, C, SYM, MODE>;
-    IPDE_TRY(allow_lds(ctx, k, lds));
+    static std::atomic<unsigned long long> done{0};
+    IPDE_TRY(allow_lds(ctx, k, lds, done));
     hipLaunchKernelGGL(k, dim3(grid), dim3(C * T), lds, ctx->stream, W, (int)p.pitch, nblocks, (int)p.ny,
                        2.0 * M_PI / (p.nx * p.hx), 2.0 * M_PI / (p.ny * p.hy), k2h, scale,
                        (const cd*)p.tw_x, spec_out);
