@@ -118,6 +118,26 @@ class Context:
             self.handle = None
 
 
+# every tuning knob of a context (ipde_ctx_set_option; csrc/ctx.hip option_slot)
+OPTION_NAMES = ("laplace_variant", "stokes_variant", "modhelm_variant", "dense_pairs", "dense_persistent",
+                "gmres_graphs", "gmres_persistent", "gmres_lookahead", "gmres_fused_scale", "annular_fused_fft",
+                "annular_grouped", "fft2d", "interp_shifted")
+
+
+def snapshot_options():
+    """{context: {option: value}} of the shared contexts (the knobs are per-context state a caller
+    may have changed): what tests/conftest.py restores after every GPU test, whatever the test did."""
+    return {ctx: {n: ctx.get_option(n) for n in OPTION_NAMES} for ctx in list(_contexts.values()) if ctx.handle}
+
+
+def restore_options(snapshot):
+    for ctx, opts in snapshot.items():
+        if ctx.handle:
+            for n, v in opts.items():
+                if ctx.get_option(n) != v:
+                    ctx.set_option(n, v)
+
+
 def get_context(device=None):
     """Process-wide context of a device (created on first use)."""
     if device is None:

@@ -705,3 +705,14 @@ def test_hip_stokes_outputs_satisfy_momentum_and_mass(lp, layer):
     scale = max(np.max(np.abs(px)), np.max(np.abs(py)))
     assert max(np.max(np.abs(lu - px)), np.max(np.abs(lv - py))) < 1e-6 * scale
     assert np.max(np.abs(div)) < 1e-8 * scale
+
+
+def test_a_knob_left_set_by_a_test(ctx):
+    """(with the next test: tests/conftest.py puts the library's knobs back after every GPU test)"""
+    assert ctx.get_option("laplace_variant") == 9
+    ctx.set_option("laplace_variant", 3)
+    ctx.set_option("fft2d", 0)
+
+
+def test_is_back_to_what_it_was_for_the_next_one(ctx):
+    assert ctx.get_option("laplace_variant") == 9 and ctx.get_option("fft2d") == 1
