@@ -67,10 +67,11 @@ def test_config4_multi_stokes_three_bodies_4096_grid():
     """configs[4]: examples/multi_stokes.py, outer 11-arm star + two holes, stokeslet +
     stresslet kernels, 4096^2 grid, dense evaluator.  n_b = 2400 (9600 + 2 x 2400 nodes; the
     boundary spacing asks for a 4112^2 grid, the 4096^2 one is 0.4 % coarser).  n_b = 2390 is
-    the value whose matched grid is exactly 4096^2, but 2390 = 2 * 5 * 239: the annular
-    solvers' length-9560 / 2390 transforms then run through rocFFT's Bluestein path, whose
-    rounding this ill-conditioned pipeline (QFS densities ~1e4) amplifies to 5e-10 —
-    measured, profiles/r02_stokes_nb_sweep.log."""
+    the value whose matched grid is exactly 4096^2 and gives 5e-10 — not through its transform
+    lengths (9560 / 2390 have the prime factor 239, but the transforms are as accurate there as
+    anywhere: profiles/r03_fft1_accuracy.txt) and whatever the grid: the error of this pipeline
+    fluctuates between neighbouring n_b (6e-12 .. 5e-10 over n_b = 2386 .. 2396,
+    profiles/r03_stokes_nb_neighbours.log), the noise of QFS systems of condition ~1e15."""
     import multi_stokes
     ue, ve, pe, scale, T = multi_stokes.run(nb=2400, M=14, ng=4096)
     print(ue, ve, pe, scale, T)
