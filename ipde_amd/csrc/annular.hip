@@ -645,16 +645,30 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     IPDE_TRY(gmres_reserve(ctx, g, NB, restart));
     if (iters_done == 0) IPDE_HIP_CHECK(ctx, hipMemsetAsync(g.x, 0, NB * sizeof(cd), st));
     cd* hp = (cd*)ctx->h_pinned;  // pinned: [restart+2] entries used per transfer
-    // ||b||
+    // ||b||.  With the look-ahead (default) the host does NOT wait for it: v_0 = b / ||b|| is formed on
+    // the device from the device-resident squared norm (the same sqrt and division, so the same
+    // bits), the squared norm travels to a pinned slot of its own, and the host first reads it when
+    // it waits for the first Hessenberg column anyway — one synchronisation (~50 us of idle GPU per
+    // annular solve) less.  The launch-per-wait paths and a continued solve read it at once.
     hipLaunchKernelGGL(multidot_kernel, dim3(1, MD_SPLIT), dim3(256), 0, st, b, NB, b, NB, g.hdev, g.mdpart,
                        g.mdticket);
-    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp, g.hdev, sizeof(cd), hipMemcpyDeviceToHost, st));
-    IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    const double bnorm = sqrt(hp[0].x);
+    const size_t hstride0 = (size_t)(2 * restart + 4);
+    const bool defer_bnorm = ctx->opt_gmres_lookahead && !(ctx->opt_gmres_graphs && st != nullptr && g.graph_failures < 3) &&
+                             iters_done == 0 && ((3 * hstride0 + 1) * sizeof(cd) + 16 <= ctx->h_pinned_bytes);
+    cd* hp_b = defer_bnorm ? hp + 3 * hstride0 : hp;
+    IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hp_b, g.hdev, sizeof(cd), hipMemcpyDeviceToHost, st));
+    double bnorm = -1.0;      // < 0: not read yet
+    if (defer_bnorm) {
+        hipLaunchKernelGGL(cscale_copy_rnorm_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.V, b, NB, (const cd*)g.hdev);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+    } else {
+        IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        bnorm = sqrt(hp[0].x);
+    }
     int iters = iters_done;
     double resid = 0.0;
     int status = IPDE_OK;
-    if (!(bnorm > 0.0)) {
+    if (!defer_bnorm && !(bnorm > 0.0)) {
         *iters_out = 0;
         *resid_out = 0.0;
         return IPDE_OK;
@@ -674,6 +688,15 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
             g.col_ev[i] = nullptr;
             lookahead = false;
         }
+    if (bnorm < 0.0 && !lookahead) {      // (no look-ahead after all: read ||b|| now)
+        IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        bnorm = sqrt(hp_b[0].x);
+        if (!(bnorm > 0.0)) {
+            *iters_out = 0;
+            *resid_out = 0.0;
+            return IPDE_OK;
+        }
+    }
     {
         const long long sig = ((long long)restart << 8) ^ ((long long)(uintptr_t)st << 20) ^
                               (ctx->opt_annular_grouped ? 1 : 0) ^ (ctx->opt_annular_fused_fft ? 2 : 0) ^
@@ -690,9 +713,10 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
         // r = b - A x   (x = 0 in the first cycle)
         double beta;
         if (first_cycle) {
-            hipLaunchKernelGGL(cscale_copy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.V, b, NB,
-                               1.0 / bnorm);
-            beta = bnorm;
+            if (!defer_bnorm)
+                hipLaunchKernelGGL(cscale_copy_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.V, b, NB,
+                                   1.0 / bnorm);
+            beta = bnorm;         // (deferred: filled in at the first column, below)
             first_cycle = false;
         } else {
             IPDE_TRY(op.apply(g.x, g.w));
@@ -716,7 +740,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
         gv[0] = hc{beta, 0.0};
         int j = 0;
         int enq = 0;                                   // inner iterations of this cycle already in the stream
-        double r_prev = beta / bnorm, r_prev2 = 0.0;   // residual history for the look-ahead's guess
+        double r_prev = bnorm < 0.0 ? 1.0 : beta / bnorm, r_prev2 = 0.0;   // residual history for the look-ahead's guess
         for (; j < restart && iters < maxiter; ++j) {
             // Inner iteration j, everything up to the host's look at the new Hessenberg column:
             // preconditioner, operator, CGS2, the column's way to pinned memory, and the
@@ -777,6 +801,17 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
                 }
                 IPDE_HIP_CHECK(ctx, hipEventSynchronize(g.col_ev[j & 1]));
                 hpj = hp + (size_t)(j & 1) * hstride;
+                if (bnorm < 0.0) {      // the deferred ||b||: its copy precedes column 0's in the stream
+                    bnorm = sqrt(hp_b[0].x);
+                    if (!(bnorm > 0.0)) {     // b = 0: x = 0 (the iteration that ran wrote nothing a caller reads)
+                        IPDE_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                        IPDE_HIP_CHECK(ctx, hipMemsetAsync(g.x, 0, NB * sizeof(cd), st));
+                        *iters_out = 0;
+                        *resid_out = 0.0;
+                        return IPDE_OK;
+                    }
+                    gv[0] = hc{bnorm, 0.0};
+                }
             } else {
             bool replayed = false;
             if (use_graphs) {

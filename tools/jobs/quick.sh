@@ -4,4 +4,6 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r03
 mkdir -p $O
-timeout -k 10 1000 python3 tools/diag_stokes.py 2386,14,4096 2388,14,4096 2390,14,4096 2390,14,4100 2394,14,4096 2396,14,4096 2390,14,4160 2> /dev/null | cut -c1-140 | tee $O/stokes_nb_neighbours.log
+timeout -k 10 600 python3 -m pytest tests/test_annular_gpu.py tests/test_solver_gpu.py -m gpu -x -q 2>&1 | tail -4
+timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | tail -1
+timeout -k 10 300 python3 tools/profile_stokes_solve.py 2>&1 | tail -1
