@@ -441,7 +441,9 @@ __global__ __launch_bounds__(256) void multiaxpy_norm_kernel(cd* __restrict__ w,
                                                              int64_t ld, const cd* __restrict__ h, int nv,
                                                              int64_t n, double* __restrict__ partial,
                                                              unsigned* __restrict__ ticket,
-                                                             cd* __restrict__ nrm2) {
+                                                             cd* __restrict__ nrm2,
+                                                             const cd* __restrict__ col_src = nullptr,
+                                                             cd* __restrict__ col_host = nullptr, int ncol = 0) {
     int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double s = 0.0;
     if (k < n) {
@@ -479,6 +481,17 @@ __global__ __launch_bounds__(256) void multiaxpy_norm_kernel(cd* __restrict__ w,
     if (threadIdx.x == 0) {
         *nrm2 = cd{tot, 0.0};
         __hip_atomic_store((ann_gu32*)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // The iteration's Hessenberg column (both Gram-Schmidt passes' inner products, written by the two
+    // multidot launches before this one, and the norm just formed) goes to the host's pinned area from
+    // HERE: the last block stores it into the mapped host memory, instead of a copy node of its own
+    // behind this kernel (one launch less per iteration; the host waits for the event recorded next).
+    if (col_host) {
+        for (int i = threadIdx.x; i < ncol; i += 256) {
+            cd v = col_src[i];
+            if (col_src + i == nrm2) v = cd{tot, 0.0};
+            col_host[i] = v;
+        }
     }
 }
 // y = sum_i c[i] V_i  (c on device)
@@ -645,6 +658,12 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
     IPDE_TRY(gmres_reserve(ctx, g, NB, restart));
     if (iters_done == 0) IPDE_HIP_CHECK(ctx, hipMemsetAsync(g.x, 0, NB * sizeof(cd), st));
     cd* hp = (cd*)ctx->h_pinned;  // pinned: [restart+2] entries used per transfer
+    cd* hp_dev = hp;              // the same buffer as the device sees it (hipHostMalloc memory is mapped)
+    {
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, hp, 0) == hipSuccess && d) hp_dev = (cd*)d;
+        else (void)hipGetLastError();
+    }
     // ||b||.  With the look-ahead (default) the host does NOT wait for it: v_0 = b / ||b|| is formed on
     // the device from the device-resident squared norm (the same sqrt and division, so the same
     // bits), the squared norm travels to a pinned slot of its own, and the host first reads it when
@@ -750,6 +769,7 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
             // 8.75 / 9.11 ms eager vs 9.02 / 8.94 replayed, 3-body Stokes 20.4 / 21.7 vs 20.4 / 20.7;
             // the critical stream is bound by its own chain of 5-25 us kernels (the outer Stokes body:
             // 21 kernels, 255 us per iteration), not by the host's launch rate.  Off by default.
+            auto hpj_dev = [&](cd* host_ptr) -> cd* { return hp_dev + (host_ptr - hp); };
             auto enqueue = [&](hipStream_t st, int j, cd* hpj, hipEvent_t done) -> int {
                 cd* vj = g.V + (size_t)j * NB;
                 // v_j = w / ||w|| of the previous iteration is formed INSIDE the preconditioner's
@@ -771,10 +791,8 @@ int gmres_solve(LinOp& op, GmresWork& g, const cd* b, double tol, int maxiter, i
                                    (const cd*)g.w, NB, h2, g.mdpart, g.mdticket);
                 hipLaunchKernelGGL(multiaxpy_norm_kernel, dim3(nb256(NB)), dim3(256), 0, st, g.w, (const cd*)g.V, NB,
                                    (const cd*)h2, j + 1, NB, g.nrmpart, g.mdticket + (restart + 2),
-                                   h1 + (j + 1));
+                                   h1 + (j + 1), (const cd*)g.hdev, hpj_dev(hpj), 2 * restart + 4);
                 IPDE_HIP_CHECK(ctx, hipGetLastError());
-                IPDE_HIP_CHECK(ctx, hipMemcpyAsync(hpj, g.hdev, (size_t)(2 * restart + 4) * sizeof(cd),
-                                                   hipMemcpyDeviceToHost, st));
                 if (done) IPDE_HIP_CHECK(ctx, hipEventRecord(done, st));
                 if (!fused) {
                     hipLaunchKernelGGL(cscale_copy_rnorm_kernel, dim3(nb256(NB)), dim3(256), 0, st,
