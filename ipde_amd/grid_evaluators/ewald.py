@@ -77,48 +77,87 @@ def fast_fft_size(n):
         m += 2
 
 
-def _trunc_sgf_quadrant(kqx, kqy, L, helmholtz_k):
-    """Truncated spectral Green's function on the quadrant kqx x kqy of wavenumbers (host
-    scipy J0/J1 — torch.special.bessel_j0/j1 are only good to 4e-7; for a square grid only
-    the i <= j octant is evaluated and mirrored)."""
-    from scipy.special import j0, j1
-    square = kqx.shape == kqy.shape and np.array_equal(kqx, kqy)
-    if square:
-        iu, ju = np.triu_indices(kqx.shape[0])
-        kk = np.hypot(kqx[iu], kqy[ju])
-    else:
-        kk = np.hypot(kqx[:, None], kqy[None, :]).ravel()
-    def symbol(kk):
-        if helmholtz_k is None:
-            ks = np.where(kk == 0, 1.0, kk)
-            ts = (1.0 - j0(L * kk)) / ks ** 2 - L * np.log(L) * j1(L * kk) / ks
-            ts[kk == 0] = -L ** 2 * np.log(L) + L ** 2 * (1 + 2 * np.log(L)) / 4
-            return ts
-        kap = float(helmholtz_k)
-        return (1.0 + L * kk * j1(L * kk) * k0(L * kap) - L * kap * j0(L * kk) * k1(L * kap)) \
-            / (kk ** 2 + kap ** 2)
-    # scipy's Bessel ufuncs release the GIL: chunks in a thread pool (8.6 M evaluations of
-    # J0 and J1 for a 4096^2 grid take 1.9 s on one core)
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-    nthreads = max(1, min(16, os.cpu_count() or 1))
-    ts = np.empty_like(kk)
-    step = max(65536, -(-kk.shape[0] // (4 * nthreads)))
-    chunks = [(a, min(kk.shape[0], a + step)) for a in range(0, kk.shape[0], step)]
+# ---- J0, J1 where the symbol is evaluated (the device) -------------------------------------------
+# The truncated spectral Green's functions need J0(L |k|) and J1(L |k|) at every wavenumber of the
+# 2x finer spectral grid: 17.6 M points for a 2048^2 evaluator, 70 M at 4096^2.  scipy on the host
+# (Cephes, ~0.2 us per value and thread) was most of the evaluator's set-up, and torch's own
+# bessel_j0 / j1 are good to 4e-7 only.  Here: degree-10 polynomials on intervals of width 1/2 —
+# fitted once per range on the host at Chebyshev nodes FROM scipy's J0 / J1 (a few 1e5 evaluations;
+# the interpolation error of an entire function of exponential type 1 on such an interval is
+# (1/8)^11 / 11! ~ 3e-18), evaluated on the device by a gather and Clenshaw's recurrence.
+_J01_W = 0.5
+_J01_DEG = 10
+_j01_cache = {}
 
-    def work(ab):
-        ts[ab[0]:ab[1]] = symbol(kk[ab[0]:ab[1]])
-    if nthreads == 1 or len(chunks) == 1:
-        for ab in chunks:
-            work(ab)
-    else:
-        with ThreadPoolExecutor(nthreads) as ex:
-            list(ex.map(work, chunks))
-    if not square:
-        return ts.reshape(kqx.shape[0], kqy.shape[0])
-    out = np.empty((kqx.shape[0], kqx.shape[0]))
-    out[iu, ju] = ts
-    out[ju, iu] = ts
+
+def _j01_table(xmax, device):
+    """(2, n_intervals, deg + 1) Chebyshev coefficients in t in [-1, 1] of J0 and J1 on [i W, (i + 1) W]
+    (kept in the Chebyshev basis: the monomial form of degree 10 loses three digits)"""
+    import torch
+    from scipy.special import j0, j1
+    ni = int(np.ceil(xmax / _J01_W)) + 2
+    key = (str(device), ni)
+    tab = _j01_cache.get(key)
+    if tab is None:
+        tc = np.cos(np.pi * (np.arange(_J01_DEG + 1) + 0.5) / (_J01_DEG + 1))          # Chebyshev nodes
+        x = (np.arange(ni)[:, None] + 0.5 * (tc[None, :] + 1.0)) * _J01_W
+        # values at the nodes -> Chebyshev coefficients (discrete orthogonality)
+        k = np.arange(_J01_DEG + 1)
+        Tk = np.cos(k[:, None] * np.arccos(tc)[None, :])                                # (deg + 1, nodes)
+        scale = np.full(_J01_DEG + 1, 2.0 / (_J01_DEG + 1))
+        scale[0] = 1.0 / (_J01_DEG + 1)
+        M = scale[:, None] * Tk                                                          # (deg + 1, nodes)
+        tab = np.stack([j0(x) @ M.T, j1(x) @ M.T])
+        tab = _j01_cache[key] = torch.as_tensor(tab, device=device)
+        if len(_j01_cache) > 8:
+            _j01_cache.pop(next(iter(_j01_cache)))
+    return tab
+
+
+def bessel_j01(x):
+    """(J0(x), J1(x)) of a tensor of non-negative reals, on the tensor's device, to ~1e-16 absolute"""
+    import torch
+    xmax = float(x.max()) if x.numel() else 0.0
+    tab = _j01_table(xmax, x.device)
+    s = x * (1.0 / _J01_W)
+    idx = torch.clamp(s.floor().long(), 0, tab.shape[1] - 1)
+    t = 2.0 * (s - idx.to(x.dtype)) - 1.0
+    out = []
+    for f in range(2):
+        c = tab[f][idx.reshape(-1)]                    # (n, deg + 1)
+        tt = t.reshape(-1)
+        b1 = c[:, _J01_DEG]
+        b2 = torch.zeros_like(b1)
+        for d in range(_J01_DEG - 1, 0, -1):           # Clenshaw
+            b1, b2 = c[:, d] + 2.0 * tt * b1 - b2, b1
+        out.append((c[:, 0] + tt * b1 - b2).reshape(x.shape))
+        del c
+    return out[0], out[1]
+
+
+def _trunc_sgf_quadrant(kqx, kqy, L, helmholtz_k, device):
+    """Truncated spectral Green's function (reference laplace_grid_evaluator.py:21-33,
+    modified_helmholtz_grid_evaluator.py:14-17) on the quadrant kqx x kqy of wavenumbers, as a device
+    tensor; J0 / J1 by `bessel_j01`, in row blocks (the coefficient gather is 88 bytes per point)."""
+    import torch
+    kx = torch.as_tensor(np.ascontiguousarray(kqx), device=device)
+    ky = torch.as_tensor(np.ascontiguousarray(kqy), device=device)
+    out = torch.empty((kx.shape[0], ky.shape[0]), dtype=torch.float64, device=device)
+    rows = max(1, int(4.0e6 // max(1, ky.shape[0])))
+    lnL = float(np.log(L))
+    if helmholtz_k is not None:
+        kap = float(helmholtz_k)
+        K0, K1 = float(k0(L * kap)), float(k1(L * kap))
+    for a in range(0, kx.shape[0], rows):
+        kk = torch.hypot(kx[a:a + rows, None], ky[None, :])
+        J0, J1 = bessel_j01(L * kk)
+        if helmholtz_k is None:
+            ks = torch.where(kk == 0, torch.ones_like(kk), kk)
+            ts = (1.0 - J0) / ks ** 2 - (L * lnL) * J1 / ks
+            ts = torch.where(kk == 0, torch.full_like(kk, -L ** 2 * lnL + L ** 2 * (1 + 2 * lnL) / 4), ts)
+        else:
+            ts = (1.0 + L * kk * J1 * K0 - (L * kap) * J0 * K1) / (kk ** 2 + kap ** 2)
+        out[a:a + rows] = ts
     return out
 
 
@@ -134,7 +173,7 @@ def truncated_operator(nbx, nby, h, L, helmholtz_k, device):
     # one quadrant of |k| is enough: the function is even in both indices
     kqx = np.abs(np.fft.fftfreq(Nx, h / (2 * np.pi))[:Nx // 2 + 1])
     kqy = np.abs(np.fft.fftfreq(Ny, h / (2 * np.pi))[:Ny // 2 + 1])
-    ts = torch.as_tensor(_trunc_sgf_quadrant(kqx, kqy, L, helmholtz_k), device=device)
+    ts = _trunc_sgf_quadrant(kqx, kqy, L, helmholtz_k, device)
     full = torch.empty((Nx, Ny), dtype=torch.float64, device=device)
     full[:Nx // 2 + 1, :Ny // 2 + 1] = ts
     full[Nx // 2 + 1:, :Ny // 2 + 1] = torch.flip(ts[1:Nx // 2, :], dims=(0,))

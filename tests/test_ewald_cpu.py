@@ -94,3 +94,31 @@ def test_product_tables_and_fft_size():
             while mm % p == 0:
                 mm //= p
         assert mm == 1
+
+
+def test_device_side_bessel_j0_j1_and_truncated_symbols():
+    """grid_evaluators/ewald.py: J0 / J1 by degree-10 Chebyshev pieces fitted from scipy's values (the
+    evaluator's set-up evaluates them at 1.8e7 .. 7e7 wavenumbers: on the device since round 3) against
+    scipy itself (whose own error grows to ~8e-15 at x ~ 2e4), and the truncated spectral Green's
+    functions built on them against the reference's formulas (laplace_grid_evaluator.py:21-33,
+    modified_helmholtz_grid_evaluator.py:14-17) evaluated with scipy."""
+    import torch
+    from scipy.special import j0, j1, k0, k1
+    from ipde_amd.grid_evaluators.ewald import bessel_j01, _trunc_sgf_quadrant
+    rng = np.random.default_rng(0)
+    for lo, hi, tol in ((0.0, 100.0, 5e-15), (100.0, 3.0e4, 3e-14)):
+        x = np.concatenate([rng.uniform(lo, hi, 20000), [lo, hi - 1e-9]])
+        J0, J1 = bessel_j01(torch.as_tensor(x))
+        assert np.abs(J0.numpy() - j0(x)).max() < tol and np.abs(J1.numpy() - j1(x)).max() < tol
+    kq = np.abs(np.fft.fftfreq(400, 0.01 / (2 * np.pi))[:201])
+    L = 3.7
+    kk = np.hypot(kq[:, None], kq[None, :])
+    ks = np.where(kk == 0, 1.0, kk)
+    ref = (1.0 - j0(L * kk)) / ks ** 2 - L * np.log(L) * j1(L * kk) / ks
+    ref[kk == 0] = -L ** 2 * np.log(L) + L ** 2 * (1 + 2 * np.log(L)) / 4
+    got = _trunc_sgf_quadrant(kq, kq[:150], L, None, 'cpu').numpy()
+    assert got.shape == (201, 150) and np.abs(got - ref[:, :150]).max() < 1e-14 * np.abs(ref).max()
+    kap = 10.0
+    ref = (1.0 + L * kk * j1(L * kk) * k0(L * kap) - L * kap * j0(L * kk) * k1(L * kap)) / (kk ** 2 + kap ** 2)
+    got = _trunc_sgf_quadrant(kq, kq, L, kap, 'cpu').numpy()
+    assert np.abs(got - ref).max() < 1e-14 * np.abs(ref).max()
