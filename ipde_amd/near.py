@@ -166,15 +166,15 @@ def band_mask(bdy, grid, reach):
     return mask
 
 
-def points_inside_curve(bdy, px, py, r=None, found=None):
+def points_inside_curve(bdy, px, py, r=None, found=None, upsample=_UP):
     """Boolean: inside the closed curve, for scattered points.  Points with local
     coordinates are decided by the sign of r (exact to coordinate tolerance); the rest
-    by a polygon test on the 8x upsampled curve.  O(points x vertices): use
+    by a polygon test on the `upsample`-times (8x) upsampled curve.  O(points x vertices): use
     `grid_inside_curve` for whole grids."""
     from matplotlib.path import Path
     px = np.asarray(px, dtype=float)
     py = np.asarray(py, dtype=float)
-    fine = fourier_resample(bdy.c, _UP * bdy.N)
+    fine = fourier_resample(bdy.c, upsample * bdy.N) if upsample > 1 else np.asarray(bdy.c)
     inside = Path(np.column_stack([fine.real, fine.imag])).contains_points(
         np.column_stack([px.ravel(), py.ravel()])).reshape(px.shape)
     if r is not None:
