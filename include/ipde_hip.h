@@ -71,7 +71,10 @@ int ipde_ctx_create(int device_id, ipde_ctx** ctx);
 int ipde_ctx_destroy(ipde_ctx* ctx);
 int ipde_ctx_sync(ipde_ctx* ctx);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all
-   subsequent work; pass NULL to return to the context's own stream. */
+   subsequent work; pass NULL to return to the context's own stream, hipStreamLegacy
+   ((hipStream_t)1) for the legacy default stream (what the Python host gives the
+   process-wide context: torch's default stream is that one, and a solve that
+   alternates library kernels with torch operations then stays on one queue). */
 int ipde_ctx_set_stream(ipde_ctx* ctx, void* hip_stream);
 void* ipde_ctx_get_stream(ipde_ctx* ctx);
 const char* ipde_last_error(ipde_ctx* ctx);
@@ -369,6 +372,17 @@ int ipde_curve_local_coordinates(ipde_ctx* ctx, int64_t nf, const double* curve_
                                  const double* bary_w, int64_t npts, const double* px,
                                  const double* py, const double* t0, double width, double tol,
                                  int maxiter, double* r_out, double* t_out);
+
+/*
+ * Inside mask of a whole nx x ny grid (row-major) from the near band alone: the nband cells
+ * (ix[i], iy[i]) take r[i] < 0; every other cell takes the state of the last band cell before it
+ * in its row (0 before the first).  The band index pairs must lie inside the grid (checked by the
+ * caller: they come from the grid's own index arrays).  Replaces the full-grid half of the
+ * reference's point classification (ipde/ebdy_collection.py:330-372 over
+ * ipde/embedded_boundary.py:185-214).  ix, iy, r, inside: DEVICE; inside: nx*ny bytes, 0/1.
+ */
+int ipde_grid_inside_scan(ipde_ctx* ctx, int64_t nx, int64_t ny, int64_t nband, const int64_t* ix,
+                          const int64_t* iy, const double* r, uint8_t* inside);
 
 /*
  * Radial -> grid interpolation, gather half (replaces the per-mode type-2 NUFFT of

@@ -109,6 +109,7 @@ SIGNATURES = {
     "ipde_dense_gemv": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _int]),
     "ipde_radial_to_grid": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ipde_curve_local_coordinates": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
+    "ipde_grid_inside_scan": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "ipde_ewald_create": (_int, [_vp, _int, _dbl, _dbl, _int, _vp, _int, _int, _c_void_pp]),
     "ipde_ewald_destroy": (_int, [_vp]),
     "ipde_ewald_spread": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _dbl, _dbl, _i64, _i64, _i64, _i64,

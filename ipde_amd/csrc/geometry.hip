@@ -496,3 +496,70 @@ extern "C" int ipde_grid_gather(ipde_ctx* ctx, int64_t nidx, const int64_t* idx,
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Inside/outside classification of a whole grid from the near band alone (host form:
+// ipde_amd/near.py grid_inside_curve; the reference classifies with the sign of r in the band
+// and a polygon test elsewhere, ipde/embedded_boundary.py:185-214 + ebdy_collection.py:330-372).
+// Band cells carry the sign of their r; every other cell of a row inherits the state of the
+// last band cell before it (rows start outside).  A workgroup per row: each thread owns a
+// contiguous chunk, publishes the state its chunk ends in, looks back over the chunks before
+// it for its carry-in, then fills.  16.8 MB of bytes at 4096^2 - microseconds; the host scan
+// (int64 running maximum + gather) took 0.13 s.
+namespace {
+
+constexpr unsigned char CELL_UNKNOWN = 0xFF;
+
+__global__ __launch_bounds__(256) void band_sign_scatter_kernel(long long n, const long long* __restrict__ ix,
+                                                                const long long* __restrict__ iy,
+                                                                const double* __restrict__ r, long long ny,
+                                                                unsigned char* __restrict__ state) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    state[ix[i] * ny + iy[i]] = r[i] < 0.0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void row_state_fill_kernel(long long ny, unsigned char* __restrict__ state) {
+    __shared__ unsigned char last[256];
+    unsigned char* row = state + (long long)blockIdx.x * ny;
+    const long long chunk = (ny + 255) / 256;
+    const long long j0 = (long long)threadIdx.x * chunk;
+    const long long j1 = j0 + chunk < ny ? j0 + chunk : ny;
+    unsigned char s = CELL_UNKNOWN;
+    for (long long j = j0; j < j1; ++j) {
+        const unsigned char v = row[j];
+        if (v != CELL_UNKNOWN) s = v;
+    }
+    last[threadIdx.x] = s;
+    __syncthreads();
+    unsigned char carry = 0;                       // rows start outside
+    for (int k = (int)threadIdx.x - 1; k >= 0; --k)
+        if (last[k] != CELL_UNKNOWN) {
+            carry = last[k];
+            break;
+        }
+    for (long long j = j0; j < j1; ++j) {
+        const unsigned char v = row[j];
+        if (v != CELL_UNKNOWN) carry = v;
+        else row[j] = carry;
+    }
+}
+
+}  // namespace
+
+extern "C" int ipde_grid_inside_scan(ipde_ctx* ctx, int64_t nx, int64_t ny, int64_t nband, const int64_t* ix,
+                                     const int64_t* iy, const double* r, uint8_t* inside) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, nx >= 0 && ny >= 0 && nband >= 0 && nx < (1ll << 31) && ny < (1ll << 31));
+    if (nx == 0 || ny == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, inside && (nband == 0 || (ix && iy && r)));
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    IPDE_HIP_CHECK(ctx, hipMemsetAsync(inside, CELL_UNKNOWN, (size_t)nx * (size_t)ny, ctx->stream));
+    if (nband)
+        hipLaunchKernelGGL(band_sign_scatter_kernel, dim3((unsigned)((nband + 255) / 256)), dim3(256), 0,
+                           ctx->stream, (long long)nband, (const long long*)ix, (const long long*)iy, r,
+                           (long long)ny, inside);
+    hipLaunchKernelGGL(row_state_fill_kernel, dim3((unsigned)nx), dim3(256), 0, ctx->stream, (long long)ny, inside);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}

@@ -182,13 +182,39 @@ def points_inside_curve(bdy, px, py, r=None, found=None, upsample=_UP):
     return inside
 
 
+GRID_SCAN_ON_DEVICE_MIN = 1_000_000
+
+
+def _grid_inside_curve_device(shape, IX, IY, r, dev):
+    """The row scan of `grid_inside_curve` as HIP kernels (csrc/geometry.hip, ipde_grid_inside_scan)."""
+    import torch
+    from .device import get_context, ptr
+    IX = np.ascontiguousarray(IX, dtype=np.int64)
+    IY = np.ascontiguousarray(IY, dtype=np.int64)
+    if IX.size and (IX.min() < 0 or IX.max() >= shape[0] or IY.min() < 0 or IY.max() >= shape[1]):
+        raise IndexError("grid_inside_curve: band index outside the grid")
+    ctx = get_context(dev.index)
+    ix = torch.as_tensor(IX, device=dev)
+    iy = torch.as_tensor(IY, device=dev)
+    rr = torch.as_tensor(np.ascontiguousarray(r, dtype=float), device=dev)
+    out = torch.empty(tuple(shape), dtype=torch.uint8, device=dev)
+    ctx.check(ctx.lib.ipde_grid_inside_scan(ctx.handle, int(shape[0]), int(shape[1]), int(IX.size), ptr(ix),
+                                            ptr(iy), ptr(rr), ptr(out)))
+    return out.cpu().numpy().view(bool)
+
+
 def grid_inside_curve(shape, IX, IY, r):
     """Inside mask of a whole grid from the near-band coordinates alone: cells with
     coordinates are decided by the sign of r; every other cell inherits the state of
     the last decided cell before it in its row (rows start outside: the grid has a
     margin around the curve).  The band (>= 1.5 annulus widths either side) is far
     thicker than a cell, so a row cannot pass from outside to inside without crossing
-    it.  O(grid)."""
+    it.  O(grid).  Grids of a million points and more run the same scan as a HIP kernel when there
+    is a GPU (4096^2: 0.13 s per boundary on the host)."""
+    if shape[0] * shape[1] >= GRID_SCAN_ON_DEVICE_MIN:
+        dev = _torch_device()
+        if dev is not None:
+            return _grid_inside_curve_device(shape, IX, IY, r, dev)
     state = np.full(shape, -1, dtype=np.int8)
     state[IX, IY] = (r < 0.0).astype(np.int8)
     idx = np.where(state >= 0, np.arange(shape[1], dtype=np.int64)[None, :], -1)

@@ -374,3 +374,22 @@ def test_grid_evaluator_is_chosen_by_problem_size():
     # an explicit choice is kept
     _, _, solver_d, _, _ = interior_poisson.run(nb=600, M=16, grid_backend='hip')
     assert solver_d.grid_backend == 'hip' and not solver_d.split_grid_evaluation
+
+
+def test_grid_classification_scan_on_device_equals_the_host_scan(monkeypatch):
+    """Large grids (>= near.GRID_SCAN_ON_DEVICE_MIN points) classify inside/outside by the same row
+    scan in torch on the GPU; forced here on a small grid and compared bit for bit."""
+    from ipde_amd import near
+    from ipde_amd.pybie2d_compat import Global_Smooth_Boundary as GSB, Grid, star
+    b = GSB(c=star(600, a=0.2, f=5))
+    width = 16 * b.dt * b.speed.min()
+    grid = Grid([-1.6037, 1.5963], 300, [-1.6011, 1.5989], 260, x_endpoints=[True, False],
+                y_endpoints=[True, False])
+    IX, IY = np.meshgrid(np.arange(300), np.arange(260), indexing="ij")
+    r, t, found = near.local_coordinates(b, grid.xg.ravel(), grid.yg.ravel(), width)
+    args = (grid.shape, IX.ravel()[found], IY.ravel()[found], r[found])
+    host = near.grid_inside_curve(*args)
+    monkeypatch.setattr(near, "GRID_SCAN_ON_DEVICE_MIN", 1)
+    dev = near.grid_inside_curve(*args)
+    assert dev.dtype == host.dtype and np.array_equal(dev, host)
+    assert np.array_equal(dev, near.points_inside_curve(b, grid.xg, grid.yg))

@@ -2,8 +2,16 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r03
+O=gpurun_out/r03/legacy_stream
 mkdir -p $O
-timeout -k 10 900 python3 tools/hostprof_stokes_setup.py > $O/hostprof_stokes_setup.txt 2>&1
-head -45 $O/hostprof_stokes_setup.txt | cut -c1-165
-timeout -k 10 600 python3 -m pytest tests/test_solver_gpu.py tests/test_dense_gpu.py -m gpu -x -q -k "stokes or qfs or Stokes" 2>&1 | tail -3
+export IPDE_PROFILE_SOLVES=60
+for i in 1 2 3; do
+IPDE_CTX_OWN_STREAM=1 timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | grep "warm solve" | sed 's/^/own    /' | tee -a $O/ab.txt
+timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | grep "warm solve" | sed 's/^/legacy /' | tee -a $O/ab.txt
+done
+export IPDE_PROFILE_SOLVES=20
+for i in 1 2; do
+IPDE_CTX_OWN_STREAM=1 timeout -k 10 300 python3 tools/profile_stokes_solve.py 2>&1 | grep "warm" | sed 's/^/own    /' | tee -a $O/ab.txt
+timeout -k 10 300 python3 tools/profile_stokes_solve.py 2>&1 | grep "warm" | sed 's/^/legacy /' | tee -a $O/ab.txt
+done
+timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $O/gputest.txt

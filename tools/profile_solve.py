@@ -15,12 +15,18 @@ import interior_poisson  # noqa: E402
 from ipde_amd.embedded_function import EmbeddedFunction  # noqa: E402
 
 err, scale, solver, ue, T = interior_poisson.run(nb=4096, M=20, Ns=[2048, 2048], solver_tol=1e-12)
+if os.environ.get("IPDE_AB_NULL_STREAM") == "1":   # A/B: the library's work on the legacy default stream, where torch's is
+    import ctypes
+    from ipde_amd import device as _dv
+    for _c in list(_dv._contexts.values()):
+        _c.sync()
+        _c.check(_c.lib.ipde_ctx_set_stream(_c.handle, ctypes.c_void_p(1)))
 f = EmbeddedFunction(solver.ebdyc)
 f.define_via_function(lambda x, y: np.sin(x) * np.cos(y))
 solver(f, tol=1e-12, maxiter=100, restart=20)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 10
+n = int(os.environ.get('IPDE_PROFILE_SOLVES', '10'))
 for _ in range(n):
     solver(f, tol=1e-12, maxiter=100, restart=20)
 torch.cuda.synchronize()

@@ -22,7 +22,7 @@ def wrapped(self, fu, fv, **kw):
         orig(self, fu, fv, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 10
+        n = int(os.environ.get('IPDE_PROFILE_SOLVES', '10'))
         for _ in range(n):
             orig(self, fu, fv, **kw)
         torch.cuda.synchronize()
