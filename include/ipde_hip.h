@@ -182,6 +182,26 @@ int ipde_laplace_apply_patches(ipde_ctx* ctx,
                                double* out);
 
 /*
+ * The same sums again with the FAR sources of every block of patches collapsed into a local
+ * (Taylor) expansion about the block's centre — the place of the reference's grid_backend='fmm2d'
+ * (fmm2dpy.rfmm2d at eps = 1e-14, ipde/solvers/internals/poisson.py:28-32) and 'flexmm'
+ * (ipde/solvers/multi_boundary/poisson.py:50-55) choices, here one level deep and to rounding:
+ * 64 consecutive patches must be ONE 8 x 8 block of tiles (ipde_target_plan_build_blocks with
+ * block 8 x 8 and pad_blocks = 1).  With c the block's centre and r its half-diagonal, a source
+ * z_j beyond 4 r of c enters 27 complex coefficients (log|z - z_j|^2 = log|c - z_j|^2 -
+ * 2 Re sum_k ((z - c)/(z_j - c))^k / k, ratio <= 1/4, 26 terms: truncation 3e-18 of sum|w_sigma|);
+ * nearer sources are summed pair by pair exactly as in ipde_laplace_apply_patches.  Same
+ * arguments and output convention as ipde_laplace_apply_patches; values agree with it to a few
+ * roundings of the largest partial sum.
+ */
+int ipde_laplace_apply_patches_far(ipde_ctx* ctx,
+                                   int64_t ns, const double* sx, const double* sy,
+                                   const double* w_sigma,
+                                   const double* nx, const double* ny, const double* w_tau,
+                                   int64_t np, const double* pxy, const int32_t* pout,
+                                   double* out);
+
+/*
  * The cut of a target list (HOST arrays x, y of nt points) into those patches, on the host — no
  * GPU work, callable from any thread.  Grid lines are the coordinate values at least
  * line_min_points points share (exact comparisons); tiles of the lattice of lines that hold a
@@ -199,6 +219,13 @@ int ipde_target_plan_build(int64_t nt, const double* x, const double* y,
                            int block_i, int block_j, double partial_min_fill,
                            int64_t min_patches, int line_min_points,
                            ipde_target_plan** plan);
+/* the same; pad_blocks != 0: every block that holds a patch is filled up to block_i * block_j
+   patches with copies of its first one that store nothing (pout = -1): patches
+   [k B, (k + 1) B), B = block_i block_j, are then exactly one block of tiles */
+int ipde_target_plan_build_blocks(int64_t nt, const double* x, const double* y,
+                                  int block_i, int block_j, double partial_min_fill,
+                                  int64_t min_patches, int line_min_points, int pad_blocks,
+                                  ipde_target_plan** plan);
 int ipde_target_plan_sizes(const ipde_target_plan* plan, int64_t* np, int64_t* nrest);
 int ipde_target_plan_export(const ipde_target_plan* plan, double* pxy, int32_t* pout, int64_t* rest);
 int ipde_target_plan_destroy(ipde_target_plan* plan);
@@ -493,6 +520,18 @@ int ipde_ewald_spread_stokes(ipde_ewald* e, int loc, int64_t ns, const double* s
                              const double* sy, const double* fx, const double* fy, double x0,
                              double y0, double cx, double cy, int64_t nbx, int64_t nby,
                              int64_t offx, int64_t offy, double* loc3, double* op6);
+
+/*
+ * Set-up of the split evaluator: the truncated spectral Green's function of radius L on the
+ * wavenumber quadrant kx (nx) x ky (ny), row-major into out (reference
+ * ipde/grid_evaluators/laplace_grid_evaluator.py:21-33, modified_helmholtz_grid_evaluator.py:14-17;
+ * helmholtz != 0: parameter kap with K0 = K0(L kap), K1 = K1(L kap) from the host).  J0 / J1 from
+ * j01_tab: 2 x ni x (deg + 1) Chebyshev coefficients on pieces [i w, (i + 1) w] of the argument
+ * (arguments beyond the table use its last piece: the caller sizes the table).  All arrays DEVICE.
+ */
+int ipde_trunc_sgf_quadrant(ipde_ctx* ctx, int64_t nx, int64_t ny, const double* kx, const double* ky,
+                            double L, int helmholtz, double kap, double K0, double K1,
+                            const double* j01_tab, int64_t ni, int deg, double piece_width, double* out);
 
 /* batched 1-D complex FFT along the last axis of a (batch, n) array:
    ipde.utilities.fft / ifft (ipde/utilities.py:5-12). direction -1 / +1 (scaled). */

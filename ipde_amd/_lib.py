@@ -75,7 +75,9 @@ SIGNATURES = {
     "ipde_laplace_apply": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                   _vp, _int]),
     "ipde_laplace_apply_patches": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "ipde_laplace_apply_patches_far": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ipde_target_plan_build": (_int, [_i64, _vp, _vp, _int, _int, _dbl, _i64, _int, _c_void_pp]),
+    "ipde_target_plan_build_blocks": (_int, [_i64, _vp, _vp, _int, _int, _dbl, _i64, _int, _int, _c_void_pp]),
     "ipde_target_plan_sizes": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "ipde_target_plan_export": (_int, [_vp, _vp, _vp, _vp]),
     "ipde_target_plan_destroy": (_int, [_vp]),
@@ -110,6 +112,8 @@ SIGNATURES = {
     "ipde_radial_to_grid": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ipde_curve_local_coordinates": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
     "ipde_grid_inside_scan": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "ipde_trunc_sgf_quadrant": (_int, [_vp, _i64, _i64, _vp, _vp, _dbl, _int, _dbl, _dbl, _dbl, _vp, _i64, _int,
+                                       _dbl, _vp]),
     "ipde_ewald_create": (_int, [_vp, _int, _dbl, _dbl, _int, _vp, _int, _int, _c_void_pp]),
     "ipde_ewald_destroy": (_int, [_vp]),
     "ipde_ewald_spread": (_int, [_vp, _int, _i64, _vp, _vp, _vp, _dbl, _dbl, _i64, _i64, _i64, _i64,

@@ -303,12 +303,13 @@ __global__ __launch_bounds__(NT) void laplace_rowrun_kernel(
 // words (two v_min3/v_min per axis, an add, a min: 6 per 16 pairs).
 // Layout: pxy[8][np] (rows 0-3 the xs, 4-7 the ys), pout[16][np] the positions in `out` of
 // target (a, b) at row 4a + b: every load and the partial stores are coalesced.
+// (one batch of IPDE_SRC_PAD sources against the lane's patch)
 template <int MODE>
-__device__ __forceinline__ void laplace_patch_loop(const double* __restrict__ rec, int j0, int j1,
-                                                   const double2* ltab, TabAddr& ta,
-                                                   const double (&xs)[4], const double (&ys)[4],
-                                                   double (&acc)[16]) {
-    for (int b = j0 / IPDE_SRC_PAD; b < j1 / IPDE_SRC_PAD; ++b) {
+__device__ __forceinline__ void laplace_patch_block(const double* __restrict__ rec, int b,
+                                                    const double2* ltab, TabAddr& ta,
+                                                    const double (&xs)[4], const double (&ys)[4],
+                                                    double (&acc)[16]) {
+    {
         SrcRow sx, sy, sq, sax, say;
         sx.load(rec, b, 0);
         sy.load(rec, b, 1);
@@ -371,6 +372,14 @@ __device__ __forceinline__ void laplace_patch_loop(const double* __restrict__ re
             }
         }
     }
+}
+
+template <int MODE>
+__device__ __forceinline__ void laplace_patch_loop(const double* __restrict__ rec, int j0, int j1,
+                                                   const double2* ltab, TabAddr& ta,
+                                                   const double (&xs)[4], const double (&ys)[4],
+                                                   double (&acc)[16]) {
+    for (int b = j0 / IPDE_SRC_PAD; b < j1 / IPDE_SRC_PAD; ++b) laplace_patch_block<MODE>(rec, b, ltab, ta, xs, ys, acc);
 }
 
 template <int MODE, int NT>
@@ -458,6 +467,275 @@ int launch_laplace_patches(ipde_ctx* ctx, const double* rec, int64_t ns, const d
                            ctx->stream, (const double*)partial, g.nchunk, 16 * np, pout, out);
         IPDE_HIP_CHECK(ctx, hipGetLastError());
     }
+    return IPDE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Patches with the far sources in local expansions (ipde_laplace_apply_patches_far).
+//
+// The 64 patches of a wave are one 8 x 8 block of tiles (a plan built with padded blocks,
+// target_plan.hip): 32 x 32 grid points with centre c and half-diagonal r.  For a source z_j with
+// |z_j - c| >= r / FAR_RHO every target z of the block has |t| <= FAR_RHO, t = (z - c) v,
+// v = 1 / (z_j - c), and with delta = z - z_j = (c - z_j)(1 - t):
+//     q log|delta|^2        = q log|c - z_j|^2 - 2 q Re sum_{k>=1} t^k / k
+//     (a . d) / |d|^2       = Re(alpha / delta) = -Re sum_{k>=0} alpha v^(k+1) (z - c)^k
+// so the block's far sources collapse into FAR_P + 1 complex coefficients
+//     B_k = -(2 / k) sum_j q_j v_j^k - sum_j alpha_j v_j^(k+1)        (B_0: sum_j q_j log|c - z_j|^2 - ...)
+// and a target costs FAR_P complex Horner steps instead of one table logarithm per source.  The
+// truncation: FAR_RHO^(FAR_P+1) / ((FAR_P + 1)(1 - FAR_RHO)) = 3e-18 of sum|q_j| (0.25, 26 terms) —
+// below the rounding of the direct sum.  (Everything is kept in the block's own units: vt = r v,
+// zeta = (z - c) / r, so no power over- or underflows whatever the coordinate scale is.)
+// Sources nearer than that go through the table kernel's body, batch by batch: the coefficient
+// kernel leaves a bit per batch of eight sources and block.  2048^2 targets x 4096 sources: ~1 % of
+// the pairs are near ones; 3.3 ms -> see DESIGN.md.
+constexpr int FAR_P = 26;
+constexpr double FAR_RHO = 0.25;
+constexpr int FAR_NCOEF = 2 * (FAR_P + 2);      // doubles per block and kind: k = 0 .. FAR_P + 1, complex
+constexpr int FAR_HDR = 4;                      // cx, cy, 1 / r, (spare)
+
+// WHICH = MODE_SLP: head[g] = {cx, cy, 1/r, 0}; cs[g][2k], cs[g][2k+1] = sum q vt^k (k >= 1), cs[g][0] = sum q log d^2
+// WHICH = MODE_DLP: cd[g][2k], [2k+1] = sum (alpha / r) vt^k, k = 1 .. FAR_P + 1
+// near[g][chunk]: bit b set = batch 8 chunk + b has a source nearer than r / FAR_RHO: the whole batch is summed directly
+template <int WHICH>
+__global__ __launch_bounds__(256) void laplace_far_coeff_kernel(const double* __restrict__ rec, int ns_pad,
+                                                               const double* __restrict__ pxy, int64_t np,
+                                                               const ApplyParams* __restrict__ prm,
+                                                               double* __restrict__ head, double* __restrict__ coef,
+                                                               unsigned* __restrict__ near, int nch, int write_near) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g * 64 >= np) return;                          // (whole waves)
+    const double s1 = ldexp(1.0, prm->sh);
+    const int64_t t = min(g * 64 + lane, np - 1);
+    double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double x = pxy[(int64_t)a * np + t] * s1, y = pxy[(int64_t)(4 + a) * np + t] * s1;
+        xlo = fmin(xlo, x);
+        xhi = fmax(xhi, x);
+        ylo = fmin(ylo, y);
+        yhi = fmax(yhi, y);
+    }
+    xlo = wave_min(xlo);
+    xhi = wave_max(xhi);
+    ylo = wave_min(ylo);
+    yhi = wave_max(yhi);
+    const double cx = 0.5 * (xlo + xhi), cy = 0.5 * (ylo + yhi);
+    const double hx = 0.5 * (xhi - xlo), hy = 0.5 * (yhi - ylo);
+    const double r2 = hx * hx + hy * hy;
+    const double r = sqrt(r2);
+    const double thr = r2 * (1.0 / (FAR_RHO * FAR_RHO)) * (1.0 + 0x1p-40);
+    constexpr int K1 = WHICH == MODE_SLP ? FAR_P : FAR_P + 1;
+    double sre[K1 + 1], sim[K1 + 1];
+#pragma unroll
+    for (int k = 0; k <= K1; ++k) sre[k] = sim[k] = 0.0;
+    for (int j0 = 0; j0 < ns_pad; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < ns_pad;
+        const int jj = valid ? j : ns_pad - 1;
+        const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
+        const double d2 = fma(dy, dy, dx * dx);
+        // a batch of eight sources goes one way as a whole: into the expansion only if all eight are far
+        const unsigned long long m = __ballot(valid && !(d2 >= thr && !prm->pad));
+        const bool far = valid && ((m >> (lane & ~7)) & 0xFFull) == 0;
+        if (write_near && lane == 0) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) bits |= ((m >> (8 * b)) & 0xFFull) ? (1u << b) : 0u;
+            near[g * nch + (j0 >> 6)] = bits;
+        }
+        // near sources ride along with zero weight at a harmless position
+        const double inv = far ? r / d2 : 0.0;
+        const double vre = dx * inv, vim = -dy * inv;        // vt = r / (z_j - c)
+        double wre, wim;
+        if (WHICH == MODE_SLP) {
+            wre = far ? rec[ipde_rec_index(jj, 2)] : 0.0;
+            wim = 0.0;
+            sre[0] = fma(wre, log(far ? d2 : 1.0), sre[0]);
+        } else {
+            wre = far ? rec[ipde_rec_index(jj, 3)] / r : 0.0;
+            wim = far ? rec[ipde_rec_index(jj, 4)] / r : 0.0;
+        }
+        double pre = vre, pim = vim;                            // vt^k
+#pragma unroll
+        for (int k = 1; k <= K1; ++k) {
+            if (WHICH == MODE_SLP) {
+                sre[k] = fma(wre, pre, sre[k]);
+                sim[k] = fma(wre, pim, sim[k]);
+            } else {
+                sre[k] += wre * pre - wim * pim;
+                sim[k] += wre * pim + wim * pre;
+            }
+            const double nre = pre * vre - pim * vim;
+            pim = fma(pre, vim, pim * vre);
+            pre = nre;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k <= K1; ++k) {
+        sre[k] = wave_sum(sre[k]);
+        sim[k] = wave_sum(sim[k]);
+    }
+    if (lane == 0) {
+        if (WHICH == MODE_SLP || write_near) {
+            head[g * FAR_HDR + 0] = cx;
+            head[g * FAR_HDR + 1] = cy;
+            head[g * FAR_HDR + 2] = 1.0 / r;
+            head[g * FAR_HDR + 3] = 0.0;
+        }
+        double* c = coef + g * FAR_NCOEF;
+#pragma unroll
+        for (int k = 0; k <= K1; ++k) {
+            c[2 * k] = sre[k];
+            c[2 * k + 1] = sim[k];
+        }
+    }
+}
+
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void laplace_patch_far_kernel(
+    const double* __restrict__ rec, int ns_pad, const double* __restrict__ pxy, int64_t np,
+    const int* __restrict__ pout, double* __restrict__ out, const ApplyParams* __restrict__ prm,
+    const double2* __restrict__ gtab, unsigned key_lo, unsigned nkeys, const double* __restrict__ head,
+    const double* __restrict__ cs, const double* __restrict__ cdl, const unsigned* __restrict__ near, int nch) {
+    extern __shared__ double2 ltab[];
+    for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
+    __syncthreads();
+    TabAddr ta;
+    const double s1 = ldexp(1.0, prm->sh);
+    const int64_t lane = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t g = __builtin_amdgcn_readfirstlane((int)(lane >> 6));
+    if (g * 64 >= np) return;                          // (whole waves, after the only barrier)
+    const int64_t t = min(lane, np - 1);
+    double xs[4], ys[4], acc[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        xs[a] = pxy[(int64_t)a * np + t] * s1;
+        ys[a] = pxy[(int64_t)(4 + a) * np + t] * s1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+    // near sources: the table body, batch by batch
+    const unsigned* nm = near + g * nch;
+    for (int c = 0; c < nch; ++c) {
+        unsigned m = nm[c];
+        while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1;
+            laplace_patch_block<MODE>(rec, 8 * c + b, ltab, ta, xs, ys, acc);
+        }
+    }
+    if (!ta.all_inside(key_lo) || prm->pad) {
+        // a pair of this patch may have left the table (or the scaling failed: then no source is in
+        // an expansion either): all its sources again with the generic math
+        const bool everything = prm->pad != 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double xa[4] = {xs[a], xs[a], xs[a], xs[a]};
+            double gsum[4] = {0.0, 0.0, 0.0, 0.0};
+            if (everything) {
+                laplace_generic_loop<MODE, false, 4>(rec, 0, ns_pad, xa, ys, gsum);
+            } else {
+                for (int c = 0; c < nch; ++c) {
+                    unsigned m = nm[c];
+                    while (m) {
+                        const int b = __builtin_ctz(m);
+                        m &= m - 1;
+                        laplace_generic_loop<MODE, false, 4>(rec, 8 * (8 * c + b), 8 * (8 * c + b) + 8, xa, ys, gsum);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[4 * a + r] = gsum[r];
+        }
+    }
+    // far sources: Re sum_k B_k zeta^k by Horner, B_k = -(2/k) S_k - D_(k+1)
+    {
+        const double* h = head + g * FAR_HDR;
+        const double cx = h[0], cy = h[1], rinv = h[2];
+        const double* S = cs + g * FAR_NCOEF;
+        const double* D = cdl + g * FAR_NCOEF;
+        double zx[4], zy[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            zx[a] = (xs[a] - cx) * rinv;
+            zy[a] = (ys[a] - cy) * rinv;
+        }
+        double vre[16], vim[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vre[i] = vim[i] = 0.0;
+        for (int k = FAR_P; k >= 1; --k) {
+            double bre = 0.0, bim = 0.0;
+            if (MODE & MODE_SLP) {
+                const double f = -2.0 / (double)k;
+                bre = f * S[2 * k];
+                bim = f * S[2 * k + 1];
+            }
+            if (MODE & MODE_DLP) {
+                bre -= D[2 * (k + 1)];
+                bim -= D[2 * (k + 1) + 1];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = 4 * a + b;
+                    // v = (v + B_k) zeta
+                    const double ure = vre[i] + bre, uim = vim[i] + bim;
+                    vre[i] = ure * zx[a] - uim * zy[b];
+                    vim[i] = fma(ure, zy[b], uim * zx[a]);
+                }
+        }
+        double b0 = 0.0;
+        if (MODE & MODE_SLP) b0 = S[0];
+        if (MODE & MODE_DLP) b0 -= D[2];
+        if (!prm->pad) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += vre[i] + b0;
+        }
+    }
+    if (lane >= np) return;
+    const double corr = prm->corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = pout[(int64_t)r * np + t];
+        if (i >= 0) out[i] = acc[r] + corr;
+    }
+}
+
+template <int MODE>
+int launch_laplace_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, const double* pxy, int64_t np,
+                               const int* pout, double* out, const ApplyParams* prm) {
+    constexpr int NT = 1024;
+    const LogTable& lt = ctx->logtab;
+    const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
+    const int64_t ng = ceil_div64(np, 64);
+    const int nch = (int)ceil_div64(ns_pad, 64);
+    // workspace: head | S coefficients | D coefficients | near bits
+    const size_t nd = (size_t)ng * (FAR_HDR + 2 * FAR_NCOEF);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
+    double* head = (double*)ctx->partial.p;
+    double* cs = head + (size_t)ng * FAR_HDR;
+    double* cdl = cs + (size_t)ng * FAR_NCOEF;
+    unsigned* near = (unsigned*)(cdl + (size_t)ng * FAR_NCOEF);
+    const unsigned gb = (unsigned)ceil_div64(ng, 4);
+    ipde_time_begin(ctx);
+    if (MODE & MODE_SLP)
+        hipLaunchKernelGGL(laplace_far_coeff_kernel<MODE_SLP>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy,
+                           np, prm, head, cs, near, nch, 1);
+    if (MODE & MODE_DLP)
+        hipLaunchKernelGGL(laplace_far_coeff_kernel<MODE_DLP>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy,
+                           np, prm, head, cdl, near, nch, (MODE & MODE_SLP) ? 0 : 1);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    const size_t lds = (size_t)lt.nkeys * sizeof(double2);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_patch_far_kernel<MODE, NT>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((laplace_patch_far_kernel<MODE, NT>), dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds,
+                       ctx->stream, rec, ns_pad, pxy, np, pout, out, prm, (const double2*)lt.d_tab,
+                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)cs,
+                       (const double*)cdl, (const unsigned*)near, nch);
+    ipde_time_end(ctx);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }
 
@@ -663,4 +941,45 @@ extern "C" int ipde_laplace_apply_patches(ipde_ctx* ctx, int64_t ns, const doubl
     if (mode == MODE_SLP) return launch_laplace_patches<MODE_SLP>(ctx, rec, ns, pxy, np, pout, out, prm);
     if (mode == MODE_DLP) return launch_laplace_patches<MODE_DLP>(ctx, rec, ns, pxy, np, pout, out, prm);
     return launch_laplace_patches<MODE_BOTH>(ctx, rec, ns, pxy, np, pout, out, prm);
+}
+
+// The same sum with the far sources of every 64-patch block in a local expansion (see
+// laplace_far_coeff_kernel): the plan must come from ipde_target_plan_build_blocks(..., 8, 8, ...,
+// pad_blocks = 1), 64 consecutive patches = one block of tiles.
+extern "C" int ipde_laplace_apply_patches_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                              const double* w_sigma, const double* nx, const double* ny,
+                                              const double* w_tau, int64_t np, const double* pxy,
+                                              const int32_t* pout, double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ns >= 0 && np >= 0 && ns < (1LL << 30) && np < (1LL << 27));
+    IPDE_CHECK_ARG(ctx, w_sigma != nullptr || w_tau != nullptr);
+    IPDE_CHECK_ARG(ctx, w_tau == nullptr || (nx != nullptr && ny != nullptr));
+    if (np == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, pxy && pout && out);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    PackArgs pa{};
+    pa.sx = sx;
+    pa.sy = sy;
+    pa.ch[0] = w_sigma;
+    pa.mul[0] = -0.25 / M_PI;
+    pa.ch[1] = w_tau ? nx : nullptr;
+    pa.mulby[1] = w_tau;
+    pa.mul[1] = 0.5 / M_PI;
+    pa.pw[1] = 1;
+    pa.ch[2] = w_tau ? ny : nullptr;
+    pa.mulby[2] = w_tau;
+    pa.mul[2] = 0.5 / M_PI;
+    pa.pw[2] = 1;
+    pa.corr_ch = 0;
+    pa.corr2_ch = -1;
+    pa.use_scale = 1;
+    pa.exp_hi = ctx->logtab.exp_hi;
+    const double* rec;
+    const ApplyParams* prm;
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, pxy, pxy + 4 * np, 4 * np, &rec, &prm));
+    const int mode = (w_sigma ? MODE_SLP : 0) | (w_tau ? MODE_DLP : 0);
+    if (mode == MODE_SLP) return launch_laplace_patches_far<MODE_SLP>(ctx, rec, ns, pxy, np, pout, out, prm);
+    if (mode == MODE_DLP) return launch_laplace_patches_far<MODE_DLP>(ctx, rec, ns, pxy, np, pout, out, prm);
+    return launch_laplace_patches_far<MODE_BOTH>(ctx, rec, ns, pxy, np, pout, out, prm);
 }

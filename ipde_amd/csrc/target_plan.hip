@@ -111,9 +111,24 @@ void all_rest(ipde_target_plan& p) {
 
 }  // namespace
 
+extern "C" int ipde_target_plan_build_blocks(int64_t nt, const double* x, const double* y, int block_i, int block_j,
+                                             double partial_min_fill, int64_t min_patches, int line_min_points,
+                                             int pad_blocks, ipde_target_plan** out);
+
 extern "C" int ipde_target_plan_build(int64_t nt, const double* x, const double* y, int block_i, int block_j,
                                       double partial_min_fill, int64_t min_patches, int line_min_points,
                                       ipde_target_plan** out) {
+    return ipde_target_plan_build_blocks(nt, x, y, block_i, block_j, partial_min_fill, min_patches,
+                                         line_min_points, 0, out);
+}
+
+// pad_blocks != 0: every block of block_i x block_j tiles that holds a patch is filled up to
+// block_i * block_j patches with copies of its first one that store nothing (pout = -1), so that
+// patches [k B, (k + 1) B), B = block_i block_j, are exactly one block — what
+// ipde_laplace_apply_patches_far takes (B = 64: a wave per block).
+extern "C" int ipde_target_plan_build_blocks(int64_t nt, const double* x, const double* y, int block_i, int block_j,
+                                             double partial_min_fill, int64_t min_patches, int line_min_points,
+                                             int pad_blocks, ipde_target_plan** out) {
     if (!out) return IPDE_ERR_INVALID;
     *out = nullptr;
     if (nt < 0 || nt >= (1LL << 31) || (nt > 0 && (!x || !y)) || block_i < 1 || block_j < 1 || line_min_points < 1)
@@ -184,12 +199,29 @@ extern "C" int ipde_target_plan_build(int64_t nt, const double* x, const double*
             return IPDE_OK;
         }
         // (4) patches in the lanes' order
+        if (pad_blocks) {
+            const int64_t B = (int64_t)block_i * block_j;
+            int64_t nblocks = 0;
+            for (int64_t Ib = 0; Ib < ni; Ib += block_i)
+                for (int64_t Jb = 0; Jb < nj; Jb += block_j) {
+                    bool any = false;
+                    for (int64_t I = Ib; I < std::min<int64_t>(ni, Ib + block_i) && !any; ++I)
+                        for (int64_t J = Jb; J < std::min<int64_t>(nj, Jb + block_j) && !any; ++J) any = used(I, J);
+                    nblocks += any;
+                }
+            np = nblocks * B;
+            if (np >= (1LL << 27)) {
+                all_rest(*p);
+                return IPDE_OK;
+            }
+        }
         p->np = np;
         p->pxy.resize((size_t)8 * np);
         p->pout.resize((size_t)16 * np);
         int64_t q = 0;
         for (int64_t Ib = 0; Ib < ni; Ib += block_i)
-            for (int64_t Jb = 0; Jb < nj; Jb += block_j)
+            for (int64_t Jb = 0; Jb < nj; Jb += block_j) {
+                const int64_t q0 = q;
                 for (int64_t I = Ib; I < std::min<int64_t>(ni, Ib + block_i); ++I)
                     for (int64_t J = Jb; J < std::min<int64_t>(nj, Jb + block_j); ++J) {
                         if (!used(I, J)) continue;
@@ -201,6 +233,12 @@ extern "C" int ipde_target_plan_build(int64_t nt, const double* x, const double*
                         }
                         ++q;
                     }
+                if (pad_blocks && q > q0)
+                    for (const int64_t qe = q0 + (int64_t)block_i * block_j; q < qe; ++q) {
+                        for (int r = 0; r < 8; ++r) p->pxy[(size_t)r * np + q] = p->pxy[(size_t)r * np + q0];
+                        for (int r = 0; r < 16; ++r) p->pout[(size_t)r * np + q] = -1;
+                    }
+            }
         // (5) the remainder, in list order
         for (int64_t i = 0; i < nt; ++i) {
             bool in_patch = false;

@@ -142,7 +142,27 @@ def bessel_j01(x, xmax=None):
 def _trunc_sgf_quadrant(kqx, kqy, L, helmholtz_k, device):
     """Truncated spectral Green's function (reference laplace_grid_evaluator.py:21-33,
     modified_helmholtz_grid_evaluator.py:14-17) on the quadrant kqx x kqy of wavenumbers, as a device
-    tensor; J0 / J1 by `bessel_j01`, in row blocks (the coefficient gather is 88 bytes per point)."""
+    tensor: one kernel (csrc/ewald.hip, ipde_trunc_sgf_quadrant) over the J0 / J1 table of
+    `_j01_table`.  (`bessel_j01` is the same evaluation in torch operations: the tests' cross-check.)"""
+    import torch
+    from ..device import get_context, ptr
+    ctx = get_context(device.index if device.index is not None else torch.cuda.current_device())
+    kx = torch.as_tensor(np.ascontiguousarray(kqx, dtype=float), device=device)
+    ky = torch.as_tensor(np.ascontiguousarray(kqy, dtype=float), device=device)
+    out = torch.empty((kx.shape[0], ky.shape[0]), dtype=torch.float64, device=device)
+    xmax = L * float(np.hypot(np.max(kqx), np.max(kqy)))
+    tab = _j01_table(xmax, device)
+    helm = helmholtz_k is not None
+    kap = float(helmholtz_k) if helm else 0.0
+    K0, K1 = (float(k0(L * kap)), float(k1(L * kap))) if helm else (0.0, 0.0)
+    ctx.check(ctx.lib.ipde_trunc_sgf_quadrant(ctx.handle, kx.shape[0], ky.shape[0], ptr(kx), ptr(ky), float(L),
+                                              int(helm), kap, K0, K1, ptr(tab), int(tab.shape[1]), _J01_DEG,
+                                              _J01_W, ptr(out)))
+    return out
+
+
+def _trunc_sgf_quadrant_torch(kqx, kqy, L, helmholtz_k, device):
+    """The same by torch operations in row blocks (the kernel's checker in tests/test_ewald_gpu.py)."""
     import torch
     kx = torch.as_tensor(np.ascontiguousarray(kqx), device=device)
     ky = torch.as_tensor(np.ascontiguousarray(kqy), device=device)

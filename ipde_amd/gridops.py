@@ -31,10 +31,14 @@ def add_at(idx, src, out, ctx=None):
     return out
 
 
-def gather(idx, grid, ctx=None):
-    """grid[idx] as a new tensor"""
+def gather(idx, grid, ctx=None, out=None):
+    """grid[idx] as a new tensor (or into `out`, a contiguous fp64 tensor of idx's length)"""
     ctx = ctx or get_context()
-    out = torch.empty(idx.shape[0], dtype=torch.float64, device=grid.device)
+    if out is None:
+        out = torch.empty(idx.shape[0], dtype=torch.float64, device=grid.device)
+    elif not (out.is_contiguous() and out.dtype == torch.float64 and out.numel() == idx.shape[0]
+              and out.device == grid.device):
+        raise ValueError("gridops.gather: `out` must be a contiguous fp64 tensor of len(idx) on the grid's device")
     _check(idx, grid)
     ctx.check(ctx.lib.ipde_grid_gather(ctx.handle, idx.shape[0], ptr(idx), ptr(grid), ptr(out)))
     return out

@@ -44,10 +44,12 @@ class DeviceTargets:
     `grid_pnai` / `radial_targ` / `grid_and_radial_pts` sets in every solve;
     reference ipde/ebdy_collection.py:426-429,488-491)."""
 
-    def __init__(self, x, y=None, ctx=None, plan=False):
+    def __init__(self, x, y=None, ctx=None, plan=False, far=False):
         """plan=True: the list is also cut into 4 x 4 tensor patches for the Laplace patch kernel
         (ipde_amd/target_plan.py) — in a background thread; the first Laplace apply onto the set
-        joins it.  For the big grid lists (grid_pnai); lists under 2^18 points keep the list kernel."""
+        joins it.  For the big grid lists (grid_pnai); lists under 2^18 points keep the list kernel.
+        far=True (with plan): blocks of 8 x 8 patches padded to whole waves, and Laplace sums onto the
+        set take every block's far sources through a local expansion (ipde_laplace_apply_patches_far)."""
         if y is None:  # a PointSet-like object
             x, y = x.x, x.y
         self.ctx = ctx or get_context()
@@ -62,6 +64,7 @@ class DeviceTargets:
             if not isinstance(y, torch.Tensor) else y.to(torch.float64).contiguous().view(-1)
         self.N = int(self.x.shape[0])
         self._plan, self._plan_thread, self._plan_error = None, None, None
+        self.far = bool(far) and bool(plan)
         if plan:
             self.request_plan()
 
@@ -79,7 +82,7 @@ class DeviceTargets:
                 with torch.cuda.stream(side):
                     if self._host_xy is not None:   # the library's host routine, then four uploads
                         plan = target_plan.build_host(*self._host_xy, device=dev,
-                                                      min_patches=target_plan.MIN_PATCHES)
+                                                      min_patches=target_plan.MIN_PATCHES, pad_blocks=self.far)
                     else:                           # a list that only exists on the device: torch sorts
                         plan = target_plan.build(self.x, self.y, min_patches=target_plan.MIN_PATCHES)
                 side.synchronize()
@@ -293,7 +296,8 @@ def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=N
                                          w_sigma=_weighted(charge, src.weights),
                                          nx=None if dipstr is None else src.normal_x,
                                          ny=None if dipstr is None else src.normal_y,
-                                         w_tau=_weighted(dipstr, src.weights), ctx=target.ctx)
+                                         w_tau=_weighted(dipstr, src.weights), ctx=target.ctx,
+                                         far=target.far and plan.padded_blocks)
     return laplace_apply(src.x, src.y, tx, ty,
                          w_sigma=_weighted(charge, src.weights),
                          nx=None if dipstr is None else src.normal_x,

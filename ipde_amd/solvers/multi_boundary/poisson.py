@@ -8,7 +8,8 @@ from ...grid_evaluators.laplace_grid_evaluator import (LaplaceFreespaceGridEvalu
 
 
 class PoissonSolver(ScalarSolver):
-    PATCH_TARGETS = True      # ipde_laplace_apply_patches for the sum onto grid_pnai
+    PATCH_TARGETS = True      # ipde_laplace_apply_patches for the sum onto grid_pnai ...
+    FAR_EXPANSION = True      # ... far sources block by block in local expansions (..._patches_far)
 
     def __init__(self, ebdyc, solver_type='spectral', AS_list=None, grid_backend=None):
         super().__init__(ebdyc, solver_type, AS_list, grid_backend)
@@ -60,6 +61,13 @@ class PoissonSolver(ScalarSolver):
             self.split_grid_evaluation = True
         else:
             # the reference's default branch (:57-62): one dense sum onto grid_pnai,
-            # here with the target set resident on the device
+            # here with the target set resident on the device.  The reference's names for that
+            # branch: 'pybie2d' = every pair directly (internals/poisson.py:33-35), 'fmm2d' / 'flexmm'
+            # = far sources through expansions (:28-32, multi_boundary/poisson.py:50-55); None /
+            # 'hip' take the class default (expansions: the same numbers to rounding)
+            if self.grid_backend == 'pybie2d':
+                self.FAR_EXPANSION = False
+            elif self.grid_backend in ('fmm2d', 'flexmm'):
+                self.FAR_EXPANSION = True
             self.Grid_Evaluator = self._pnai_evaluator()
             self.split_grid_evaluation = False

@@ -119,6 +119,8 @@ class ScalarSolver(object):
         self._define_grid_evaluator()
         if os.environ.get("IPDE_PATCH_TARGETS", "1") == "0":
             self.PATCH_TARGETS = False      # A/B switch: the list kernel
+        if os.environ.get("IPDE_FAR_EXPANSION", "1") == "0":
+            self.FAR_EXPANSION = False      # A/B switch: every pair directly
         if self.PATCH_TARGETS and hasattr(self.Grid_Evaluator, "prepare"):
             # the grid_pnai list into HBM and into patches now, in the background of the set-up,
             # instead of inside the first solve
@@ -126,6 +128,10 @@ class ScalarSolver(object):
 
     # the dense sum onto grid_pnai through the 4 x 4 patch kernel (kernels that have one: Laplace)
     PATCH_TARGETS = False
+    # ... with the far sources of every 8 x 8 block of patches in a local expansion (Laplace:
+    # ipde_laplace_apply_patches_far; to rounding, 2048^2 x 4096: 3.3 -> 0.3 ms; IPDE_FAR_EXPANSION=0
+    # or this attribute False: every pair directly)
+    FAR_EXPANSION = False
 
     # grid_backend None / 'auto': the package's choice — the exact dense sum up to this many
     # source-target pairs per solve (BASELINE configs[1-2]: 1e10), beyond it, in a single process, the
@@ -185,7 +191,8 @@ class ScalarSolver(object):
         from ...pybie2d_compat import PointSet
         return make_pnai_evaluator(lambda src, trg, ch: self.Layer_Apply(src, trg, ch),
                                    self.grid_sources, self.ebdyc.grid_pnai,
-                                   lambda x, y: DeviceTargets(PointSet(x=x, y=y), plan=self.PATCH_TARGETS))
+                                   lambda x, y: DeviceTargets(PointSet(x=x, y=y), plan=self.PATCH_TARGETS,
+                                                              far=self.PATCH_TARGETS and self.FAR_EXPANSION))
 
     def _get_helper(self, ebdy, helper):
         raise NotImplementedError
@@ -243,8 +250,14 @@ class ScalarSolver(object):
         Nx, Ny = self.grid.shape
         fr_list = f.get_radial_value_list()
         # fc = (grid values) * grid_step on the full grid  (embedded_function.py:135-138)
-        fp = torch.empty(e.grid_phys.N, dtype=torch.float64, device=self._dev)
-        hostio.upload(fp, f['grid'], self._pin_in)
+        resident = isinstance(f, hostio.DeviceFunction)      # right-hand side (and answer) in HBM
+        if resident:
+            if f.ebdyc is not e or f.data.device != self._dev:
+                raise ValueError("DeviceFunction of another collection or device")
+            fp = f.grid_values
+        else:
+            fp = torch.empty(e.grid_phys.N, dtype=torch.float64, device=self._dev)
+            hostio.upload(fp, f['grid'], self._pin_in)
         fc = gridops.scatter(self._phys_idx, fp, Nx * Ny, scale=self._grid_step_d).view(Nx, Ny)
         uch, uc = self._grid_solve(fc)
         uc = uc.contiguous()
@@ -309,6 +322,14 @@ class ScalarSolver(object):
         # (only the physical points leave the device: the reference's masking of the rest, :117, has
         # nothing to act on)
         # the answer is built over pinned memory: the device->host copy writes the caller's array
+        if resident:
+            if owned is not None:
+                raise ValueError("sharded_result answers are host containers (the `owned` mask)")
+            ud = hostio.DeviceFunction(e, device=self._dev)
+            for sl, ur in zip(ud.radial_slices, urs):
+                ud.data[sl].copy_(torch.as_tensor(ur, device=self._dev).reshape(-1))
+            gridops.gather(self._phys_idx, ucf, out=ud.data[:ud.n_grid])
+            return ud
         ue, block = hostio.pinned_function(e)
         for i, (sl, ur) in enumerate(zip(ue.radial_slices, urs)):
             if isinstance(ur, torch.Tensor):     # device flow: the annular solutions' one transfer

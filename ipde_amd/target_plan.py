@@ -37,11 +37,14 @@ class TargetPlan:
     point; rest (nrest,) int64: the list positions no patch holds, with their coordinates
     rest_x, rest_y."""
 
-    def __init__(self, n, pxy, pout, rest, rest_x, rest_y):
+    def __init__(self, n, pxy, pout, rest, rest_x, rest_y, padded_blocks=False):
         self.n, self.pxy, self.pout = int(n), pxy, pout
         self.rest, self.rest_x, self.rest_y = rest, rest_x, rest_y
         self.np = int(pxy.shape[1])
         self.nrest = int(rest.shape[0])
+        # 64 consecutive patches are one 8 x 8 block of tiles (build_host(pad_blocks=True)): what the
+        # far-field form of the sum needs (ipde_laplace_apply_patches_far)
+        self.padded_blocks = bool(padded_blocks)
 
 
 def build(x, y, block=DEFAULT_BLOCK, min_patches=0):
@@ -97,11 +100,13 @@ def build(x, y, block=DEFAULT_BLOCK, min_patches=0):
     return TargetPlan(n, pxy, pout, rest, x[rest].contiguous(), y[rest].contiguous())
 
 
-def build_host(x, y, device=None, block=DEFAULT_BLOCK, min_patches=0):
+def build_host(x, y, device=None, block=DEFAULT_BLOCK, min_patches=0, pad_blocks=False):
     """The same cut by the library's host routine (ipde_target_plan_build, csrc/target_plan.hip):
     x, y numpy arrays; the plan's arrays are uploaded to `device` (None: they stay on the host).
     What the solvers use — no GPU library is touched, so it runs beside a cold set-up for free
-    (torch's first sort loads ~0.6 s of code objects)."""
+    (torch's first sort loads ~0.6 s of code objects).  pad_blocks: every block of tiles is filled up
+    to a whole wave of patches (copies that store nothing), block (8, 8) only: the plan then also
+    serves `laplace_apply(..., far=True)`."""
     import ctypes
     import numpy as np
     from . import _lib
@@ -111,9 +116,11 @@ def build_host(x, y, device=None, block=DEFAULT_BLOCK, min_patches=0):
     n = int(x.shape[0])
     assert y.shape[0] == n
     handle = ctypes.c_void_p()
-    _lib.check(lib.ipde_target_plan_build(n, ptr(x), ptr(y), int(block[0]), int(min(block[1], 2 ** 30)),
-                                          float(PARTIAL_MIN_FILL), int(min_patches), int(LINE_MIN_POINTS),
-                                          ctypes.byref(handle)))
+    if pad_blocks and tuple(block) != (8, 8):
+        raise ValueError("pad_blocks needs block = (8, 8): one wave of patches per block")
+    _lib.check(lib.ipde_target_plan_build_blocks(n, ptr(x), ptr(y), int(block[0]), int(min(block[1], 2 ** 30)),
+                                                 float(PARTIAL_MIN_FILL), int(min_patches), int(LINE_MIN_POINTS),
+                                                 int(bool(pad_blocks)), ctypes.byref(handle)))
     try:
         np_, nrest = ctypes.c_int64(), ctypes.c_int64()
         _lib.check(lib.ipde_target_plan_sizes(handle, ctypes.byref(np_), ctypes.byref(nrest)))
@@ -125,13 +132,14 @@ def build_host(x, y, device=None, block=DEFAULT_BLOCK, min_patches=0):
         lib.ipde_target_plan_destroy(handle)
     up = (lambda a: torch.from_numpy(a)) if device is None else (lambda a: torch.as_tensor(a, device=device))
     return TargetPlan(n, up(pxy), up(pout), up(rest), up(np.ascontiguousarray(x[rest])),
-                      up(np.ascontiguousarray(y[rest])))
+                      up(np.ascontiguousarray(y[rest])), padded_blocks=bool(pad_blocks) and np_.value > 0)
 
 
-def laplace_apply(plan, sx, sy, w_sigma=None, nx=None, ny=None, w_tau=None, ctx=None, out=None):
+def laplace_apply(plan, sx, sy, w_sigma=None, nx=None, ny=None, w_tau=None, ctx=None, out=None, far=False):
     """ipde_laplace_apply over a planned list (device tensors; densities weight-multiplied as in
     layer_potentials.laplace_apply): the patches through ipde_laplace_apply_patches, the
-    remainder through ipde_laplace_apply."""
+    remainder through ipde_laplace_apply.  far=True (plans with padded blocks): the patches through
+    ipde_laplace_apply_patches_far — every block's far sources in a local expansion."""
     from . import _lib
     from .layer_potentials import _match, laplace_apply as list_apply
     ctx = ctx or get_context()
@@ -145,7 +153,9 @@ def laplace_apply(plan, sx, sy, w_sigma=None, nx=None, ny=None, w_tau=None, ctx=
     if plan.nrest:
         part = list_apply(sx, sy, plan.rest_x, plan.rest_y, w_sigma=w_sigma, nx=nx, ny=ny, w_tau=w_tau, ctx=ctx)
         out[plan.rest] = part
-    ctx.check(ctx.lib.ipde_laplace_apply_patches(ctx.handle, int(sx.shape[0]), ptr(sx), ptr(sy), ptr(w_sigma),
-                                                 ptr(nx), ptr(ny), ptr(w_tau), plan.np, ptr(plan.pxy),
-                                                 ptr(plan.pout), ptr(out)))
+    if far and not plan.padded_blocks:
+        raise ValueError("far=True needs a plan built with pad_blocks=True")
+    fn = ctx.lib.ipde_laplace_apply_patches_far if far else ctx.lib.ipde_laplace_apply_patches
+    ctx.check(fn(ctx.handle, int(sx.shape[0]), ptr(sx), ptr(sy), ptr(w_sigma), ptr(nx), ptr(ny), ptr(w_tau),
+                 plan.np, ptr(plan.pxy), ptr(plan.pout), ptr(out)))
     return out

@@ -98,13 +98,14 @@ def test_product_tables_and_fft_size():
 
 def test_device_side_bessel_j0_j1_and_truncated_symbols():
     """grid_evaluators/ewald.py: J0 / J1 by degree-10 Chebyshev pieces fitted from scipy's values (the
-    evaluator's set-up evaluates them at 1.8e7 .. 7e7 wavenumbers: on the device since round 3) against
+    evaluator's set-up evaluates them at 1.8e7 .. 7e7 wavenumbers: on the device since round 3; here the
+    torch form, the HIP kernel's checker in tests/test_ewald_gpu.py) against
     scipy itself (whose own error grows to ~8e-15 at x ~ 2e4), and the truncated spectral Green's
     functions built on them against the reference's formulas (laplace_grid_evaluator.py:21-33,
     modified_helmholtz_grid_evaluator.py:14-17) evaluated with scipy."""
     import torch
     from scipy.special import j0, j1, k0, k1
-    from ipde_amd.grid_evaluators.ewald import bessel_j01, _trunc_sgf_quadrant
+    from ipde_amd.grid_evaluators.ewald import bessel_j01, _trunc_sgf_quadrant_torch as _trunc_sgf_quadrant
     rng = np.random.default_rng(0)
     for lo, hi, tol in ((0.0, 100.0, 5e-15), (100.0, 3.0e4, 3e-14)):
         x = np.concatenate([rng.uniform(lo, hi, 20000), [lo, hi - 1e-9]])

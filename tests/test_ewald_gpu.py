@@ -163,3 +163,30 @@ def test_stokes_solver_refuses_the_split_evaluator():
         multi_stokes.run(nb=400, M=12, simple=True, grid_backend='ewald')
     ud, vd, pd, scale, T = multi_stokes.run(nb=400, M=12, simple=True, grid_backend='hip')
     assert max(ud, vd) / scale < 2e-8
+
+
+def test_truncated_symbol_kernel_against_scipy_and_the_torch_form():
+    """ipde_trunc_sgf_quadrant (one kernel: hypot, J0 / J1 by the Chebyshev table, the symbol) against
+    the reference's formulas evaluated with scipy (laplace_grid_evaluator.py:21-33,
+    modified_helmholtz_grid_evaluator.py:14-17) and against the torch-operation form it replaced."""
+    import torch
+    from scipy.special import j0, j1, k0, k1
+    from ipde_amd.grid_evaluators.ewald import _trunc_sgf_quadrant, _trunc_sgf_quadrant_torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    kq = np.abs(np.fft.fftfreq(400, 0.01 / (2 * np.pi))[:201])
+    L = 3.7
+    kk = np.hypot(kq[:, None], kq[None, :])
+    ks = np.where(kk == 0, 1.0, kk)
+    ref = (1.0 - j0(L * kk)) / ks ** 2 - L * np.log(L) * j1(L * kk) / ks
+    ref[kk == 0] = -L ** 2 * np.log(L) + L ** 2 * (1 + 2 * np.log(L)) / 4
+    got = _trunc_sgf_quadrant(kq, kq[:150], L, None, dev)
+    assert got.shape == (201, 150)
+    assert np.abs(got.cpu().numpy() - ref[:, :150]).max() < 1e-14 * np.abs(ref).max()
+    old = _trunc_sgf_quadrant_torch(kq, kq[:150], L, None, dev)
+    assert float((got - old).abs().max()) < 2e-15 * np.abs(ref).max()
+    kap = 10.0
+    ref = (1.0 + L * kk * j1(L * kk) * k0(L * kap) - L * kap * j0(L * kk) * k1(L * kap)) / (kk ** 2 + kap ** 2)
+    got = _trunc_sgf_quadrant(kq, kq, L, kap, dev)
+    assert np.abs(got.cpu().numpy() - ref).max() < 1e-14 * np.abs(ref).max()
+    old = _trunc_sgf_quadrant_torch(kq, kq, L, kap, dev)
+    assert float((got - old).abs().max()) < 2e-15 * np.abs(ref).max()

@@ -641,6 +641,98 @@ def test_laplace_patches_full_size_through_the_high_level_call(lp):
                                                  0, None, None, None))
 
 
+# ---------------------------------------------------------------------------
+# patches with the far sources of every 8 x 8 block of tiles in a local expansion
+# (ipde_laplace_apply_patches_far; the reference's grid_backend='fmm2d' place, internals/poisson.py:28-32)
+@pytest.mark.parametrize("mode", ["slp", "dlp", "both"])
+@pytest.mark.parametrize("ngrid,nb", [(200, 192), (640, 512), (1024, 1500)])
+def test_laplace_far_expansion_against_oracle_and_direct_patches(lp, mode, ngrid, nb):
+    """Blocks padded to whole waves (dummy patches store nothing), far sources through 27
+    coefficients per block, near ones pair by pair: against the C oracle on a sample and against the
+    direct patch kernel everywhere.  The smallest case has no far source at all for most blocks (the
+    curve is never four block radii away), the largest one mostly far ones; nb = 1500 leaves a
+    partial batch of sources."""
+    from ipde_amd import target_plan
+    c = Curve(nb, a=0.2, f=5)
+    trg, h = grid_targets(c, ngrid, clearance=2.0)
+    rng = np.random.default_rng(ngrid + nb)
+    kw = _patch_kw(c, mode, rng.standard_normal(c.N), rng.standard_normal(c.N))
+    dev = lp.get_context().torch_device()
+    plan = target_plan.build_host(trg.x, trg.y, device=dev, pad_blocks=True)
+    plain = target_plan.build_host(trg.x, trg.y, device=dev)
+    assert plan.padded_blocks and plan.np % 64 == 0 and plan.np >= plain.np and plan.nrest == plain.nrest == 0
+    # every block: its 64 patches inside one 32 x 32 window of the lattice
+    pxy = plan.pxy.cpu().numpy().reshape(8, -1, 64)
+    assert (pxy[:4].max(axis=(0, 2)) - pxy[:4].min(axis=(0, 2))).max() <= 31.5 * h
+    assert (pxy[4:].max(axis=(0, 2)) - pxy[4:].min(axis=(0, 2))).max() <= 31.5 * h
+    far = target_plan.laplace_apply(plan, c.x, c.y, far=True, **kw).cpu().numpy()
+    direct = target_plan.laplace_apply(plain, c.x, c.y, **kw).cpu().numpy()
+    same_plan_direct = target_plan.laplace_apply(plan, c.x, c.y, **kw).cpu().numpy()
+    assert np.array_equal(direct, same_plan_direct)          # padding changes nothing for the direct kernel
+    idx = rng.choice(trg.N, min(trg.N, 6000), replace=False)
+    ref = oracle.c_laplace_apply(c.x, c.y, trg.x[idx], trg.y[idx], **kw)
+    assert rel_err(far[idx], ref) < TOL
+    assert np.abs(far - direct).max() < 1e-13 * np.abs(direct).max()
+    with pytest.raises(ValueError):
+        target_plan.laplace_apply(plain, c.x, c.y, far=True, **kw)
+
+
+@pytest.mark.parametrize("mode", ["slp", "both"])
+def test_laplace_far_expansion_table_miss_and_scattered_sources(lp, mode):
+    """Sources 1e-9 / 1e-13 from grid targets (near pairs leave the LDS table: those patches' NEAR
+    sources are redone with the generic math, the far ones stay in the expansion), sources exactly on
+    unstored points, and a handful far outside the grid (every block has them in its expansion)."""
+    from ipde_amd import target_plan
+    c = Curve(400, a=0.2, f=5)
+    trg, h = grid_targets(c, 512, clearance=2.0)
+    rng = np.random.default_rng(7)
+    sx, sy = c.x.copy(), c.y.copy()
+    hit = rng.choice(trg.N, 12, replace=False)
+    sx[:12] = trg.x[hit] + np.where(np.arange(12) % 2 == 0, 1e-9, 1e-13)
+    sy[:12] = trg.y[hit] - np.where(np.arange(12) % 3 == 0, 1e-9, 3e-13)
+    v = np.linspace(-1.5, 1.5, 512, endpoint=False)
+    present = set(zip(trg.x.tolist(), trg.y.tolist()))
+    holes = [(a, b) for a in v[::7] for b in v[::5] if (a, b) not in present]
+    holes = [holes[i] for i in rng.choice(len(holes), 10, replace=False)]
+    sx[12:22], sy[12:22] = [p[0] for p in holes], [p[1] for p in holes]
+    sx[22:30], sy[22:30] = rng.uniform(4.0, 9.0, 8), rng.uniform(-7.0, 7.0, 8)
+    kw = _patch_kw(c, mode, rng.standard_normal(c.N), rng.standard_normal(c.N))
+    plan = target_plan.build_host(trg.x, trg.y, device=lp.get_context().torch_device(), pad_blocks=True)
+    got = target_plan.laplace_apply(plan, sx, sy, far=True, **kw).cpu().numpy()
+    ref = oracle.c_laplace_apply(sx, sy, trg.x, trg.y, **kw)
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - ref) <= TOL * np.maximum(np.abs(ref), np.abs(ref[np.abs(ref) < 1e3]).max()))
+
+
+def test_laplace_far_expansion_full_size_and_scaled_coordinates(lp):
+    """BASELINE configs[1] through DeviceTargets(plan=True, far=True): against the direct patch kernel
+    everywhere and the C oracle on a sample; the same after scaling every coordinate by 2^-30 and by
+    1e6 (the expansion works in the block's own units: nothing over- or underflows)."""
+    import torch
+    c = Curve(4096, a=0.2, f=5)
+    trg, h = grid_targets(c, 2048)
+    far = lp.DeviceTargets(trg, plan=True, far=True)
+    plain = lp.DeviceTargets(trg, plan=True)
+    assert far.plan().padded_blocks and not plain.plan().padded_blocks
+    rng = np.random.default_rng(11)
+    s1, s2 = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    for kw in (dict(charge=s1), dict(charge=s1, dipstr=s2)):
+        a = lp.Laplace_Layer_Apply(c, plain, **kw)
+        b = lp.Laplace_Layer_Apply(c, far, **kw)
+        assert float((a - b).abs().max()) < 1e-13 * float(a.abs().max())
+    idx = rng.choice(trg.N, 4096, replace=False)
+    ref = oracle.c_laplace_apply(c.x, c.y, trg.x[idx], trg.y[idx], w_sigma=s1 * c.weights)
+    u = lp.Laplace_Layer_Apply(c, far, charge=s1)
+    assert np.max(np.abs(u.cpu().numpy()[idx] - ref)) < 1e-12 * float(u.abs().max())
+    from ipde_amd import target_plan
+    for scale in (2.0 ** -30, 1.0e6):
+        plan = target_plan.build_host(trg.x * scale, trg.y * scale, device=u.device, pad_blocks=True)
+        w = s1 * c.weights * scale
+        got = target_plan.laplace_apply(plan, c.x * scale, c.y * scale, w_sigma=w, far=True)
+        want = target_plan.laplace_apply(plan, c.x * scale, c.y * scale, w_sigma=w)
+        assert float((got - want).abs().max()) < 1e-13 * float(want.abs().max())
+
+
 # -- the kernels no reference code computes, tied to the pinned ones through derivative relations
 #    (tests/test_oracle_layer_relations.py has the same checks for the oracle; here every
 #    evaluation is a HIP kernel call and nothing goes through the oracle's closed formulas) -------

@@ -378,7 +378,7 @@ def test_grid_evaluator_is_chosen_by_problem_size():
 
 def test_grid_classification_scan_on_device_equals_the_host_scan(monkeypatch):
     """Large grids (>= near.GRID_SCAN_ON_DEVICE_MIN points) classify inside/outside by the same row
-    scan in torch on the GPU; forced here on a small grid and compared bit for bit."""
+    scan as a HIP kernel (ipde_grid_inside_scan); forced here on a small grid and compared bit for bit."""
     from ipde_amd import near
     from ipde_amd.pybie2d_compat import Global_Smooth_Boundary as GSB, Grid, star
     b = GSB(c=star(600, a=0.2, f=5))
@@ -393,3 +393,45 @@ def test_grid_classification_scan_on_device_equals_the_host_scan(monkeypatch):
     dev = near.grid_inside_curve(*args)
     assert dev.dtype == host.dtype and np.array_equal(dev, host)
     assert np.array_equal(dev, near.points_inside_curve(b, grid.xg, grid.yg))
+
+
+def test_device_resident_right_hand_side_and_answer_equal_the_host_containers():
+    """hostio.DeviceFunction in, DeviceFunction out: the same solve without the two PCIe crossings,
+    bit for bit; chaining (the answer as the next right-hand side) stays on the device."""
+    import torch
+    import interior_poisson
+    from ipde_amd import hostio
+    from ipde_amd.embedded_function import EmbeddedFunction
+    err, scale, solver, ue, T = interior_poisson.run(nb=400, M=12, solver_tol=1e-12)
+    f = EmbeddedFunction(solver.ebdyc)
+    f.define_via_function(lambda x, y: np.sin(2 * x) * np.cos(y) + x)
+    kw = dict(tol=1e-12, maxiter=60, restart=30)
+    u_host = solver(f, **kw)
+    fd = hostio.DeviceFunction.from_host(f)
+    ud = solver(fd, **kw)
+    assert isinstance(ud, hostio.DeviceFunction) and ud.data.is_cuda
+    back = ud.to_host()
+    assert isinstance(back, EmbeddedFunction)
+    assert np.array_equal(np.asarray(back), np.asarray(u_host))
+    u2_host = solver(u_host, **kw)
+    u2_dev = solver(ud, **kw).to_host()
+    assert np.array_equal(np.asarray(u2_dev), np.asarray(u2_host))
+    with pytest.raises(ValueError):
+        hostio.DeviceFunction(solver.ebdyc, torch.zeros(3, dtype=torch.float64, device="cuda"))
+
+
+def test_poisson_solver_far_expansion_equals_pair_by_pair_grid_sum():
+    """PoissonSolver's dense sum onto grid_pnai: far sources in local expansions (class default, and
+    the reference's grid_backend names 'fmm2d' / 'flexmm') against every pair directly ('pybie2d'):
+    the same solution to rounding, the same manufactured-solution error."""
+    import interior_poisson
+    from ipde_amd.embedded_function import EmbeddedFunction
+    res = {}
+    for gb in (None, 'pybie2d', 'fmm2d'):
+        err, scale, solver, ue, T = interior_poisson.run(nb=1200, M=16, Ns=[1024, 1024], solver_tol=1e-12,
+                                                         grid_backend=gb)
+        res[gb] = (err / scale, np.asarray(ue).copy(), solver.FAR_EXPANSION)
+    assert res[None][2] and res['fmm2d'][2] and not res['pybie2d'][2]
+    assert res[None][0] < 1e-11 and res['pybie2d'][0] < 1e-11
+    assert np.array_equal(res[None][1], res['fmm2d'][1])
+    assert np.abs(res[None][1] - res['pybie2d'][1]).max() < 1e-13 * np.abs(res['pybie2d'][1]).max()

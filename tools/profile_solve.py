@@ -14,7 +14,10 @@ import torch  # noqa: E402
 import interior_poisson  # noqa: E402
 from ipde_amd.embedded_function import EmbeddedFunction  # noqa: E402
 
-err, scale, solver, ue, T = interior_poisson.run(nb=4096, M=20, Ns=[2048, 2048], solver_tol=1e-12)
+T = {}
+err, scale, solver, ue, T = interior_poisson.run(nb=4096, M=20, Ns=[2048, 2048], solver_tol=1e-12, timings=T,
+                                                 grid_backend=os.environ.get('IPDE_PROFILE_GRID_BACKEND') or None)
+print('error %.3e  timings %s' % (err / scale if scale else err, {k: round(v, 4) for k, v in T.items() if isinstance(v, float)}))
 if os.environ.get("IPDE_AB_NULL_STREAM") == "1":   # A/B: the library's work on the legacy default stream, where torch's is
     import ctypes
     from ipde_amd import device as _dv
@@ -23,6 +26,9 @@ if os.environ.get("IPDE_AB_NULL_STREAM") == "1":   # A/B: the library's work on 
         _c.check(_c.lib.ipde_ctx_set_stream(_c.handle, ctypes.c_void_p(1)))
 f = EmbeddedFunction(solver.ebdyc)
 f.define_via_function(lambda x, y: np.sin(x) * np.cos(y))
+if os.environ.get("IPDE_PROFILE_RESIDENT") == "1":     # right-hand side and answer stay in HBM
+    from ipde_amd import hostio
+    f = hostio.DeviceFunction.from_host(f)
 solver(f, tol=1e-12, maxiter=100, restart=20)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
