@@ -115,9 +115,16 @@ def full_poisson_solve(nb=4096, ng=2048, M=20):
         return out
 
     warm, warm_res = warm_ms(solver)
+    far_default = bool(solver.FAR_EXPANSION)
+    # every pair of the sum onto grid_pnai directly (the reference's grid_backend='pybie2d' branch)
+    del solver, ue
+    torch.cuda.empty_cache()
+    err_p, scale_p, solver_p, _, _ = interior_poisson.run(nb=nb, M=M, Ns=[ng, ng], solver_tol=1e-12,
+                                                          grid_backend='pybie2d')
+    warm_p, warm_p_res = warm_ms(solver_p)
     # the same solve with the O(N_s sw^2 + n^2 log n) split grid evaluator instead of the
     # dense sum onto the grid (grid_backend='ewald', 7e-15 from the dense sum)
-    del solver, ue
+    del solver_p
     torch.cuda.empty_cache()
     Te = {}
     err_e, scale_e, solver_e, _, Te = interior_poisson.run(nb=nb, M=M, Ns=[ng, ng], solver_tol=1e-12,
@@ -134,6 +141,11 @@ def full_poisson_solve(nb=4096, ng=2048, M=20):
         "homogeneous_correction_s": T["homogeneous_form_s"] + T["homogeneous_apply_s"],
         "end_to_end_s": total, "warm_inhomogeneous_solve_ms": warm,
         "warm_inhomogeneous_solve_resident_ms": warm_res,
+        "grid_sum": "far sources of every 8 x 8 block of patches in local expansions (ipde_laplace_apply_patches_far)"
+                    if far_default else "every pair directly",
+        "pair_by_pair_grid_sum": {"max_rel_err_vs_manufactured_solution": err_p / scale_p,
+                                  "warm_inhomogeneous_solve_ms": warm_p,
+                                  "warm_inhomogeneous_solve_resident_ms": warm_p_res},
         "ewald_grid_backend": {"max_rel_err_vs_manufactured_solution": err_e / scale_e,
                                "setup_s": Te["setup_s"],
                                "warm_inhomogeneous_solve_ms": warm_e,
@@ -324,6 +336,32 @@ def main():
         target_plan.laplace_apply(plan, sx, sy, w_sigma=sig_full * w, ctx=ctx, out=out)
         ctx.sync()
     ctx.enable_timing(False)
+    # the same sum with every 8 x 8 block's far sources in a local expansion (what PoissonSolver
+    # uses for its sum onto grid_pnai): a separate, labelled figure — `value` and `roofline` above are the
+    # pair-by-pair kernel's
+    expansion = None
+    if plan is not None and world == 1:
+        dtf = lp.DeviceTargets(trg.x[sl], trg.y[sl], ctx=ctx, plan=True, far=True)
+        planf = dtf.plan()
+        outf = torch.empty(dt.N, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            target_plan.laplace_apply(planf, sx, sy, w_sigma=sig_full * w, ctx=ctx, out=outf, far=True)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        nf = 20
+        for _ in range(nf):
+            target_plan.laplace_apply(planf, sx, sy, w_sigma=sig_full * w, ctx=ctx, out=outf, far=True)
+        torch.cuda.synchronize()
+        msf = 1e3 * (time.perf_counter() - tf0) / nf
+        expansion = {"what": "ipde_laplace_apply_patches_far: sources beyond 4 block radii of a 32 x 32-point block "
+                             "enter 27 complex local-expansion coefficients (truncation 3e-18 of sum|w|), nearer "
+                             "batches of eight sources are summed pair by pair",
+                     "ms_per_apply": msf,
+                     "effective_pair_interactions_per_s": float(NBDY) * float(dt.N) / (msf * 1e-3),
+                     "max_abs_diff_vs_pair_by_pair": float((outf - out).abs().max()),
+                     "max_abs_pair_by_pair": float(out.abs().max()),
+                     "padded_patches": planf.np}
+        del dtf, planf, outf
 
     def allreduce_max(x):
         tt = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -430,6 +468,7 @@ def main():
                 "traffic_source": traffic_src,
             },
         }
+        result["expansion_form"] = expansion
         if not args.no_fft and world == 1:
             result["fft"] = fft_block()
         if not args.no_cpu_baseline and world == 1:

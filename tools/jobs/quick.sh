@@ -4,10 +4,14 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r03/far
 mkdir -p $O
-timeout -k 10 900 python3 -m pytest tests/test_layer_gpu.py tests/test_solver_gpu.py -m gpu -x -q -k "far_expansion or patches or resident" 2>&1 | tail -5
-export IPDE_PROFILE_SOLVES=60
-for i in 1 2; do
-IPDE_FAR_EXPANSION=0 timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | grep "warm solve\|error" | cut -c1-60 | sed 's/^/direct          /' | tee -a $O/ab_solve.txt
-timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | grep "warm solve\|error" | cut -c1-60 | sed 's/^/far             /' | tee -a $O/ab_solve.txt
-IPDE_PROFILE_RESIDENT=1 timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | grep "warm solve" | sed 's/^/far resident    /' | tee -a $O/ab_solve.txt
-done
+rm -rf $O/solve_trace
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/solve_trace -- python3 tools/profile_solve.py > $O/solve_trace.log 2>&1
+ms=$(grep "warm solve" $O/solve_trace.log | awk '{print $3}')
+python3 tools/analyze_trace.py $O/solve_trace $ms 10 > $O/poisson_solve_budget_far.json
+find $O/solve_trace -name "*.csv" -size +20M -delete
+python3 - <<'PY'
+import json
+d=json.load(open("gpurun_out/r03/far/poisson_solve_budget_far.json"))
+print(d["warm_solve_ms"], d["gpu_busy_ms_per_solve"], d["launches_per_solve"])
+for k,v in list(d["kernels_ms_per_solve"].items())[:16]: print("%8.3f %5.1f  %s"%(v["ms"],v["launches"],k[:80]))
+PY
