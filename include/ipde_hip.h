@@ -264,6 +264,21 @@ int ipde_stokes_apply(ipde_ctx* ctx, int loc,
                       int64_t nt, const double* tx, const double* ty,
                       double* out_u, double* out_v, double* out_p, int flags);
 
+/*
+ * The Stokeslet sums (wfx, wfy; with pressure when out_p != NULL) onto a target list handed over
+ * as 4 x 4 patches whose groups of 64 are 8 x 8 blocks of tiles (ipde_target_plan_build_blocks with
+ * pad_blocks = 1; layout as in ipde_laplace_apply_patches), every block's sources beyond four block
+ * radii through local expansions (three families of 27 complex coefficients: log|d|, d/conj(d) and
+ * 1/d about the block's centre, 26 terms at ratio <= 1/4), the nearer batches of eight sources pair
+ * by pair.  The place of the reference's FMM call for this sum (pyfmmlib2d SFMM,
+ * ipde/solvers/internals/stokes.py:25-35).  DEVICE pointers; values agree with ipde_stokes_apply to
+ * a few roundings of the largest partial sum.
+ */
+int ipde_stokes_apply_patches_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                  const double* wfx, const double* wfy,
+                                  int64_t np, const double* pxy, const int32_t* pout,
+                                  double* out_u, double* out_v, double* out_p);
+
 /* ------------------------------------------------------------------------- */
 /* periodic spectral grid operators                  */
 

@@ -333,6 +333,305 @@ __global__ __launch_bounds__(NT) void stokes_rowrun_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Stokeslet sums onto patch lists with the far sources of every 8 x 8 block of tiles in a local
+// expansion (ipde_stokes_apply_patches_far; the Laplace form of this is in layer_laplace.hip, where
+// the scheme is described).  With F = f'_x + i f'_y, delta = z - z_j, U = u + i v:
+//     U = sum_j  -F log|delta| + F/2 + (conj F / 2) delta / conj(delta),     sum_j (f'.d)/d^2 = Re sum_j F / delta
+// and for a source beyond 4 block radii r of the block's centre c, vt = r / (z_j - c), zeta = (z - c)/r:
+//     log|delta| = log|c - z_j| - Re sum_{k>=1} (zeta vt)^k / k,     1/delta = -(vt/r) sum_{k>=0} (zeta vt)^k
+// which leaves three families of coefficients X_k = sum_j W_j vt_j^k per block,
+//     X1: W = F (k = 1..P+1),   X2: W = conj F (k = 1..P),   X3: W = F vt / conj(vt) (k = 0..P),
+// C0 = sum_j (F/2 - F log|c - z_j|), and with S2 = sum_{k>=0} X1_{k+1} zeta^k
+//     U = C0 + sum_{k>=1} X1_k zeta^k / (2k) + sum_{k>=0} [conj(X3_k)/2 + conj(X2_k)/(2k)] conj(zeta)^k - zeta conj(S2) / 2
+//     sum_j (f'.d)/d^2 = -Re S2 / r.
+// Three coefficient launches (a family fills the register file), then the patch kernel: expansion
+// values first, then the near batches pair by pair through the table.
+constexpr int SFAR_P = 26;
+constexpr double SFAR_RHO = 0.25;
+constexpr int SFAR_NCOEF = 2 * (SFAR_P + 2);
+constexpr int SFAR_HDR = 4;
+
+template <int WHICH>
+__global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __restrict__ rec, int ns_pad,
+                                                              const double* __restrict__ pxy, int64_t np,
+                                                              const ApplyParams* __restrict__ prm,
+                                                              double* __restrict__ head, double* __restrict__ coef,
+                                                              unsigned* __restrict__ near, int nch) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g * 64 >= np) return;                          // (whole waves)
+    const double s1 = ldexp(1.0, prm->sh);
+    const int64_t t = min(g * 64 + lane, np - 1);
+    double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double x = pxy[(int64_t)a * np + t] * s1, y = pxy[(int64_t)(4 + a) * np + t] * s1;
+        xlo = fmin(xlo, x);
+        xhi = fmax(xhi, x);
+        ylo = fmin(ylo, y);
+        yhi = fmax(yhi, y);
+    }
+    xlo = wave_min(xlo);
+    xhi = wave_max(xhi);
+    ylo = wave_min(ylo);
+    yhi = wave_max(yhi);
+    const double cx = 0.5 * (xlo + xhi), cy = 0.5 * (ylo + yhi);
+    const double hx = 0.5 * (xhi - xlo), hy = 0.5 * (yhi - ylo);
+    const double r2 = hx * hx + hy * hy;
+    const double r = sqrt(r2);
+    const double thr = r2 * (1.0 / (SFAR_RHO * SFAR_RHO)) * (1.0 + 0x1p-40);
+    constexpr int K0 = WHICH == 3 ? 0 : 1;
+    constexpr int K1 = WHICH == 1 ? SFAR_P + 1 : SFAR_P;
+    double sre[K1 + 1], sim[K1 + 1];
+#pragma unroll
+    for (int k = 0; k <= K1; ++k) sre[k] = sim[k] = 0.0;
+    for (int j0 = 0; j0 < ns_pad; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < ns_pad;
+        const int jj = valid ? j : ns_pad - 1;
+        const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
+        const double d2 = fma(dy, dy, dx * dx);
+        // a batch of eight sources goes one way as a whole
+        const unsigned long long m = __ballot(valid && !(d2 >= thr && !prm->pad));
+        const bool far = valid && ((m >> (lane & ~7)) & 0xFFull) == 0;
+        if (WHICH == 1 && lane == 0) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) bits |= ((m >> (8 * b)) & 0xFFull) ? (1u << b) : 0u;
+            near[g * nch + (j0 >> 6)] = bits;
+        }
+        const double inv = far ? r / d2 : 0.0;
+        const double vre = dx * inv, vim = -dy * inv;        // vt = r / (z_j - c)
+        const double fx = far ? rec[ipde_rec_index(jj, 2)] : 0.0, fy = far ? rec[ipde_rec_index(jj, 3)] : 0.0;
+        double wre, wim;
+        if (WHICH == 1) {
+            wre = fx;
+            wim = fy;
+            const double h = fma(-0.5, log(far ? d2 : 1.0), 0.5);     // 1/2 - log|c - z_j|
+            sre[0] = fma(fx, h, sre[0]);
+            sim[0] = fma(fy, h, sim[0]);
+        } else if (WHICH == 2) {
+            wre = fx;
+            wim = -fy;
+        } else {
+            // F vt / conj(vt) = F vt^2 / |vt|^2 = F (dx - i dy)^2 / d2
+            const double id = far ? 1.0 / d2 : 0.0;
+            const double ure = (dx * dx - dy * dy) * id, uim = -2.0 * dx * dy * id;
+            wre = fx * ure - fy * uim;
+            wim = fx * uim + fy * ure;
+        }
+        double pre = K0 == 0 ? 1.0 : vre, pim = K0 == 0 ? 0.0 : vim;      // vt^k
+#pragma unroll
+        for (int k = K0; k <= K1; ++k) {
+            sre[k] += wre * pre - wim * pim;
+            sim[k] += wre * pim + wim * pre;
+            const double nre = pre * vre - pim * vim;
+            pim = fma(pre, vim, pim * vre);
+            pre = nre;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k <= K1; ++k) {
+        sre[k] = wave_sum(sre[k]);
+        sim[k] = wave_sum(sim[k]);
+    }
+    if (lane == 0) {
+        if (WHICH == 1) {
+            head[g * SFAR_HDR + 0] = cx;
+            head[g * SFAR_HDR + 1] = cy;
+            head[g * SFAR_HDR + 2] = 1.0 / r;
+            head[g * SFAR_HDR + 3] = 0.0;
+        }
+        double* c = coef + g * SFAR_NCOEF;
+#pragma unroll
+        for (int k = 0; k <= K1; ++k) {
+            c[2 * k] = sre[k];
+            c[2 * k + 1] = sim[k];
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
+    const double* __restrict__ rec, int ns_pad, const double* __restrict__ pxy, int64_t np,
+    const int* __restrict__ pout, double* __restrict__ ou, double* __restrict__ ov, double* __restrict__ op,
+    const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab, unsigned key_lo, unsigned nkeys,
+    const double* __restrict__ head, const double* __restrict__ c1, const double* __restrict__ c2,
+    const double* __restrict__ c3, const unsigned* __restrict__ near, int nch) {
+    extern __shared__ double2 ltab[];
+    for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
+    __syncthreads();
+    TabAddr ta;
+    const double s1 = ldexp(1.0, prm->sh);
+    const int64_t lane = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t g = __builtin_amdgcn_readfirstlane((int)(lane >> 6));
+    if (g * 64 >= np) return;                          // (whole waves, after the only barrier)
+    const int64_t t = min(lane, np - 1);
+    double xs[4], ys[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        xs[a] = pxy[(int64_t)a * np + t] * s1;
+        ys[a] = pxy[(int64_t)(4 + a) * np + t] * s1;
+    }
+    StokesAcc acc[16];
+    // far sources first: the expansion's values are the accumulators' starting values
+    {
+        const double* h = head + g * SFAR_HDR;
+        const double cx = h[0], cy = h[1], rinv = h[2];
+        const double* X1 = c1 + g * SFAR_NCOEF;
+        const double* X2 = c2 + g * SFAR_NCOEF;
+        const double* X3 = c3 + g * SFAR_NCOEF;
+        double zy[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) zy[b] = (ys[b] - cy) * rinv;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double zx = (xs[a] - cx) * rinv;
+            double s1r[4], s1i[4], s2r[4], s2i[4], s3r[4], s3i[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s1r[b] = s1i[b] = s2r[b] = s2i[b] = s3r[b] = s3i[b] = 0.0;
+            for (int k = SFAR_P; k >= 0; --k) {
+                const double hk = k >= 1 ? 0.5 / (double)k : 0.0;
+                const double a1r = k >= 1 ? hk * X1[2 * k] : 0.0, a1i = k >= 1 ? hk * X1[2 * k + 1] : 0.0;
+                const double a2r = X1[2 * (k + 1)], a2i = X1[2 * (k + 1) + 1];
+                // b_k = conj(X3_k)/2 + conj(X2_k)/(2k)
+                const double b3r = 0.5 * X3[2 * k] + (k >= 1 ? hk * X2[2 * k] : 0.0);
+                const double b3i = -0.5 * X3[2 * k + 1] - (k >= 1 ? hk * X2[2 * k + 1] : 0.0);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    double nr = s1r[b] * zx - s1i[b] * zy[b] + a1r;
+                    s1i[b] = fma(s1r[b], zy[b], s1i[b] * zx) + a1i;
+                    s1r[b] = nr;
+                    nr = s2r[b] * zx - s2i[b] * zy[b] + a2r;
+                    s2i[b] = fma(s2r[b], zy[b], s2i[b] * zx) + a2i;
+                    s2r[b] = nr;
+                    // conj(zeta) = zx - i zy
+                    nr = s3r[b] * zx + s3i[b] * zy[b] + b3r;
+                    s3i[b] = fma(-s3r[b], zy[b], s3i[b] * zx) + b3i;
+                    s3r[b] = nr;
+                }
+            }
+            const double c0r = X1[0], c0i = X1[1];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                // zeta conj(S2) = (zx + i zy)(s2r - i s2i)
+                const double qr = zx * s2r[b] + zy[b] * s2i[b], qi = zy[b] * s2r[b] - zx * s2i[b];
+                StokesAcc v;
+                v.uL = 0.0;
+                v.vL = 0.0;
+                v.u = c0r + s1r[b] + s3r[b] - 0.5 * qr;
+                v.v = c0i + s1i[b] + s3i[b] - 0.5 * qi;
+                v.p = -rinv * s2r[b];
+                acc[4 * a + b] = v;
+            }
+        }
+    }
+    // near sources: batch by batch through the table
+    const unsigned* nm = near + g * nch;
+    for (int c = 0; c < nch; ++c) {
+        unsigned m = nm[c];
+        while (m) {
+            const int bt = __builtin_ctz(m);
+            m &= m - 1;
+            const double* row = rec + ((size_t)(8 * c + bt) * IPDE_SRC_NCH) * IPDE_SRC_PAD;
+#pragma unroll
+            for (int u = 0; u < IPDE_SRC_PAD; ++u) {
+                const double sx = row[u], sy = row[IPDE_SRC_PAD + u];
+                const double fx = row[2 * IPDE_SRC_PAD + u], fy = row[3 * IPDE_SRC_PAD + u];
+                double dy[4], dy2[4], fydy[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    dy[b] = ys[b] - sy;
+                    dy2[b] = dy[b] * dy[b];
+                    fydy[b] = fy * dy[b];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const double dx = xs[a] - sx;
+                    const double dx2 = dx * dx, fxdx = fx * dx;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const double d2 = dx2 + dy2[b];
+                        const double2 e = ta.lookup(ltab, d2);
+                        const double yy = tab_y(d2, e.x);
+                        const double ri = rcp_from_y_fast(e.x, yy);
+                        const double L = log_from_y(yy, e.y);
+                        const double tt = (fxdx + fydy[b]) * ri;
+                        StokesAcc& A = acc[4 * a + b];
+                        A.uL = fma(fx, L, A.uL);
+                        A.vL = fma(fy, L, A.vL);
+                        A.u = fma(tt, dx, A.u);
+                        A.v = fma(tt, dy[b], A.v);
+                        A.p += tt;
+                    }
+                }
+            }
+        }
+    }
+    if (!ta.all_inside(key_lo) || prm->pad) {
+        // a near pair of this patch left the table (or the scaling failed: then nothing is in an
+        // expansion): all sources of its targets again, with the generic math
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double xa[4] = {xs[a], xs[a], xs[a], xs[a]};
+            StokesAcc gs[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) gs[b] = StokesAcc{0, 0, 0, 0, 0};
+            stokes_generic_loop<MODE_SLP, false, 4>(rec, 0, ns_pad, xa, ys, gs);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[4 * a + b] = gs[b];
+        }
+    }
+    if (lane >= np) return;
+    const double cu = prm->corr, cv = prm->corr2;
+    const double ps = 2.0 * s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = pout[(int64_t)r * np + t];
+        if (i >= 0) {
+            ou[i] = fma(-0.5, acc[r].uL + cu, acc[r].u);
+            ov[i] = fma(-0.5, acc[r].vL + cv, acc[r].v);
+            if (op) op[i] = ps * acc[r].p;
+        }
+    }
+}
+
+int launch_stokes_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, const double* pxy, int64_t np,
+                              const int* pout, double* ou, double* ov, double* op, const ApplyParams* prm) {
+    constexpr int NT = 512;
+    const LogTable& lt = ctx->logtab;
+    const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
+    const int64_t ng = ceil_div64(np, 64);
+    const int nch = (int)ceil_div64(ns_pad, 64);
+    const size_t nd = (size_t)ng * (SFAR_HDR + 3 * SFAR_NCOEF);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
+    double* head = (double*)ctx->partial.p;
+    double* c1 = head + (size_t)ng * SFAR_HDR;
+    double* c2 = c1 + (size_t)ng * SFAR_NCOEF;
+    double* c3 = c2 + (size_t)ng * SFAR_NCOEF;
+    unsigned* near = (unsigned*)(c3 + (size_t)ng * SFAR_NCOEF);
+    const unsigned gb = (unsigned)ceil_div64(ng, 4);
+    ipde_time_begin(ctx);
+    hipLaunchKernelGGL(stokes_far_coeff_kernel<1>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                       head, c1, near, nch);
+    hipLaunchKernelGGL(stokes_far_coeff_kernel<2>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                       head, c2, near, nch);
+    hipLaunchKernelGGL(stokes_far_coeff_kernel<3>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                       head, c3, near, nch);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    const size_t lds = (size_t)lt.nkeys * sizeof(double2);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stokes_patch_far_kernel<NT>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((stokes_patch_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds,
+                       ctx->stream, rec, ns_pad, pxy, np, pout, ou, ov, op, prm, (const double2*)lt.d_tab,
+                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)c1,
+                       (const double*)c2, (const double*)c3, (const unsigned*)near, nch);
+    ipde_time_end(ctx);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
 template <int MODE>
 int launch_stokes(ipde_ctx* ctx, const double* rec, int64_t ns, const double* tx, const double* ty,
                   int64_t nt, double* ou, double* ov, double* op, const ApplyParams* prm,
@@ -477,4 +776,34 @@ extern "C" int ipde_stokes_apply(ipde_ctx* ctx, int loc, int64_t ns, const doubl
     IPDE_TRY(ipde_stage_finish(ctx, loc, 9, out_v, nt));
     IPDE_TRY(ipde_stage_finish(ctx, loc, 10, out_p, nt));
     return IPDE_OK;
+}
+
+// Stokeslet sums (with pressure) onto a patch list whose 64-patch groups are 8 x 8 blocks of tiles
+// (ipde_target_plan_build_blocks, pad_blocks = 1): far sources block by block in local expansions.
+extern "C" int ipde_stokes_apply_patches_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                             const double* wfx, const double* wfy, int64_t np,
+                                             const double* pxy, const int32_t* pout, double* out_u,
+                                             double* out_v, double* out_p) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ns >= 0 && np >= 0 && ns < (1LL << 30) && np < (1LL << 27));
+    if (np == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, pxy && pout && out_u && out_v);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && wfx && wfy);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    PackArgs pa{};
+    pa.sx = sx;
+    pa.sy = sy;
+    pa.ch[0] = wfx;
+    pa.mul[0] = 0.25 / M_PI;
+    pa.ch[1] = wfy;
+    pa.mul[1] = 0.25 / M_PI;
+    pa.stokes_ng = 0;
+    pa.corr_ch = 0;
+    pa.corr2_ch = 1;
+    pa.use_scale = 1;
+    pa.exp_hi = ctx->logtab.exp_hi;
+    const double* rec;
+    const ApplyParams* prm;
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, pxy, pxy + 4 * np, 4 * np, &rec, &prm));
+    return launch_stokes_patches_far(ctx, rec, ns, pxy, np, pout, out_u, out_v, out_p, prm);
 }

@@ -340,6 +340,11 @@ def Stokes_Layer_Apply(source, target=None, forces=None, dipstr=None, pressure=T
     src = _source_side(source, trg)
     f = _weighted(forces, src.weights, rows=2)
     g = _weighted(dipstr, src.weights, rows=2)
+    if g is None and not self_eval and isinstance(target, DeviceTargets) and target.far:
+        plan = target.plan()
+        if plan is not None and plan.padded_blocks:      # far sources block by block in local expansions
+            from . import target_plan
+            return target_plan.stokes_apply(plan, src.x, src.y, f[0], f[1], pressure=pressure, ctx=target.ctx)
     return stokes_apply(src.x, src.y, tx, ty,
                         wfx=None if f is None else f[0], wfy=None if f is None else f[1],
                         nx=None if g is None else src.normal_x,

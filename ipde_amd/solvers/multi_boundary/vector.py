@@ -5,6 +5,8 @@ ipde/solvers/multi_boundary/vector.py:6-114 step for step:
   radial->grid.
 As in the scalar driver the grid-sized arrays stay in HBM for the whole solve.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -22,10 +24,16 @@ from ...spectral import get_plan
 
 
 class VectorSolver(object):
+    # the dense sum onto grid_pnai with every 8 x 8 block's far sources in local expansions
+    # (ipde_stokes_apply_patches_far; IPDE_FAR_EXPANSION=0 or this attribute False: every pair directly)
+    FAR_EXPANSION = True
+
     def __init__(self, ebdyc, solver_type='spectral', helpers=None, grid_backend=None, **kwargs):
         self.ebdyc = ebdyc
         self.solver_type = solver_type
         self.grid_backend = grid_backend
+        if os.environ.get("IPDE_FAR_EXPANSION", "1") == "0":
+            self.FAR_EXPANSION = False      # A/B switch
         if helpers is None:
             helpers = [None, ] * self.ebdyc.N
         self._extract_extra_kwargs(**kwargs)
@@ -101,7 +109,7 @@ class VectorSolver(object):
                              "ipde_amd.grid_evaluators.stokes_grid_evaluator stays available on its own")
         self.Grid_Evaluator = make_pnai_evaluator(
             lambda src, trg, f: self.Layer_Apply(src, trg, f), self.grid_sources, e.grid_pnai,
-            lambda x, y: DeviceTargets(PointSet(x=x, y=y)))
+            lambda x, y: DeviceTargets(PointSet(x=x, y=y), plan=self.FAR_EXPANSION, far=self.FAR_EXPANSION))
         self.split_grid_evaluation = False
         self._pin_in = torch.empty((2, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
 

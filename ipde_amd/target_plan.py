@@ -159,3 +159,29 @@ def laplace_apply(plan, sx, sy, w_sigma=None, nx=None, ny=None, w_tau=None, ctx=
     ctx.check(fn(ctx.handle, int(sx.shape[0]), ptr(sx), ptr(sy), ptr(w_sigma), ptr(nx), ptr(ny), ptr(w_tau),
                  plan.np, ptr(plan.pxy), ptr(plan.pout), ptr(out)))
     return out
+
+
+def stokes_apply(plan, sx, sy, wfx, wfy, pressure=True, ctx=None):
+    """Stokeslet sums (u, v, p) over a planned list with padded blocks: the patches through
+    ipde_stokes_apply_patches_far (every block's far sources in local expansions), the remainder
+    through ipde_stokes_apply.  Device tensors; wfx, wfy weight-multiplied."""
+    from . import _lib
+    from .layer_potentials import _match, stokes_apply as list_apply
+    ctx = ctx or get_context()
+    if not plan.padded_blocks:
+        raise ValueError("the far-field form needs a plan built with pad_blocks=True")
+    sx, sy, wfx, wfy = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (sx, sy, wfx, wfy))
+    dev = plan.pxy.device
+    u = torch.empty(plan.n, dtype=torch.float64, device=dev)
+    v = torch.empty(plan.n, dtype=torch.float64, device=dev)
+    p = torch.empty(plan.n, dtype=torch.float64, device=dev) if pressure else None
+    if plan.nrest:
+        ru, rv, rp = list_apply(sx, sy, plan.rest_x, plan.rest_y, wfx=wfx, wfy=wfy, pressure=pressure, ctx=ctx)
+        u[plan.rest] = ru
+        v[plan.rest] = rv
+        if pressure:
+            p[plan.rest] = rp
+    ctx.check(ctx.lib.ipde_stokes_apply_patches_far(ctx.handle, int(sx.shape[0]), ptr(sx), ptr(sy), ptr(wfx),
+                                                    ptr(wfy), plan.np, ptr(plan.pxy), ptr(plan.pout), ptr(u),
+                                                    ptr(v), ptr(p)))
+    return u, v, p

@@ -40,3 +40,22 @@ for name, kw in (("slp", dict(charge=s1)), ("dlp", dict(dipstr=s2)), ("both", di
             lp.Laplace_Layer_Apply(c, t, **kw)
         torch.cuda.synchronize()
         print("   %-6s %.3f ms per apply (wall, %d applies)" % (tname, (time.perf_counter() - t0) / n * 1e3, n))
+
+# Stokeslet sums with pressure
+f = rng.standard_normal((2, c.N))
+a = lp.Stokes_Layer_Apply(c, lp.DeviceTargets(trg), forces=f)
+b = lp.Stokes_Layer_Apply(c, far, forces=f)
+torch.cuda.synchronize()
+for name, x, y in zip("uvp", a, b):
+    print("stokes %s max|direct| %.3e  max|far - direct| %.3e" % (name, float(x.abs().max()), float((x - y).abs().max())))
+plain_list = lp.DeviceTargets(trg)
+for tname, t in (("direct", plain_list), ("far", far)):
+    for _ in range(3):
+        lp.Stokes_Layer_Apply(c, t, forces=f)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        lp.Stokes_Layer_Apply(c, t, forces=f)
+    torch.cuda.synchronize()
+    print("   stokes %-6s %.3f ms per apply (wall, %d applies)" % (tname, (time.perf_counter() - t0) / n * 1e3, n))

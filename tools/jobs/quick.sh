@@ -4,14 +4,10 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r03/far
 mkdir -p $O
-rm -rf $O/solve_trace
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/solve_trace -- python3 tools/profile_solve.py > $O/solve_trace.log 2>&1
-ms=$(grep "warm solve" $O/solve_trace.log | awk '{print $3}')
-python3 tools/analyze_trace.py $O/solve_trace $ms 10 > $O/poisson_solve_budget_far.json
-find $O/solve_trace -name "*.csv" -size +20M -delete
-python3 - <<'PY'
-import json
-d=json.load(open("gpurun_out/r03/far/poisson_solve_budget_far.json"))
-print(d["warm_solve_ms"], d["gpu_busy_ms_per_solve"], d["launches_per_solve"])
-for k,v in list(d["kernels_ms_per_solve"].items())[:16]: print("%8.3f %5.1f  %s"%(v["ms"],v["launches"],k[:80]))
-PY
+timeout -k 10 300 python3 tools/ab_far_expansion.py 2>&1 | tee $O/ab_far_2048_b.txt
+timeout -k 10 900 python3 -m pytest tests/test_layer_gpu.py -m gpu -x -q -k "far_expansion" 2>&1 | tail -5
+export IPDE_PROFILE_SOLVES=20
+for i in 1 2; do
+IPDE_FAR_EXPANSION=0 timeout -k 10 300 python3 tools/profile_stokes_solve.py 2>&1 | grep "warm\|err" | sed 's/^/direct /' | tee -a $O/ab_stokes_solve.txt
+timeout -k 10 300 python3 tools/profile_stokes_solve.py 2>&1 | grep "warm\|err" | sed 's/^/far    /' | tee -a $O/ab_stokes_solve.txt
+done
