@@ -529,46 +529,55 @@ __global__ __launch_bounds__(256) void laplace_far_coeff_kernel(const double* __
     double sre[K1 + 1], sim[K1 + 1];
 #pragma unroll
     for (int k = 0; k <= K1; ++k) sre[k] = sim[k] = 0.0;
-    for (int j0 = 0; j0 < ns_pad; j0 += 64) {
-        const int j = j0 + lane;
-        const bool valid = j < ns_pad;
-        const int jj = valid ? j : ns_pad - 1;
-        const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
-        const double d2 = fma(dy, dy, dx * dx);
-        // a batch of eight sources goes one way as a whole: into the expansion only if all eight are far
-        const unsigned long long m = __ballot(valid && !(d2 >= thr && !prm->pad));
-        const bool far = valid && ((m >> (lane & ~7)) & 0xFFull) == 0;
-        if (write_near && lane == 0) {
-            unsigned bits = 0;
+    // two sources per lane and trip: two independent power chains in flight
+    for (int j0 = 0; j0 < ns_pad; j0 += 128) {
+        double vre[2], vim[2], wre[2], wim[2];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) bits |= ((m >> (8 * b)) & 0xFFull) ? (1u << b) : 0u;
-            near[g * nch + (j0 >> 6)] = bits;
+        for (int h = 0; h < 2; ++h) {
+            const int jb = j0 + 64 * h;                    // (wave-uniform)
+            const int j = jb + lane;
+            const bool valid = j < ns_pad;
+            const int jj = valid ? j : ns_pad - 1;
+            const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
+            const double d2 = fma(dy, dy, dx * dx);
+            // a batch of eight sources goes one way as a whole: into the expansion only if all eight are far
+            const unsigned long long m = __ballot(valid && !(d2 >= thr && !prm->pad));
+            const bool far = valid && ((m >> (lane & ~7)) & 0xFFull) == 0;
+            if (write_near && lane == 0 && jb < ns_pad) {
+                unsigned bits = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) bits |= ((m >> (8 * b)) & 0xFFull) ? (1u << b) : 0u;
+                near[g * nch + (jb >> 6)] = bits;
+            }
+            // near sources ride along with zero weight at a harmless position
+            const double inv = far ? r / d2 : 0.0;
+            vre[h] = dx * inv;
+            vim[h] = -dy * inv;                            // vt = r / (z_j - c)
+            if (WHICH == MODE_SLP) {
+                wre[h] = far ? rec[ipde_rec_index(jj, 2)] : 0.0;
+                wim[h] = 0.0;
+                sre[0] = fma(wre[h], log(far ? d2 : 1.0), sre[0]);
+            } else {
+                wre[h] = far ? rec[ipde_rec_index(jj, 3)] / r : 0.0;
+                wim[h] = far ? rec[ipde_rec_index(jj, 4)] / r : 0.0;
+            }
         }
-        // near sources ride along with zero weight at a harmless position
-        const double inv = far ? r / d2 : 0.0;
-        const double vre = dx * inv, vim = -dy * inv;        // vt = r / (z_j - c)
-        double wre, wim;
-        if (WHICH == MODE_SLP) {
-            wre = far ? rec[ipde_rec_index(jj, 2)] : 0.0;
-            wim = 0.0;
-            sre[0] = fma(wre, log(far ? d2 : 1.0), sre[0]);
-        } else {
-            wre = far ? rec[ipde_rec_index(jj, 3)] / r : 0.0;
-            wim = far ? rec[ipde_rec_index(jj, 4)] / r : 0.0;
-        }
-        double pre = vre, pim = vim;                            // vt^k
+        double pre[2] = {vre[0], vre[1]}, pim[2] = {vim[0], vim[1]};      // vt^k
 #pragma unroll
         for (int k = 1; k <= K1; ++k) {
-            if (WHICH == MODE_SLP) {
-                sre[k] = fma(wre, pre, sre[k]);
-                sim[k] = fma(wre, pim, sim[k]);
-            } else {
-                sre[k] += wre * pre - wim * pim;
-                sim[k] += wre * pim + wim * pre;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (WHICH == MODE_SLP) {
+                    sre[k] = fma(wre[h], pre[h], sre[k]);
+                    sim[k] = fma(wre[h], pim[h], sim[k]);
+                } else {
+                    sre[k] += wre[h] * pre[h] - wim[h] * pim[h];
+                    sim[k] += wre[h] * pim[h] + wim[h] * pre[h];
+                }
+                const double nre = pre[h] * vre[h] - pim[h] * vim[h];
+                pim[h] = fma(pre[h], vim[h], pim[h] * vre[h]);
+                pre[h] = nre;
             }
-            const double nre = pre * vre - pim * vim;
-            pim = fma(pre, vim, pim * vre);
-            pre = nre;
         }
     }
 #pragma unroll

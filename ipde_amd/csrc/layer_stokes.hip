@@ -386,49 +386,64 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
     double sre[K1 + 1], sim[K1 + 1];
 #pragma unroll
     for (int k = 0; k <= K1; ++k) sre[k] = sim[k] = 0.0;
-    for (int j0 = 0; j0 < ns_pad; j0 += 64) {
-        const int j = j0 + lane;
-        const bool valid = j < ns_pad;
-        const int jj = valid ? j : ns_pad - 1;
-        const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
-        const double d2 = fma(dy, dy, dx * dx);
-        // a batch of eight sources goes one way as a whole
-        const unsigned long long m = __ballot(valid && !(d2 >= thr && !prm->pad));
-        const bool far = valid && ((m >> (lane & ~7)) & 0xFFull) == 0;
-        if (WHICH == 1 && lane == 0) {
-            unsigned bits = 0;
+    // two sources per lane and trip: two independent power chains in flight (the chain of complex
+    // products is the critical path at two waves per SIMD)
+    for (int j0 = 0; j0 < ns_pad; j0 += 128) {
+        double vre[2], vim[2], wre[2], wim[2];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) bits |= ((m >> (8 * b)) & 0xFFull) ? (1u << b) : 0u;
-            near[g * nch + (j0 >> 6)] = bits;
+        for (int h = 0; h < 2; ++h) {
+            const int jb = j0 + 64 * h;                    // (wave-uniform)
+            const int j = jb + lane;
+            const bool valid = j < ns_pad;
+            const int jj = valid ? j : ns_pad - 1;
+            const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
+            const double d2 = fma(dy, dy, dx * dx);
+            // a batch of eight sources goes one way as a whole
+            const unsigned long long m = __ballot(valid && !(d2 >= thr && !prm->pad));
+            const bool far = valid && ((m >> (lane & ~7)) & 0xFFull) == 0;
+            if (WHICH == 1 && lane == 0 && jb < ns_pad) {
+                unsigned bits = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) bits |= ((m >> (8 * b)) & 0xFFull) ? (1u << b) : 0u;
+                near[g * nch + (jb >> 6)] = bits;
+            }
+            const double inv = far ? r / d2 : 0.0;
+            vre[h] = dx * inv;
+            vim[h] = -dy * inv;                            // vt = r / (z_j - c)
+            const double fx = far ? rec[ipde_rec_index(jj, 2)] : 0.0, fy = far ? rec[ipde_rec_index(jj, 3)] : 0.0;
+            if (WHICH == 1) {
+                wre[h] = fx;
+                wim[h] = fy;
+                const double hl = fma(-0.5, log(far ? d2 : 1.0), 0.5);     // 1/2 - log|c - z_j|
+                sre[0] = fma(fx, hl, sre[0]);
+                sim[0] = fma(fy, hl, sim[0]);
+            } else if (WHICH == 2) {
+                wre[h] = fx;
+                wim[h] = -fy;
+            } else {
+                // F vt / conj(vt) = F vt^2 / |vt|^2 = F (dx - i dy)^2 / d2
+                const double id = far ? 1.0 / d2 : 0.0;
+                const double ure = (dx * dx - dy * dy) * id, uim = -2.0 * dx * dy * id;
+                wre[h] = fx * ure - fy * uim;
+                wim[h] = fx * uim + fy * ure;
+            }
         }
-        const double inv = far ? r / d2 : 0.0;
-        const double vre = dx * inv, vim = -dy * inv;        // vt = r / (z_j - c)
-        const double fx = far ? rec[ipde_rec_index(jj, 2)] : 0.0, fy = far ? rec[ipde_rec_index(jj, 3)] : 0.0;
-        double wre, wim;
-        if (WHICH == 1) {
-            wre = fx;
-            wim = fy;
-            const double h = fma(-0.5, log(far ? d2 : 1.0), 0.5);     // 1/2 - log|c - z_j|
-            sre[0] = fma(fx, h, sre[0]);
-            sim[0] = fma(fy, h, sim[0]);
-        } else if (WHICH == 2) {
-            wre = fx;
-            wim = -fy;
-        } else {
-            // F vt / conj(vt) = F vt^2 / |vt|^2 = F (dx - i dy)^2 / d2
-            const double id = far ? 1.0 / d2 : 0.0;
-            const double ure = (dx * dx - dy * dy) * id, uim = -2.0 * dx * dy * id;
-            wre = fx * ure - fy * uim;
-            wim = fx * uim + fy * ure;
+        double pre[2], pim[2];                             // vt^k
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            pre[h] = K0 == 0 ? 1.0 : vre[h];
+            pim[h] = K0 == 0 ? 0.0 : vim[h];
         }
-        double pre = K0 == 0 ? 1.0 : vre, pim = K0 == 0 ? 0.0 : vim;      // vt^k
 #pragma unroll
         for (int k = K0; k <= K1; ++k) {
-            sre[k] += wre * pre - wim * pim;
-            sim[k] += wre * pim + wim * pre;
-            const double nre = pre * vre - pim * vim;
-            pim = fma(pre, vim, pim * vre);
-            pre = nre;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                sre[k] += wre[h] * pre[h] - wim[h] * pim[h];
+                sim[k] += wre[h] * pim[h] + wim[h] * pre[h];
+                const double nre = pre[h] * vre[h] - pim[h] * vim[h];
+                pim[h] = fma(pre[h], vim[h], pim[h] * vre[h]);
+                pre[h] = nre;
+            }
         }
     }
 #pragma unroll

@@ -151,8 +151,12 @@ class VectorHelper(object):
         dev = bu.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
         fr, ft = new(M, N), new(M, N)
-        fu, fv = (np.ascontiguousarray(a, dtype=float) for a in (fur, fvr))
-        ctx.check(ctx.lib.ipde_stokes_rotate(ctx.handle, _lib.IPDE_HOST, M, N, ptr(fu), ptr(fv), ptr(c['geom']), 1,
+        if isinstance(fur, torch.Tensor):       # forcing resident in HBM (hostio.DeviceFunction)
+            loc, fu, fv = _lib.IPDE_DEVICE, fur.contiguous(), fvr.contiguous()
+        else:
+            loc = _lib.IPDE_HOST
+            fu, fv = (np.ascontiguousarray(a, dtype=float) for a in (fur, fvr))
+        ctx.check(ctx.lib.ipde_stokes_rotate(ctx.handle, loc, M, N, ptr(fu), ptr(fv), ptr(c['geom']), 1,
                                              ptr(fr), ptr(ft)))
         z = c['zero']
         rr, tr, pr = self.annular_solver.solve(self.RAG, fr, ft, z, z, z, z, **kwargs)

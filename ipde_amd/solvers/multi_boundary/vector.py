@@ -147,9 +147,19 @@ class VectorSolver(object):
         Nx, Ny = self.grid.shape
         fur_list = fu.get_radial_value_list()
         fvr_list = fv.get_radial_value_list()
-        fp = torch.empty((2, e.grid_phys.N), dtype=torch.float64, device=self._dev)
-        hostio.upload(fp[0], fu['grid'], self._pin_in[0])
-        hostio.upload(fp[1], fv['grid'], self._pin_in[1])
+        # hostio.DeviceFunction forcings: everything stays in HBM, the answers come back the same way
+        resident = isinstance(fu, hostio.DeviceFunction)
+        if resident != isinstance(fv, hostio.DeviceFunction):
+            raise ValueError("fu and fv must be the same kind of container")
+        if resident:
+            for f in (fu, fv):
+                if f.ebdyc is not e or f.data.device != self._dev:
+                    raise ValueError("DeviceFunction of another collection or device")
+            fp = (fu.grid_values, fv.grid_values)
+        else:
+            fp = torch.empty((2, e.grid_phys.N), dtype=torch.float64, device=self._dev)
+            hostio.upload(fp[0], fu['grid'], self._pin_in[0])
+            hostio.upload(fp[1], fv['grid'], self._pin_in[1])
         fc = [gridops.scatter(self._phys_idx, fp[k], Nx * Ny, scale=self._grid_step_d).view(Nx, Ny) for k in (0, 1)]
         uc, vc, pc = (a.contiguous() for a in self._grid_solve(fc[0], fc[1]))
         # velocity and stress of the grid solution on every interface node (:66-82)
@@ -206,11 +216,18 @@ class VectorSolver(object):
             for h, r in zip(self.helpers, res):
                 h.ur, h.vr, h.pr = r[0], r[1], r[2]
         urs, vrs, prs = zip(*res)
-        # the answers are built over pinned memory: the device->host copies write the caller's arrays
-        made = [hostio.pinned_function(e) for _ in range(3)]
         # the three fields of a boundary share their targets: one library call per boundary
         for b, (idx, xi, t) in enumerate(self._ia):
             radial_to_grid([urs[b], vrs[b], prs[b]], xi, t, idx=idx, outs=list(fields))
+        if resident:
+            outs = [hostio.DeviceFunction(e, device=self._dev) for _ in range(3)]
+            for d, f, rs in zip(outs, fields, (urs, vrs, prs)):
+                gridops.gather(self._phys_idx, f, out=d.data[:d.n_grid])
+                for sl, r in zip(d.radial_slices, rs):
+                    d.data[sl].copy_(torch.as_tensor(r, device=self._dev).reshape(-1))
+            return tuple(outs)
+        # the answers are built over pinned memory: the device->host copies write the caller's arrays
+        made = [hostio.pinned_function(e) for _ in range(3)]
         for (g, block), f, rs in zip(made, fields, (urs, vrs, prs)):
             block[:e.grid_phys.N].copy_(gridops.gather(self._phys_idx, f), non_blocking=True)
             for i, (sl, r) in enumerate(zip(g.radial_slices, rs)):

@@ -435,3 +435,30 @@ def test_poisson_solver_far_expansion_equals_pair_by_pair_grid_sum():
     assert res[None][0] < 1e-11 and res['pybie2d'][0] < 1e-11
     assert np.array_equal(res[None][1], res['fmm2d'][1])
     assert np.abs(res[None][1] - res['pybie2d'][1]).max() < 1e-13 * np.abs(res['pybie2d'][1]).max()
+
+
+def test_stokes_solver_device_resident_forcings_and_answers():
+    """StokesSolver with hostio.DeviceFunction forcings: (u, v, p) come back as DeviceFunctions, bit for
+    bit the host-container answers (3 bodies; the grid sum takes the far-field form, 1370^2 grid)."""
+    import multi_stokes as ms
+    from ipde_amd import hostio
+    kept = {}
+    orig = ms.StokesSolver.__call__
+
+    def wrapped(self, fu, fv, **kw):
+        kept.setdefault("args", (self, fu, fv, kw))
+        return orig(self, fu, fv, **kw)
+    ms.StokesSolver.__call__ = wrapped
+    try:
+        ms.run(nb=800, M=14)
+    finally:
+        ms.StokesSolver.__call__ = orig
+    solver, fu, fv, kw = kept["args"]
+    assert solver.FAR_EXPANSION
+    host = solver(fu, fv, **kw)
+    dev = solver(hostio.DeviceFunction.from_host(fu), hostio.DeviceFunction.from_host(fv), **kw)
+    assert all(isinstance(d, hostio.DeviceFunction) for d in dev)
+    for d, h in zip(dev, host):
+        assert np.array_equal(np.asarray(d.to_host()), np.asarray(h))
+    with pytest.raises(ValueError):
+        solver(hostio.DeviceFunction.from_host(fu), fv, **kw)

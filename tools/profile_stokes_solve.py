@@ -19,6 +19,9 @@ def wrapped(self, fu, fv, **kw):
     out = orig(self, fu, fv, **kw)
     if 'done' not in state:
         state['done'] = True
+        if os.environ.get("IPDE_PROFILE_RESIDENT") == "1":     # forcings and answers stay in HBM
+            from ipde_amd import hostio
+            fu, fv = hostio.DeviceFunction.from_host(fu), hostio.DeviceFunction.from_host(fv)
         orig(self, fu, fv, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -39,4 +42,5 @@ if os.environ.get("IPDE_VECTOR_DEVICE_FLOW") is not None:      # A/B of the help
     from ipde_amd.solvers.multi_boundary.vector import VectorSolver
     VectorSolver.DEVICE_FLOW = os.environ["IPDE_VECTOR_DEVICE_FLOW"] != "0"
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 800
-ms.run(nb, 14)
+ng = int(sys.argv[2]) if len(sys.argv) > 2 else None       # 4096: BASELINE configs[4] (with nb = 2400)
+ms.run(nb, 14, **({} if ng is None else {'ng': ng}))
