@@ -175,3 +175,35 @@ def test_host_builder_argument_checks():
     assert lib.ipde_target_plan_sizes(None, ctypes.byref(n1), ctypes.byref(n2)) == _lib.IPDE_ERR_INVALID
     assert lib.ipde_target_plan_destroy(h) == _lib.IPDE_OK
     assert lib.ipde_target_plan_destroy(None) == _lib.IPDE_OK
+
+
+def test_padded_blocks_are_whole_waves_of_one_block_of_tiles():
+    """build_host(pad_blocks=True) (ipde_target_plan_build_blocks): the same real patches in the same
+    order as the unpadded plan, every 8 x 8 block of tiles filled up to 64 patches with copies of its
+    first one that store nothing — so that patches [64 k, 64 k + 64) lie in one 32 x 32 window of the
+    lattice (what the far-field kernels' per-wave expansions assume)."""
+    x, y = _band_list(200, clearance=2.5)
+    x = np.concatenate([x, [0.123456, -0.7]])         # two off-lattice points: the remainder
+    y = np.concatenate([y, [0.654321, 0.31]])
+    plain = target_plan.build_host(x, y)
+    pad = target_plan.build_host(x, y, pad_blocks=True)
+    _check_partition(x, y, pad)
+    assert pad.padded_blocks and not plain.padded_blocks
+    assert pad.np % 64 == 0 and pad.np > plain.np and pad.nrest == plain.nrest == 2
+    pout, pxy = pad.pout.numpy(), pad.pxy.numpy()
+    real = (pout >= 0).any(axis=0)
+    assert int(real.sum()) == plain.np
+    assert np.array_equal(pout[:, real], plain.pout.numpy()) and np.array_equal(pxy[:, real], plain.pxy.numpy())
+    h = 3.0 / 200
+    blocks = pxy.reshape(8, -1, 64)
+    assert (blocks[:4].max(axis=(0, 2)) - blocks[:4].min(axis=(0, 2))).max() < 31.5 * h
+    assert (blocks[4:].max(axis=(0, 2)) - blocks[4:].min(axis=(0, 2))).max() < 31.5 * h
+    # a dummy is a copy of its block's first patch
+    first = np.repeat(blocks[:, :, :1], 64, axis=2).reshape(8, -1)
+    assert np.array_equal(pxy[:, ~real], first[:, ~real])
+    with pytest.raises(ValueError):
+        target_plan.build_host(x, y, block=(4, 4), pad_blocks=True)
+    # fewer patches than asked for, or no grid: no plan, padded or not
+    assert target_plan.build_host(x, y, min_patches=10 ** 6, pad_blocks=True).np == 0
+    assert not target_plan.build_host(np.random.default_rng(0).uniform(size=500),
+                                      np.random.default_rng(1).uniform(size=500), pad_blocks=True).padded_blocks
