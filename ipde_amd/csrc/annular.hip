@@ -1456,6 +1456,7 @@ struct ipde_annular_stokes : public LinOp {
     double *psi0 = nullptr, *psi1 = nullptr, *ipsi1 = nullptr, *ipsi2 = nullptr;
     double *combo1 = nullptr, *combo2 = nullptr, *c3 = nullptr, *c4 = nullptr, *DRpsi2 = nullptr;
     cd *A = nullptr, *Bw = nullptr;   // complex work, (6M) x n each
+    cd* Cw = nullptr;                 // complex work, (3M) x n: the last transform's input (merged launches)
     double* Rw = nullptr;             // real work (4M) x n
     cd *xs = nullptr, *ys = nullptr;  // preconditioner stacking (B, ns)
     cd* bvec = nullptr;
@@ -1487,7 +1488,7 @@ struct ipde_annular_stokes : public LinOp {
         for (double** p : {&R01, &R12, &R02, &D01, &D12, &BC, &VI1, &psi0, &psi1, &ipsi1, &ipsi2,
                            &combo1, &combo2, &c3, &c4, &DRpsi2, &Rw, &rstage})
             if (*p) hipFree(*p);
-        for (cd** p : {&Kt, &iks, &A, &Bw, &xs, &ys, &bvec, &hin, &hout})
+        for (cd** p : {&Kt, &iks, &A, &Bw, &Cw, &xs, &ys, &bvec, &hin, &hout})
             if (*p) hipFree(*p);
         gmres_free(gw);
     }
@@ -1542,7 +1543,9 @@ struct MixTerm {
 };
 constexpr int MIX_MAXT = 6, MIX_MAXO = 3;
 struct MixOut {
-    double* out;         // (rows, n)
+    double* out;         // (rows, n); nullable when cout is given
+    cd* cout;            // nullable: the same rows as complex numbers (imaginary part 0), the next
+                         // transform's input (what r2c_copy_kernel made of `out` in a launch of its own)
     int rows;
     int nterms;
     MixTerm t[MIX_MAXT];
@@ -1584,7 +1587,8 @@ __global__ __launch_bounds__(256) void mix_multi_kernel(MixBatch B, int n) {
         }
         acc = (k == 0) ? s : fma(1.0, acc, s);
     }
-    O.out[(size_t)a * n + j] = acc;
+    if (O.out) O.out[(size_t)a * n + j] = acc;
+    if (O.cout) O.cout[(size_t)a * n + j] = cd{1.0 * acc, 0.0};
 }
 
 // the six splats of the operator's first stage: A rows [ur | ut | p | ik ur | ik ut | ik p]
@@ -1657,6 +1661,54 @@ __global__ __launch_bounds__(256) void bc2_kernel(cd* __restrict__ out0, cd* __r
         si = fma(Ar[b], v.y, si);
     }
     out[(size_t)a * ldo + j] = cd{1.0 * sr, 1.0 * si};
+}
+// desplat3 + bc2 + pressure_mean in one launch (the three write disjoint entries of `out`, except
+// that the pressure-mean fix adds to column 0 of the p block: the thread that desplats such an
+// entry adds the sum itself).  Same operations in the same order as the three kernels: bitwise
+// their result.  idx < nd: desplat entries; then 4 ns boundary-condition entries.
+__global__ __launch_bounds__(256) void stokes_finish_kernel(cd* __restrict__ out, int64_t NU,
+                                                            const cd* __restrict__ FH, int M, int n,
+                                                            const double* __restrict__ BC,
+                                                            const cd* __restrict__ urh, const cd* __restrict__ uth,
+                                                            const double* __restrict__ VI1,
+                                                            const cd* __restrict__ ph) {
+    const int m1 = M - 1, m2 = M - 2, ns = n - 1, N2 = n / 2;
+    const int64_t nd = (int64_t)(2 * m2 + m1) * ns;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < nd) {
+        int a = (int)(idx / ns), js = (int)(idx - (int64_t)a * ns);
+        int j = js < N2 ? js : js + 1;
+        cd v = FH[(size_t)a * n + j];
+        int blk = a < m2 ? 0 : (a < 2 * m2 ? 1 : 2);
+        int r = a - (blk == 0 ? 0 : (blk == 1 ? m2 : 2 * m2));
+        v = cd{1.0 * v.x, 1.0 * v.y};
+        if (blk == 2 && js == 0) {
+            double sr = 0.0, si = 0.0;
+            for (int b = 0; b < m1; ++b) {
+                cd w = ph[(size_t)b * ns];
+                sr = fma(VI1[b], w.x, sr);
+                si = fma(VI1[b], w.y, si);
+            }
+            v = cd{v.x + sr, v.y + si};
+        }
+        out[(size_t)blk * NU + (size_t)r * ns + js] = v;
+        return;
+    }
+    idx -= nd;
+    if (idx >= (int64_t)4 * ns) return;
+    const int z = (int)(idx / (2 * ns));                 // 0: ur, 1: ut
+    const int a = (int)((idx - (int64_t)z * 2 * ns) / ns);
+    const int j = (int)(idx - (int64_t)z * 2 * ns - (int64_t)a * ns);
+    const cd* in = z == 0 ? urh : uth;
+    const double* Ar = BC + (size_t)a * M;
+    double sr = 0.0, si = 0.0;
+#pragma unroll 4
+    for (int b = 0; b < M; ++b) {
+        cd v = in[(size_t)b * ns + j];
+        sr = fma(Ar[b], v.x, sr);
+        si = fma(Ar[b], v.y, si);
+    }
+    out[(size_t)z * NU + (size_t)(m2 + a) * ns + j] = cd{1.0 * sr, 1.0 * si};
 }
 }  // namespace
 
@@ -1809,6 +1861,9 @@ int ipde_annular_stokes::apply_grouped(const cd* uuh, cd* out) {
     const cd* ph = uuh + 2 * NU;
     const size_t Mn = (size_t)M * n;
     const int rowsA = 4 * M + 2 * m1;
+    // annular_grouped = 2: the real-to-complex copies ride in the term-list launches and the three
+    // closing launches are one (13 -> 9 launches per operator application, same bits)
+    const bool merged = ctx->opt_annular_grouped >= 2;
     hipLaunchKernelGGL(splat6_kernel, dim3(nb256((int64_t)rowsA * n)), b, 0, st, A, urh, uth, ph, (const cd*)iks,
                        M, n);
     IPDE_TRY(ipde_fft1_exec(ctx, rowsA, n, +1, A, Bw));
@@ -1850,12 +1905,19 @@ int ipde_annular_stokes::apply_grouped(const cd* uuh, cd* out) {
         B.o[0].t[0] = term(R01, M, dur, 1, nullptr, ipsi1, in);
         B.o[1].t[0] = term(R01, M, dut, 1, nullptr, ipsi1, in);
         B.o[2].t[0] = term(R01, M, dut, 1, nullptr, nullptr, in);
+        if (merged) {      // X straight into the transform's input (A is free: its splats are transformed)
+            B.o[0].out = nullptr;
+            B.o[1].out = nullptr;
+            B.o[0].cout = A;
+            B.o[1].cout = A + (size_t)m1 * n;
+        }
         hipLaunchKernelGGL(mix_multi_kernel, dim3(nb256(n), m1, 3), b, 0, st, B, n);
     }
     cd* C1 = A;
     cd* C2 = A + (size_t)2 * m1 * n;
-    hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, C1, (const double*)X,
-                       (int64_t)2 * m1 * n, 1.0);
+    if (!merged)
+        hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, C1, (const double*)X,
+                           (int64_t)2 * m1 * n, 1.0);
     IPDE_TRY(ipde_fft1_exec(ctx, 2 * m1, n, -1, C1, C2));
     hipLaunchKernelGGL(nyquist_mul_kernel, dim3(nb256((int64_t)2 * m1 * n)), b, 0, st, C1, (const cd*)C2, 2 * m1,
                        n, (const cd*)iks);
@@ -1877,6 +1939,10 @@ int ipde_annular_stokes::apply_grouped(const cd* uuh, cd* out) {
         B.o[2].nterms = 2;
         B.o[2].t[0] = term(D01, M, ur, 1, psi0, ipsi1, in);
         B.o[2].t[1] = term(nullptr, 0, W2, 0, nullptr, ipsi1, 1.0);
+        if (merged) {      // rows [Fr | Ft | Fp] of the last transform's input: Fp from here
+            B.o[2].out = nullptr;
+            B.o[2].cout = Cw + (size_t)2 * m2 * n;
+        }
         hipLaunchKernelGGL(mix_multi_kernel, dim3(nb256(n), m1, 3), b, 0, st, B, n);
     }
     {   // Fr = mu (-lap_ur + t1 + t2 + t3) + t4,  Ft = mu (-lap_ut - t1 + t2 - t3) + t4
@@ -1899,9 +1965,23 @@ int ipde_annular_stokes::apply_grouped(const cd* uuh, cd* out) {
         B.o[1].t[3] = term(R02, M, ut, 1, nullptr, combo2, mu * in);
         B.o[1].t[4] = term(R02, M, ur, 1, nullptr, c4, -mu * in);
         B.o[1].t[5] = term(R12, m1, dp, 1, nullptr, ipsi2, in);
+        if (merged) {
+            B.o[0].out = nullptr;
+            B.o[1].out = nullptr;
+            B.o[0].cout = Cw;
+            B.o[1].cout = Cw + (size_t)m2 * n;
+        }
         hipLaunchKernelGGL(mix_multi_kernel, dim3(nb256(n), m2, 2), b, 0, st, B, n);
     }
     const int rowsF = 2 * m2 + m1;
+    if (merged) {
+        cd* FH = A;        // (urt2 / utt2 in A + 2 m1 n are spent: the term lists above were their last readers)
+        IPDE_TRY(ipde_fft1_exec(ctx, rowsF, n, -1, Cw, FH));
+        hipLaunchKernelGGL(stokes_finish_kernel, dim3(nb256((int64_t)rowsF * ns + 4 * (int64_t)ns)), b, 0, st, out,
+                           (int64_t)NU, (const cd*)FH, M, n, (const double*)BC, urh, uth, (const double*)VI1, ph);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+        return IPDE_OK;
+    }
     hipLaunchKernelGGL(r2c_copy_kernel, dim3(nb256((int64_t)rowsF * n)), b, 0, st, A, (const double*)Fr,
                        (int64_t)rowsF * n, 1.0);
     cd* FH = A + (size_t)rowsF * n;
@@ -1988,6 +2068,7 @@ extern "C" int ipde_annular_stokes_create(ipde_ctx* ctx, int M, int n, double mu
     al((void**)&h->DRpsi2, (size_t)m2 * n * 8);
     al((void**)&h->A, (size_t)(6 * M + 8) * n * sizeof(cd));
     al((void**)&h->Bw, (size_t)(6 * M + 8) * n * sizeof(cd));
+    al((void**)&h->Cw, (size_t)(3 * M + 8) * n * sizeof(cd));
     al((void**)&h->Rw, (size_t)(8 * M + 8) * n * 8);
     al((void**)&h->bvec, (size_t)h->NB * sizeof(cd));
     al((void**)&h->hin, (size_t)h->NB * sizeof(cd));

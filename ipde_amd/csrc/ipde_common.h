@@ -61,7 +61,7 @@ struct ipde_ctx {
     int num_cu = 256;
     // tuning knobs (ipde_ctx_set_option)
     int opt_laplace_variant = 9;   // row-run single layer (variant 1 for the other modes)
-    int opt_annular_grouped = 1;  // Stokes annular operator with grouped launches (0: one launch per term)
+    int opt_annular_grouped = 2;  // Stokes annular operator: 0 = one launch per term, 1 = grouped launches, 2 = grouped, copies and closing launches merged
     int opt_annular_fused_fft = 1; // scalar annular operator: transform pairs as one kernel for power-of-two n <= 4096 (0: rocFFT + pointwise)
     int opt_gmres_lookahead = 1;  // annular GMRES: inner iteration j + 1 enters the stream before the host has read column j (0: enqueue, wait, enqueue)
     int opt_gmres_fused_scale = 1; // annular GMRES: v_j = w / ||w|| formed inside the preconditioner's kernel (0: a launch of its own)

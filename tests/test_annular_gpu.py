@@ -132,14 +132,17 @@ def test_stokes_solver_matches_oracle_mid_size():
     v = rng.standard_normal(S.NB) + 1j * rng.standard_normal(S.NB)
     grouped = S._apply_optim_real(v)
     assert rel_err(grouped, O.apply(v, orag)) < 1e-12
-    # the operator with one launch per term (what the grouped launches replace): same
-    # arithmetic in the same order, bit for bit
-    S.ctx.set_option("annular_grouped", 0)
-    try:
-        single = S._apply_optim_real(v)
-    finally:
-        S.ctx.set_option("annular_grouped", 1)
-    assert np.array_equal(np.asarray(grouped), np.asarray(single))
+    # the operator with one launch per term (what the grouped launches replace) and with grouped
+    # launches but separate real-to-complex copies and closing launches (annular_grouped = 1; the
+    # default, 2, merges those): same arithmetic in the same order, bit for bit
+    assert S.ctx.get_option("annular_grouped") == 2
+    for variant in (0, 1):
+        S.ctx.set_option("annular_grouped", variant)
+        try:
+            other = S._apply_optim_real(v)
+        finally:
+            S.ctx.set_option("annular_grouped", 2)
+        assert np.array_equal(np.asarray(grouped), np.asarray(other)), variant
     assert rel_err(S._preconditioner(v), O.precondition(v)) < 1e-11
     T = t[None, :]
     rv = aag.rv0[:, None]
