@@ -246,6 +246,21 @@ int ipde_modhelm_apply(ipde_ctx* ctx, int loc, double k,
                        double* out, int flags);
 
 /*
+ * The single-layer sums K0(k r) w_sigma / (2 pi) onto a target list handed over as 4 x 4 patches whose
+ * groups of 64 are 8 x 8 blocks of tiles (ipde_target_plan_build_blocks with pad_blocks = 1; layout as
+ * in ipde_laplace_apply_patches): every block's sources beyond four block radii enter 27 complex
+ * coefficients of a local expansion (Graf's addition theorem: K0(|z - z_j|) = sum_m eps_m K_m(rho_j)
+ * I_m(rho) cos(m (phi - phi_j)) about the block's centre, scaled so that nothing over- or underflows),
+ * nearer batches of eight sources are summed pair by pair through the table of ipde_modhelm_apply.
+ * Blocks whose half-diagonal exceeds 1/k keep every source pair by pair.  The place of the
+ * reference's grid_backend='fmm2d' branch (fmm2dpy.hfmm2d with zk = i k,
+ * ipde/solvers/internals/modified_helmholtz.py:29-35).  DEVICE pointers.
+ */
+int ipde_modhelm_apply_patches_far(ipde_ctx* ctx, double k, int64_t ns, const double* sx, const double* sy,
+                                   const double* w_sigma, int64_t np, const double* pxy, const int32_t* pout,
+                                   double* out);
+
+/*
  * Stokes (mu=1) Stokeslet + stresslet with pressure:
  *   SLP: u = (1/4pi) sum [ -log r f + (d.f) d / r^2 ] ,  p = (1/2pi) sum (d.f)/r^2
  *   DLP: u = (1/pi)  sum (d.n)(d.g) d / r^4 ,

@@ -207,6 +207,306 @@ __global__ __launch_bounds__(NT) void modhelm_table_kernel(
     modhelm_store<R, NT>(acc, base, nt, out, accumulate);
 }
 
+// ---------------------------------------------------------------------------
+// Single-layer sums onto patch lists with the far sources of every 8 x 8 block of tiles in a local
+// expansion (ipde_modhelm_apply_patches_far; the Laplace form, with the scheme, is in
+// layer_laplace.hip).  In the scaled coordinates (k absorbed) Graf's addition theorem gives, for a
+// source z_j = c + rho_j e^{i phi_j} and a target z = c + rho e^{i phi}, rho < rho_j,
+//     K0(|z - z_j|) = sum_m eps_m K_m(rho_j) I_m(rho) cos(m (phi - phi_j)),   eps_0 = 1, eps_m = 2,
+// so a block keeps C_m = eps_m sum_j q_j Kh_m(rho_j) e^{-i m phi_j}, m <= 26, with
+// Kh_m = K_m s_m, s_m = (r/2)^m / m! (r the block's half-diagonal): bounded by (r/rho_j)^m / 2m, by the
+// upward recurrence Kh_{m+1} = Kh_{m-1} (r^2/4)/(m (m+1)) + Kh_m (m/(m+1)) (r/rho_j) from K0 and K1.
+// A target evaluates Re sum_m C_m zeta^m T_m(w), zeta = (z - c)/r, w = (rho/2)^2,
+// T_m = I_m(rho) m! (2/rho)^m = sum_n w^n m!/(n! (m+n)!): T_27 and T_26 by their series (12 terms:
+// 2e-20 at w = 4), the rest by T_{m-1} = T_m + w T_{m+1} / (m (m+1)) inside the Horner loop.  Blocks with
+// r > 4 (k times the half-diagonal) use no expansion.  Sources beyond 4 r: ratio <= 1/4, truncation as
+// for the Laplace form.  And whatever the block: a batch of sources all farther than r + 45 from the
+// centre is DROPPED — K0(45) = 5e-21 against near-field values of O(1) (at k = 100 on a 3-unit domain
+// that is most of the boundary for most blocks).
+constexpr int MFAR_P = 26;
+constexpr double MFAR_RHO = 0.25;
+constexpr double MFAR_RMAX = 4.0;
+constexpr double MFAR_DROP = 45.0;      // K0(45) = 5e-21
+constexpr int MFAR_TN = 12;
+constexpr int MFAR_NCOEF = 2 * (MFAR_P + 2);
+constexpr int MFAR_HDR = 4;      // cx, cy, 1/r, r^2/4
+
+__global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __restrict__ rec, int ns_pad,
+                                                               const double* __restrict__ pxy, int64_t np,
+                                                               const ApplyParams* __restrict__ prm,
+                                                               double* __restrict__ head, double* __restrict__ coef,
+                                                               unsigned* __restrict__ near, int nch) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g * 64 >= np) return;                          // (whole waves)
+    const double s1 = prm->scale;
+    const int64_t t = min(g * 64 + lane, np - 1);
+    double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double x = pxy[(int64_t)a * np + t] * s1, y = pxy[(int64_t)(4 + a) * np + t] * s1;
+        xlo = fmin(xlo, x);
+        xhi = fmax(xhi, x);
+        ylo = fmin(ylo, y);
+        yhi = fmax(yhi, y);
+    }
+    xlo = wave_min(xlo);
+    xhi = wave_max(xhi);
+    ylo = wave_min(ylo);
+    yhi = wave_max(yhi);
+    const double cx = 0.5 * (xlo + xhi), cy = 0.5 * (ylo + yhi);
+    const double hx = 0.5 * (xhi - xlo), hy = 0.5 * (yhi - ylo);
+    const double r2 = hx * hx + hy * hy;
+    const double r = sqrt(r2);
+    const double r2q = 0.25 * r2;
+    const bool block_ok = r <= MFAR_RMAX;
+    const double thr = r2 * (1.0 / (MFAR_RHO * MFAR_RHO)) * (1.0 + 0x1p-40);
+    const double drop2 = (r + MFAR_DROP) * (r + MFAR_DROP);
+    double sre[MFAR_P + 1], sim[MFAR_P + 1];
+#pragma unroll
+    for (int k = 0; k <= MFAR_P; ++k) sre[k] = sim[k] = 0.0;
+    for (int j0 = 0; j0 < ns_pad; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < ns_pad;
+        const int jj = valid ? j : ns_pad - 1;
+        const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
+        const double d2 = fma(dy, dy, dx * dx);
+        // a batch of eight sources goes one way as a whole: dropped (all eight beyond r + 45), else
+        // into the expansion (all eight beyond 4 r, block narrow enough), else pair by pair
+        const bool negligible = d2 >= drop2;
+        const unsigned long long mk = __ballot(valid && !negligible);       // lanes that matter at all
+        const unsigned long long m = __ballot(valid && !(block_ok && d2 >= thr));
+        const int sh = lane & ~7;
+        const bool kept = ((mk >> sh) & 0xFFull) != 0;
+        const bool far = valid && kept && ((m >> sh) & 0xFFull) == 0;
+        if (lane == 0) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                bits |= (((m >> (8 * b)) & 0xFFull) && ((mk >> (8 * b)) & 0xFFull)) ? (1u << b) : 0u;
+            near[g * nch + (j0 >> 6)] = bits;
+        }
+        if (__ballot(far && !negligible) == 0) continue;              // (wave-uniform)
+        const double y = far ? d2 : 1.0;
+        const double q = (far && !negligible) ? rec[ipde_rec_index(jj, 2)] : 0.0;
+        double k0 = 0.0, k1x = 0.0;
+        bessel_k01<3>(y, k0, k1x);
+        const double rho = sqrt(y), irho = 1.0 / rho;
+        const double ere = dx * irho, eim = -dy * irho;        // e^{-i phi_j} (near lanes: weight 0)
+        const double rr = r * irho;
+        double km1 = k0, km = k1x * y * (0.5 * r) * irho;      // Kh_0, Kh_1 = K1(rho) r / 2
+        sre[0] = fma(q, km1, sre[0]);
+        double pre = ere, pim = eim;                            // e^{-i m phi_j}
+        const double q2 = 2.0 * q;
+#pragma unroll
+        for (int mm = 1; mm <= MFAR_P; ++mm) {
+            const double wq = q2 * km;
+            sre[mm] = fma(wq, pre, sre[mm]);
+            sim[mm] = fma(wq, pim, sim[mm]);
+            const double kn = fma(km1, r2q * (1.0 / ((double)mm * (mm + 1))), km * (((double)mm / (mm + 1)) * rr));
+            km1 = km;
+            km = kn;
+            const double nre = pre * ere - pim * eim;
+            pim = fma(pre, eim, pim * ere);
+            pre = nre;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k <= MFAR_P; ++k) {
+        sre[k] = wave_sum(sre[k]);
+        sim[k] = wave_sum(sim[k]);
+    }
+    if (lane == 0) {
+        head[g * MFAR_HDR + 0] = cx;
+        head[g * MFAR_HDR + 1] = cy;
+        head[g * MFAR_HDR + 2] = 1.0 / r;
+        head[g * MFAR_HDR + 3] = r2q;
+        double* c = coef + g * MFAR_NCOEF;
+#pragma unroll
+        for (int k = 0; k <= MFAR_P; ++k) {
+            c[2 * k] = sre[k];
+            c[2 * k + 1] = sim[k];
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void modhelm_patch_far_kernel(
+    const double* __restrict__ rec, int ns_pad, const double* __restrict__ pxy, int64_t np,
+    const int* __restrict__ pout, double* __restrict__ out, const ApplyParams* __restrict__ prm,
+    const double2* __restrict__ gtab, const double* __restrict__ head, const double* __restrict__ coef,
+    const unsigned* __restrict__ near, int nch) {
+    extern __shared__ double2 ltab[];
+    const bool nowin = prm->pad >= KT_NWIN;
+    const int win = nowin ? KT_NWIN - 1 : prm->pad;
+    gtab += (size_t)win * KT_NKEYS * (KT_ENTRY / 2);
+    for (unsigned i = threadIdx.x; i < KT_NKEYS * (KT_ENTRY / 2); i += NT) ltab[i] = gtab[i];
+    __syncthreads();
+    const unsigned key_lo = (unsigned)((1023 + KT_EXP_LO + 2 * win) << KT_B);
+    unsigned hmin = 0xFFFFFFFFu;
+    const double s1 = prm->scale;
+    const int64_t lane = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t g = __builtin_amdgcn_readfirstlane((int)(lane >> 6));
+    if (g * 64 >= np) return;                          // (whole waves, after the only barrier)
+    const int64_t t = min(lane, np - 1);
+    double xs[4], ys[4], acc[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        xs[a] = pxy[(int64_t)a * np + t] * s1;
+        ys[a] = pxy[(int64_t)(4 + a) * np + t] * s1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+    const unsigned* nm = near + g * nch;
+    if (!nowin) {
+        for (int c = 0; c < nch; ++c) {
+            unsigned m = nm[c];
+            while (m) {
+                const int bt = __builtin_ctz(m);
+                m &= m - 1;
+                SrcRow sx, sy, sq;
+                sx.load(rec, 8 * c + bt, 0);
+                sy.load(rec, 8 * c + bt, 1);
+                sq.load(rec, 8 * c + bt, 2);
+#pragma unroll
+                for (int u = 0; u < IPDE_SRC_PAD; ++u) {
+                    double dx2[4], dy2[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const double dx = xs[a] - sx.v[u], dy = ys[a] - sy.v[u];
+                        dx2[a] = dx * dx;
+                        dy2[a] = dy * dy;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        double d2[4];
+                        double2 e[4][KT_READS];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            d2[b] = dx2[a] + dy2[b];
+                            const unsigned hi = (unsigned)__double2hiint(d2[b]);
+                            hmin = min(hmin, hi);
+                            unsigned idx;
+                            asm("v_bfe_u32 %0, %1, 14, 11" : "=v"(idx) : "v"(hi));
+                            const double2* ep = (const double2*)((const char*)ltab + __umul24(idx, KT_ENTRY * 8u));
+#pragma unroll
+                            for (int cc = 0; cc < KT_READS; ++cc) e[b][cc] = ep[cc];
+                        }
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const unsigned hi = (unsigned)__double2hiint(d2[b]);
+                            const double ctr = __hiloint2double((int)((hi & 0xFFFFC000u) | 0x2000u), 0);
+                            const double z = d2[b] - ctr;
+                            double p = fma(e[b][2].y, z, e[b][2].x);
+                            p = fma(p, z, e[b][1].y);
+                            p = fma(p, z, e[b][1].x);
+                            p = fma(p, z, e[b][0].y);
+                            p = fma(p, z, e[b][0].x);
+                            acc[4 * a + b] = fma(sq.v[u], p, acc[4 * a + b]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (nowin || (hmin >> KT_SHIFT) < key_lo) {
+        // no table window for this launch, or a near pair below the window: the near batches of this
+        // patch again with the series / Chebyshev code
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double xa[4] = {xs[a], xs[a], xs[a], xs[a]};
+            double gs[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < nch; ++c) {
+                unsigned m = nm[c];
+                while (m) {
+                    const int bt = __builtin_ctz(m);
+                    m &= m - 1;
+                    modhelm_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, xa, ys, gs);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[4 * a + b] = gs[b];
+        }
+    }
+    // far sources: Re sum_m C_m zeta^m T_m(w), Horner downwards with T's recurrence alongside
+    {
+        const double* h = head + g * MFAR_HDR;
+        const double cx = h[0], cy = h[1], rinv = h[2], r2q = h[3];
+        const double* C = coef + g * MFAR_NCOEF;
+        double zy[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) zy[b] = (ys[b] - cy) * rinv;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double zx = (xs[a] - cx) * rinv;
+            double w[4], tm[4], tp[4], vr[4], vi[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                w[b] = r2q * (zx * zx + zy[b] * zy[b]);        // (rho / 2)^2
+                // T_m = sum_n w^n m! / (n! (m + n)!), MFAR_TN terms, m = P + 1 and P
+                double s1p = 1.0, s0p = 1.0;
+#pragma unroll
+                for (int n = MFAR_TN; n >= 1; --n) {
+                    s1p = fma(s1p, w[b] * (1.0 / ((double)n * (MFAR_P + 1 + n))), 1.0);
+                    s0p = fma(s0p, w[b] * (1.0 / ((double)n * (MFAR_P + n))), 1.0);
+                }
+                tp[b] = s1p;
+                tm[b] = s0p;
+                vr[b] = vi[b] = 0.0;
+            }
+            for (int m = MFAR_P; m >= 0; --m) {
+                const double cr = C[2 * m], ci = C[2 * m + 1];
+                const double f = m >= 1 ? 1.0 / ((double)m * (m + 1)) : 0.0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    // v = v zeta + C_m T_m
+                    const double nr = vr[b] * zx - vi[b] * zy[b];
+                    vi[b] = fma(vr[b], zy[b], vi[b] * zx) + ci * tm[b];
+                    vr[b] = nr + cr * tm[b];
+                    // T_{m-1} = T_m + w T_{m+1} / (m (m + 1))
+                    const double tn = fma(w[b] * f, tp[b], tm[b]);
+                    tp[b] = tm[b];
+                    tm[b] = tn;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[4 * a + b] += vr[b];
+        }
+    }
+    if (lane >= np) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = pout[(int64_t)r * np + t];
+        if (i >= 0) out[i] = acc[r];
+    }
+}
+
+int launch_modhelm_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, const double* pxy, int64_t np,
+                               const int* pout, double* out, const ApplyParams* prm) {
+    constexpr int NT = 1024;
+    const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
+    const int64_t ng = ceil_div64(np, 64);
+    const int nch = (int)ceil_div64(ns_pad, 64);
+    const size_t nd = (size_t)ng * (MFAR_HDR + MFAR_NCOEF);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
+    double* head = (double*)ctx->partial.p;
+    double* coef = head + (size_t)ng * MFAR_HDR;
+    unsigned* near = (unsigned*)(coef + (size_t)ng * MFAR_NCOEF);
+    ipde_time_begin(ctx);
+    hipLaunchKernelGGL(modhelm_far_coeff_kernel, dim3((unsigned)ceil_div64(ng, 4)), dim3(256), 0, ctx->stream, rec,
+                       ns_pad, pxy, np, prm, head, coef, near, nch);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    const size_t lds = (size_t)KT_NKEYS * KT_ENTRY * sizeof(double);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)modhelm_patch_far_kernel<NT>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((modhelm_patch_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds,
+                       ctx->stream, rec, ns_pad, pxy, np, pout, out, prm, (const double2*)ctx->d_ktab,
+                       (const double*)head, (const double*)coef, (const unsigned*)near, nch);
+    ipde_time_end(ctx);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_acc(const double* __restrict__ part,
                                                            int nchunk, int64_t nt,
                                                            double* __restrict__ out,
@@ -430,4 +730,33 @@ extern "C" int ipde_modhelm_apply(ipde_ctx* ctx, int loc, double k, int64_t ns, 
     if (w_tau)
         IPDE_TRY(launch_modhelm<MODE_DLP>(ctx, rec, ns, d_tx, d_ty, nt, d_out, prm, flags, accumulate));
     return ipde_stage_finish(ctx, loc, 7, out, nt);
+}
+
+// Single-layer sums K0(k r) w_sigma / (2 pi) onto a patch list whose 64-patch groups are 8 x 8 blocks of
+// tiles (ipde_target_plan_build_blocks, pad_blocks = 1): far sources block by block in local expansions
+// (Graf's addition theorem), near batches through the table.
+extern "C" int ipde_modhelm_apply_patches_far(ipde_ctx* ctx, double k, int64_t ns, const double* sx,
+                                              const double* sy, const double* w_sigma, int64_t np,
+                                              const double* pxy, const int32_t* pout, double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ns >= 0 && np >= 0 && ns < (1LL << 30) && np < (1LL << 27));
+    IPDE_CHECK_ARG(ctx, k > 0.0);
+    if (np == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, pxy && pout && out);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && w_sigma);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_ktab) IPDE_TRY(ipde_build_k_table(ctx));
+    PackArgs pa{};
+    pa.sx = sx;
+    pa.sy = sy;
+    pa.ch[0] = w_sigma;
+    pa.mul[0] = 0.5 / M_PI;
+    pa.corr_ch = -1;
+    pa.corr2_ch = -1;
+    pa.use_scale = 1;
+    pa.fixed_scale = k;
+    const double* rec;
+    const ApplyParams* prm;
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, pxy, pxy + 4 * np, 4 * np, &rec, &prm));
+    return launch_modhelm_patches_far(ctx, rec, ns, pxy, np, pout, out, prm);
 }

@@ -318,6 +318,11 @@ def Modified_Helmholtz_Layer_Apply(source, target=None, k=1.0, charge=None, dips
     if charge is None and dipstr is None:
         raise ValueError("need a charge and/or a dipstr density")
     src = _source_side(source, trg)
+    if dipstr is None and not self_eval and isinstance(target, DeviceTargets) and target.far:
+        plan = target.plan()
+        if plan is not None and plan.padded_blocks:      # far sources block by block in local expansions
+            from . import target_plan
+            return target_plan.modhelm_apply(plan, k, src.x, src.y, _weighted(charge, src.weights), ctx=target.ctx)
     return modified_helmholtz_apply(src.x, src.y, tx, ty, k,
                                     w_sigma=_weighted(charge, src.weights),
                                     nx=None if dipstr is None else src.normal_x,

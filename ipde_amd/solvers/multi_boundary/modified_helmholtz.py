@@ -7,6 +7,9 @@ from ...grid_evaluators.modified_helmholtz_grid_evaluator import (
 
 
 class ModifiedHelmholtzSolver(ScalarSolver):
+    PATCH_TARGETS = True      # the grid_pnai list planned into patches ...
+    FAR_EXPANSION = True      # ... and summed with far sources in local expansions (ipde_modhelm_apply_patches_far)
+
     def __init__(self, ebdyc, k, solver_type='spectral', helpers=None, grid_backend=None,
                  source_upsample_factor=1.0):
         self.k = k

@@ -133,16 +133,21 @@ class ScalarSolver(object):
     # or this attribute False: every pair directly)
     FAR_EXPANSION = False
 
-    # grid_backend None / 'auto': the package's choice — the exact dense sum up to this many
-    # source-target pairs per solve (BASELINE configs[1-2]: 1e10), beyond it, in a single process, the
-    # Ewald-type split of the reference's grid evaluators (1e-13; configs[3], 8.5e10 pairs: warm solve
-    # 52 -> 24 ms for +0.6 s of set-up).  Under torch.distributed the dense sum, sharded over the ranks.
+    # grid_backend None / 'auto': the package's choice — the dense sum; for a solver WITHOUT the far-field
+    # form of it, beyond this many source-target pairs per solve and in a single process, the Ewald-type
+    # split of the reference's grid evaluators (1e-13; configs[3], 8.5e10 pairs: 46 -> 16 ms for +0.3 s of
+    # set-up; with the far-field form the dense sum takes 14-16 ms there).  Under torch.distributed the
+    # dense sum, sharded over the ranks.
     AUTO_EWALD_MIN_PAIRS = 5.0e10
 
     def _resolve_grid_backend(self):
         if self.grid_backend in (None, 'auto'):
             pairs = float(self.grid_sources.N) * float(self.ebdyc.grid_pnai.N)
-            big = pairs >= self.AUTO_EWALD_MIN_PAIRS and not is_distributed()
+            # (solvers whose dense sum takes the far sources through local expansions — Poisson,
+            # modified Helmholtz — keep it at every size: configs[3] 14-16 ms either way, and the
+            # split costs 0.3 s of set-up)
+            far = self.PATCH_TARGETS and self.FAR_EXPANSION and os.environ.get("IPDE_FAR_EXPANSION", "1") != "0"
+            big = pairs >= self.AUTO_EWALD_MIN_PAIRS and not is_distributed() and not far
             self.grid_backend = 'ewald' if big else 'hip'
 
     CONCURRENT_ANNULAR = True     # False: annular solves one boundary after the other

@@ -185,3 +185,24 @@ def stokes_apply(plan, sx, sy, wfx, wfy, pressure=True, ctx=None):
                                                     ptr(wfy), plan.np, ptr(plan.pxy), ptr(plan.pout), ptr(u),
                                                     ptr(v), ptr(p)))
     return u, v, p
+
+
+def modhelm_apply(plan, k, sx, sy, w_sigma, ctx=None, out=None):
+    """Modified Helmholtz single-layer sums over a planned list with padded blocks: the patches
+    through ipde_modhelm_apply_patches_far (far sources block by block in local expansions), the
+    remainder through ipde_modhelm_apply.  Device tensors; w_sigma weight-multiplied."""
+    from . import _lib
+    from .layer_potentials import _match, modified_helmholtz_apply as list_apply
+    ctx = ctx or get_context()
+    if not plan.padded_blocks:
+        raise ValueError("the far-field form needs a plan built with pad_blocks=True")
+    sx, sy, w_sigma = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (sx, sy, w_sigma))
+    if out is None:
+        out = torch.empty(plan.n, dtype=torch.float64, device=plan.pxy.device)
+    assert out.is_contiguous() and out.dtype == torch.float64 and out.numel() == plan.n
+    if plan.nrest:
+        out[plan.rest] = list_apply(sx, sy, plan.rest_x, plan.rest_y, float(k), w_sigma=w_sigma, ctx=ctx)
+    ctx.check(ctx.lib.ipde_modhelm_apply_patches_far(ctx.handle, float(k), int(sx.shape[0]), ptr(sx), ptr(sy),
+                                                     ptr(w_sigma), plan.np, ptr(plan.pxy), ptr(plan.pout),
+                                                     ptr(out)))
+    return out

@@ -49,15 +49,32 @@ def test_config2_full_interior_poisson_2048():
 @pytest.mark.parametrize("grid_backend", ["hip", "ewald", None])
 def test_config3_interior_modified_helmholtz_k10_4096_grid_8192_nodes(grid_backend):
     """configs[3]: examples/interior_modified_helmholtz.py, k = 10, 4096^2 grid, 8192-node
-    boundary, the whole target set on one GPU.  'hip': the dense sum onto grid_pnai
-    (modhelm_table_kernel at 8.5e10 pairs per solve — what every rank of the 8-GPU split runs on its
-    slice); 'ewald': the split evaluator; None: the package's choice at this size (the split)."""
+    boundary, the whole target set on one GPU.  'hip': the dense sum onto grid_pnai (8.5e10 pairs per
+    solve, far sources through local expansions: what every rank of the 8-GPU split runs on its slice);
+    'ewald': the split evaluator; None: the package's choice — the dense sum in its far-field form at
+    every size (test_configs_gpu's pair-by-pair leg: test_config3_pair_by_pair_dense_sum)."""
     import interior_modified_helmholtz as imh
     err, scale, solver, ue, T = imh.run(nb=8192, M=20, helmholtz_k=10.0, Ns=[4096, 4096],
                                         grid_backend=grid_backend)
     print(grid_backend, err / scale, T)
     assert list(T['grid']) == [4096, 4096] and T['dof'] > 8e6
-    assert solver.split_grid_evaluation == (grid_backend != 'hip')      # None: the split at this size
+    assert solver.split_grid_evaluation == (grid_backend == 'ewald')
+    assert err / scale < 1e-12
+    del solver, ue
+    _free()
+
+
+def test_config3_pair_by_pair_dense_sum():
+    """configs[3] with every pair of the sum onto grid_pnai through modhelm_table_kernel (the far-field
+    form off): the dense kernel at full size under the 1e-12 bar."""
+    import interior_modified_helmholtz as imh
+    from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver
+    ModifiedHelmholtzSolver.FAR_EXPANSION = False
+    try:
+        err, scale, solver, ue, T = imh.run(nb=8192, M=20, helmholtz_k=10.0, Ns=[4096, 4096], grid_backend='hip')
+    finally:
+        ModifiedHelmholtzSolver.FAR_EXPANSION = True
+    assert not solver.split_grid_evaluation and not solver.Grid_Evaluator.prepare().far
     assert err / scale < 1e-12
     del solver, ue
     _free()

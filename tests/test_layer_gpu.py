@@ -798,6 +798,60 @@ def test_stokes_far_expansion_table_miss_and_high_level_call(lp):
         assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
 
 
+@pytest.mark.parametrize("k", [0.7, 10.0, 40.0, 300.0])
+@pytest.mark.parametrize("ngrid,nb", [(200, 192), (640, 512), (1024, 1500)])
+def test_modhelm_far_expansion_against_oracle_and_list_kernel(lp, k, ngrid, nb):
+    """Modified Helmholtz single-layer sums with far sources in local expansions (Graf's addition
+    theorem; ipde_modhelm_apply_patches_far) against the C oracle on a sample and the list kernel
+    everywhere, relative to max|u| (the parity bar of the dense kernels).  k = 300 makes every block
+    wider than 1/k at the coarse grids: those blocks keep all their sources pair by pair."""
+    from ipde_amd import target_plan
+    c = Curve(nb, a=0.2, f=5)
+    trg, h = grid_targets(c, ngrid, clearance=2.0)
+    rng = np.random.default_rng(ngrid + nb)
+    w = rng.standard_normal(c.N) * c.weights
+    dev = lp.get_context().torch_device()
+    plan = target_plan.build_host(trg.x, trg.y, device=dev, pad_blocks=True)
+    far = target_plan.modhelm_apply(plan, k, c.x, c.y, w).cpu().numpy()
+    lst = lp.modified_helmholtz_apply(c.x, c.y, trg.x, trg.y, k, w_sigma=w)
+    assert np.abs(far - lst).max() < 1e-13 * np.abs(lst).max()
+    idx = rng.choice(trg.N, min(trg.N, 1500), replace=False)
+    ref = olp.modified_helmholtz_layer_apply(c.x, c.y, trg.x[idx], trg.y[idx], k, charge=w)
+    assert np.abs(far[idx] - ref).max() < TOL * np.abs(lst).max()
+
+
+def test_modhelm_far_expansion_near_misses_and_high_level_call(lp):
+    """Sources 1e-9 from grid targets (below the table window: those patches' near batches are redone
+    with the series code), and the route the solver takes: DeviceTargets(plan=True, far=True) ->
+    Modified_Helmholtz_Layer_Apply; a dipole density keeps the list kernel."""
+    import torch
+    from ipde_amd import target_plan
+    c = Curve(600, a=0.2, f=5)
+    trg, h = grid_targets(c, 640, clearance=2.0)
+    rng = np.random.default_rng(4)
+    sx, sy = c.x.copy(), c.y.copy()
+    hit = rng.choice(trg.N, 6, replace=False)
+    sx[:6], sy[:6] = trg.x[hit] + 1e-9, trg.y[hit] - 2e-9
+    w = rng.standard_normal(c.N) * c.weights
+    plan = target_plan.build_host(trg.x, trg.y, device=lp.get_context().torch_device(), pad_blocks=True)
+    for k in (2.0, 25.0):
+        got = target_plan.modhelm_apply(plan, k, sx, sy, w).cpu().numpy()
+        idx = np.concatenate([hit, rng.choice(trg.N, 1500, replace=False)])
+        ref = olp.modified_helmholtz_layer_apply(sx, sy, trg.x[idx], trg.y[idx], k, charge=w)
+        # (the six targets 2e-9 from a source: the distance itself carries 1e-7 relative rounding)
+        assert np.all(np.isfinite(got)) and np.abs(got[idx] - ref)[6:].max() < TOL * np.abs(ref).max()
+        assert np.abs(got[idx] - ref)[:6].max() < 1e-8 * np.abs(ref).max()
+    far = lp.DeviceTargets(trg, plan=True, far=True)
+    plain = lp.DeviceTargets(trg)
+    s = rng.standard_normal(c.N)
+    a = lp.Modified_Helmholtz_Layer_Apply(c, far, k=10.0, charge=s)
+    b = lp.Modified_Helmholtz_Layer_Apply(c, plain, k=10.0, charge=s)
+    assert float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max()) < 1e-13 * float(torch.as_tensor(b).abs().max())
+    a = lp.Modified_Helmholtz_Layer_Apply(c, far, k=10.0, charge=s, dipstr=s[::-1].copy())
+    b = lp.Modified_Helmholtz_Layer_Apply(c, plain, k=10.0, charge=s, dipstr=s[::-1].copy())
+    assert torch.equal(torch.as_tensor(a), torch.as_tensor(b))
+
+
 # -- the kernels no reference code computes, tied to the pinned ones through derivative relations
 #    (tests/test_oracle_layer_relations.py has the same checks for the oracle; here every
 #    evaluation is a HIP kernel call and nothing goes through the oracle's closed formulas) -------

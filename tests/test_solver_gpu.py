@@ -356,19 +356,25 @@ def test_process_that_ends_during_the_warm_up_exits_cleanly():
 
 
 def test_grid_evaluator_is_chosen_by_problem_size():
-    """grid_backend None: the exact dense sum below ScalarSolver.AUTO_EWALD_MIN_PAIRS source-target
-    pairs (BASELINE configs[1-2]), the Ewald-type split above it (configs[3]); both reach the
+    """grid_backend None: solvers whose dense sum has the far-field form (Poisson, modified Helmholtz)
+    keep it at every size; without it (FAR_EXPANSION off) the exact dense sum below
+    ScalarSolver.AUTO_EWALD_MIN_PAIRS source-target pairs, the Ewald-type split above; all reach the
     manufactured solution"""
     import interior_poisson
     from ipde_amd.solvers.multi_boundary.scalar import ScalarSolver
+    from ipde_amd.solvers.multi_boundary.poisson import PoissonSolver
     err, scale, solver, _, _ = interior_poisson.run(nb=600, M=16)
     assert solver.grid_backend == 'hip' and not solver.split_grid_evaluation
     old = ScalarSolver.AUTO_EWALD_MIN_PAIRS
     ScalarSolver.AUTO_EWALD_MIN_PAIRS = 0.0
     try:
+        _, _, solver_f, _, _ = interior_poisson.run(nb=600, M=16)
+        assert solver_f.grid_backend == 'hip' and not solver_f.split_grid_evaluation     # far-field form: kept
+        PoissonSolver.FAR_EXPANSION = False
         err_e, scale_e, solver_e, _, _ = interior_poisson.run(nb=600, M=16)
     finally:
         ScalarSolver.AUTO_EWALD_MIN_PAIRS = old
+        PoissonSolver.FAR_EXPANSION = True
     assert solver_e.split_grid_evaluation
     assert err / scale < 1e-10 and err_e / scale_e < 1e-10
     # an explicit choice is kept
@@ -420,17 +426,21 @@ def test_device_resident_right_hand_side_and_answer_equal_the_host_containers():
         hostio.DeviceFunction(solver.ebdyc, torch.zeros(3, dtype=torch.float64, device="cuda"))
 
 
-def test_poisson_solver_far_expansion_equals_pair_by_pair_grid_sum():
+def test_poisson_solver_far_expansion_equals_pair_by_pair_grid_sum(monkeypatch):
     """PoissonSolver's dense sum onto grid_pnai: far sources in local expansions (class default, and
     the reference's grid_backend names 'fmm2d' / 'flexmm') against every pair directly ('pybie2d'):
     the same solution to rounding, the same manufactured-solution error."""
     import interior_poisson
+    from ipde_amd import target_plan
     from ipde_amd.embedded_function import EmbeddedFunction
+    monkeypatch.setattr(target_plan, "MIN_PATCHES", 1024)      # (lists under 2^18 points are not planned otherwise)
     res = {}
     for gb in (None, 'pybie2d', 'fmm2d'):
         err, scale, solver, ue, T = interior_poisson.run(nb=1200, M=16, Ns=[1024, 1024], solver_tol=1e-12,
                                                          grid_backend=gb)
         res[gb] = (err / scale, np.asarray(ue).copy(), solver.FAR_EXPANSION)
+        dt = solver.Grid_Evaluator.prepare()
+        assert dt.plan() is not None and dt.plan().padded_blocks == solver.FAR_EXPANSION and dt.far == solver.FAR_EXPANSION
     assert res[None][2] and res['fmm2d'][2] and not res['pybie2d'][2]
     assert res[None][0] < 1e-11 and res['pybie2d'][0] < 1e-11
     assert np.array_equal(res[None][1], res['fmm2d'][1])
@@ -462,3 +472,24 @@ def test_stokes_solver_device_resident_forcings_and_answers():
         assert np.array_equal(np.asarray(d.to_host()), np.asarray(h))
     with pytest.raises(ValueError):
         solver(hostio.DeviceFunction.from_host(fu), fv, **kw)
+
+
+def test_modified_helmholtz_solver_far_expansion_equals_pair_by_pair_grid_sum(monkeypatch):
+    """ModifiedHelmholtzSolver's sum onto grid_pnai with far sources in local expansions (default)
+    against every pair directly (FAR_EXPANSION off): the same solution to rounding."""
+    import interior_modified_helmholtz as imh
+    from ipde_amd import target_plan
+    from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver
+    monkeypatch.setattr(target_plan, "MIN_PATCHES", 1024)      # (lists under 2^18 points are not planned otherwise)
+    res = {}
+    for far in (True, False):
+        ModifiedHelmholtzSolver.FAR_EXPANSION = far
+        try:
+            err, scale, solver, ue, T = imh.run(nb=1200, M=16, helmholtz_k=8.0, Ns=[1024, 1024])
+        finally:
+            ModifiedHelmholtzSolver.FAR_EXPANSION = True
+        res[far] = (err / scale, np.asarray(ue).copy())
+        dt = solver.Grid_Evaluator.prepare()
+        assert dt.far == far and dt.plan() is not None and dt.plan().padded_blocks == far
+    assert res[True][0] < 1e-11 and res[False][0] < 1e-11
+    assert np.abs(res[True][1] - res[False][1]).max() < 1e-13 * np.abs(res[False][1]).max()

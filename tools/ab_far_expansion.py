@@ -59,3 +59,22 @@ for tname, t in (("direct", plain_list), ("far", far)):
         lp.Stokes_Layer_Apply(c, t, forces=f)
     torch.cuda.synchronize()
     print("   stokes %-6s %.3f ms per apply (wall, %d applies)" % (tname, (time.perf_counter() - t0) / n * 1e3, n))
+
+# modified Helmholtz single layer
+for k in (10.0, 100.0):
+    s = rng.standard_normal(c.N)
+    a = lp.Modified_Helmholtz_Layer_Apply(c, plain_list, k=k, charge=s)
+    b = lp.Modified_Helmholtz_Layer_Apply(c, far, k=k, charge=s)
+    torch.cuda.synchronize()
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    print("modhelm k = %g  max|direct| %.3e  max|far - direct| %.3e" % (k, float(a.abs().max()), float((a - b).abs().max())))
+    for tname, t in (("direct", plain_list), ("far", far)):
+        for _ in range(3):
+            lp.Modified_Helmholtz_Layer_Apply(c, t, k=k, charge=s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            lp.Modified_Helmholtz_Layer_Apply(c, t, k=k, charge=s)
+        torch.cuda.synchronize()
+        print("   modhelm %-6s %.3f ms per apply (wall, %d applies)" % (tname, (time.perf_counter() - t0) / n * 1e3, n))

@@ -4,4 +4,4 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r03/far
 mkdir -p $O
-timeout -k 10 300 python3 tools/slice_scaling.py 2>&1 | tee $O/slice_scaling.txt
+timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $O/gputest_mh_far.txt
