@@ -160,6 +160,43 @@ def full_poisson_solve(nb=4096, ng=2048, M=20):
     }
 
 
+def baseline_configs():
+    """BASELINE configs[3] and configs[4] on ONE GPU (the 8-GPU split of their target sets is the
+    driver's to run): errors against the manufactured solutions, set-up and warm solve of the
+    examples as shipped (grid sums in their far-field forms)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import interior_modified_helmholtz as imh
+    import multi_stokes as ms
+    from ipde_amd.embedded_function import EmbeddedFunction
+    out = {}
+    err, scale, solver, ue, T = imh.run(nb=8192, M=20, helmholtz_k=10.0, Ns=[4096, 4096])
+    f = f_like(solver, EmbeddedFunction)
+    solver(f, tol=1e-12, maxiter=100, restart=20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        solver(f, tol=1e-12, maxiter=100, restart=20)
+    torch.cuda.synchronize()
+    out["configs[3]"] = {"workload": "interior modified Helmholtz k = 10, 4096^2 grid, 8192-node boundary, %d dof, one GPU"
+                                     % T["dof"],
+                         "max_rel_err_vs_manufactured_solution": err / scale, "setup_s": T["setup_s"],
+                         "warm_inhomogeneous_solve_ms": 1e3 * (time.perf_counter() - t0) / 5,
+                         "grid_backend": str(solver.grid_backend), "gmres_iterations": T["gmres_iterations"]}
+    del solver, ue, f
+    torch.cuda.empty_cache()
+    ue, ve, pe, scale, T = ms.run(nb=2400, M=14, ng=4096, warm=True)
+    out["configs[4]"] = {"workload": "multi_stokes, 3 bodies (9600 + 2 x 2400 nodes), 4096^2 grid, %d dof, one GPU"
+                                     % T["dof"],
+                         "max_err_u_v": max(ue, ve), "max_err_p": pe, "scale": scale, "setup_s": T["setup_s"],
+                         "warm_inhomogeneous_solve_ms": 1e3 * T["warm_inhomogeneous_solve_s"],
+                         "warm_solve_note": "the example's own second solve, one sample (means of 8: "
+                                            "profiles/r03_stokes_resident_ab.txt)",
+                         "gmres_iterations": T["gmres_iterations"]}
+    torch.cuda.empty_cache()
+    return out
+
+
 def fft_block(n=NGRID, reps=40):
     """The spectral half of the path at the BASELINE grid: `_grid_solve`
     (Poisson) and `fourier` (d/dx), device resident.  GB/s on the algorithmic 16 B per grid
@@ -217,6 +254,7 @@ def main():
                     help="strong (default): one 2048^2 target list split over the ranks; "
                          "weak: one 2048^2 grid per rank")
     ap.add_argument("--no-fft", action="store_true", help="skip the spectral-path measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] solves")
     ap.add_argument("--no-patches", action="store_true",
                     help="the list kernel (laplace_rowrun_kernel) instead of the 4 x 4 patch kernel")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
@@ -479,6 +517,8 @@ def main():
         # grid", configs[2]): measured after, and outside, the timed region above
         if not args.no_full_solve and world == 1:
             result["full_poisson_solve"] = full_poisson_solve()
+        if not args.no_configs and not args.no_full_solve and world == 1:
+            result["baseline_configs"] = baseline_configs()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

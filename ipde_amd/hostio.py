@@ -20,7 +20,9 @@ import torch
 
 from .embedded_function import EmbeddedFunction
 
-STAGE_THREADS = 4
+import os as _os
+
+STAGE_THREADS = int(_os.environ.get("IPDE_STAGE_THREADS", "4"))
 _MIN_CHUNK = 1 << 18      # doubles; below this a chunk's thread hand-off costs more than its copy
 _pool = None
 
