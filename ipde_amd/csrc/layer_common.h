@@ -55,6 +55,44 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------
+// Shared by the far-field forms (ipde_{laplace,modhelm,stokes}_apply_patches_far): the block of
+// patches a wave owns — patches [64 g, 64 g + 64) of pxy[8][np], coordinates times `scale` — as a
+// disc: centre of the bounding box, half-diagonal r.  Whatever the grouping of the plan, every
+// target of the wave lies within r of the centre.
+struct FarBlock {
+    double cx, cy, r, r2;
+    __device__ __forceinline__ void init(const double* __restrict__ pxy, int64_t np, int64_t g, int lane,
+                                         double scale) {
+        const int64_t t = min(g * 64 + lane, np - 1);
+        double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double x = pxy[(int64_t)a * np + t] * scale, y = pxy[(int64_t)(4 + a) * np + t] * scale;
+            xlo = fmin(xlo, x);
+            xhi = fmax(xhi, x);
+            ylo = fmin(ylo, y);
+            yhi = fmax(yhi, y);
+        }
+        xlo = wave_min(xlo);
+        xhi = wave_max(xhi);
+        ylo = wave_min(ylo);
+        yhi = wave_max(yhi);
+        cx = 0.5 * (xlo + xhi);
+        cy = 0.5 * (ylo + yhi);
+        const double hx = 0.5 * (xhi - xlo), hy = 0.5 * (yhi - ylo);
+        r2 = hx * hx + hy * hy;
+        r = sqrt(r2);
+    }
+};
+// one bit per batch of eight lanes: set where the 64-bit lane mask has any lane of the batch
+__device__ __forceinline__ unsigned far_batch_bits(unsigned long long m) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) bits |= ((m >> (8 * b)) & 0xFFull) ? (1u << b) : 0u;
+    return bits;
+}
+
+// ---------------------------------------------------------------------------
 // Table-driven log / reciprocal.  For every key = hi32(x) >> 12 (sign, exponent and
 // the top IPDE_TAB_B = 8 mantissa bits of x) of the 32 covered binades the table
 // holds {Rh, T} with R ~ 1/centre(interval), Rh = R/2, T = -log R, stored at

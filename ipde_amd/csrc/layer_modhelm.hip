@@ -240,24 +240,9 @@ __global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g * 64 >= np) return;                          // (whole waves)
     const double s1 = prm->scale;
-    const int64_t t = min(g * 64 + lane, np - 1);
-    double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const double x = pxy[(int64_t)a * np + t] * s1, y = pxy[(int64_t)(4 + a) * np + t] * s1;
-        xlo = fmin(xlo, x);
-        xhi = fmax(xhi, x);
-        ylo = fmin(ylo, y);
-        yhi = fmax(yhi, y);
-    }
-    xlo = wave_min(xlo);
-    xhi = wave_max(xhi);
-    ylo = wave_min(ylo);
-    yhi = wave_max(yhi);
-    const double cx = 0.5 * (xlo + xhi), cy = 0.5 * (ylo + yhi);
-    const double hx = 0.5 * (xhi - xlo), hy = 0.5 * (yhi - ylo);
-    const double r2 = hx * hx + hy * hy;
-    const double r = sqrt(r2);
+    FarBlock blk;
+    blk.init(pxy, np, g, lane, s1);
+    const double cx = blk.cx, cy = blk.cy, r = blk.r, r2 = blk.r2;
     const double r2q = 0.25 * r2;
     const bool block_ok = r <= MFAR_RMAX;
     const double thr = r2 * (1.0 / (MFAR_RHO * MFAR_RHO)) * (1.0 + 0x1p-40);
@@ -280,11 +265,7 @@ __global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __
         const bool kept = ((mk >> sh) & 0xFFull) != 0;
         const bool far = valid && kept && ((m >> sh) & 0xFFull) == 0;
         if (lane == 0) {
-            unsigned bits = 0;
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-                bits |= (((m >> (8 * b)) & 0xFFull) && ((mk >> (8 * b)) & 0xFFull)) ? (1u << b) : 0u;
-            near[g * nch + (j0 >> 6)] = bits;
+            near[g * nch + (j0 >> 6)] = far_batch_bits(m) & far_batch_bits(mk);
         }
         if (__ballot(far && !negligible) == 0) continue;              // (wave-uniform)
         const double y = far ? d2 : 1.0;

@@ -362,24 +362,9 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g * 64 >= np) return;                          // (whole waves)
     const double s1 = ldexp(1.0, prm->sh);
-    const int64_t t = min(g * 64 + lane, np - 1);
-    double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const double x = pxy[(int64_t)a * np + t] * s1, y = pxy[(int64_t)(4 + a) * np + t] * s1;
-        xlo = fmin(xlo, x);
-        xhi = fmax(xhi, x);
-        ylo = fmin(ylo, y);
-        yhi = fmax(yhi, y);
-    }
-    xlo = wave_min(xlo);
-    xhi = wave_max(xhi);
-    ylo = wave_min(ylo);
-    yhi = wave_max(yhi);
-    const double cx = 0.5 * (xlo + xhi), cy = 0.5 * (ylo + yhi);
-    const double hx = 0.5 * (xhi - xlo), hy = 0.5 * (yhi - ylo);
-    const double r2 = hx * hx + hy * hy;
-    const double r = sqrt(r2);
+    FarBlock blk;
+    blk.init(pxy, np, g, lane, s1);
+    const double cx = blk.cx, cy = blk.cy, r = blk.r, r2 = blk.r2;
     const double thr = r2 * (1.0 / (SFAR_RHO * SFAR_RHO)) * (1.0 + 0x1p-40);
     constexpr int K0 = WHICH == 3 ? 0 : 1;
     constexpr int K1 = WHICH == 1 ? SFAR_P + 1 : SFAR_P;
@@ -402,9 +387,7 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
             const unsigned long long m = __ballot(valid && !(d2 >= thr && !prm->pad));
             const bool far = valid && ((m >> (lane & ~7)) & 0xFFull) == 0;
             if (WHICH == 1 && lane == 0 && jb < ns_pad) {
-                unsigned bits = 0;
-#pragma unroll
-                for (int b = 0; b < 8; ++b) bits |= ((m >> (8 * b)) & 0xFFull) ? (1u << b) : 0u;
+                const unsigned bits = far_batch_bits(m);
                 near[g * nch + (jb >> 6)] = bits;
             }
             const double inv = far ? r / d2 : 0.0;

@@ -4,7 +4,5 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r03/far
 mkdir -p $O
-SECONDS=0; python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -30 $O/bench_default.err; exit 1; }
-echo "bench wall ${SECONDS} s"
-python3 -c "
-import json; r=json.load(open('$O/bench_default.json')); print(r['value'], r['ms_per_step'], r['roofline']['frac']); print(json.dumps(r['baseline_configs'], indent=1)); print({k: v for k, v in r['full_poisson_solve'].items() if 'warm' in k and 'note' not in k})"
+timeout -k 10 900 python3 -m pytest tests/test_layer_gpu.py tests/test_solver_gpu.py -m gpu -x -q -k "far" 2>&1 | tail -3
+timeout -k 10 300 python3 tools/ab_far_expansion.py 2>&1 | grep "far  \|far -" | tee $O/ab_far_after_refactor.txt
