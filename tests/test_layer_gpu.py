@@ -725,6 +725,15 @@ def test_laplace_far_expansion_full_size_and_scaled_coordinates(lp):
     u = lp.Laplace_Layer_Apply(c, far, charge=s1)
     assert np.max(np.abs(u.cpu().numpy()[idx] - ref)) < 1e-12 * float(u.abs().max())
     from ipde_amd import target_plan
+    # (2^420: beyond what the power-of-two scaling can bring under the table — the launch's `pad` flag:
+    # no source enters an expansion, every pair takes the generic math; on a coarser list, it is slow)
+    small, _ = grid_targets(c, 600)
+    big = 2.0 ** 420
+    plan = target_plan.build_host(small.x * big, small.y * big, device=u.device, pad_blocks=True)
+    w = s1 * c.weights
+    got = target_plan.laplace_apply(plan, c.x * big, c.y * big, w_sigma=w, far=True)
+    want = target_plan.laplace_apply(plan, c.x * big, c.y * big, w_sigma=w)
+    assert bool(torch.isfinite(got).all()) and float((got - want).abs().max()) < 1e-13 * float(want.abs().max())
     for scale in (2.0 ** -30, 1.0e6):
         plan = target_plan.build_host(trg.x * scale, trg.y * scale, device=u.device, pad_blocks=True)
         w = s1 * c.weights * scale
