@@ -61,17 +61,23 @@ __device__ __forceinline__ double wave_sum(double v) {
 // target of the wave lies within r of the centre.
 struct FarBlock {
     double cx, cy, r, r2;
+    // PPL patches per lane: the wave owns patches [64 PPL g, 64 PPL (g + 1)) (PPL = 16: a parent block
+    // of sixteen consecutive blocks)
+    template <int PPL = 1>
     __device__ __forceinline__ void init(const double* __restrict__ pxy, int64_t np, int64_t g, int lane,
                                          double scale) {
-        const int64_t t = min(g * 64 + lane, np - 1);
         double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const double x = pxy[(int64_t)a * np + t] * scale, y = pxy[(int64_t)(4 + a) * np + t] * scale;
-            xlo = fmin(xlo, x);
-            xhi = fmax(xhi, x);
-            ylo = fmin(ylo, y);
-            yhi = fmax(yhi, y);
+        for (int i = 0; i < PPL; ++i) {
+            const int64_t t = min((g * PPL + i) * 64 + lane, np - 1);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const double x = pxy[(int64_t)a * np + t] * scale, y = pxy[(int64_t)(4 + a) * np + t] * scale;
+                xlo = fmin(xlo, x);
+                xhi = fmax(xhi, x);
+                ylo = fmin(ylo, y);
+                yhi = fmax(yhi, y);
+            }
         }
         xlo = wave_min(xlo);
         xhi = wave_max(xhi);

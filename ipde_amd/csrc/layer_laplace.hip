@@ -496,18 +496,29 @@ constexpr int FAR_HDR = 4;                      // cx, cy, 1 / r, (spare)
 // WHICH = MODE_SLP: head[g] = {cx, cy, 1/r, 0}; cs[g][2k], cs[g][2k+1] = sum q vt^k (k >= 1), cs[g][0] = sum q log d^2
 // WHICH = MODE_DLP: cd[g][2k], [2k+1] = sum (alpha / r) vt^k, k = 1 .. FAR_P + 1
 // near[g][chunk]: bit b set = batch 8 chunk + b has a source nearer than r / FAR_RHO: the whole batch is summed directly
-template <int WHICH>
+// Two levels: PPL = 16 runs first, a wave per PARENT block (sixteen consecutive blocks: a 4 x 4 group in
+// the plan's Z order) — the batches all of whose sources are beyond 4 parent radii enter the parent's
+// coefficients and get a bit in `bits`; PPL = 1 then runs per block with `skip` = those bits (parent g / 16):
+// such batches are neither near nor far for the block, the rest as before (`bits` = the near batches).
+template <int WHICH, int PPL>
 __global__ __launch_bounds__(256) void laplace_far_coeff_kernel(const double* __restrict__ rec, int ns_pad,
                                                                const double* __restrict__ pxy, int64_t np,
                                                                const ApplyParams* __restrict__ prm,
                                                                double* __restrict__ head, double* __restrict__ coef,
-                                                               unsigned* __restrict__ near, int nch, int write_near) {
+                                                               unsigned* __restrict__ near, int nch, int write_near,
+                                                               const unsigned* __restrict__ skip, int nslice) {
+    // (parent level: `nslice` waves per parent, each over a slice of the sources — 256 parents alone
+    // would leave most of the GPU idle; the slices' sums are added up, in order, where they are used)
     const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g * 64 >= np) return;                          // (whole waves)
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t g = gw / nslice;
+    const int slice = (int)(gw - g * nslice);
+    if (g * 64 * PPL >= np) return;                    // (whole waves)
+    const int trips = (ns_pad + 127) / 128, tps = (trips + nslice - 1) / nslice;
+    const int jlo = slice * tps * 128, jhi = min(ns_pad, (slice + 1) * tps * 128);
     const double s1 = ldexp(1.0, prm->sh);
     FarBlock blk;
-    blk.init(pxy, np, g, lane, s1);
+    blk.init<PPL>(pxy, np, g, lane, s1);
     const double cx = blk.cx, cy = blk.cy, r = blk.r, r2 = blk.r2;
     const double thr = r2 * (1.0 / (FAR_RHO * FAR_RHO)) * (1.0 + 0x1p-40);
     constexpr int K1 = WHICH == MODE_SLP ? FAR_P : FAR_P + 1;
@@ -515,8 +526,9 @@ __global__ __launch_bounds__(256) void laplace_far_coeff_kernel(const double* __
 #pragma unroll
     for (int k = 0; k <= K1; ++k) sre[k] = sim[k] = 0.0;
     // two sources per lane and trip: two independent power chains in flight
-    for (int j0 = 0; j0 < ns_pad; j0 += 128) {
+    for (int j0 = jlo; j0 < jhi; j0 += 128) {
         double vre[2], vim[2], wre[2], wim[2];
+        bool anyfar = false;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int jb = j0 + 64 * h;                    // (wave-uniform)
@@ -526,11 +538,17 @@ __global__ __launch_bounds__(256) void laplace_far_coeff_kernel(const double* __
             const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
             const double d2 = fma(dy, dy, dx * dx);
             // a batch of eight sources goes one way as a whole: into the expansion only if all eight are far
-            const unsigned long long m = __ballot(valid && !(d2 >= thr && !prm->pad));
-            const bool far = valid && ((m >> (lane & ~7)) & 0xFFull) == 0;
+            // (batches the parent block took are nobody's here)
+            const unsigned taken = (PPL == 1 && skip && jb < ns_pad) ? skip[(g >> 4) * nch + (jb >> 6)] : 0u;
+            const bool mine = valid && !((taken >> (lane >> 3)) & 1u);
+            const unsigned long long m = __ballot(mine && !(d2 >= thr && !prm->pad));
+            const unsigned long long mv = __ballot(valid);
+            const bool far = mine && ((m >> (lane & ~7)) & 0xFFull) == 0;
+            anyfar = anyfar || far;
             if (write_near && lane == 0 && jb < ns_pad) {
-                const unsigned bits = far_batch_bits(m);
-                near[g * nch + (jb >> 6)] = bits;
+                const unsigned nearbits = far_batch_bits(m);
+                // parent level: the bits of the batches it takes (all of a batch's sources far)
+                near[g * nch + (jb >> 6)] = PPL == 1 ? nearbits : (far_batch_bits(mv) & ~nearbits);
             }
             // near sources ride along with zero weight at a harmless position
             const double inv = far ? r / d2 : 0.0;
@@ -539,12 +557,13 @@ __global__ __launch_bounds__(256) void laplace_far_coeff_kernel(const double* __
             if (WHICH == MODE_SLP) {
                 wre[h] = far ? rec[ipde_rec_index(jj, 2)] : 0.0;
                 wim[h] = 0.0;
-                sre[0] = fma(wre[h], log(far ? d2 : 1.0), sre[0]);
+                if (__ballot(far)) sre[0] = fma(wre[h], log(far ? d2 : 1.0), sre[0]);
             } else {
                 wre[h] = far ? rec[ipde_rec_index(jj, 3)] / r : 0.0;
                 wim[h] = far ? rec[ipde_rec_index(jj, 4)] / r : 0.0;
             }
         }
+        if (__ballot(anyfar) == 0) continue;               // nothing of this trip enters the expansion (wave-uniform)
         double pre[2] = {vre[0], vre[1]}, pim[2] = {vim[0], vim[1]};      // vt^k
 #pragma unroll
         for (int k = 1; k <= K1; ++k) {
@@ -569,13 +588,13 @@ __global__ __launch_bounds__(256) void laplace_far_coeff_kernel(const double* __
         sim[k] = wave_sum(sim[k]);
     }
     if (lane == 0) {
-        if (WHICH == MODE_SLP || write_near) {
+        if ((WHICH == MODE_SLP || write_near) && slice == 0) {
             head[g * FAR_HDR + 0] = cx;
             head[g * FAR_HDR + 1] = cy;
             head[g * FAR_HDR + 2] = 1.0 / r;
             head[g * FAR_HDR + 3] = 0.0;
         }
-        double* c = coef + g * FAR_NCOEF;
+        double* c = coef + gw * FAR_NCOEF;
 #pragma unroll
         for (int k = 0; k <= K1; ++k) {
             c[2 * k] = sre[k];
@@ -589,16 +608,58 @@ __global__ __launch_bounds__(NT) void laplace_patch_far_kernel(
     const double* __restrict__ rec, int ns_pad, const double* __restrict__ pxy, int64_t np,
     const int* __restrict__ pout, double* __restrict__ out, const ApplyParams* __restrict__ prm,
     const double2* __restrict__ gtab, unsigned key_lo, unsigned nkeys, const double* __restrict__ head,
-    const double* __restrict__ cs, const double* __restrict__ cdl, const unsigned* __restrict__ near, int nch) {
+    const double* __restrict__ cs, const double* __restrict__ cdl, const unsigned* __restrict__ near, int nch,
+    const double* __restrict__ head2, const double* __restrict__ cs2, const double* __restrict__ cdl2,
+    int nslice2) {
     extern __shared__ double2 ltab[];
     for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
     __syncthreads();
     TabAddr ta;
     const double s1 = ldexp(1.0, prm->sh);
-    const int64_t lane = (int64_t)blockIdx.x * NT + threadIdx.x;
-    const int64_t g = __builtin_amdgcn_readfirstlane((int)(lane >> 6));
+    // wave w of workgroup b takes block w * gridDim.x + b: the sixteen waves of a workgroup (one CU)
+    // are spread over the list — consecutive blocks are neighbours in space, and a workgroup of
+    // sixteen neighbours next to the curve would carry sixteen times the near work of one far from it
+    const int wv = threadIdx.x >> 6;
+    const int64_t g = __builtin_amdgcn_readfirstlane((int)(wv * gridDim.x + blockIdx.x));
     if (g * 64 >= np) return;                          // (whole waves, after the only barrier)
+    const int64_t lane = g * 64 + (threadIdx.x & 63);
     const int64_t t = min(lane, np - 1);
+    // the wave's expansion coefficients, combined (B_k = -(2/k) S_k - D_(k+1), B_0 real) and parked in LDS
+    // behind the table: the Horner loops read them by broadcast ds_read_b128 (as scalar loads from HBM each
+    // step was an exposed round trip: +100 us at two levels)
+    double2* wc = ltab + nkeys + wv * (2 * (FAR_P + 1));
+    {
+        const int k = threadIdx.x & 63;
+#pragma unroll
+        for (int level = 0; level < 2; ++level) {
+            const int ns = level == 0 ? 1 : nslice2;          // (the parent's sums come in slices)
+            const int64_t gl = level == 0 ? g : (g >> 4) * ns;
+            const double* S = (level == 0 ? cs : cs2) + gl * FAR_NCOEF;
+            const double* D = (level == 0 ? cdl : cdl2) + gl * FAR_NCOEF;
+            if (k <= FAR_P) {
+                double bre = 0.0, bim = 0.0;
+                for (int sl = 0; sl < ns; ++sl) {
+                    const double* Ss = S + (size_t)sl * FAR_NCOEF;
+                    const double* Ds = D + (size_t)sl * FAR_NCOEF;
+                    if (k == 0) {
+                        if (MODE & MODE_SLP) bre += Ss[0];
+                        if (MODE & MODE_DLP) bre -= Ds[2];
+                    } else {
+                        if (MODE & MODE_SLP) {
+                            const double f = -2.0 / (double)k;
+                            bre += f * Ss[2 * k];
+                            bim += f * Ss[2 * k + 1];
+                        }
+                        if (MODE & MODE_DLP) {
+                            bre -= Ds[2 * (k + 1)];
+                            bim -= Ds[2 * (k + 1) + 1];
+                        }
+                    }
+                }
+                wc[level * (FAR_P + 1) + k] = double2{bre, bim};
+            }
+        }
+    }
     double xs[4], ys[4], acc[16];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -641,49 +702,40 @@ __global__ __launch_bounds__(NT) void laplace_patch_far_kernel(
             for (int r = 0; r < 4; ++r) acc[4 * a + r] = gsum[r];
         }
     }
-    // far sources: Re sum_k B_k zeta^k by Horner, B_k = -(2/k) S_k - D_(k+1)
-    {
-        const double* h = head + g * FAR_HDR;
-        const double cx = h[0], cy = h[1], rinv = h[2];
-        const double* S = cs + g * FAR_NCOEF;
-        const double* D = cdl + g * FAR_NCOEF;
-        double zx[4], zy[4];
+    // far sources: Re sum_k B_k zeta^k by Horner — the block's own expansion (level 0) and its parent's
+    // (level 1: the sources beyond four parent radii)
+    __builtin_amdgcn_wave_barrier();
+    if (!prm->pad) {
+#pragma unroll 1
+        for (int level = 0; level < 2; ++level) {
+            const int64_t gl = level == 0 ? g : (g >> 4);
+            const double* h = (level == 0 ? head : head2) + gl * FAR_HDR;
+            const double cx = h[0], cy = h[1], rinv = h[2];
+            const double2* B = wc + level * (FAR_P + 1);
+            const double b0 = B[0].x;
+            double zy[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            zx[a] = (xs[a] - cx) * rinv;
-            zy[a] = (ys[a] - cy) * rinv;
-        }
-        double vre[16], vim[16];
+            for (int bb = 0; bb < 4; ++bb) zy[bb] = (ys[bb] - cy) * rinv;
+            // a row of the patch at a time: eight chain registers instead of thirty-two (the kernel runs at
+            // 128 VGPRs: sixteen waves share the table)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) vre[i] = vim[i] = 0.0;
-        for (int k = FAR_P; k >= 1; --k) {
-            double bre = 0.0, bim = 0.0;
-            if (MODE & MODE_SLP) {
-                const double f = -2.0 / (double)k;
-                bre = f * S[2 * k];
-                bim = f * S[2 * k + 1];
-            }
-            if (MODE & MODE_DLP) {
-                bre -= D[2 * (k + 1)];
-                bim -= D[2 * (k + 1) + 1];
-            }
+            for (int a = 0; a < 4; ++a) {
+                const double zx = (xs[a] - cx) * rinv;
+                double vre[4] = {0.0, 0.0, 0.0, 0.0}, vim[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+                for (int k = FAR_P; k >= 1; --k) {
+                    const double2 bk = B[k];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int i = 4 * a + b;
-                    // v = (v + B_k) zeta
-                    const double ure = vre[i] + bre, uim = vim[i] + bim;
-                    vre[i] = ure * zx[a] - uim * zy[b];
-                    vim[i] = fma(ure, zy[b], uim * zx[a]);
+                    for (int bb = 0; bb < 4; ++bb) {
+                        // v = (v + B_k) zeta
+                        const double ure = vre[bb] + bk.x, uim = vim[bb] + bk.y;
+                        vre[bb] = ure * zx - uim * zy[bb];
+                        vim[bb] = fma(ure, zy[bb], uim * zx);
+                    }
                 }
-        }
-        double b0 = 0.0;
-        if (MODE & MODE_SLP) b0 = S[0];
-        if (MODE & MODE_DLP) b0 -= D[2];
-        if (!prm->pad) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] += vre[i] + b0;
+                for (int bb = 0; bb < 4; ++bb) acc[4 * a + bb] += vre[bb] + b0;
+            }
         }
     }
     if (lane >= np) return;
@@ -702,30 +754,47 @@ int launch_laplace_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, con
     const LogTable& lt = ctx->logtab;
     const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
     const int64_t ng = ceil_div64(np, 64);
+    const int64_t ng2 = ceil_div64(ng, 16);            // parent blocks
     const int nch = (int)ceil_div64(ns_pad, 64);
-    // workspace: head | S coefficients | D coefficients | near bits
-    const size_t nd = (size_t)ng * (FAR_HDR + 2 * FAR_NCOEF);
-    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
+    constexpr int NSL = 8;                             // waves (slices of the sources) per parent
+    // workspace: blocks: head | S | D; parents: head | S, D per slice; then the near bits and the parents' bits
+    const size_t nd = (size_t)ng * (FAR_HDR + 2 * FAR_NCOEF) + (size_t)ng2 * (FAR_HDR + 2 * NSL * FAR_NCOEF);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial,
+                                 nd * sizeof(double) + (size_t)(ng + ng2) * nch * sizeof(unsigned)));
     double* head = (double*)ctx->partial.p;
     double* cs = head + (size_t)ng * FAR_HDR;
     double* cdl = cs + (size_t)ng * FAR_NCOEF;
-    unsigned* near = (unsigned*)(cdl + (size_t)ng * FAR_NCOEF);
-    const unsigned gb = (unsigned)ceil_div64(ng, 4);
+    double* head2 = cdl + (size_t)ng * FAR_NCOEF;
+    double* cs2 = head2 + (size_t)ng2 * FAR_HDR;
+    double* cdl2 = cs2 + (size_t)ng2 * NSL * FAR_NCOEF;
+    unsigned* near = (unsigned*)(cdl2 + (size_t)ng2 * NSL * FAR_NCOEF);
+    unsigned* taken = near + (size_t)ng * nch;
+    const unsigned gb = (unsigned)ceil_div64(ng, 4), gb2 = (unsigned)ceil_div64(ng2 * NSL, 4);
     ipde_time_begin(ctx);
+    // parents first (their bits steer the blocks' pass)
     if (MODE & MODE_SLP)
-        hipLaunchKernelGGL(laplace_far_coeff_kernel<MODE_SLP>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy,
-                           np, prm, head, cs, near, nch, 1);
+        hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_SLP, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad,
+                           pxy, np, prm, head2, cs2, taken, nch, 1, (const unsigned*)nullptr, NSL);
     if (MODE & MODE_DLP)
-        hipLaunchKernelGGL(laplace_far_coeff_kernel<MODE_DLP>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy,
-                           np, prm, head, cdl, near, nch, (MODE & MODE_SLP) ? 0 : 1);
+        hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_DLP, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad,
+                           pxy, np, prm, head2, cdl2, taken, nch, (MODE & MODE_SLP) ? 0 : 1, (const unsigned*)nullptr,
+                           NSL);
+    if (MODE & MODE_SLP)
+        hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_SLP, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
+                           pxy, np, prm, head, cs, near, nch, 1, (const unsigned*)taken, 1);
+    if (MODE & MODE_DLP)
+        hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_DLP, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
+                           pxy, np, prm, head, cdl, near, nch, (MODE & MODE_SLP) ? 0 : 1, (const unsigned*)taken, 1);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
-    const size_t lds = (size_t)lt.nkeys * sizeof(double2);
+    // the table, then 2 levels x 27 combined coefficients for each of the workgroup's waves
+    const size_t lds = ((size_t)lt.nkeys + (size_t)(NT / 64) * 2 * (FAR_P + 1)) * sizeof(double2);
     IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_patch_far_kernel<MODE, NT>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((laplace_patch_far_kernel<MODE, NT>), dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds,
                        ctx->stream, rec, ns_pad, pxy, np, pout, out, prm, (const double2*)lt.d_tab,
                        (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)cs,
-                       (const double*)cdl, (const unsigned*)near, nch);
+                       (const double*)cdl, (const unsigned*)near, nch, (const double*)head2, (const double*)cs2,
+                       (const double*)cdl2, NSL);
     ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;

@@ -218,27 +218,43 @@ extern "C" int ipde_target_plan_build_blocks(int64_t nt, const double* x, const 
         p->np = np;
         p->pxy.resize((size_t)8 * np);
         p->pout.resize((size_t)16 * np);
-        int64_t q = 0;
+        // blocks in row-major order of their tile coordinates; padded plans: in Z (Morton) order, so
+        // that 16 consecutive blocks are a 4 x 4 group of blocks, 256 a 16 x 16 one (the far-field
+        // kernels' second level takes 16 consecutive blocks as one parent block)
+        std::vector<std::pair<uint64_t, std::pair<int64_t, int64_t>>> blocks;
         for (int64_t Ib = 0; Ib < ni; Ib += block_i)
             for (int64_t Jb = 0; Jb < nj; Jb += block_j) {
-                const int64_t q0 = q;
-                for (int64_t I = Ib; I < std::min<int64_t>(ni, Ib + block_i); ++I)
-                    for (int64_t J = Jb; J < std::min<int64_t>(nj, Jb + block_j); ++J) {
-                        if (!used(I, J)) continue;
-                        for (int a = 0; a < 4; ++a) {
-                            p->pxy[(size_t)a * np + q] = ux[std::min<int64_t>(nx - 1, 4 * I + a)];
-                            p->pxy[(size_t)(4 + a) * np + q] = uy[std::min<int64_t>(ny - 1, 4 * J + a)];
-                            for (int b = 0; b < 4; ++b)
-                                p->pout[(size_t)(4 * a + b) * np + q] = pos[(size_t)(4 * I + a) * nyp + 4 * J + b];
-                        }
-                        ++q;
-                    }
-                if (pad_blocks && q > q0)
-                    for (const int64_t qe = q0 + (int64_t)block_i * block_j; q < qe; ++q) {
-                        for (int r = 0; r < 8; ++r) p->pxy[(size_t)r * np + q] = p->pxy[(size_t)r * np + q0];
-                        for (int r = 0; r < 16; ++r) p->pout[(size_t)r * np + q] = -1;
-                    }
+                uint64_t key = (uint64_t)blocks.size();
+                if (pad_blocks) {
+                    const uint64_t a = (uint64_t)(Ib / block_i), b = (uint64_t)(Jb / block_j);
+                    key = 0;
+                    for (int bit = 0; bit < 32; ++bit)
+                        key |= ((a >> bit) & 1ull) << (2 * bit + 1) | ((b >> bit) & 1ull) << (2 * bit);
+                }
+                blocks.push_back({key, {Ib, Jb}});
             }
+        if (pad_blocks) std::sort(blocks.begin(), blocks.end());
+        int64_t q = 0;
+        for (const auto& blk : blocks) {
+            const int64_t Ib = blk.second.first, Jb = blk.second.second;
+            const int64_t q0 = q;
+            for (int64_t I = Ib; I < std::min<int64_t>(ni, Ib + block_i); ++I)
+                for (int64_t J = Jb; J < std::min<int64_t>(nj, Jb + block_j); ++J) {
+                    if (!used(I, J)) continue;
+                    for (int a = 0; a < 4; ++a) {
+                        p->pxy[(size_t)a * np + q] = ux[std::min<int64_t>(nx - 1, 4 * I + a)];
+                        p->pxy[(size_t)(4 + a) * np + q] = uy[std::min<int64_t>(ny - 1, 4 * J + a)];
+                        for (int b = 0; b < 4; ++b)
+                            p->pout[(size_t)(4 * a + b) * np + q] = pos[(size_t)(4 * I + a) * nyp + 4 * J + b];
+                    }
+                    ++q;
+                }
+            if (pad_blocks && q > q0)
+                for (const int64_t qe = q0 + (int64_t)block_i * block_j; q < qe; ++q) {
+                    for (int r = 0; r < 8; ++r) p->pxy[(size_t)r * np + q] = p->pxy[(size_t)r * np + q0];
+                    for (int r = 0; r < 16; ++r) p->pout[(size_t)r * np + q] = -1;
+                }
+        }
         // (5) the remainder, in list order
         for (int64_t i = 0; i < nt; ++i) {
             bool in_patch = false;

@@ -2,4 +2,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout -k 10 600 python3 -m pytest tests/test_layer_gpu.py -m gpu -x -q -k "far_expansion_full_size" 2>&1 | tail -8
+O=gpurun_out/r03/far; mkdir -p $O
+timeout -k 10 900 python3 -m pytest tests/test_layer_gpu.py tests/test_solver_gpu.py -m gpu -x -q -k "far or patches or poisson" 2>&1 | tail -4
+export IPDE_PROFILE_SOLVES=60
+for i in 1 2; do timeout -k 10 300 python3 tools/profile_solve.py 2>&1 | grep "warm solve"; done
