@@ -352,18 +352,26 @@ constexpr double SFAR_RHO = 0.25;
 constexpr int SFAR_NCOEF = 2 * (SFAR_P + 2);
 constexpr int SFAR_HDR = 4;
 
-template <int WHICH>
+// Two levels as in layer_laplace.hip: PPL = 16 first, `nslice` waves (slices of the sources) per parent
+// block of sixteen consecutive blocks, `bits` = the batches the parent takes; PPL = 1 then per block with
+// `skip` = those bits, `bits` = its near batches.
+template <int WHICH, int PPL>
 __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __restrict__ rec, int ns_pad,
                                                               const double* __restrict__ pxy, int64_t np,
                                                               const ApplyParams* __restrict__ prm,
                                                               double* __restrict__ head, double* __restrict__ coef,
-                                                              unsigned* __restrict__ near, int nch) {
+                                                              unsigned* __restrict__ near, int nch,
+                                                              const unsigned* __restrict__ skip, int nslice) {
     const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g * 64 >= np) return;                          // (whole waves)
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t g = gw / nslice;
+    const int slice = (int)(gw - g * nslice);
+    if (g * 64 * PPL >= np) return;                    // (whole waves)
+    const int trips = (ns_pad + 127) / 128, tps = (trips + nslice - 1) / nslice;
+    const int jlo = slice * tps * 128, jhi = min(ns_pad, (slice + 1) * tps * 128);
     const double s1 = ldexp(1.0, prm->sh);
     FarBlock blk;
-    blk.init(pxy, np, g, lane, s1);
+    blk.init<PPL>(pxy, np, g, lane, s1);
     const double cx = blk.cx, cy = blk.cy, r = blk.r, r2 = blk.r2;
     const double thr = r2 * (1.0 / (SFAR_RHO * SFAR_RHO)) * (1.0 + 0x1p-40);
     constexpr int K0 = WHICH == 3 ? 0 : 1;
@@ -373,8 +381,9 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
     for (int k = 0; k <= K1; ++k) sre[k] = sim[k] = 0.0;
     // two sources per lane and trip: two independent power chains in flight (the chain of complex
     // products is the critical path at two waves per SIMD)
-    for (int j0 = 0; j0 < ns_pad; j0 += 128) {
+    for (int j0 = jlo; j0 < jhi; j0 += 128) {
         double vre[2], vim[2], wre[2], wim[2];
+        bool anyfar = false;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int jb = j0 + 64 * h;                    // (wave-uniform)
@@ -383,12 +392,16 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
             const int jj = valid ? j : ns_pad - 1;
             const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
             const double d2 = fma(dy, dy, dx * dx);
-            // a batch of eight sources goes one way as a whole
-            const unsigned long long m = __ballot(valid && !(d2 >= thr && !prm->pad));
-            const bool far = valid && ((m >> (lane & ~7)) & 0xFFull) == 0;
+            // a batch of eight sources goes one way as a whole (batches the parent took are nobody's here)
+            const unsigned taken = (PPL == 1 && skip && jb < ns_pad) ? skip[(g >> 4) * nch + (jb >> 6)] : 0u;
+            const bool mine = valid && !((taken >> (lane >> 3)) & 1u);
+            const unsigned long long m = __ballot(mine && !(d2 >= thr && !prm->pad));
+            const unsigned long long mv = __ballot(valid);
+            const bool far = mine && ((m >> (lane & ~7)) & 0xFFull) == 0;
+            anyfar = anyfar || far;
             if (WHICH == 1 && lane == 0 && jb < ns_pad) {
-                const unsigned bits = far_batch_bits(m);
-                near[g * nch + (jb >> 6)] = bits;
+                const unsigned nearbits = far_batch_bits(m);
+                near[g * nch + (jb >> 6)] = PPL == 1 ? nearbits : (far_batch_bits(mv) & ~nearbits);
             }
             const double inv = far ? r / d2 : 0.0;
             vre[h] = dx * inv;
@@ -411,6 +424,7 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
                 wim[h] = fx * uim + fy * ure;
             }
         }
+        if (__ballot(anyfar) == 0) continue;               // nothing of this trip enters the expansion (wave-uniform)
         double pre[2], pim[2];                             // vt^k
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -435,13 +449,13 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
         sim[k] = wave_sum(sim[k]);
     }
     if (lane == 0) {
-        if (WHICH == 1) {
+        if (WHICH == 1 && slice == 0) {
             head[g * SFAR_HDR + 0] = cx;
             head[g * SFAR_HDR + 1] = cy;
             head[g * SFAR_HDR + 2] = 1.0 / r;
             head[g * SFAR_HDR + 3] = 0.0;
         }
-        double* c = coef + g * SFAR_NCOEF;
+        double* c = coef + gw * SFAR_NCOEF;
 #pragma unroll
         for (int k = 0; k <= K1; ++k) {
             c[2 * k] = sre[k];
@@ -456,16 +470,54 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
     const int* __restrict__ pout, double* __restrict__ ou, double* __restrict__ ov, double* __restrict__ op,
     const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab, unsigned key_lo, unsigned nkeys,
     const double* __restrict__ head, const double* __restrict__ c1, const double* __restrict__ c2,
-    const double* __restrict__ c3, const unsigned* __restrict__ near, int nch) {
+    const double* __restrict__ c3, const unsigned* __restrict__ near, int nch,
+    const unsigned* __restrict__ taken) {
     extern __shared__ double2 ltab[];
     for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
     __syncthreads();
     TabAddr ta;
     const double s1 = ldexp(1.0, prm->sh);
-    const int64_t lane = (int64_t)blockIdx.x * NT + threadIdx.x;
-    const int64_t g = __builtin_amdgcn_readfirstlane((int)(lane >> 6));
+    // wave w of workgroup b takes block w * gridDim.x + b (see laplace_patch_far_kernel)
+    const int wv = threadIdx.x >> 6;
+    const int64_t g = __builtin_amdgcn_readfirstlane((int)(wv * gridDim.x + blockIdx.x));
     if (g * 64 >= np) return;                          // (whole waves, after the only barrier)
+    const int64_t lane = g * 64 + (threadIdx.x & 63);
     const int64_t t = min(lane, np - 1);
+    // per level and k, combined and parked in LDS behind the table (lane k stages entry k):
+    //   [3k]   a1_k = X1_k / (2k) (k >= 1; k = 0: C0),   [3k+1] a2_k = X1_(k+1),
+    //   [3k+2] b_k = conj(X3_k)/2 + conj(X2_k)/(2k)
+    constexpr int WCL = 3 * (SFAR_P + 1);
+    double2* wc = ltab + nkeys + wv * WCL;
+    {
+        const int k = threadIdx.x & 63;
+        {
+            constexpr int level = 0;
+            const int ns = 1;
+            const int64_t gl = g;
+            const double* X1 = c1 + gl * SFAR_NCOEF;
+            const double* X2 = c2 + gl * SFAR_NCOEF;
+            const double* X3 = c3 + gl * SFAR_NCOEF;
+            if (k <= SFAR_P) {
+                double a1r = 0.0, a1i = 0.0, a2r = 0.0, a2i = 0.0, br = 0.0, bi = 0.0;
+                const double hk = k >= 1 ? 0.5 / (double)k : 1.0;       // (k = 0: C0 itself)
+                for (int sl = 0; sl < ns; ++sl) {
+                    const double* Y1 = X1 + (size_t)sl * SFAR_NCOEF;
+                    const double* Y2 = X2 + (size_t)sl * SFAR_NCOEF;
+                    const double* Y3 = X3 + (size_t)sl * SFAR_NCOEF;
+                    a1r += hk * Y1[2 * k];
+                    a1i += hk * Y1[2 * k + 1];
+                    a2r += Y1[2 * (k + 1)];
+                    a2i += Y1[2 * (k + 1) + 1];
+                    br += 0.5 * Y3[2 * k] + (k >= 1 ? hk * Y2[2 * k] : 0.0);
+                    bi -= 0.5 * Y3[2 * k + 1] + (k >= 1 ? hk * Y2[2 * k + 1] : 0.0);
+                }
+                wc[level * WCL + 3 * k] = double2{a1r, a1i};
+                wc[level * WCL + 3 * k + 1] = double2{a2r, a2i};
+                wc[level * WCL + 3 * k + 2] = double2{br, bi};
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
     double xs[4], ys[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -473,13 +525,14 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
         ys[a] = pxy[(int64_t)(4 + a) * np + t] * s1;
     }
     StokesAcc acc[16];
-    // far sources first: the expansion's values are the accumulators' starting values
+    // far sources first: the block's expansion values are the accumulators' starting values (the parent's
+    // expansion is added by stokes_far_parent_kernel afterwards: this kernel is at its register limit)
     {
+        constexpr int level = 0;
         const double* h = head + g * SFAR_HDR;
         const double cx = h[0], cy = h[1], rinv = h[2];
-        const double* X1 = c1 + g * SFAR_NCOEF;
-        const double* X2 = c2 + g * SFAR_NCOEF;
-        const double* X3 = c3 + g * SFAR_NCOEF;
+        const double2* W = wc;
+        const double2 c0 = W[0];
         double zy[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) zy[b] = (ys[b] - cy) * rinv;
@@ -489,39 +542,39 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
             double s1r[4], s1i[4], s2r[4], s2i[4], s3r[4], s3i[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) s1r[b] = s1i[b] = s2r[b] = s2i[b] = s3r[b] = s3i[b] = 0.0;
+#pragma unroll 1
             for (int k = SFAR_P; k >= 0; --k) {
-                const double hk = k >= 1 ? 0.5 / (double)k : 0.0;
-                const double a1r = k >= 1 ? hk * X1[2 * k] : 0.0, a1i = k >= 1 ? hk * X1[2 * k + 1] : 0.0;
-                const double a2r = X1[2 * (k + 1)], a2i = X1[2 * (k + 1) + 1];
-                // b_k = conj(X3_k)/2 + conj(X2_k)/(2k)
-                const double b3r = 0.5 * X3[2 * k] + (k >= 1 ? hk * X2[2 * k] : 0.0);
-                const double b3i = -0.5 * X3[2 * k + 1] - (k >= 1 ? hk * X2[2 * k + 1] : 0.0);
+                const double2 a1 = k >= 1 ? W[3 * k] : double2{0.0, 0.0};
+                const double2 a2 = W[3 * k + 1];
+                const double2 b3 = W[3 * k + 2];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    double nr = s1r[b] * zx - s1i[b] * zy[b] + a1r;
-                    s1i[b] = fma(s1r[b], zy[b], s1i[b] * zx) + a1i;
+                    double nr = s1r[b] * zx - s1i[b] * zy[b] + a1.x;
+                    s1i[b] = fma(s1r[b], zy[b], s1i[b] * zx) + a1.y;
                     s1r[b] = nr;
-                    nr = s2r[b] * zx - s2i[b] * zy[b] + a2r;
-                    s2i[b] = fma(s2r[b], zy[b], s2i[b] * zx) + a2i;
+                    nr = s2r[b] * zx - s2i[b] * zy[b] + a2.x;
+                    s2i[b] = fma(s2r[b], zy[b], s2i[b] * zx) + a2.y;
                     s2r[b] = nr;
                     // conj(zeta) = zx - i zy
-                    nr = s3r[b] * zx + s3i[b] * zy[b] + b3r;
-                    s3i[b] = fma(-s3r[b], zy[b], s3i[b] * zx) + b3i;
+                    nr = s3r[b] * zx + s3i[b] * zy[b] + b3.x;
+                    s3i[b] = fma(-s3r[b], zy[b], s3i[b] * zx) + b3.y;
                     s3r[b] = nr;
                 }
             }
-            const double c0r = X1[0], c0i = X1[1];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 // zeta conj(S2) = (zx + i zy)(s2r - i s2i)
                 const double qr = zx * s2r[b] + zy[b] * s2i[b], qi = zy[b] * s2r[b] - zx * s2i[b];
-                StokesAcc v;
-                v.uL = 0.0;
-                v.vL = 0.0;
-                v.u = c0r + s1r[b] + s3r[b] - 0.5 * qr;
-                v.v = c0i + s1i[b] + s3i[b] - 0.5 * qi;
-                v.p = -rinv * s2r[b];
-                acc[4 * a + b] = v;
+                const double fu = c0.x + s1r[b] + s3r[b] - 0.5 * qr;
+                const double fv = c0.y + s1i[b] + s3i[b] - 0.5 * qi;
+                const double fq = -rinv * s2r[b];
+                if (level == 0) {
+                    acc[4 * a + b] = StokesAcc{0.0, 0.0, fu, fv, fq};
+                } else {
+                    acc[4 * a + b].u += fu;
+                    acc[4 * a + b].v += fv;
+                    acc[4 * a + b].p += fq;
+                }
             }
         }
     }
@@ -569,14 +622,25 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
     }
     if (!ta.all_inside(key_lo) || prm->pad) {
         // a near pair of this patch left the table (or the scaling failed: then nothing is in an
-        // expansion): all sources of its targets again, with the generic math
+        // expansion): all sources of its targets again with the generic math — all but the batches the
+        // parent block took (stokes_far_parent_kernel adds those to whatever is stored here)
+        const unsigned* tk = taken + (g >> 4) * nch;
+        const int nbatch = ns_pad / IPDE_SRC_PAD;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const double xa[4] = {xs[a], xs[a], xs[a], xs[a]};
             StokesAcc gs[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) gs[b] = StokesAcc{0, 0, 0, 0, 0};
-            stokes_generic_loop<MODE_SLP, false, 4>(rec, 0, ns_pad, xa, ys, gs);
+            for (int c = 0; c < nch; ++c) {
+                unsigned m = ~tk[c] & 0xFFu;
+                while (m) {
+                    const int bt = __builtin_ctz(m);
+                    m &= m - 1;
+                    if (8 * c + bt < nbatch)
+                        stokes_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, xa, ys, gs);
+                }
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[4 * a + b] = gs[b];
         }
@@ -595,36 +659,136 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
     }
 }
 
+// The parent blocks' expansions added to the stored values (one lane per patch, all of the parent's
+// sixteen blocks read the same 3 x 27 combined coefficients: staged in LDS by the workgroup = one parent).
+__global__ __launch_bounds__(1024) void stokes_far_parent_kernel(const double* __restrict__ pxy, int64_t np,
+                                                                 const int* __restrict__ pout, double* __restrict__ ou,
+                                                                 double* __restrict__ ov, double* __restrict__ op,
+                                                                 const ApplyParams* __restrict__ prm,
+                                                                 const double* __restrict__ head2,
+                                                                 const double* __restrict__ p1,
+                                                                 const double* __restrict__ p2,
+                                                                 const double* __restrict__ p3, int nslice) {
+    constexpr int WCL = 3 * (SFAR_P + 1);
+    __shared__ double2 W[WCL];
+    const int64_t par = blockIdx.x;                    // patches [1024 par, 1024 par + 1024)
+    if (threadIdx.x <= SFAR_P) {
+        const int k = threadIdx.x;
+        const double* X1 = p1 + par * nslice * SFAR_NCOEF;
+        const double* X2 = p2 + par * nslice * SFAR_NCOEF;
+        const double* X3 = p3 + par * nslice * SFAR_NCOEF;
+        double a1r = 0.0, a1i = 0.0, a2r = 0.0, a2i = 0.0, br = 0.0, bi = 0.0;
+        const double hk = k >= 1 ? 0.5 / (double)k : 1.0;
+        for (int sl = 0; sl < nslice; ++sl) {
+            const double* Y1 = X1 + (size_t)sl * SFAR_NCOEF;
+            const double* Y2 = X2 + (size_t)sl * SFAR_NCOEF;
+            const double* Y3 = X3 + (size_t)sl * SFAR_NCOEF;
+            a1r += hk * Y1[2 * k];
+            a1i += hk * Y1[2 * k + 1];
+            a2r += Y1[2 * (k + 1)];
+            a2i += Y1[2 * (k + 1) + 1];
+            br += 0.5 * Y3[2 * k] + (k >= 1 ? hk * Y2[2 * k] : 0.0);
+            bi -= 0.5 * Y3[2 * k + 1] + (k >= 1 ? hk * Y2[2 * k + 1] : 0.0);
+        }
+        W[3 * k] = double2{a1r, a1i};
+        W[3 * k + 1] = double2{a2r, a2i};
+        W[3 * k + 2] = double2{br, bi};
+    }
+    __syncthreads();
+    const int64_t t = par * 1024 + threadIdx.x;
+    if (t >= np || prm->pad) return;
+    const double s1 = ldexp(1.0, prm->sh);
+    const double cx = head2[par * SFAR_HDR], cy = head2[par * SFAR_HDR + 1], rinv = head2[par * SFAR_HDR + 2];
+    const double2 c0 = W[0];
+    const double ps = 2.0 * s1;
+    double zy[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) zy[b] = (pxy[(int64_t)(4 + b) * np + t] * s1 - cy) * rinv;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double zx = (pxy[(int64_t)a * np + t] * s1 - cx) * rinv;
+        double s1r[4], s1i[4], s2r[4], s2i[4], s3r[4], s3i[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s1r[b] = s1i[b] = s2r[b] = s2i[b] = s3r[b] = s3i[b] = 0.0;
+#pragma unroll 2
+        for (int k = SFAR_P; k >= 0; --k) {
+            const double2 a1 = k >= 1 ? W[3 * k] : double2{0.0, 0.0};
+            const double2 a2 = W[3 * k + 1];
+            const double2 b3 = W[3 * k + 2];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                double nr = s1r[b] * zx - s1i[b] * zy[b] + a1.x;
+                s1i[b] = fma(s1r[b], zy[b], s1i[b] * zx) + a1.y;
+                s1r[b] = nr;
+                nr = s2r[b] * zx - s2i[b] * zy[b] + a2.x;
+                s2i[b] = fma(s2r[b], zy[b], s2i[b] * zx) + a2.y;
+                s2r[b] = nr;
+                nr = s3r[b] * zx + s3i[b] * zy[b] + b3.x;
+                s3i[b] = fma(-s3r[b], zy[b], s3i[b] * zx) + b3.y;
+                s3r[b] = nr;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = pout[(int64_t)(4 * a + b) * np + t];
+            if (i < 0) continue;
+            const double qr = zx * s2r[b] + zy[b] * s2i[b], qi = zy[b] * s2r[b] - zx * s2i[b];
+            ou[i] += c0.x + s1r[b] + s3r[b] - 0.5 * qr;
+            ov[i] += c0.y + s1i[b] + s3i[b] - 0.5 * qi;
+            if (op) op[i] += ps * (-rinv * s2r[b]);
+        }
+    }
+}
+
 int launch_stokes_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, const double* pxy, int64_t np,
                               const int* pout, double* ou, double* ov, double* op, const ApplyParams* prm) {
     constexpr int NT = 512;
+    constexpr int NSL = 8;                             // waves (slices of the sources) per parent block
     const LogTable& lt = ctx->logtab;
     const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
     const int64_t ng = ceil_div64(np, 64);
+    const int64_t ng2 = ceil_div64(ng, 16);
     const int nch = (int)ceil_div64(ns_pad, 64);
-    const size_t nd = (size_t)ng * (SFAR_HDR + 3 * SFAR_NCOEF);
-    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
+    const size_t nd = (size_t)ng * (SFAR_HDR + 3 * SFAR_NCOEF) + (size_t)ng2 * (SFAR_HDR + 3 * NSL * SFAR_NCOEF);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial,
+                                 nd * sizeof(double) + (size_t)(ng + ng2) * nch * sizeof(unsigned)));
     double* head = (double*)ctx->partial.p;
     double* c1 = head + (size_t)ng * SFAR_HDR;
     double* c2 = c1 + (size_t)ng * SFAR_NCOEF;
     double* c3 = c2 + (size_t)ng * SFAR_NCOEF;
-    unsigned* near = (unsigned*)(c3 + (size_t)ng * SFAR_NCOEF);
-    const unsigned gb = (unsigned)ceil_div64(ng, 4);
+    double* head2 = c3 + (size_t)ng * SFAR_NCOEF;
+    double* p1 = head2 + (size_t)ng2 * SFAR_HDR;
+    double* p2 = p1 + (size_t)ng2 * NSL * SFAR_NCOEF;
+    double* p3 = p2 + (size_t)ng2 * NSL * SFAR_NCOEF;
+    unsigned* near = (unsigned*)(p3 + (size_t)ng2 * NSL * SFAR_NCOEF);
+    unsigned* taken = near + (size_t)ng * nch;
+    const unsigned gb = (unsigned)ceil_div64(ng, 4), gb2 = (unsigned)ceil_div64(ng2 * NSL, 4);
+    const unsigned* none = nullptr;
     ipde_time_begin(ctx);
-    hipLaunchKernelGGL(stokes_far_coeff_kernel<1>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
-                       head, c1, near, nch);
-    hipLaunchKernelGGL(stokes_far_coeff_kernel<2>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
-                       head, c2, near, nch);
-    hipLaunchKernelGGL(stokes_far_coeff_kernel<3>, dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
-                       head, c3, near, nch);
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<1, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                       head2, p1, taken, nch, none, NSL);
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<2, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                       head2, p2, taken, nch, none, NSL);
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<3, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                       head2, p3, taken, nch, none, NSL);
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<1, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                       head, c1, near, nch, (const unsigned*)taken, 1);
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<2, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                       head, c2, near, nch, (const unsigned*)taken, 1);
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<3, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                       head, c3, near, nch, (const unsigned*)taken, 1);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
-    const size_t lds = (size_t)lt.nkeys * sizeof(double2);
+    // the table, then 27 x 3 combined coefficients for each of the workgroup's waves
+    const size_t lds = ((size_t)lt.nkeys + (size_t)(NT / 64) * 3 * (SFAR_P + 1)) * sizeof(double2);
     IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stokes_patch_far_kernel<NT>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((stokes_patch_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds,
                        ctx->stream, rec, ns_pad, pxy, np, pout, ou, ov, op, prm, (const double2*)lt.d_tab,
                        (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)c1,
-                       (const double*)c2, (const double*)c3, (const unsigned*)near, nch);
+                       (const double*)c2, (const double*)c3, (const unsigned*)near, nch, (const unsigned*)taken);
+    hipLaunchKernelGGL(stokes_far_parent_kernel, dim3((unsigned)ng2), dim3(1024), 0, ctx->stream, pxy, np, pout, ou,
+                       ov, op, prm, (const double*)head2, (const double*)p1, (const double*)p2, (const double*)p3,
+                       NSL);
     ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
