@@ -231,17 +231,26 @@ constexpr int MFAR_TN = 12;
 constexpr int MFAR_NCOEF = 2 * (MFAR_P + 2);
 constexpr int MFAR_HDR = 4;      // cx, cy, 1/r, r^2/4
 
+// Two levels as in layer_laplace.hip: PPL = 16 first, `nslice` waves (slices of the sources) per parent
+// block of sixteen consecutive blocks, `bits` = the batches the parent takes or drops; PPL = 1 then per
+// block with `skip` = those bits, `bits` = its near batches.
+template <int PPL>
 __global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __restrict__ rec, int ns_pad,
                                                                const double* __restrict__ pxy, int64_t np,
                                                                const ApplyParams* __restrict__ prm,
                                                                double* __restrict__ head, double* __restrict__ coef,
-                                                               unsigned* __restrict__ near, int nch) {
+                                                               unsigned* __restrict__ near, int nch,
+                                                               const unsigned* __restrict__ skip, int nslice) {
     const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g * 64 >= np) return;                          // (whole waves)
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t g = gw / nslice;
+    const int slice = (int)(gw - g * nslice);
+    if (g * 64 * PPL >= np) return;                    // (whole waves)
+    const int trips = (ns_pad + 63) / 64, tps = (trips + nslice - 1) / nslice;
+    const int jlo = slice * tps * 64, jhi = min(ns_pad, (slice + 1) * tps * 64);
     const double s1 = prm->scale;
     FarBlock blk;
-    blk.init(pxy, np, g, lane, s1);
+    blk.init<PPL>(pxy, np, g, lane, s1);
     const double cx = blk.cx, cy = blk.cy, r = blk.r, r2 = blk.r2;
     const double r2q = 0.25 * r2;
     const bool block_ok = r <= MFAR_RMAX;
@@ -250,22 +259,28 @@ __global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __
     double sre[MFAR_P + 1], sim[MFAR_P + 1];
 #pragma unroll
     for (int k = 0; k <= MFAR_P; ++k) sre[k] = sim[k] = 0.0;
-    for (int j0 = 0; j0 < ns_pad; j0 += 64) {
+    for (int j0 = jlo; j0 < jhi; j0 += 64) {
         const int j = j0 + lane;
         const bool valid = j < ns_pad;
         const int jj = valid ? j : ns_pad - 1;
         const double dx = rec[ipde_rec_index(jj, 0)] - cx, dy = rec[ipde_rec_index(jj, 1)] - cy;
         const double d2 = fma(dy, dy, dx * dx);
         // a batch of eight sources goes one way as a whole: dropped (all eight beyond r + 45), else
-        // into the expansion (all eight beyond 4 r, block narrow enough), else pair by pair
+        // into the expansion (all eight beyond 4 r, block narrow enough), else pair by pair; batches the
+        // parent block took or dropped are nobody's here
+        const unsigned taken = (PPL == 1 && skip) ? skip[(g >> 4) * nch + (j0 >> 6)] : 0u;
+        const bool mine = valid && !((taken >> (lane >> 3)) & 1u);
         const bool negligible = d2 >= drop2;
-        const unsigned long long mk = __ballot(valid && !negligible);       // lanes that matter at all
-        const unsigned long long m = __ballot(valid && !(block_ok && d2 >= thr));
+        const unsigned long long mk = __ballot(mine && !negligible);       // lanes that matter at all
+        const unsigned long long m = __ballot(mine && !(block_ok && d2 >= thr));
+        const unsigned long long mv = __ballot(valid);
         const int sh = lane & ~7;
         const bool kept = ((mk >> sh) & 0xFFull) != 0;
-        const bool far = valid && kept && ((m >> sh) & 0xFFull) == 0;
+        const bool far = mine && kept && ((m >> sh) & 0xFFull) == 0;
         if (lane == 0) {
-            near[g * nch + (j0 >> 6)] = far_batch_bits(m) & far_batch_bits(mk);
+            const unsigned nearbits = far_batch_bits(m) & far_batch_bits(mk);
+            // parent level: everything it does not leave to its blocks (taken into its expansion, or dropped)
+            near[g * nch + (j0 >> 6)] = PPL == 1 ? nearbits : (far_batch_bits(mv) & ~nearbits);
         }
         if (__ballot(far && !negligible) == 0) continue;              // (wave-uniform)
         const double y = far ? d2 : 1.0;
@@ -298,11 +313,13 @@ __global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __
         sim[k] = wave_sum(sim[k]);
     }
     if (lane == 0) {
-        head[g * MFAR_HDR + 0] = cx;
-        head[g * MFAR_HDR + 1] = cy;
-        head[g * MFAR_HDR + 2] = 1.0 / r;
-        head[g * MFAR_HDR + 3] = r2q;
-        double* c = coef + g * MFAR_NCOEF;
+        if (slice == 0) {
+            head[g * MFAR_HDR + 0] = cx;
+            head[g * MFAR_HDR + 1] = cy;
+            head[g * MFAR_HDR + 2] = 1.0 / r;
+            head[g * MFAR_HDR + 3] = r2q;
+        }
+        double* c = coef + gw * MFAR_NCOEF;
 #pragma unroll
         for (int k = 0; k <= MFAR_P; ++k) {
             c[2 * k] = sre[k];
@@ -326,9 +343,10 @@ __global__ __launch_bounds__(NT) void modhelm_patch_far_kernel(
     const unsigned key_lo = (unsigned)((1023 + KT_EXP_LO + 2 * win) << KT_B);
     unsigned hmin = 0xFFFFFFFFu;
     const double s1 = prm->scale;
-    const int64_t lane = (int64_t)blockIdx.x * NT + threadIdx.x;
-    const int64_t g = __builtin_amdgcn_readfirstlane((int)(lane >> 6));
+    // wave w of workgroup b takes block w * gridDim.x + b (see laplace_patch_far_kernel)
+    const int64_t g = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x));
     if (g * 64 >= np) return;                          // (whole waves, after the only barrier)
+    const int64_t lane = g * 64 + (threadIdx.x & 63);
     const int64_t t = min(lane, np - 1);
     double xs[4], ys[4], acc[16];
 #pragma unroll
@@ -462,20 +480,94 @@ __global__ __launch_bounds__(NT) void modhelm_patch_far_kernel(
     }
 }
 
+// The parent blocks' expansions added to the stored values (a workgroup per parent: its 27 coefficients,
+// summed over the source slices, staged in LDS; a lane per patch).
+__global__ __launch_bounds__(1024) void modhelm_far_parent_kernel(const double* __restrict__ pxy, int64_t np,
+                                                                  const int* __restrict__ pout, double* __restrict__ out,
+                                                                  const ApplyParams* __restrict__ prm,
+                                                                  const double* __restrict__ head2,
+                                                                  const double* __restrict__ coef2, int nslice) {
+    __shared__ double2 C[MFAR_P + 1];
+    const int64_t par = blockIdx.x;                    // patches [1024 par, 1024 par + 1024)
+    if (threadIdx.x <= MFAR_P) {
+        const int k = threadIdx.x;
+        double cr = 0.0, ci = 0.0;
+        for (int sl = 0; sl < nslice; ++sl) {
+            cr += coef2[(par * nslice + sl) * MFAR_NCOEF + 2 * k];
+            ci += coef2[(par * nslice + sl) * MFAR_NCOEF + 2 * k + 1];
+        }
+        C[k] = double2{cr, ci};
+    }
+    __syncthreads();
+    const int64_t t = par * 1024 + threadIdx.x;
+    if (t >= np) return;
+    const double s1 = prm->scale;
+    const double* h = head2 + par * MFAR_HDR;
+    const double cx = h[0], cy = h[1], rinv = h[2], r2q = h[3];
+    double zy[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) zy[b] = (pxy[(int64_t)(4 + b) * np + t] * s1 - cy) * rinv;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double zx = (pxy[(int64_t)a * np + t] * s1 - cx) * rinv;
+        double w[4], tm[4], tp[4], vr[4], vi[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            w[b] = r2q * (zx * zx + zy[b] * zy[b]);
+            double s1p = 1.0, s0p = 1.0;
+#pragma unroll
+            for (int n = MFAR_TN; n >= 1; --n) {
+                s1p = fma(s1p, w[b] * (1.0 / ((double)n * (MFAR_P + 1 + n))), 1.0);
+                s0p = fma(s0p, w[b] * (1.0 / ((double)n * (MFAR_P + n))), 1.0);
+            }
+            tp[b] = s1p;
+            tm[b] = s0p;
+            vr[b] = vi[b] = 0.0;
+        }
+#pragma unroll 2
+        for (int m = MFAR_P; m >= 0; --m) {
+            const double2 c = C[m];
+            const double f = m >= 1 ? 1.0 / ((double)m * (m + 1)) : 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double nr = vr[b] * zx - vi[b] * zy[b];
+                vi[b] = fma(vr[b], zy[b], vi[b] * zx) + c.y * tm[b];
+                vr[b] = nr + c.x * tm[b];
+                const double tn = fma(w[b] * f, tp[b], tm[b]);
+                tp[b] = tm[b];
+                tm[b] = tn;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = pout[(int64_t)(4 * a + b) * np + t];
+            if (i >= 0) out[i] += vr[b];
+        }
+    }
+}
+
 int launch_modhelm_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, const double* pxy, int64_t np,
                                const int* pout, double* out, const ApplyParams* prm) {
     constexpr int NT = 1024;
+    constexpr int NSL = 8;                             // waves (slices of the sources) per parent block
     const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
     const int64_t ng = ceil_div64(np, 64);
+    const int64_t ng2 = ceil_div64(ng, 16);
     const int nch = (int)ceil_div64(ns_pad, 64);
-    const size_t nd = (size_t)ng * (MFAR_HDR + MFAR_NCOEF);
-    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
+    const size_t nd = (size_t)ng * (MFAR_HDR + MFAR_NCOEF) + (size_t)ng2 * (MFAR_HDR + NSL * MFAR_NCOEF);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial,
+                                 nd * sizeof(double) + (size_t)(ng + ng2) * nch * sizeof(unsigned)));
     double* head = (double*)ctx->partial.p;
     double* coef = head + (size_t)ng * MFAR_HDR;
-    unsigned* near = (unsigned*)(coef + (size_t)ng * MFAR_NCOEF);
+    double* head2 = coef + (size_t)ng * MFAR_NCOEF;
+    double* coef2 = head2 + (size_t)ng2 * MFAR_HDR;
+    unsigned* near = (unsigned*)(coef2 + (size_t)ng2 * NSL * MFAR_NCOEF);
+    unsigned* taken = near + (size_t)ng * nch;
     ipde_time_begin(ctx);
-    hipLaunchKernelGGL(modhelm_far_coeff_kernel, dim3((unsigned)ceil_div64(ng, 4)), dim3(256), 0, ctx->stream, rec,
-                       ns_pad, pxy, np, prm, head, coef, near, nch);
+    hipLaunchKernelGGL(modhelm_far_coeff_kernel<16>, dim3((unsigned)ceil_div64(ng2 * NSL, 4)), dim3(256), 0, ctx->stream,
+                       rec, ns_pad, pxy, np, prm, head2, coef2, taken, nch, (const unsigned*)nullptr, NSL);
+    hipLaunchKernelGGL(modhelm_far_coeff_kernel<1>, dim3((unsigned)ceil_div64(ng, 4)), dim3(256), 0, ctx->stream, rec,
+                       ns_pad, pxy, np, prm, head, coef, near, nch, (const unsigned*)taken, 1);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     const size_t lds = (size_t)KT_NKEYS * KT_ENTRY * sizeof(double);
     IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)modhelm_patch_far_kernel<NT>,
@@ -483,6 +575,8 @@ int launch_modhelm_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, con
     hipLaunchKernelGGL((modhelm_patch_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds,
                        ctx->stream, rec, ns_pad, pxy, np, pout, out, prm, (const double2*)ctx->d_ktab,
                        (const double*)head, (const double*)coef, (const unsigned*)near, nch);
+    hipLaunchKernelGGL(modhelm_far_parent_kernel, dim3((unsigned)ng2), dim3(1024), 0, ctx->stream, pxy, np, pout, out,
+                       prm, (const double*)head2, (const double*)coef2, NSL);
     ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
