@@ -2,5 +2,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r03/far; mkdir -p $O
-timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $O/gputest_two_level.txt
+O=gpurun_out/r03/scratch; mkdir -p $O
+timeout -k 10 300 python3 tools/ab_far_expansion.py 2>&1 | tee $O/ab_far.txt
