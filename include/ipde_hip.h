@@ -193,6 +193,12 @@ int ipde_laplace_apply_patches(ipde_ctx* ctx,
  * nearer sources are summed pair by pair exactly as in ipde_laplace_apply_patches.  Same
  * arguments and output convention as ipde_laplace_apply_patches; values agree with it to a few
  * roundings of the largest partial sum.
+ * Two levels: sixteen consecutive blocks (1024 patches) are taken as one PARENT block — the plan
+ * builder orders the blocks in Z order so that they are a 4 x 4 group — whose sources beyond four
+ * parent radii enter the parent's coefficients once instead of sixteen blocks' (the same holds for
+ * the modified Helmholtz and Stokes forms below).  The geometry of blocks and parents is taken from
+ * the bounding boxes of their patches: ANY list of patches gives correct sums, a plan from
+ * ipde_target_plan_build_blocks the fast ones.
  */
 int ipde_laplace_apply_patches_far(ipde_ctx* ctx,
                                    int64_t ns, const double* sx, const double* sy,
@@ -221,7 +227,8 @@ int ipde_target_plan_build(int64_t nt, const double* x, const double* y,
                            ipde_target_plan** plan);
 /* the same; pad_blocks != 0: every block that holds a patch is filled up to block_i * block_j
    patches with copies of its first one that store nothing (pout = -1): patches
-   [k B, (k + 1) B), B = block_i block_j, are then exactly one block of tiles */
+   [k B, (k + 1) B), B = block_i block_j, are then exactly one block of tiles; the blocks come in
+   Z (Morton) order of their block coordinates: 4^l consecutive blocks are a 2^l x 2^l group */
 int ipde_target_plan_build_blocks(int64_t nt, const double* x, const double* y,
                                   int block_i, int block_j, double partial_min_fill,
                                   int64_t min_patches, int line_min_points, int pad_blocks,
