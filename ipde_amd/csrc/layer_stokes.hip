@@ -464,6 +464,29 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
     }
 }
 
+// Entry k of the combined coefficients the Horner loops read (the three families summed over `nslice`
+// rows each):  [3k] a1_k = X1_k / (2k) (k = 0: C0),  [3k+1] a2_k = X1_(k+1),  [3k+2] b_k = conj(X3_k)/2 + conj(X2_k)/(2k)
+__device__ __forceinline__ void sfar_combine(double2* __restrict__ W, int k, const double* __restrict__ X1,
+                                             const double* __restrict__ X2, const double* __restrict__ X3,
+                                             int nslice) {
+    double a1r = 0.0, a1i = 0.0, a2r = 0.0, a2i = 0.0, br = 0.0, bi = 0.0;
+    const double hk = k >= 1 ? 0.5 / (double)k : 1.0;
+    for (int sl = 0; sl < nslice; ++sl) {
+        const double* Y1 = X1 + (size_t)sl * SFAR_NCOEF;
+        const double* Y2 = X2 + (size_t)sl * SFAR_NCOEF;
+        const double* Y3 = X3 + (size_t)sl * SFAR_NCOEF;
+        a1r += hk * Y1[2 * k];
+        a1i += hk * Y1[2 * k + 1];
+        a2r += Y1[2 * (k + 1)];
+        a2i += Y1[2 * (k + 1) + 1];
+        br += 0.5 * Y3[2 * k] + (k >= 1 ? hk * Y2[2 * k] : 0.0);
+        bi -= 0.5 * Y3[2 * k + 1] + (k >= 1 ? hk * Y2[2 * k + 1] : 0.0);
+    }
+    W[3 * k] = double2{a1r, a1i};
+    W[3 * k + 1] = double2{a2r, a2i};
+    W[3 * k + 2] = double2{br, bi};
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
     const double* __restrict__ rec, int ns_pad, const double* __restrict__ pxy, int64_t np,
@@ -483,40 +506,11 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
     if (g * 64 >= np) return;                          // (whole waves, after the only barrier)
     const int64_t lane = g * 64 + (threadIdx.x & 63);
     const int64_t t = min(lane, np - 1);
-    // per level and k, combined and parked in LDS behind the table (lane k stages entry k):
-    //   [3k]   a1_k = X1_k / (2k) (k >= 1; k = 0: C0),   [3k+1] a2_k = X1_(k+1),
-    //   [3k+2] b_k = conj(X3_k)/2 + conj(X2_k)/(2k)
+    // the block's combined coefficients, parked in LDS behind the table (lane k stages entry k)
     constexpr int WCL = 3 * (SFAR_P + 1);
     double2* wc = ltab + nkeys + wv * WCL;
-    {
-        const int k = threadIdx.x & 63;
-        {
-            constexpr int level = 0;
-            const int ns = 1;
-            const int64_t gl = g;
-            const double* X1 = c1 + gl * SFAR_NCOEF;
-            const double* X2 = c2 + gl * SFAR_NCOEF;
-            const double* X3 = c3 + gl * SFAR_NCOEF;
-            if (k <= SFAR_P) {
-                double a1r = 0.0, a1i = 0.0, a2r = 0.0, a2i = 0.0, br = 0.0, bi = 0.0;
-                const double hk = k >= 1 ? 0.5 / (double)k : 1.0;       // (k = 0: C0 itself)
-                for (int sl = 0; sl < ns; ++sl) {
-                    const double* Y1 = X1 + (size_t)sl * SFAR_NCOEF;
-                    const double* Y2 = X2 + (size_t)sl * SFAR_NCOEF;
-                    const double* Y3 = X3 + (size_t)sl * SFAR_NCOEF;
-                    a1r += hk * Y1[2 * k];
-                    a1i += hk * Y1[2 * k + 1];
-                    a2r += Y1[2 * (k + 1)];
-                    a2i += Y1[2 * (k + 1) + 1];
-                    br += 0.5 * Y3[2 * k] + (k >= 1 ? hk * Y2[2 * k] : 0.0);
-                    bi -= 0.5 * Y3[2 * k + 1] + (k >= 1 ? hk * Y2[2 * k + 1] : 0.0);
-                }
-                wc[level * WCL + 3 * k] = double2{a1r, a1i};
-                wc[level * WCL + 3 * k + 1] = double2{a2r, a2i};
-                wc[level * WCL + 3 * k + 2] = double2{br, bi};
-            }
-        }
-    }
+    if ((threadIdx.x & 63) <= SFAR_P)
+        sfar_combine(wc, threadIdx.x & 63, c1 + g * SFAR_NCOEF, c2 + g * SFAR_NCOEF, c3 + g * SFAR_NCOEF, 1);
     __builtin_amdgcn_wave_barrier();
     double xs[4], ys[4];
 #pragma unroll
@@ -528,7 +522,6 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
     // far sources first: the block's expansion values are the accumulators' starting values (the parent's
     // expansion is added by stokes_far_parent_kernel afterwards: this kernel is at its register limit)
     {
-        constexpr int level = 0;
         const double* h = head + g * SFAR_HDR;
         const double cx = h[0], cy = h[1], rinv = h[2];
         const double2* W = wc;
@@ -565,16 +558,8 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
             for (int b = 0; b < 4; ++b) {
                 // zeta conj(S2) = (zx + i zy)(s2r - i s2i)
                 const double qr = zx * s2r[b] + zy[b] * s2i[b], qi = zy[b] * s2r[b] - zx * s2i[b];
-                const double fu = c0.x + s1r[b] + s3r[b] - 0.5 * qr;
-                const double fv = c0.y + s1i[b] + s3i[b] - 0.5 * qi;
-                const double fq = -rinv * s2r[b];
-                if (level == 0) {
-                    acc[4 * a + b] = StokesAcc{0.0, 0.0, fu, fv, fq};
-                } else {
-                    acc[4 * a + b].u += fu;
-                    acc[4 * a + b].v += fv;
-                    acc[4 * a + b].p += fq;
-                }
+                acc[4 * a + b] = StokesAcc{0.0, 0.0, c0.x + s1r[b] + s3r[b] - 0.5 * qr,
+                                           c0.y + s1i[b] + s3i[b] - 0.5 * qi, -rinv * s2r[b]};
             }
         }
     }
@@ -672,28 +657,9 @@ __global__ __launch_bounds__(1024) void stokes_far_parent_kernel(const double* _
     constexpr int WCL = 3 * (SFAR_P + 1);
     __shared__ double2 W[WCL];
     const int64_t par = blockIdx.x;                    // patches [1024 par, 1024 par + 1024)
-    if (threadIdx.x <= SFAR_P) {
-        const int k = threadIdx.x;
-        const double* X1 = p1 + par * nslice * SFAR_NCOEF;
-        const double* X2 = p2 + par * nslice * SFAR_NCOEF;
-        const double* X3 = p3 + par * nslice * SFAR_NCOEF;
-        double a1r = 0.0, a1i = 0.0, a2r = 0.0, a2i = 0.0, br = 0.0, bi = 0.0;
-        const double hk = k >= 1 ? 0.5 / (double)k : 1.0;
-        for (int sl = 0; sl < nslice; ++sl) {
-            const double* Y1 = X1 + (size_t)sl * SFAR_NCOEF;
-            const double* Y2 = X2 + (size_t)sl * SFAR_NCOEF;
-            const double* Y3 = X3 + (size_t)sl * SFAR_NCOEF;
-            a1r += hk * Y1[2 * k];
-            a1i += hk * Y1[2 * k + 1];
-            a2r += Y1[2 * (k + 1)];
-            a2i += Y1[2 * (k + 1) + 1];
-            br += 0.5 * Y3[2 * k] + (k >= 1 ? hk * Y2[2 * k] : 0.0);
-            bi -= 0.5 * Y3[2 * k + 1] + (k >= 1 ? hk * Y2[2 * k + 1] : 0.0);
-        }
-        W[3 * k] = double2{a1r, a1i};
-        W[3 * k + 1] = double2{a2r, a2i};
-        W[3 * k + 2] = double2{br, bi};
-    }
+    if (threadIdx.x <= SFAR_P)
+        sfar_combine(W, threadIdx.x, p1 + par * nslice * SFAR_NCOEF, p2 + par * nslice * SFAR_NCOEF,
+                     p3 + par * nslice * SFAR_NCOEF, nslice);
     __syncthreads();
     const int64_t t = par * 1024 + threadIdx.x;
     if (t >= np || prm->pad) return;
