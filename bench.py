@@ -385,16 +385,19 @@ def main():
         for _ in range(3):
             target_plan.laplace_apply(planf, sx, sy, w_sigma=sig_full * w, ctx=ctx, out=outf, far=True)
         torch.cuda.synchronize()
+        ctx.enable_timing(True)
         tf0 = time.perf_counter()
         nf = 20
         for _ in range(nf):
             target_plan.laplace_apply(planf, sx, sy, w_sigma=sig_full * w, ctx=ctx, out=outf, far=True)
         torch.cuda.synchronize()
         msf = 1e3 * (time.perf_counter() - tf0) / nf
+        kmsf = float(np.mean(ctx.kernel_ms_history()[-nf:]))       # parents + blocks + patches, by the library's events
+        ctx.enable_timing(False)
         expansion = {"what": "ipde_laplace_apply_patches_far: sources beyond 4 block radii of a 32 x 32-point block "
                              "enter 27 complex local-expansion coefficients (truncation 3e-18 of sum|w|), nearer "
                              "batches of eight sources are summed pair by pair",
-                     "ms_per_apply": msf,
+                     "ms_per_apply": msf, "kernels_ms": kmsf,
                      "effective_pair_interactions_per_s": float(NBDY) * float(dt.N) / (msf * 1e-3),
                      "max_abs_diff_vs_pair_by_pair": float((outf - out).abs().max()),
                      "max_abs_pair_by_pair": float(out.abs().max()),
