@@ -861,6 +861,51 @@ def test_modhelm_far_expansion_near_misses_and_high_level_call(lp):
     assert torch.equal(torch.as_tensor(a), torch.as_tensor(b))
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_far_forms_on_ragged_rectangular_lattices_with_scattered_sources(lp, seed):
+    """The three far-field forms against their pair-by-pair kernels on lists that are no solver's:
+    rectangular lattices with unequal, non-uniform spacings, random holes (tiles with unstored
+    points, blocks and parent blocks partly empty), sources scattered inside the lattice's hull (never
+    on a target), around it and far away, in no order along any curve."""
+    from ipde_amd import target_plan
+    rng = np.random.default_rng(seed)
+    nx, ny = int(rng.integers(300, 700)), int(rng.integers(300, 700))
+    xv = np.cumsum(rng.uniform(0.8, 1.2, nx)) * 2.5e-3 - 0.9
+    yv = np.cumsum(rng.uniform(0.8, 1.2, ny)) * 3.5e-3 - 1.1
+    X, Y = np.meshgrid(xv, yv, indexing="ij")
+    keep = np.ones((nx, ny), dtype=bool)
+    for _ in range(12):                                   # rectangular holes
+        i, j = int(rng.integers(0, nx - 40)), int(rng.integers(0, ny - 40))
+        keep[i:i + int(rng.integers(5, 60)), j:j + int(rng.integers(5, 60))] = False
+    tx, ty = X[keep], Y[keep]
+    ns = int(rng.integers(700, 1500))
+    sx = rng.uniform(xv[0] - 0.5, xv[-1] + 0.5, ns)
+    sy = rng.uniform(yv[0] - 0.5, yv[-1] + 0.5, ns)
+    sx[:20], sy[:20] = rng.uniform(5, 9, 20), rng.uniform(-9, 9, 20)          # far away
+    # keep sources off the targets: move any within a third of a cell of a lattice point
+    ix = np.clip(np.searchsorted(xv, sx), 1, nx - 1)
+    iy = np.clip(np.searchsorted(yv, sy), 1, ny - 1)
+    sx = np.where((sx > xv[0]) & (sx < xv[-1]), 0.5 * (xv[ix - 1] + xv[ix]), sx)
+    sy = np.where((sy > yv[0]) & (sy < yv[-1]), 0.5 * (yv[iy - 1] + yv[iy]), sy)
+    w1, w2 = rng.standard_normal(ns) * 1e-2, rng.standard_normal(ns) * 1e-2
+    nrm = rng.standard_normal((2, ns))
+    nrm /= np.hypot(nrm[0], nrm[1])
+    dev = lp.get_context().torch_device()
+    plan = target_plan.build_host(tx, ty, device=dev, pad_blocks=True)
+    assert plan.padded_blocks and plan.nrest == 0
+    got = target_plan.laplace_apply(plan, sx, sy, w_sigma=w1, nx=nrm[0], ny=nrm[1], w_tau=w2, far=True).cpu().numpy()
+    want = target_plan.laplace_apply(plan, sx, sy, w_sigma=w1, nx=nrm[0], ny=nrm[1], w_tau=w2).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
+    for k in (3.0, 60.0):
+        got = target_plan.modhelm_apply(plan, k, sx, sy, w1).cpu().numpy()
+        want = lp.modified_helmholtz_apply(sx, sy, tx, ty, k, w_sigma=w1)
+        assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
+    gu, gv, gp = (a.cpu().numpy() for a in target_plan.stokes_apply(plan, sx, sy, w1, w2))
+    wu, wv, wp = lp.stokes_apply(sx, sy, tx, ty, wfx=w1, wfy=w2)
+    for g_, w_ in ((gu, wu), (gv, wv), (gp, wp)):
+        assert np.abs(g_ - w_).max() < 2e-13 * np.abs(w_).max()
+
+
 # -- the kernels no reference code computes, tied to the pinned ones through derivative relations
 #    (tests/test_oracle_layer_relations.py has the same checks for the oracle; here every
 #    evaluation is a HIP kernel call and nothing goes through the oracle's closed formulas) -------
