@@ -185,13 +185,31 @@ def baseline_configs():
                          "grid_backend": str(solver.grid_backend), "gmres_iterations": T["gmres_iterations"]}
     del solver, ue, f
     torch.cuda.empty_cache()
-    ue, ve, pe, scale, T = ms.run(nb=2400, M=14, ng=4096, warm=True)
+    kept = {}
+    orig_call = ms.StokesSolver.__call__
+
+    def keeping(self, fu, fv, **kw):          # (the example's own solver and forcings, for the warm solves below)
+        kept.setdefault("args", (self, fu, fv, kw))
+        return orig_call(self, fu, fv, **kw)
+    ms.StokesSolver.__call__ = keeping
+    try:
+        ue, ve, pe, scale, T = ms.run(nb=2400, M=14, ng=4096, warm=True)
+    finally:
+        ms.StokesSolver.__call__ = orig_call
+    slv, fu, fv, kw = kept["args"]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        slv(fu, fv, **kw)
+    torch.cuda.synchronize()
+    warm4 = 1e3 * (time.perf_counter() - t0) / 5
+    del slv, fu, fv, kept
     out["configs[4]"] = {"workload": "multi_stokes, 3 bodies (9600 + 2 x 2400 nodes), 4096^2 grid, %d dof, one GPU"
                                      % T["dof"],
                          "max_err_u_v": max(ue, ve), "max_err_p": pe, "scale": scale, "setup_s": T["setup_s"],
-                         "warm_inhomogeneous_solve_ms": 1e3 * T["warm_inhomogeneous_solve_s"],
-                         "warm_solve_note": "the example's own second solve, one sample (means of 8: "
-                                            "profiles/r03_stokes_resident_ab.txt)",
+                         "warm_inhomogeneous_solve_ms": warm4,
+                         "second_solve_ms": 1e3 * T["warm_inhomogeneous_solve_s"],
+                         "warm_solve_note": "mean of five solves after the example's own two",
                          "gmres_iterations": T["gmres_iterations"]}
     torch.cuda.empty_cache()
     return out
