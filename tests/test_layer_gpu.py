@@ -791,6 +791,17 @@ def test_stokes_far_expansion_table_miss_and_high_level_call(lp):
         assert np.all(np.isfinite(got)) and np.abs(got - ref).max() < TOL * np.abs(ref).max()
     assert np.abs(p - rp)[far_pts].max() < 10 * TOL * np.abs(rp[far_pts]).max()
     assert np.all(np.abs(p - rp)[hit] < 1e-5 * np.abs(rp[hit]))       # (f.d)/d^2 at d = 2e-10: conditioning
+    # coordinates beyond what the power-of-two scaling can bring under the table (the launch's `pad` flag):
+    # nothing enters an expansion, every pair takes the generic math, as in the list kernel
+    small, _ = grid_targets(c, 300)
+    big = 2.0 ** 420
+    planb = target_plan.build_host(small.x * big, small.y * big, device=lp.get_context().torch_device(),
+                                   pad_blocks=True)
+    got = target_plan.stokes_apply(planb, c.x * big, c.y * big, fx, fy)
+    want = lp.stokes_apply(c.x * big, c.y * big, small.x * big, small.y * big, wfx=fx, wfy=fy)
+    for g_, w_ in zip(got[:2], want[:2]):
+        g_ = g_.cpu().numpy()
+        assert np.all(np.isfinite(g_)) and np.abs(g_ - w_).max() < 2e-13 * np.abs(w_).max()
     far = lp.DeviceTargets(trg, plan=True, far=True)
     plain = lp.DeviceTargets(trg)
     assert far.plan() is not None and far.plan().padded_blocks

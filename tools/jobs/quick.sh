@@ -2,8 +2,4 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r03/scratch; mkdir -p $O
-SECONDS=0; python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || { tail -30 $O/bench.err; exit 1; }
-echo "bench wall ${SECONDS} s"
-python3 -c "
-import json; r=json.load(open('$O/bench.json')); print(json.dumps(r['baseline_configs']['configs[4]'])[:600])"
+timeout -k 10 600 python3 -m pytest tests/test_layer_gpu.py -m gpu -x -q -k "stokes_far_expansion_table_miss" 2>&1 | tail -12
