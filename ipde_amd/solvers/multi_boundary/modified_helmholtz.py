@@ -14,7 +14,32 @@ class ModifiedHelmholtzSolver(ScalarSolver):
                  source_upsample_factor=1.0):
         self.k = k
         self.source_upsample_factor = source_upsample_factor
-        super().__init__(ebdyc, solver_type, helpers, grid_backend)
+        # the kernel's K0 / K1 tables (one set per device: ~0.2 s of long-double Bessel evaluations on the
+        # host at the first modified Helmholtz sum of a process) under the rest of the set-up instead of in
+        # front of the first solve: a one-pair sum on a context of its own, in a thread joined below
+        import threading
+        warm = threading.Thread(target=self._build_kernel_tables, name="ipde-ktab", daemon=True)
+        warm.start()
+        try:
+            super().__init__(ebdyc, solver_type, helpers, grid_backend)
+        finally:
+            warm.join()
+
+    @staticmethod
+    def _build_kernel_tables():
+        try:
+            import numpy as np
+            import torch
+            from ...device import private_context
+            from ...layer_potentials import modified_helmholtz_apply
+            if not torch.cuda.is_available():
+                return
+            ctx = private_context()
+            one = np.ones(1)
+            modified_helmholtz_apply(one * 0.0, one * 0.0, one, one, 1.0, w_sigma=one, ctx=ctx)
+            ctx.sync()
+        except Exception:       # (the first sum builds them then, as before)
+            pass
 
     def _get_helper_combatibility(self, ebdy, helper):
         """0: start over; 1: the annular solver can be reused; 2: reuse the helper"""

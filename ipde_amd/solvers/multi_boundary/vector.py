@@ -14,7 +14,7 @@ from ...derivatives import fd_x_4, fd_y_4
 from ...embedded_function import EmbeddedFunction
 from ...interp import periodic_interp2d, radial_to_grid
 from ...layer_potentials import DeviceTargets
-from ...pybie2d_compat import BoundaryCollection
+from ...pybie2d_compat import BoundaryCollection, PointSet
 from ...qfs import call_many, u2s_many
 from .scalar import _finish_all, _concurrent_helpers, _owned, _run_owned
 from ...device import prewarm_wait, prewarm_submit
@@ -37,6 +37,12 @@ class VectorSolver(object):
         if helpers is None:
             helpers = [None, ] * self.ebdyc.N
         self._extract_extra_kwargs(**kwargs)
+        # the grid_pnai list into HBM and into its patch plan now (host work in a thread of its own: under
+        # the helpers' set-up instead of in front of the first solve; see ScalarSolver)
+        self._early_pnai = None
+        if self.FAR_EXPANSION and not is_distributed():
+            pn = self.ebdyc.grid_pnai
+            self._early_pnai = (pn.x, pn.y, DeviceTargets(PointSet(x=pn.x, y=pn.y), plan=True, far=True))
         self.helpers = [self._get_helper(ebdy, helper) for ebdy, helper in zip(self.ebdyc, helpers)]
         self.AS_list = [helper.annular_solver for helper in self.helpers]
         self.grid = self.ebdyc.grid
@@ -109,7 +115,9 @@ class VectorSolver(object):
                              "ipde_amd.grid_evaluators.stokes_grid_evaluator stays available on its own")
         self.Grid_Evaluator = make_pnai_evaluator(
             lambda src, trg, f: self.Layer_Apply(src, trg, f), self.grid_sources, e.grid_pnai,
-            lambda x, y: DeviceTargets(PointSet(x=x, y=y), plan=self.FAR_EXPANSION, far=self.FAR_EXPANSION))
+            lambda x, y: self._early_pnai[2] if (self._early_pnai is not None and self.FAR_EXPANSION
+                                                  and x is self._early_pnai[0] and y is self._early_pnai[1])
+            else DeviceTargets(PointSet(x=x, y=y), plan=self.FAR_EXPANSION, far=self.FAR_EXPANSION))
         self.split_grid_evaluation = False
         self._pin_in = torch.empty((2, e.grid_phys.N), dtype=torch.float64, pin_memory=True)
 
