@@ -42,3 +42,26 @@ def gather(idx, grid, ctx=None, out=None):
     _check(idx, grid)
     ctx.check(ctx.lib.ipde_grid_gather(ctx.handle, idx.shape[0], ptr(idx), ptr(grid), ptr(out)))
     return out
+
+
+def rows(tensors):
+    """The 1-D device tensors as the rows of one (len, n) tensor — by device-to-device copies (no torch
+    kernel: `torch.stack` loads its code object at first use, 9 ms of a first solve, and costs a launch
+    each time)."""
+    first = tensors[0]
+    out = torch.empty((len(tensors), first.shape[0]), dtype=first.dtype, device=first.device)
+    for i, t in enumerate(tensors):
+        out[i].copy_(t.reshape(-1))
+    return out
+
+
+def concat(tensors):
+    """1-D device tensors end to end (one of them: itself, no copy)."""
+    if len(tensors) == 1:
+        return tensors[0]
+    out = torch.empty(sum(int(t.shape[0]) for t in tensors), dtype=tensors[0].dtype, device=tensors[0].device)
+    a = 0
+    for t in tensors:
+        out[a:a + t.shape[0]].copy_(t)
+        a += int(t.shape[0])
+    return out

@@ -128,7 +128,8 @@ class ScalarHelper(object):
         # solver's context (csrc/annular.hip: ipde_scalar_interface_jumps)
         ctx = getattr(self.annular_solver, 'ctx', None) or get_context()
         M, N = ur.shape
-        bdata = torch.stack([bv, bx, by]).contiguous()
+        from ... import gridops
+        bdata = gridops.rows([bv, bx, by])
         slp = torch.empty(N, dtype=torch.float64, device=bv.device)
         dlp = torch.empty(N, dtype=torch.float64, device=bv.device)
         ctx.check(ctx.lib.ipde_scalar_interface_jumps(ctx.handle, M, N, ptr(ur), ptr(c['in_est']), ptr(c['nrm']),

@@ -161,7 +161,8 @@ class VectorHelper(object):
         z = c['zero']
         rr, tr, pr = self.annular_solver.solve(self.RAG, fr, ft, z, z, z, z, **kwargs)
         self.iterations_last_call = self.annular_solver.iterations_last_call
-        bdata = torch.stack([bu, bv, btxx, btxy, btyy]).contiguous()
+        from ... import gridops
+        bdata = gridops.rows([bu, bv, btxx, btxy, btyy])
         ur, vr, taus, taud = new(M, N), new(M, N), new(2 * N), new(2 * N)
         ctx.check(ctx.lib.ipde_stokes_interface_jumps(
             ctx.handle, M, N, ptr(rr), ptr(tr), ptr(pr), ptr(c['geom']), ptr(c['rs']), ptr(c['irs']), ptr(c['D00']),

@@ -326,7 +326,7 @@ class ScalarSolver(object):
             sigmag_list, its = exchange_owned(sigmag_list, [(h.interface_qfs_g.source.N,) for h in self.helpers],
                                               device=self._dev, extra=its)
         self.iteration_counts = [int(i) for i in its]
-        sigmag = torch.cat(list(sigmag_list)) if device_flow else np.concatenate(sigmag_list)
+        sigmag = gridops.concat(list(sigmag_list)) if device_flow else np.concatenate(sigmag_list)
         n_pna = e.grid_pna.N
         ucf = uc.view(-1)
         owned = None
