@@ -268,6 +268,17 @@ int ipde_modhelm_apply_patches_far(ipde_ctx* ctx, double k, int64_t ns, const do
                                    double* out);
 
 /*
+ * The same far-field form for the radial grid of an annulus: targets (M, N) row-major (tx, ty: DEVICE,
+ * M * N doubles each), column j = the M points of one radial line, neighbouring columns neighbouring lines
+ * (ipde/embedded_boundary.py:280-358 `radial_x`, `radial_y` raveled).  Blocks of 64 columns; a block's far
+ * sources in its local expansion, the near batches pair by pair.  The radial sums of correct()
+ * (ipde/solvers/internals/scalar.py:113-114).  out: DEVICE, M * N doubles.
+ */
+int ipde_modhelm_apply_columns_far(ipde_ctx* ctx, double k, int64_t ns, const double* sx, const double* sy,
+                                   const double* w_sigma, int M, int64_t N, const double* tx, const double* ty,
+                                   double* out);
+
+/*
  * Stokes (mu=1) Stokeslet + stresslet with pressure:
  *   SLP: u = (1/4pi) sum [ -log r f + (d.f) d / r^2 ] ,  p = (1/2pi) sum (d.f)/r^2
  *   DLP: u = (1/pi)  sum (d.n)(d.g) d / r^4 ,

@@ -582,6 +582,167 @@ int launch_modhelm_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, con
     return IPDE_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The far-field form for the radial grids of the annuli (ipde_modhelm_apply_columns_far): targets
+// (M, N) row-major, column j = the M points of one radial line.  No lattice, but a group of 64
+// neighbouring columns is compact (an arc of the annulus), and a radial line is a straight segment: the
+// bounding box of a column is that of its two end points — so the coefficient kernel above runs unchanged
+// on a stand-in patch list (patch j: xs = {x_0j, x_(M-1)j, ...}, ys likewise).  One level (64 columns = a
+// block; eight source slices per block: there are only N / 64 blocks); a lane owns a column and walks its
+// rows four at a time.
+__global__ __launch_bounds__(256) void columns_as_patches_kernel(const double* __restrict__ tx,
+                                                                 const double* __restrict__ ty, int M, int64_t N,
+                                                                 double* __restrict__ pxy) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const double x0 = tx[j], x1 = tx[(int64_t)(M - 1) * N + j], y0 = ty[j], y1 = ty[(int64_t)(M - 1) * N + j];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        pxy[(int64_t)a * N + j] = (a & 1) ? x1 : x0;
+        pxy[(int64_t)(4 + a) * N + j] = (a & 1) ? y1 : y0;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void modhelm_cols_far_kernel(
+    const double* __restrict__ rec, int ns_pad, const double* __restrict__ tx, const double* __restrict__ ty, int M,
+    int64_t N, double* __restrict__ out, const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab,
+    const double* __restrict__ head, const double* __restrict__ coef, int nslice,
+    const unsigned* __restrict__ near, int nch) {
+    extern __shared__ double2 ltab[];
+    const bool nowin = prm->pad >= KT_NWIN;
+    const int win = nowin ? KT_NWIN - 1 : prm->pad;
+    gtab += (size_t)win * KT_NKEYS * (KT_ENTRY / 2);
+    for (unsigned i = threadIdx.x; i < KT_NKEYS * (KT_ENTRY / 2); i += NT) ltab[i] = gtab[i];
+    __syncthreads();
+    const unsigned key_lo = (unsigned)((1023 + KT_EXP_LO + 2 * win) << KT_B);
+    const double s1 = prm->scale;
+    // a wave takes four rows of one block of 64 columns (N / 64 blocks alone would leave most of the GPU idle)
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int nrc = (M + 3) / 4;
+    const int64_t wid = __builtin_amdgcn_readfirstlane((int)(wv * gridDim.x + blockIdx.x));
+    const int64_t g = wid / nrc;
+    const int r0 = 4 * (int)(wid - g * nrc);
+    if (g * 64 >= N) return;                           // (whole waves, after the only barrier)
+    // the block's coefficients (sums over the source slices), parked in LDS behind the table
+    double2* C = ltab + KT_NKEYS * (KT_ENTRY / 2) + wv * (MFAR_P + 1);
+    if (ln <= MFAR_P) {
+        double cr = 0.0, ci = 0.0;
+        for (int sl = 0; sl < nslice; ++sl) {
+            cr += coef[(g * nslice + sl) * MFAR_NCOEF + 2 * ln];
+            ci += coef[(g * nslice + sl) * MFAR_NCOEF + 2 * ln + 1];
+        }
+        C[ln] = double2{cr, ci};
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double* h = head + g * MFAR_HDR;
+    const double cx = h[0], cy = h[1], rinv = h[2], r2q = h[3];
+    const int64_t j = g * 64 + ln, jj = min(j, N - 1);
+    const unsigned* nm = near + g * nch;
+    {
+        double x[4], y[4], acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t t = (int64_t)min(r0 + i, M - 1) * N + jj;
+            x[i] = tx[t] * s1;
+            y[i] = ty[t] * s1;
+            acc[i] = 0.0;
+        }
+        unsigned hmin = 0xFFFFFFFFu;
+        if (!nowin) {
+            for (int c = 0; c < nch; ++c) {
+                unsigned m = nm[c];
+                while (m) {
+                    const int bt = __builtin_ctz(m);
+                    m &= m - 1;
+                    SrcRow sx, sy, sq;
+                    sx.load(rec, 8 * c + bt, 0);
+                    sy.load(rec, 8 * c + bt, 1);
+                    sq.load(rec, 8 * c + bt, 2);
+#pragma unroll
+                    for (int u = 0; u < IPDE_SRC_PAD; ++u) {
+                        double d2[4];
+                        double2 e[4][KT_READS];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const double dx = x[i] - sx.v[u], dy = y[i] - sy.v[u];
+                            d2[i] = fma(dy, dy, dx * dx);
+                            const unsigned hi = (unsigned)__double2hiint(d2[i]);
+                            hmin = min(hmin, hi);
+                            unsigned idx;
+                            asm("v_bfe_u32 %0, %1, 14, 11" : "=v"(idx) : "v"(hi));
+                            const double2* ep = (const double2*)((const char*)ltab + __umul24(idx, KT_ENTRY * 8u));
+#pragma unroll
+                            for (int cc = 0; cc < KT_READS; ++cc) e[i][cc] = ep[cc];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned hi = (unsigned)__double2hiint(d2[i]);
+                            const double ctr = __hiloint2double((int)((hi & 0xFFFFC000u) | 0x2000u), 0);
+                            const double z = d2[i] - ctr;
+                            double p = fma(e[i][2].y, z, e[i][2].x);
+                            p = fma(p, z, e[i][1].y);
+                            p = fma(p, z, e[i][1].x);
+                            p = fma(p, z, e[i][0].y);
+                            p = fma(p, z, e[i][0].x);
+                            acc[i] = fma(sq.v[u], p, acc[i]);
+                        }
+                    }
+                }
+            }
+        }
+        if (nowin || (hmin >> KT_SHIFT) < key_lo) {
+            double gs[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < nch; ++c) {
+                unsigned m = nm[c];
+                while (m) {
+                    const int bt = __builtin_ctz(m);
+                    m &= m - 1;
+                    modhelm_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, x, y, gs);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = gs[i];
+        }
+        // far sources: Re sum_m C_m zeta^m T_m(w)
+        double zx[4], zy[4], w[4], tm[4], tp[4], vr[4], vi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            zx[i] = (x[i] - cx) * rinv;
+            zy[i] = (y[i] - cy) * rinv;
+            w[i] = r2q * (zx[i] * zx[i] + zy[i] * zy[i]);
+            double s1p = 1.0, s0p = 1.0;
+#pragma unroll
+            for (int n = MFAR_TN; n >= 1; --n) {
+                s1p = fma(s1p, w[i] * (1.0 / ((double)n * (MFAR_P + 1 + n))), 1.0);
+                s0p = fma(s0p, w[i] * (1.0 / ((double)n * (MFAR_P + n))), 1.0);
+            }
+            tp[i] = s1p;
+            tm[i] = s0p;
+            vr[i] = vi[i] = 0.0;
+        }
+#pragma unroll 2
+        for (int m = MFAR_P; m >= 0; --m) {
+            const double2 c = C[m];
+            const double f = m >= 1 ? 1.0 / ((double)m * (m + 1)) : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double nr = vr[i] * zx[i] - vi[i] * zy[i];
+                vi[i] = fma(vr[i], zy[i], vi[i] * zx[i]) + c.y * tm[i];
+                vr[i] = nr + c.x * tm[i];
+                const double tn = fma(w[i] * f, tp[i], tm[i]);
+                tp[i] = tm[i];
+                tm[i] = tn;
+            }
+        }
+        if (j < N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (r0 + i < M) out[(int64_t)(r0 + i) * N + j] = acc[i] + vr[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_acc(const double* __restrict__ part,
                                                            int nchunk, int64_t nt,
                                                            double* __restrict__ out,
@@ -834,4 +995,58 @@ extern "C" int ipde_modhelm_apply_patches_far(ipde_ctx* ctx, double k, int64_t n
     const ApplyParams* prm;
     IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, pxy, pxy + 4 * np, 4 * np, &rec, &prm));
     return launch_modhelm_patches_far(ctx, rec, ns, pxy, np, pout, out, prm);
+}
+
+// Single-layer sums onto an (M, N) radial grid (row-major DEVICE arrays tx, ty: column j = the M points of
+// one radial line, neighbouring columns neighbouring lines): blocks of 64 columns, far sources in the
+// block's local expansion, near batches through the table — the radial sums of the solvers' correct()
+// (reference ipde/solvers/internals/scalar.py:113-114).
+extern "C" int ipde_modhelm_apply_columns_far(ipde_ctx* ctx, double k, int64_t ns, const double* sx,
+                                              const double* sy, const double* w_sigma, int M, int64_t N,
+                                              const double* tx, const double* ty, double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ns >= 0 && N >= 0 && M >= 1 && ns < (1LL << 30) && N < (1LL << 30) && (int64_t)M * N < (1LL << 40));
+    IPDE_CHECK_ARG(ctx, k > 0.0);
+    if (N == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, tx && ty && out);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && w_sigma);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_ktab) IPDE_TRY(ipde_build_k_table(ctx));
+    PackArgs pa{};
+    pa.sx = sx;
+    pa.sy = sy;
+    pa.ch[0] = w_sigma;
+    pa.mul[0] = 0.5 / M_PI;
+    pa.corr_ch = -1;
+    pa.corr2_ch = -1;
+    pa.use_scale = 1;
+    pa.fixed_scale = k;
+    const double* rec;
+    const ApplyParams* prm;
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, tx, ty, (int64_t)M * N, &rec, &prm));
+    constexpr int NT = 256, NSL = 8;
+    const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
+    const int64_t ng = ceil_div64(N, 64);
+    const int nch = (int)ceil_div64(ns_pad, 64);
+    const size_t nd = (size_t)8 * N + (size_t)ng * (MFAR_HDR + NSL * MFAR_NCOEF);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
+    double* pxy = (double*)ctx->partial.p;
+    double* head = pxy + (size_t)8 * N;
+    double* coef = head + (size_t)ng * MFAR_HDR;
+    unsigned* near = (unsigned*)(coef + (size_t)ng * NSL * MFAR_NCOEF);
+    ipde_time_begin(ctx);
+    hipLaunchKernelGGL(columns_as_patches_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, ctx->stream, tx, ty,
+                       M, N, pxy);
+    hipLaunchKernelGGL(modhelm_far_coeff_kernel<1>, dim3((unsigned)ceil_div64(ng * NSL, 4)), dim3(256), 0, ctx->stream,
+                       rec, ns_pad, (const double*)pxy, N, prm, head, coef, near, nch, (const unsigned*)nullptr, NSL);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    const size_t lds = (size_t)KT_NKEYS * KT_ENTRY * sizeof(double) + (size_t)(NT / 64) * (MFAR_P + 1) * sizeof(double2);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)modhelm_cols_far_kernel<NT>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((modhelm_cols_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng * ((M + 3) / 4), NT)), dim3(NT), lds,
+                       ctx->stream, rec, ns_pad, tx, ty, M, N, out, prm, (const double2*)ctx->d_ktab,
+                       (const double*)head, (const double*)coef, NSL, (const unsigned*)near, nch);
+    ipde_time_end(ctx);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
 }

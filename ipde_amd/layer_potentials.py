@@ -39,12 +39,16 @@ import atexit
 atexit.register(_join_plan_threads)
 
 
+# radial grids with fewer lines than this keep the list kernel (the column form's blocks are 64 lines)
+COLUMNS_FAR_MIN = 1024
+
+
 class DeviceTargets:
     """A target point set kept resident in HBM (the solver evaluates onto the same
     `grid_pnai` / `radial_targ` / `grid_and_radial_pts` sets in every solve;
     reference ipde/ebdy_collection.py:426-429,488-491)."""
 
-    def __init__(self, x, y=None, ctx=None, plan=False, far=False):
+    def __init__(self, x, y=None, ctx=None, plan=False, far=False, columns=None):
         """plan=True: the list is also cut into 4 x 4 tensor patches for the Laplace patch kernel
         (ipde_amd/target_plan.py) — in a background thread; the first Laplace apply onto the set
         joins it.  For the big grid lists (grid_pnai); lists under 2^18 points keep the list kernel.
@@ -64,6 +68,14 @@ class DeviceTargets:
             if not isinstance(y, torch.Tensor) else y.to(torch.float64).contiguous().view(-1)
         self.N = int(self.x.shape[0])
         self._plan, self._plan_thread, self._plan_error = None, None, None
+        # columns = (M, N): the list is an (M, N) array raveled in C order whose columns are radial lines of
+        # an annulus (EmbeddedBoundary.radial_x / radial_y): sums that have a column far-field form use it
+        self.columns = None
+        if columns is not None:
+            M, N = int(columns[0]), int(columns[1])
+            if M * N != self.N or M < 2:
+                raise ValueError("columns = (M, N) must describe the whole list")
+            self.columns = (M, N)
         self.far = bool(far) and bool(plan)
         if plan:
             self.request_plan()
@@ -323,6 +335,16 @@ def Modified_Helmholtz_Layer_Apply(source, target=None, k=1.0, charge=None, dips
         if plan is not None and plan.padded_blocks:      # far sources block by block in local expansions
             from . import target_plan
             return target_plan.modhelm_apply(plan, k, src.x, src.y, _weighted(charge, src.weights), ctx=target.ctx)
+    if dipstr is None and not self_eval and isinstance(target, DeviceTargets) and target.columns is not None \
+            and target.columns[1] >= COLUMNS_FAR_MIN:
+        # a radial grid: blocks of 64 radial lines, far sources in the blocks' local expansions
+        ctx = target.ctx
+        M, N = target.columns
+        sxd, syd, wd = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (src.x, src.y, _weighted(charge, src.weights)))
+        out = torch.empty(target.N, dtype=torch.float64, device=target.x.device)
+        ctx.check(ctx.lib.ipde_modhelm_apply_columns_far(ctx.handle, float(k), int(sxd.shape[0]), ptr(sxd), ptr(syd),
+                                                         ptr(wd), M, N, ptr(target.x), ptr(target.y), ptr(out)))
+        return out
     return modified_helmholtz_apply(src.x, src.y, tx, ty, k,
                                     w_sigma=_weighted(charge, src.weights),
                                     nx=None if dipstr is None else src.normal_x,

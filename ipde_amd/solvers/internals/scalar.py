@@ -30,7 +30,7 @@ class ScalarHelper(object):
         # fixed target sets of correct(): resident in HBM
         from ...layer_potentials import DeviceTargets
         self._interface_dev = DeviceTargets(self.ebdy.interface)
-        self._radial_dev = DeviceTargets(self.ebdy.radial_targ)
+        self._radial_dev = DeviceTargets(self.ebdy.radial_targ, columns=self.ebdy.radial_shape)
         # set by the multi-boundary solver: True when every rank of a torch.distributed job
         # runs this helper's whole flow (single boundary), so that the M*N x N radial sum of
         # correct() can be split over the ranks like the grid sum

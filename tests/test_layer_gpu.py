@@ -917,6 +917,40 @@ def test_far_forms_on_ragged_rectangular_lattices_with_scattered_sources(lp, see
         assert np.abs(g_ - w_).max() < 2e-13 * np.abs(w_).max()
 
 
+def _radial_grid(c, M, width):
+    rv = 0.5 * width * (1.0 - np.cos(np.pi * (np.arange(M) + 0.5) / M))          # Chebyshev nodes in (0, width)
+    return c.x[None, :] - rv[:, None] * c.normal_x[None, :], c.y[None, :] - rv[:, None] * c.normal_y[None, :]
+
+
+@pytest.mark.parametrize("k", [0.5, 10.0, 80.0])
+@pytest.mark.parametrize("nb,M", [(2048, 20), (3000, 14), (4096, 24)])
+def test_modhelm_column_far_form_on_a_radial_grid(lp, k, nb, M):
+    """ipde_modhelm_apply_columns_far on the (M, N) radial grid of an annulus (blocks of 64 radial lines, far
+    sources in the blocks' expansions) against the list kernel: sources on a curve a few node spacings
+    outside the boundary — where the QFS source curve of the correction step sits —, M not a multiple of the
+    four rows a lane takes at a time, N not a multiple of 64."""
+    c = Curve(nb, a=0.2, f=5)
+    h = 2 * np.pi / nb
+    tx, ty = _radial_grid(c, M, M * h)
+    sx, sy = c.x + 2.5 * h * c.normal_x, c.y + 2.5 * h * c.normal_y
+    rng = np.random.default_rng(nb + M)
+    s = rng.standard_normal(c.N)
+
+    class Src:                      # (a source curve: x, y, weights)
+        pass
+    src = Src()
+    src.x, src.y, src.weights, src.N = sx, sy, c.weights, c.N
+    cols = lp.DeviceTargets(tx.ravel(), ty.ravel(), columns=(M, nb))
+    plain = lp.DeviceTargets(tx.ravel(), ty.ravel())
+    a = lp.Modified_Helmholtz_Layer_Apply(src, cols, k=k, charge=s)
+    b = lp.Modified_Helmholtz_Layer_Apply(src, plain, k=k, charge=s)
+    import torch
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    assert a.shape == b.shape and float((a - b).abs().max()) < 1e-13 * float(b.abs().max())
+    with pytest.raises(ValueError):
+        lp.DeviceTargets(tx.ravel(), ty.ravel(), columns=(M + 1, nb))
+
+
 # -- the kernels no reference code computes, tied to the pinned ones through derivative relations
 #    (tests/test_oracle_layer_relations.py has the same checks for the oracle; here every
 #    evaluation is a HIP kernel call and nothing goes through the oracle's closed formulas) -------
