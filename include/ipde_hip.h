@@ -208,6 +208,17 @@ int ipde_laplace_apply_patches_far(ipde_ctx* ctx,
                                    double* out);
 
 /*
+ * The far-field form for the radial grid of an annulus: targets (M, N) row-major (tx, ty: DEVICE, M * N
+ * doubles each), column j = the M points of one radial line, neighbouring columns neighbouring lines
+ * (ipde/embedded_boundary.py:280-358 `radial_x`, `radial_y` raveled).  Single layer; blocks of 64 columns, a
+ * block's far sources in its local expansion, near batches pair by pair: the radial sums of correct()
+ * (ipde/solvers/internals/scalar.py:113-114).  out: DEVICE, M * N doubles.
+ */
+int ipde_laplace_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                   const double* w_sigma, int M, int64_t N, const double* tx, const double* ty,
+                                   double* out);
+
+/*
  * The cut of a target list (HOST arrays x, y of nt points) into those patches, on the host — no
  * GPU work, callable from any thread.  Grid lines are the coordinate values at least
  * line_min_points points share (exact comparisons); tiles of the lattice of lines that hold a

@@ -800,6 +800,134 @@ int launch_laplace_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, con
     return IPDE_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The far-field form for the radial grids of the annuli (ipde_laplace_apply_columns_far; the scheme and
+// the stand-in patch list are described at modhelm_cols_far_kernel in layer_modhelm.hip): targets (M, N)
+// row-major, column j = one radial line; blocks of 64 columns, one level, eight source slices per block; a
+// wave takes four rows of a block.  Single layer only (what the solvers' correct() sums).
+__global__ __launch_bounds__(256) void laplace_columns_as_patches_kernel(const double* __restrict__ tx,
+                                                                         const double* __restrict__ ty, int M,
+                                                                         int64_t N, double* __restrict__ pxy) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const double x0 = tx[j], x1 = tx[(int64_t)(M - 1) * N + j], y0 = ty[j], y1 = ty[(int64_t)(M - 1) * N + j];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        pxy[(int64_t)a * N + j] = (a & 1) ? x1 : x0;
+        pxy[(int64_t)(4 + a) * N + j] = (a & 1) ? y1 : y0;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void laplace_cols_far_kernel(
+    const double* __restrict__ rec, int ns_pad, const double* __restrict__ tx, const double* __restrict__ ty, int M,
+    int64_t N, double* __restrict__ out, const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab,
+    unsigned key_lo, unsigned nkeys, const double* __restrict__ head, const double* __restrict__ cs, int nslice,
+    const unsigned* __restrict__ near, int nch) {
+    extern __shared__ double2 ltab[];
+    for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
+    __syncthreads();
+    const double s1 = ldexp(1.0, prm->sh);
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int nrc = (M + 3) / 4;
+    const int64_t wid = __builtin_amdgcn_readfirstlane((int)(wv * gridDim.x + blockIdx.x));
+    const int64_t g = wid / nrc;
+    const int r0 = 4 * (int)(wid - g * nrc);
+    if (g * 64 >= N) return;                           // (whole waves, after the only barrier)
+    // B_k = -(2/k) S_k (B_0 = S_0), the slices' sums added up, parked in LDS behind the table
+    double2* B = ltab + nkeys + wv * (FAR_P + 1);
+    if (ln <= FAR_P) {
+        double br = 0.0, bi = 0.0;
+        for (int sl = 0; sl < nslice; ++sl) {
+            br += cs[(g * nslice + sl) * FAR_NCOEF + 2 * ln];
+            bi += cs[(g * nslice + sl) * FAR_NCOEF + 2 * ln + 1];
+        }
+        const double f = ln == 0 ? 1.0 : -2.0 / (double)ln;
+        B[ln] = double2{f * br, ln == 0 ? 0.0 : f * bi};
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double* h = head + g * FAR_HDR;
+    const double cx = h[0], cy = h[1], rinv = h[2];
+    const int64_t j = g * 64 + ln, jj = min(j, N - 1);
+    double x[4], y[4], acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = (int64_t)min(r0 + i, M - 1) * N + jj;
+        x[i] = tx[t] * s1;
+        y[i] = ty[t] * s1;
+    }
+    TabAddr ta;
+    const unsigned* nm = near + g * nch;
+    for (int c = 0; c < nch; ++c) {
+        unsigned m = nm[c];
+        while (m) {
+            const int bt = __builtin_ctz(m);
+            m &= m - 1;
+            SrcRow sx, sy, sq;
+            sx.load(rec, 8 * c + bt, 0);
+            sy.load(rec, 8 * c + bt, 1);
+            sq.load(rec, 8 * c + bt, 2);
+#pragma unroll
+            for (int u = 0; u < IPDE_SRC_PAD; ++u) {
+                double d2[4];
+                double2 e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double dx = x[i] - sx.v[u], dy = y[i] - sy.v[u];
+                    d2[i] = fma(dy, dy, dx * dx);
+                    e[i] = ta.lookup(ltab, d2[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fma(sq.v[u], log_from_y(tab_y(d2[i], e[i].x), e[i].y), acc[i]);
+            }
+        }
+    }
+    if (!ta.all_inside(key_lo) || prm->pad) {
+        double gs[4] = {0.0, 0.0, 0.0, 0.0};
+        if (prm->pad) {
+            laplace_generic_loop<MODE_SLP, false, 4>(rec, 0, ns_pad, x, y, gs);
+        } else {
+            for (int c = 0; c < nch; ++c) {
+                unsigned m = nm[c];
+                while (m) {
+                    const int bt = __builtin_ctz(m);
+                    m &= m - 1;
+                    laplace_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, x, y, gs);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = gs[i];
+    }
+    if (!prm->pad) {
+        double zx[4], zy[4], vre[4] = {0.0, 0.0, 0.0, 0.0}, vim[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            zx[i] = (x[i] - cx) * rinv;
+            zy[i] = (y[i] - cy) * rinv;
+        }
+#pragma unroll 2
+        for (int k = FAR_P; k >= 1; --k) {
+            const double2 bk = B[k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double ure = vre[i] + bk.x, uim = vim[i] + bk.y;
+                vre[i] = ure * zx[i] - uim * zy[i];
+                vim[i] = fma(ure, zy[i], uim * zx[i]);
+            }
+        }
+        const double b0 = B[0].x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += vre[i] + b0;
+    }
+    if (j < N) {
+        const double corr = prm->corr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (r0 + i < M) out[(int64_t)(r0 + i) * N + j] = acc[i] + corr;
+    }
+}
+
 template <int MODE, int R, int NT>
 int launch_rowrun_variant(ipde_ctx* ctx, dim3 grid, const double* rec, const LayerGeom& g,
                           const double* tx, const double* ty, int64_t nt, double* dst,
@@ -1043,4 +1171,58 @@ extern "C" int ipde_laplace_apply_patches_far(ipde_ctx* ctx, int64_t ns, const d
     if (mode == MODE_SLP) return launch_laplace_patches_far<MODE_SLP>(ctx, rec, ns, pxy, np, pout, out, prm);
     if (mode == MODE_DLP) return launch_laplace_patches_far<MODE_DLP>(ctx, rec, ns, pxy, np, pout, out, prm);
     return launch_laplace_patches_far<MODE_BOTH>(ctx, rec, ns, pxy, np, pout, out, prm);
+}
+
+// Single-layer sums onto an (M, N) radial grid (row-major DEVICE arrays; column j = one radial line): the
+// radial sums of the solvers' correct() (reference ipde/solvers/internals/scalar.py:113-114) with the far
+// sources of every block of 64 lines in a local expansion.
+extern "C" int ipde_laplace_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                              const double* w_sigma, int M, int64_t N, const double* tx,
+                                              const double* ty, double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ns >= 0 && N >= 0 && M >= 1 && ns < (1LL << 30) && N < (1LL << 30) && (int64_t)M * N < (1LL << 40));
+    if (N == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, tx && ty && out);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && w_sigma);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    PackArgs pa{};
+    pa.sx = sx;
+    pa.sy = sy;
+    pa.ch[0] = w_sigma;
+    pa.mul[0] = -0.25 / M_PI;
+    pa.corr_ch = 0;
+    pa.corr2_ch = -1;
+    pa.use_scale = 1;
+    pa.exp_hi = ctx->logtab.exp_hi;
+    const double* rec;
+    const ApplyParams* prm;
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, tx, ty, (int64_t)M * N, &rec, &prm));
+    constexpr int NT = 256, NSL = 8;
+    const LogTable& lt = ctx->logtab;
+    const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
+    const int64_t ng = ceil_div64(N, 64);
+    const int nch = (int)ceil_div64(ns_pad, 64);
+    const size_t nd = (size_t)8 * N + (size_t)ng * (FAR_HDR + NSL * FAR_NCOEF);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
+    double* pxy = (double*)ctx->partial.p;
+    double* head = pxy + (size_t)8 * N;
+    double* cs = head + (size_t)ng * FAR_HDR;
+    unsigned* near = (unsigned*)(cs + (size_t)ng * NSL * FAR_NCOEF);
+    ipde_time_begin(ctx);
+    hipLaunchKernelGGL(laplace_columns_as_patches_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, ctx->stream,
+                       tx, ty, M, N, pxy);
+    hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_SLP, 1>), dim3((unsigned)ceil_div64(ng * NSL, 4)), dim3(256), 0,
+                       ctx->stream, rec, ns_pad, (const double*)pxy, N, prm, head, cs, near, nch, 1,
+                       (const unsigned*)nullptr, NSL);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    const size_t lds = ((size_t)lt.nkeys + (size_t)(NT / 64) * (FAR_P + 1)) * sizeof(double2);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_cols_far_kernel<NT>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((laplace_cols_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng * ((M + 3) / 4), NT)), dim3(NT),
+                       lds, ctx->stream, rec, ns_pad, tx, ty, M, N, out, prm, (const double2*)lt.d_tab,
+                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)cs, NSL,
+                       (const unsigned*)near, nch);
+    ipde_time_end(ctx);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
 }

@@ -310,6 +310,16 @@ def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=N
                                          ny=None if dipstr is None else src.normal_y,
                                          w_tau=_weighted(dipstr, src.weights), ctx=target.ctx,
                                          far=target.far and plan.padded_blocks)
+    if dipstr is None and not self_eval and isinstance(target, DeviceTargets) and target.columns is not None \
+            and target.columns[1] >= COLUMNS_FAR_MIN:
+        # a radial grid: blocks of 64 radial lines, far sources in the blocks' local expansions
+        ctx = target.ctx
+        M, N = target.columns
+        sxd, syd, wd = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (src.x, src.y, _weighted(charge, src.weights)))
+        out = torch.empty(target.N, dtype=torch.float64, device=target.x.device)
+        ctx.check(ctx.lib.ipde_laplace_apply_columns_far(ctx.handle, int(sxd.shape[0]), ptr(sxd), ptr(syd), ptr(wd), M,
+                                                         N, ptr(target.x), ptr(target.y), ptr(out)))
+        return out
     return laplace_apply(src.x, src.y, tx, ty,
                          w_sigma=_weighted(charge, src.weights),
                          nx=None if dipstr is None else src.normal_x,

@@ -951,6 +951,35 @@ def test_modhelm_column_far_form_on_a_radial_grid(lp, k, nb, M):
         lp.DeviceTargets(tx.ravel(), ty.ravel(), columns=(M + 1, nb))
 
 
+@pytest.mark.parametrize("nb,M", [(2048, 20), (3000, 14), (4096, 24)])
+def test_laplace_column_far_form_on_a_radial_grid(lp, nb, M):
+    """ipde_laplace_apply_columns_far on the (M, N) radial grid of an annulus against the list kernel and,
+    on a sample, the C oracle; a dipole density keeps the list kernel."""
+    import torch
+    c = Curve(nb, a=0.2, f=5)
+    h = 2 * np.pi / nb
+    tx, ty = _radial_grid(c, M, M * h)
+    rng = np.random.default_rng(nb + M)
+    s = rng.standard_normal(c.N)
+
+    class Src:
+        pass
+    src = Src()
+    src.x, src.y, src.weights, src.N = c.x + 2.5 * h * c.normal_x, c.y + 2.5 * h * c.normal_y, c.weights, c.N
+    src.normal_x, src.normal_y = c.normal_x, c.normal_y
+    cols = lp.DeviceTargets(tx.ravel(), ty.ravel(), columns=(M, nb))
+    plain = lp.DeviceTargets(tx.ravel(), ty.ravel())
+    a = torch.as_tensor(lp.Laplace_Layer_Apply(src, cols, charge=s))
+    b = torch.as_tensor(lp.Laplace_Layer_Apply(src, plain, charge=s))
+    assert a.shape == b.shape and float((a - b).abs().max()) < 1e-13 * float(b.abs().max())
+    idx = rng.choice(M * nb, 3000, replace=False)
+    ref = oracle.c_laplace_apply(src.x, src.y, tx.ravel()[idx], ty.ravel()[idx], w_sigma=s * c.weights)
+    assert np.abs(a.cpu().numpy()[idx] - ref).max() < TOL * np.abs(ref).max()
+    a = torch.as_tensor(lp.Laplace_Layer_Apply(src, cols, charge=s, dipstr=s))
+    b = torch.as_tensor(lp.Laplace_Layer_Apply(src, plain, charge=s, dipstr=s))
+    assert torch.equal(a, b)
+
+
 # -- the kernels no reference code computes, tied to the pinned ones through derivative relations
 #    (tests/test_oracle_layer_relations.py has the same checks for the oracle; here every
 #    evaluation is a HIP kernel call and nothing goes through the oracle's closed formulas) -------
