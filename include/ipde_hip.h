@@ -323,6 +323,17 @@ int ipde_stokes_apply_patches_far(ipde_ctx* ctx, int64_t ns, const double* sx, c
                                   int64_t np, const double* pxy, const int32_t* pout,
                                   double* out_u, double* out_v, double* out_p);
 
+/*
+ * The same far-field form for the radial grid of an annulus: targets (M, N) row-major (tx, ty: DEVICE, M * N
+ * doubles each), column j = the M points of one radial line, neighbouring columns neighbouring lines.
+ * Blocks of 64 columns, a block's far sources in its local expansions, near batches pair by pair: the radial
+ * sums of the Stokes helpers' correct() (ipde/solvers/internals/vector.py:140-162).  out_*: DEVICE, M * N
+ * doubles; out_p may be NULL.
+ */
+int ipde_stokes_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                  const double* wfx, const double* wfy, int M, int64_t N,
+                                  const double* tx, const double* ty, double* out_u, double* out_v, double* out_p);
+
 /* ------------------------------------------------------------------------- */
 /* periodic spectral grid operators                  */
 

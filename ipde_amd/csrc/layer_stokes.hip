@@ -706,6 +706,156 @@ __global__ __launch_bounds__(1024) void stokes_far_parent_kernel(const double* _
     }
 }
 
+// ---------------------------------------------------------------------------
+// The far-field form for the radial grids of the annuli (ipde_stokes_apply_columns_far; the scheme and the
+// stand-in patch list are described at modhelm_cols_far_kernel in layer_modhelm.hip): targets (M, N)
+// row-major, column j = one radial line; blocks of 64 columns, one level, eight source slices per block; a
+// wave takes four rows of a block.
+__global__ __launch_bounds__(256) void stokes_columns_as_patches_kernel(const double* __restrict__ tx,
+                                                                        const double* __restrict__ ty, int M,
+                                                                        int64_t N, double* __restrict__ pxy) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const double x0 = tx[j], x1 = tx[(int64_t)(M - 1) * N + j], y0 = ty[j], y1 = ty[(int64_t)(M - 1) * N + j];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        pxy[(int64_t)a * N + j] = (a & 1) ? x1 : x0;
+        pxy[(int64_t)(4 + a) * N + j] = (a & 1) ? y1 : y0;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void stokes_cols_far_kernel(
+    const double* __restrict__ rec, int ns_pad, const double* __restrict__ tx, const double* __restrict__ ty, int M,
+    int64_t N, double* __restrict__ ou, double* __restrict__ ov, double* __restrict__ op,
+    const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab, unsigned key_lo, unsigned nkeys,
+    const double* __restrict__ head, const double* __restrict__ c1, const double* __restrict__ c2,
+    const double* __restrict__ c3, int nslice, const unsigned* __restrict__ near, int nch) {
+    extern __shared__ double2 ltab[];
+    for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
+    __syncthreads();
+    const double s1 = ldexp(1.0, prm->sh);
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int nrc = (M + 3) / 4;
+    const int64_t wid = __builtin_amdgcn_readfirstlane((int)(wv * gridDim.x + blockIdx.x));
+    const int64_t g = wid / nrc;
+    const int r0 = 4 * (int)(wid - g * nrc);
+    if (g * 64 >= N) return;                           // (whole waves, after the only barrier)
+    constexpr int WCL = 3 * (SFAR_P + 1);
+    double2* W = ltab + nkeys + wv * WCL;
+    if (ln <= SFAR_P)
+        sfar_combine(W, ln, c1 + g * nslice * SFAR_NCOEF, c2 + g * nslice * SFAR_NCOEF, c3 + g * nslice * SFAR_NCOEF,
+                     nslice);
+    __builtin_amdgcn_wave_barrier();
+    const double* h = head + g * SFAR_HDR;
+    const double cx = h[0], cy = h[1], rinv = h[2];
+    const int64_t j = g * 64 + ln, jj = min(j, N - 1);
+    double x[4], y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = (int64_t)min(r0 + i, M - 1) * N + jj;
+        x[i] = tx[t] * s1;
+        y[i] = ty[t] * s1;
+    }
+    // far sources first
+    double fu[4], fv[4], fq[4];
+    {
+        const double2 c0 = W[0];
+        double zx[4], zy[4], s1r[4], s1i[4], s2r[4], s2i[4], s3r[4], s3i[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            zx[i] = (x[i] - cx) * rinv;
+            zy[i] = (y[i] - cy) * rinv;
+            s1r[i] = s1i[i] = s2r[i] = s2i[i] = s3r[i] = s3i[i] = 0.0;
+        }
+#pragma unroll 2
+        for (int k = SFAR_P; k >= 0; --k) {
+            const double2 a1 = k >= 1 ? W[3 * k] : double2{0.0, 0.0};
+            const double2 a2 = W[3 * k + 1];
+            const double2 b3 = W[3 * k + 2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double nr = s1r[i] * zx[i] - s1i[i] * zy[i] + a1.x;
+                s1i[i] = fma(s1r[i], zy[i], s1i[i] * zx[i]) + a1.y;
+                s1r[i] = nr;
+                nr = s2r[i] * zx[i] - s2i[i] * zy[i] + a2.x;
+                s2i[i] = fma(s2r[i], zy[i], s2i[i] * zx[i]) + a2.y;
+                s2r[i] = nr;
+                nr = s3r[i] * zx[i] + s3i[i] * zy[i] + b3.x;
+                s3i[i] = fma(-s3r[i], zy[i], s3i[i] * zx[i]) + b3.y;
+                s3r[i] = nr;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double qr = zx[i] * s2r[i] + zy[i] * s2i[i], qi = zy[i] * s2r[i] - zx[i] * s2i[i];
+            const bool on = !prm->pad;
+            fu[i] = on ? c0.x + s1r[i] + s3r[i] - 0.5 * qr : 0.0;
+            fv[i] = on ? c0.y + s1i[i] + s3i[i] - 0.5 * qi : 0.0;
+            fq[i] = on ? -rinv * s2r[i] : 0.0;
+        }
+    }
+    StokesAcc acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = StokesAcc{0, 0, 0, 0, 0};
+    TabAddr ta;
+    const unsigned* nm = near + g * nch;
+    for (int c = 0; c < nch; ++c) {
+        unsigned m = nm[c];
+        while (m) {
+            const int bt = __builtin_ctz(m);
+            m &= m - 1;
+            const double* row = rec + ((size_t)(8 * c + bt) * IPDE_SRC_NCH) * IPDE_SRC_PAD;
+#pragma unroll
+            for (int u = 0; u < IPDE_SRC_PAD; ++u) {
+                StokesSrc sr{};
+                sr.fx = row[2 * IPDE_SRC_PAD + u];
+                sr.fy = row[3 * IPDE_SRC_PAD + u];
+                const double sxu = row[u], syu = row[IPDE_SRC_PAD + u];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double dx = x[i] - sxu, dy = y[i] - syu;
+                    const double d2 = fma(dy, dy, dx * dx);
+                    const double2 e = ta.lookup(ltab, d2);
+                    const double yy = tab_y(d2, e.x);
+                    stokes_pair<MODE_SLP>(dx, dy, log_from_y(yy, e.y), rcp_from_y_fast(e.x, yy), sr, acc[i]);
+                }
+            }
+        }
+    }
+    if (!ta.all_inside(key_lo) || prm->pad) {
+        StokesAcc gs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gs[i] = StokesAcc{0, 0, 0, 0, 0};
+        if (prm->pad) {
+            stokes_generic_loop<MODE_SLP, false, 4>(rec, 0, ns_pad, x, y, gs);
+        } else {
+            for (int c = 0; c < nch; ++c) {
+                unsigned m = nm[c];
+                while (m) {
+                    const int bt = __builtin_ctz(m);
+                    m &= m - 1;
+                    stokes_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, x, y, gs);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = gs[i];
+    }
+    if (j < N) {
+        const double cu = prm->corr, cv = prm->corr2;
+        const double ps = 2.0 * s1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (r0 + i < M) {
+                const int64_t t = (int64_t)(r0 + i) * N + j;
+                ou[t] = fma(-0.5, acc[i].uL + cu, acc[i].u + fu[i]);
+                ov[t] = fma(-0.5, acc[i].vL + cv, acc[i].v + fv[i]);
+                if (op) op[t] = ps * (acc[i].p + fq[i]);
+            }
+    }
+}
+
 int launch_stokes_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, const double* pxy, int64_t np,
                               const int* pout, double* ou, double* ov, double* op, const ApplyParams* prm) {
     constexpr int NT = 512;
@@ -934,4 +1084,70 @@ extern "C" int ipde_stokes_apply_patches_far(ipde_ctx* ctx, int64_t ns, const do
     const ApplyParams* prm;
     IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, pxy, pxy + 4 * np, 4 * np, &rec, &prm));
     return launch_stokes_patches_far(ctx, rec, ns, pxy, np, pout, out_u, out_v, out_p, prm);
+}
+
+// Stokeslet sums (with pressure when out_p != NULL) onto an (M, N) radial grid (row-major DEVICE arrays;
+// column j = one radial line): the radial sums of the Stokes helpers' correct()
+// (reference ipde/solvers/internals/vector.py:140-162) with the far sources of every block of 64 lines in
+// local expansions.
+extern "C" int ipde_stokes_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                             const double* wfx, const double* wfy, int M, int64_t N,
+                                             const double* tx, const double* ty, double* out_u, double* out_v,
+                                             double* out_p) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ns >= 0 && N >= 0 && M >= 1 && ns < (1LL << 30) && N < (1LL << 30) && (int64_t)M * N < (1LL << 40));
+    if (N == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, tx && ty && out_u && out_v);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && wfx && wfy);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    PackArgs pa{};
+    pa.sx = sx;
+    pa.sy = sy;
+    pa.ch[0] = wfx;
+    pa.mul[0] = 0.25 / M_PI;
+    pa.ch[1] = wfy;
+    pa.mul[1] = 0.25 / M_PI;
+    pa.stokes_ng = 0;
+    pa.corr_ch = 0;
+    pa.corr2_ch = 1;
+    pa.use_scale = 1;
+    pa.exp_hi = ctx->logtab.exp_hi;
+    const double* rec;
+    const ApplyParams* prm;
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, tx, ty, (int64_t)M * N, &rec, &prm));
+    constexpr int NT = 256, NSL = 8;
+    const LogTable& lt = ctx->logtab;
+    const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
+    const int64_t ng = ceil_div64(N, 64);
+    const int nch = (int)ceil_div64(ns_pad, 64);
+    const size_t nd = (size_t)8 * N + (size_t)ng * (SFAR_HDR + 3 * NSL * SFAR_NCOEF);
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
+    double* pxy = (double*)ctx->partial.p;
+    double* head = pxy + (size_t)8 * N;
+    double* c1 = head + (size_t)ng * SFAR_HDR;
+    double* c2 = c1 + (size_t)ng * NSL * SFAR_NCOEF;
+    double* c3 = c2 + (size_t)ng * NSL * SFAR_NCOEF;
+    unsigned* near = (unsigned*)(c3 + (size_t)ng * NSL * SFAR_NCOEF);
+    const unsigned gb = (unsigned)ceil_div64(ng * NSL, 4);
+    const unsigned* none = nullptr;
+    ipde_time_begin(ctx);
+    hipLaunchKernelGGL(stokes_columns_as_patches_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, ctx->stream,
+                       tx, ty, M, N, pxy);
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<1, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
+                       (const double*)pxy, N, prm, head, c1, near, nch, none, NSL);
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<2, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
+                       (const double*)pxy, N, prm, head, c2, near, nch, none, NSL);
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<3, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
+                       (const double*)pxy, N, prm, head, c3, near, nch, none, NSL);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    const size_t lds = ((size_t)lt.nkeys + (size_t)(NT / 64) * 3 * (SFAR_P + 1)) * sizeof(double2);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stokes_cols_far_kernel<NT>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((stokes_cols_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng * ((M + 3) / 4), NT)), dim3(NT),
+                       lds, ctx->stream, rec, ns_pad, tx, ty, M, N, out_u, out_v, out_p, prm, (const double2*)lt.d_tab,
+                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)c1,
+                       (const double*)c2, (const double*)c3, NSL, (const unsigned*)near, nch);
+    ipde_time_end(ctx);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
 }

@@ -382,6 +382,20 @@ def Stokes_Layer_Apply(source, target=None, forces=None, dipstr=None, pressure=T
         if plan is not None and plan.padded_blocks:      # far sources block by block in local expansions
             from . import target_plan
             return target_plan.stokes_apply(plan, src.x, src.y, f[0], f[1], pressure=pressure, ctx=target.ctx)
+    if g is None and not self_eval and isinstance(target, DeviceTargets) and target.columns is not None \
+            and target.columns[1] >= COLUMNS_FAR_MIN:
+        # a radial grid: blocks of 64 radial lines, far sources in the blocks' local expansions
+        ctx = target.ctx
+        M, N = target.columns
+        sxd, syd, fxd, fyd = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (src.x, src.y, f[0], f[1]))
+        dev = target.x.device
+        u = torch.empty(target.N, dtype=torch.float64, device=dev)
+        v = torch.empty(target.N, dtype=torch.float64, device=dev)
+        p = torch.empty(target.N, dtype=torch.float64, device=dev) if pressure else None
+        ctx.check(ctx.lib.ipde_stokes_apply_columns_far(ctx.handle, int(sxd.shape[0]), ptr(sxd), ptr(syd), ptr(fxd),
+                                                        ptr(fyd), M, N, ptr(target.x), ptr(target.y), ptr(u), ptr(v),
+                                                        ptr(p)))
+        return u, v, p
     return stokes_apply(src.x, src.y, tx, ty,
                         wfx=None if f is None else f[0], wfy=None if f is None else f[1],
                         nx=None if g is None else src.normal_x,

@@ -35,7 +35,7 @@ class VectorHelper(object):
         self._define_layer_apply()
         from ...layer_potentials import DeviceTargets
         self._interface_dev = DeviceTargets(self.ebdy.interface)
-        self._radial_dev = DeviceTargets(self.ebdy.radial_targ)
+        self._radial_dev = DeviceTargets(self.ebdy.radial_targ, columns=self.ebdy.radial_shape)
         self.shard_radial_sums = False     # see ScalarHelper
         self._radial_sharded = None
 

@@ -980,6 +980,37 @@ def test_laplace_column_far_form_on_a_radial_grid(lp, nb, M):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("nb,M", [(2048, 20), (3000, 14), (4096, 24)])
+def test_stokes_column_far_form_on_a_radial_grid(lp, nb, M):
+    """ipde_stokes_apply_columns_far (u, v, p) on the (M, N) radial grid of an annulus against the list kernel;
+    without the pressure too; a stresslet density keeps the list kernel."""
+    import torch
+    c = Curve(nb, a=0.2, f=5)
+    h = 2 * np.pi / nb
+    tx, ty = _radial_grid(c, M, M * h)
+    rng = np.random.default_rng(nb + M)
+    f = rng.standard_normal((2, c.N))
+
+    class Src:
+        pass
+    src = Src()
+    src.x, src.y, src.weights, src.N = c.x + 2.5 * h * c.normal_x, c.y + 2.5 * h * c.normal_y, c.weights, c.N
+    src.normal_x, src.normal_y = c.normal_x, c.normal_y
+    cols = lp.DeviceTargets(tx.ravel(), ty.ravel(), columns=(M, nb))
+    plain = lp.DeviceTargets(tx.ravel(), ty.ravel())
+    a = lp.Stokes_Layer_Apply(src, cols, forces=f)
+    b = lp.Stokes_Layer_Apply(src, plain, forces=f)
+    for x, y in zip(a, b):
+        x, y = torch.as_tensor(x), torch.as_tensor(y)
+        assert float((x - y).abs().max()) < 2e-13 * float(y.abs().max())
+    a2 = lp.Stokes_Layer_Apply(src, cols, forces=f, pressure=False)
+    assert a2[2] is None and torch.equal(torch.as_tensor(a2[0]), torch.as_tensor(a[0]))
+    a = lp.Stokes_Layer_Apply(src, cols, forces=f, dipstr=f)
+    b = lp.Stokes_Layer_Apply(src, plain, forces=f, dipstr=f)
+    for x, y in zip(a, b):
+        assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
+
+
 # -- the kernels no reference code computes, tied to the pinned ones through derivative relations
 #    (tests/test_oracle_layer_relations.py has the same checks for the oracle; here every
 #    evaluation is a HIP kernel call and nothing goes through the oracle's closed formulas) -------
