@@ -259,6 +259,46 @@ def fft_block(n=NGRID, reps=40):
     return out
 
 
+def launch_command(n, argv, port=None):
+    """The one-node launch the driver itself uses for N > 1 (one rank per GPU over RCCL)."""
+    if port is None:
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+        [a for a in argv if a != "--print-launch"]
+
+
+def self_launch(n, argv, dry=False):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): run the ranks as a child process
+    (this process never initialises the GPU), pass its stderr through, print the ONE JSON line rank 0
+    wrote, return the child's exit status."""
+    import subprocess
+    cmd = launch_command(n, argv)
+    if dry:
+        print(json.dumps(cmd), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")                # torchrun would set 1 and say so on stderr
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = []
+    for line in child.stdout:
+        if line.startswith("{"):
+            lines.append(line.rstrip("\n"))
+        else:                                             # launcher / library chatter: not on fd 1
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
+        rc = 1
+    for l in lines[-1:]:
+        print(l, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,7 +318,16 @@ def main():
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="all ranks on cuda:0, collectives over gloo through host memory: exercises the "
                          "N > 1 code path on a one-GPU box (a rehearsal, not a measurement)")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="with --gpus N > 1 from a bare shell: print the child command the self-launch would "
+                         "run (a JSON list) and exit")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process, before this
+        # process has imported torch or touched the GPU (never re-exec a process that has), relay rank 0's
+        # single JSON line and leave with the child's status
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], dry=args.print_launch))
 
     # RCCL writes a version banner to stdout when the communicator is created:
     # keep fd 1 clean for the single JSON line by pointing it at stderr meanwhile
@@ -370,7 +419,15 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    kms_timed = ctx.kernel_ms_history()[-args.steps:]
+    # event pairs per step: the patch kernel, plus the list kernel on the plan's remainder when there is one;
+    # the ring holds 256 pairs, so a longer run averages its last whole steps
+    ppstep = 2 if (plan is not None and plan.nrest > 0) else 1
+    hist = ctx.kernel_ms_history()
+    nsteps_seen = min(args.steps, len(hist) // ppstep)
+    assert nsteps_seen >= 1, "no kernel event pairs recorded in the timed region"
+    # (a step's remainder launch, if any, is recorded BEFORE its patch kernel: the dominant kernel is the step's last pair)
+    kms_timed = [float(hist[len(hist) - ppstep * (nsteps_seen - i) + ppstep - 1]) for i in range(nsteps_seen)]
+    assert len(kms_timed) == min(args.steps, 256 // ppstep), (len(kms_timed), args.steps)
     kernel_ms_avg = float(np.mean(kms_timed))
     # the same launch isolated (a host sync after each): a separate figure, not the one frac uses
     ctx.sync()

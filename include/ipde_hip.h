@@ -77,6 +77,12 @@ int ipde_ctx_sync(ipde_ctx* ctx);
    alternates library kernels with torch operations then stays on one queue). */
 int ipde_ctx_set_stream(ipde_ctx* ctx, void* hip_stream);
 void* ipde_ctx_get_stream(ipde_ctx* ctx);
+/* The same for the legacy default stream, with the handle taken from the HIP header on the C side
+   (callers need not know that hipStreamLegacy is (hipStream_t)1).  A context's OWN stream is created
+   blocking (hipStreamDefault) on purpose: it orders itself against the legacy default stream, where a
+   host framework allocates and fills the buffers it hands to a private context; the price is that a
+   launch on the legacy stream waits for every such stream. */
+int ipde_ctx_use_legacy_stream(ipde_ctx* ctx);
 const char* ipde_last_error(ipde_ctx* ctx);
 /* Tuning knobs (kernel geometry variants); never changes results beyond rounding.
    Names: "laplace_variant", "stokes_variant", "dense_pairs", "annular_grouped",
@@ -212,7 +218,10 @@ int ipde_laplace_apply_patches_far(ipde_ctx* ctx,
  * doubles each), column j = the M points of one radial line, neighbouring columns neighbouring lines
  * (ipde/embedded_boundary.py:280-358 `radial_x`, `radial_y` raveled).  Single layer; blocks of 64 columns, a
  * block's far sources in its local expansion, near batches pair by pair: the radial sums of correct()
- * (ipde/solvers/internals/scalar.py:113-114).  out: DEVICE, M * N doubles.
+ * (ipde/solvers/internals/scalar.py:113-114).  out: DEVICE, M * N doubles.  Any (M, N) array gives correct sums
+ * (a block's disc is the bounding box of its 64 columns over ALL rows); the form is FAST when neighbouring
+ * columns are neighbouring lines.  Modified Helmholtz: sources beyond k d > 45 of a block are dropped
+ * (K0(45) = 5e-21: an ABSOLUTE bound — a target with only such sources gets 0, not a relatively accurate value).
  */
 int ipde_laplace_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
                                    const double* w_sigma, int M, int64_t N, const double* tx, const double* ty,

@@ -219,6 +219,8 @@ extern "C" int ipde_ctx_set_stream(ipde_ctx* ctx, void* s) {
     return IPDE_OK;
 }
 
+extern "C" int ipde_ctx_use_legacy_stream(ipde_ctx* ctx) { return ipde_ctx_set_stream(ctx, (void*)hipStreamLegacy); }
+
 extern "C" void* ipde_ctx_get_stream(ipde_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 extern "C" const char* ipde_last_error(ipde_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }

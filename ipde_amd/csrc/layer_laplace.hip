@@ -810,7 +810,17 @@ __global__ __launch_bounds__(256) void laplace_columns_as_patches_kernel(const d
                                                                          int64_t N, double* __restrict__ pxy) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
-    const double x0 = tx[j], x1 = tx[(int64_t)(M - 1) * N + j], y0 = ty[j], y1 = ty[(int64_t)(M - 1) * N + j];
+    // the column's bounding box over ALL its rows (round 3 took rows 0 and M - 1 only: right for a straight
+    // radial line, silently wrong for any other (M, N) array — a target outside the block's disc breaks the
+    // truncation bound); M * N extra reads, nothing next to the sum
+    double x0 = tx[j], x1 = x0, y0 = ty[j], y1 = y0;
+    for (int r = 1; r < M; ++r) {
+        const double x = tx[(int64_t)r * N + j], y = ty[(int64_t)r * N + j];
+        x0 = fmin(x0, x);
+        x1 = fmax(x1, x);
+        y0 = fmin(y0, y);
+        y1 = fmax(y1, y);
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         pxy[(int64_t)a * N + j] = (a & 1) ? x1 : x0;

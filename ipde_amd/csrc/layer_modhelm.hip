@@ -585,9 +585,9 @@ int launch_modhelm_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, con
 // ---------------------------------------------------------------------------
 // The far-field form for the radial grids of the annuli (ipde_modhelm_apply_columns_far): targets
 // (M, N) row-major, column j = the M points of one radial line.  No lattice, but a group of 64
-// neighbouring columns is compact (an arc of the annulus), and a radial line is a straight segment: the
-// bounding box of a column is that of its two end points — so the coefficient kernel above runs unchanged
-// on a stand-in patch list (patch j: xs = {x_0j, x_(M-1)j, ...}, ys likewise).  One level (64 columns = a
+// neighbouring columns is compact (an arc of the annulus): the coefficient kernel above runs unchanged
+// on a stand-in patch list (patch j: xs = {min_r x_rj, max_r x_rj, ...}, ys likewise — the column's bounding
+// box over all its rows, so ANY (M, N) array gives correct sums; compact blocks make them fast).  One level (64 columns = a
 // block; eight source slices per block: there are only N / 64 blocks); a lane owns a column and walks its
 // rows four at a time.
 __global__ __launch_bounds__(256) void columns_as_patches_kernel(const double* __restrict__ tx,
@@ -595,7 +595,17 @@ __global__ __launch_bounds__(256) void columns_as_patches_kernel(const double* _
                                                                  double* __restrict__ pxy) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
-    const double x0 = tx[j], x1 = tx[(int64_t)(M - 1) * N + j], y0 = ty[j], y1 = ty[(int64_t)(M - 1) * N + j];
+    // the column's bounding box over ALL its rows (round 3 took rows 0 and M - 1 only: right for a straight
+    // radial line, silently wrong for any other (M, N) array — a target outside the block's disc breaks the
+    // truncation bound); M * N extra reads, nothing next to the sum
+    double x0 = tx[j], x1 = x0, y0 = ty[j], y1 = y0;
+    for (int r = 1; r < M; ++r) {
+        const double x = tx[(int64_t)r * N + j], y = ty[(int64_t)r * N + j];
+        x0 = fmin(x0, x);
+        x1 = fmax(x1, x);
+        y0 = fmin(y0, y);
+        y1 = fmax(y1, y);
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         pxy[(int64_t)a * N + j] = (a & 1) ? x1 : x0;

@@ -91,6 +91,35 @@ struct ipde_multi {
         }                                                                                               \
     } while (0)
 
+// Every entry point below walks the devices with hipSetDevice: the caller's current device is put back on
+// the way out (a Python caller's torch.cuda.current_device() / get_context() must not move to another GPU).
+struct DeviceGuard {
+    int d = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&d) != hipSuccess) d = -1;
+    }
+    ~DeviceGuard() {
+        if (d >= 0) hipSetDevice(d);
+    }
+};
+
+// After a failure part-way through an apply: kernels and copies already queued on other devices still read the
+// staging buffers and write the caller's arrays — wait for all of them before the error is handed back.
+static void drain(ipde_multi* m) {
+    for (int i = 0; i < m->ndev; ++i) {
+        if (hipSetDevice(m->dev[i]) != hipSuccess || !m->ctx[i]) continue;
+        hipStreamSynchronize(m->ctx[i]->stream);
+    }
+}
+
+template <typename F>
+static int guarded_apply(ipde_multi* m, F body) {
+    DeviceGuard g;
+    const int st = body();
+    if (st != IPDE_OK) drain(m);
+    return st;
+}
+
 static constexpr int NROW = 8;   // source rows an apply can carry: x, y and up to six density / normal rows
 
 static void free_targets(ipde_multi* m) {
@@ -107,6 +136,7 @@ static void free_targets(ipde_multi* m) {
 
 extern "C" int ipde_multi_destroy(ipde_multi* m) {
     if (!m) return IPDE_ERR_INVALID;
+    DeviceGuard g;
     for (ipde_ctx* c : m->ctx)
         if (c) ipde_ctx_sync(c);
     free_targets(m);
@@ -127,6 +157,7 @@ extern "C" int ipde_multi_create(int ndev, const int* dev_ids, int flags, ipde_m
     for (int i = 0; i < ndev; ++i)
         for (int j = 0; j < i; ++j)
             if (dev_ids[i] == dev_ids[j]) return IPDE_ERR_INVALID;   // one context per physical device
+    DeviceGuard g;
     ipde_multi* m = new ipde_multi();
     m->ndev = ndev;
     m->dev.assign(dev_ids, dev_ids + ndev);
@@ -189,6 +220,7 @@ extern "C" int ipde_multi_target_slice(ipde_multi* m, int i, int64_t* start, int
 // contiguous, balanced slices (sizes differ by at most one): the partition of ipde_amd/sharding.py
 extern "C" int ipde_multi_set_targets(ipde_multi* m, int64_t nt, const double* tx, const double* ty) {
     if (!m || nt < 0 || (nt > 0 && (!tx || !ty))) return IPDE_ERR_INVALID;
+    DeviceGuard g;
     free_targets(m);
     m->t0.assign(m->ndev + 1, 0);
     const int64_t base = nt / m->ndev, rem = nt % m->ndev;
@@ -304,6 +336,7 @@ extern "C" int ipde_multi_laplace_apply(ipde_multi* m, int64_t ns, const double*
     if (!sx || !sy || !out || (!w_sigma && !w_tau) || (w_tau && (!nx || !ny))) return IPDE_ERR_INVALID;
     if (m->nt == 0) return IPDE_OK;
     const double* rows[6] = {sx, sy, w_sigma, nx, ny, w_tau};
+    return guarded_apply(m, [&]() {
     IPDE_TRY(distribute_sources(m, ns, rows, 6));
     const int64_t cap = m->ns_cap;
     double* outs[1] = {out};
@@ -312,6 +345,7 @@ extern "C" int ipde_multi_laplace_apply(ipde_multi* m, int64_t ns, const double*
         return ipde_laplace_apply(c, IPDE_DEVICE, ns, s, s + cap, w_sigma ? s + 2 * cap : nullptr,
                                   w_tau ? s + 3 * cap : nullptr, w_tau ? s + 4 * cap : nullptr,
                                   w_tau ? s + 5 * cap : nullptr, n, tx, ty, o, flags);
+    });
     });
 }
 
@@ -322,6 +356,7 @@ extern "C" int ipde_multi_modhelm_apply(ipde_multi* m, double k, int64_t ns, con
     if (!sx || !sy || !out || (!w_sigma && !w_tau) || (w_tau && (!nx || !ny))) return IPDE_ERR_INVALID;
     if (m->nt == 0) return IPDE_OK;
     const double* rows[6] = {sx, sy, w_sigma, nx, ny, w_tau};
+    return guarded_apply(m, [&]() {
     IPDE_TRY(distribute_sources(m, ns, rows, 6));
     const int64_t cap = m->ns_cap;
     double* outs[1] = {out};
@@ -330,6 +365,7 @@ extern "C" int ipde_multi_modhelm_apply(ipde_multi* m, double k, int64_t ns, con
         return ipde_modhelm_apply(c, IPDE_DEVICE, k, ns, s, s + cap, w_sigma ? s + 2 * cap : nullptr,
                                   w_tau ? s + 3 * cap : nullptr, w_tau ? s + 4 * cap : nullptr,
                                   w_tau ? s + 5 * cap : nullptr, n, tx, ty, o, flags);
+    });
     });
 }
 
@@ -343,6 +379,7 @@ extern "C" int ipde_multi_stokes_apply(ipde_multi* m, int64_t ns, const double* 
     if (m->nt == 0) return IPDE_OK;
     const double* rows[8] = {sx, sy, slp ? wfx : nullptr, slp ? wfy : nullptr, dlp ? nx : nullptr,
                              dlp ? ny : nullptr, dlp ? wdx : nullptr, dlp ? wdy : nullptr};
+    return guarded_apply(m, [&]() {
     IPDE_TRY(distribute_sources(m, ns, rows, 8));
     const int64_t cap = m->ns_cap;
     double* outs[3] = {out_u, out_v, out_p};
@@ -353,5 +390,6 @@ extern "C" int ipde_multi_stokes_apply(ipde_multi* m, int64_t ns, const double* 
                                  dlp ? s + 5 * cap : nullptr, dlp ? s + 6 * cap : nullptr,
                                  dlp ? s + 7 * cap : nullptr, n, tx, ty, o, o + n, out_p ? o + 2 * n : nullptr,
                                  flags);
+    });
     });
 }

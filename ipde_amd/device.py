@@ -86,7 +86,7 @@ class Context:
         is.  The process-wide context does (see get_context): a solve interleaves the library's
         kernels with a dozen small torch operations, and with a stream of its own every change of
         stream was a cross-queue dependency, ~17 us of idle GPU each (2048^2 Poisson: 7.3 -> 6.7 ms)."""
-        self.check(self.lib.ipde_ctx_set_stream(self.handle, ctypes.c_void_p(1)))      # hipStreamLegacy
+        self.check(self.lib.ipde_ctx_use_legacy_stream(self.handle))
 
     def set_option(self, name, value):
         self.check(self.lib.ipde_ctx_set_option(self.handle, name.encode(), int(value)))

@@ -337,7 +337,7 @@ def owner_of(i, world):
     return i % world
 
 
-def exchange_owned(values, shapes, dist=None, group=None, device=None, extra=None):
+def exchange_owned(values, shapes, dist=None, group=None, device=None, extra=None, as_tensors=None):
     """Every rank contributes the arrays of the boundaries it owns (`values[i]`, shape
     `shapes[i]`, ignored where `owner_of(i) != rank`) and receives those of all boundaries.
 
@@ -350,14 +350,19 @@ def exchange_owned(values, shapes, dist=None, group=None, device=None, extra=Non
     flat buffer ON THEIR DEVICE and come back as device tensors: with the nccl backend nothing
     passes through host memory; gloo (CPU tests, one-GPU rehearsals) moves the flat buffer through
     the host.  numpy values take the host path and come back as numpy arrays.  `device`: where the
-    collective of the numpy path runs (a CUDA device for nccl).  Returns the list of arrays (and
-    the summed `extra`, as numpy, when given)."""
+    collective of the numpy path runs (a CUDA device for nccl).  `as_tensors`: the kind of the result,
+    stated by the caller — True: device tensors on `device` WHATEVER this rank owns (a rank that owns no
+    boundary, world > number of boundaries, passes only None and must still come back with what the
+    other ranks get); False: numpy; None (legacy): inferred from the owned values.  Returns the list of
+    arrays (and the summed `extra`, as numpy, when given)."""
     import torch
     dist, rank, world = _dist_state(dist, group)
-    as_tensors = any(isinstance(v, torch.Tensor) for v in values if v is not None)
+    if as_tensors is None:
+        as_tensors = any(isinstance(v, torch.Tensor) for v in values if v is not None)
     if world == 1:
         if as_tensors:
-            vals = [v.reshape(s) for v, s in zip(values, shapes)]
+            vals = [torch.as_tensor(v, device=device if not isinstance(v, torch.Tensor) else None).reshape(s)
+                    for v, s in zip(values, shapes)]
         else:
             vals = [np.asarray(v, dtype=np.float64).reshape(s) for v, s in zip(values, shapes)]
         return vals if extra is None else (vals, np.asarray(extra, dtype=np.float64))
@@ -365,7 +370,9 @@ def exchange_owned(values, shapes, dist=None, group=None, device=None, extra=Non
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n_extra = 0 if extra is None else len(extra)
     if as_tensors:
-        tdev = next(v.device for v in values if isinstance(v, torch.Tensor))
+        tdev = next((v.device for v in values if isinstance(v, torch.Tensor)), None)
+        if tdev is None:        # nothing owned here: the caller's device
+            tdev = torch.device(device) if device is not None else torch.device("cpu")
         flat = torch.zeros(int(off[-1]) + n_extra, dtype=torch.float64, device=tdev)
         for i, (v, s) in enumerate(zip(values, shapes)):
             if owner_of(i, world) == rank:

@@ -323,8 +323,10 @@ class ScalarSolver(object):
         sigmag_list = _run_owned(self, mine, 'start_call', 'finish_call', args, call_many, **kwargs)
         its = [float(h.iterations_last_call) if i in mine else 0.0 for i, h in enumerate(self.helpers)]
         if distributed:
+            # (the kind of the result is stated, not inferred: a rank that owns no boundary — world >
+            # number of boundaries — must come back with tensors like the others)
             sigmag_list, its = exchange_owned(sigmag_list, [(h.interface_qfs_g.source.N,) for h in self.helpers],
-                                              device=self._dev, extra=its)
+                                              device=self._dev, extra=its, as_tensors=device_flow)
         self.iteration_counts = [int(i) for i in its]
         sigmag = gridops.concat(list(sigmag_list)) if device_flow else np.concatenate(sigmag_list)
         n_pna = e.grid_pna.N
@@ -348,7 +350,8 @@ class ScalarSolver(object):
         bus = e.v2l(tail if device_flow else tail.cpu().numpy())
         urs = _run_owned(self, mine, 'start_correct', 'finish_correct', [(bu,) for bu in bus], u2s_many)
         if distributed:
-            urs = exchange_owned(urs, [h.ebdy.radial_shape for h in self.helpers], device=self._dev)
+            urs = exchange_owned(urs, [h.ebdy.radial_shape for h in self.helpers], device=self._dev,
+                                 as_tensors=device_flow)
             for h, ur in zip(self.helpers, urs):
                 h.ur = ur
         for ur, (idx, xi, t) in zip(urs, self._ia):

@@ -202,7 +202,7 @@ class VectorSolver(object):
         if distributed:
             sigmag_list, its = exchange_owned(
                 sigmag_list, [(2, h.interface_qfs_g.source.N) for h in self.helpers],
-                device=self._dev, extra=its)
+                device=self._dev, extra=its, as_tensors=False)
         self.iteration_counts = [int(i) for i in its]
         sigmag = torch.cat(list(sigmag_list), dim=1) if device_flow else np.column_stack(sigmag_list)
         out = self.Grid_Evaluator(sigmag)                          # device (u, v, p) on grid_pnai
@@ -220,7 +220,7 @@ class VectorSolver(object):
         if distributed:
             shapes = [(3,) + tuple(h.ebdy.radial_shape) for h in self.helpers]
             res = exchange_owned([None if r is None else np.stack(r) for r in res], shapes,
-                                 device=self._dev)
+                                 device=self._dev, as_tensors=False)
             for h, r in zip(self.helpers, res):
                 h.ur, h.vr, h.pr = r[0], r[1], r[2]
         urs, vrs, prs = zip(*res)

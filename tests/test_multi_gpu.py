@@ -49,7 +49,12 @@ def test_multi_device_context_applies_equal_single_context_ones(force_comm):
     s2 = rng.standard_normal(c2.N)
     assert np.array_equal(md.laplace_apply(c2.x, c2.y, w_sigma=s2 * c2.weights),
                           lp.laplace_apply(c2.x, c2.y, trg.x, trg.y, w_sigma=s2 * c2.weights))
+    # the entry points walk the devices with hipSetDevice and put the caller's device back (csrc/multi.hip
+    # DeviceGuard; with one device this can only show that nothing moved)
+    import torch
+    assert torch.cuda.current_device() == 0
     md.close()
+    assert torch.cuda.current_device() == 0
 
 
 def test_multi_device_context_argument_errors():

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "examples"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--problem", choices=["poisson", "modhelm", "stokes"], default="poisson")
+    ap.add_argument("--problem", choices=["poisson", "modhelm", "multi_modhelm", "stokes"], default="poisson")
     ap.add_argument("--nb", type=int, default=800)
     ap.add_argument("--M", type=int, default=16)
     ap.add_argument("--k", type=float, default=10.0)
@@ -58,11 +58,16 @@ def main():
         err, scale, solver, ue, T = imh.run(nb=a.nb, M=a.M, helmholtz_k=a.k, Ns=Ns, grid_backend=a.grid_backend,
                                             sharded_result=a.sharded_result)
         res = {"error": err / scale}
+    elif a.problem == "multi_modhelm":
+        # three boundaries (one outer, two holes): with world > 3 some ranks own no boundary at all
+        import multi_modified_helmholtz as mmh
+        err, scale, T = mmh.run(nb=a.nb, M=a.M, helmholtz_k=a.k)
+        res = {"error": err / scale}
     else:
         import multi_stokes
         ue, ve, pe, scale, T = multi_stokes.run(nb=a.nb, M=a.M)
         res = {"error": max(ue, ve) / scale, "p_error": pe}
-    if a.problem != "stokes":
+    if a.problem in ("poisson", "modhelm"):
         # a second, warm solve of the same problem
         import numpy as np
         from ipde_amd.embedded_function import EmbeddedFunction
