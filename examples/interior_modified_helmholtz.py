@@ -14,6 +14,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from ipde_amd.ebdy_collection import EmbeddedBoundaryCollection  # noqa: E402
 from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
@@ -21,12 +22,12 @@ from ipde_amd.embedded_function import EmbeddedFunction, BoundaryFunction  # noq
 from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
 from ipde_amd.layer_potentials import Modified_Helmholtz_Layer_Apply, DeviceTargets, ShardedTargets  # noqa: E402
 from ipde_amd.pybie2d_compat import star, Global_Smooth_Boundary as GSB  # noqa: E402
-from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
+from homogeneous_correction import HomogeneousCorrection  # noqa: E402  (examples/homogeneous_correction.py)
 from ipde_amd.solvers.multi_boundary.modified_helmholtz import ModifiedHelmholtzSolver  # noqa: E402
 
 
 def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False, timings=None,
-        grid_backend=None, sharded_result=False):
+        grid_backend=None, sharded_result=False, resident=False, correction_far=True):
     T = {} if timings is None else timings
     t0 = time.perf_counter()
     MOL = SlepianMollifier(1.5 * M)
@@ -37,6 +38,10 @@ def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False
     grid = ebdyc.generate_grid(bh, Ns=Ns)
     # set-up bracket as in the reference's examples/poisson_for_paper.py:60-64: geometry, grid, solver
     solver = ModifiedHelmholtzSolver(ebdyc, k=helmholtz_k, grid_backend=grid_backend)
+    from ipde_amd.sharding import is_distributed
+    if not sharded_result and not is_distributed():
+        # grid_and_radial_pts resident for the correction stage: its patch plan is cut by a background thread
+        ebdyc.resident_grid_and_radial_pts(far=correction_far)
     T['setup_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     kk = 2 * np.pi / 3
@@ -53,6 +58,9 @@ def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False
     t0 = time.perf_counter()
     # sharded_result (torch.distributed): the answer stays sharded through the solve and the correction
     # below, `ue.owned` marks the entries complete on this rank (ipde_amd/solvers/multi_boundary/scalar.py)
+    if resident:        # right-hand side and answer stay in HBM (hostio.DeviceFunction)
+        from ipde_amd.hostio import DeviceFunction
+        T['f'] = f = DeviceFunction.from_host(f)
     ue = solver(f, tol=solver_tol, verbose=verbose, maxiter=100, restart=20, sharded_result=sharded_result)
     T['inhomogeneous_solve_s'] = time.perf_counter() - t0
     # homogeneous correction with a double layer on the boundary (interior: D - I/2)
@@ -63,21 +71,17 @@ def run(nb=800, M=20, helmholtz_k=10.0, solver_tol=1e-14, Ns=None, verbose=False
     eye = lambda n: torch.eye(n, dtype=torch.float64, device=dev)
     K = lambda src, _: df.modhelm_singular_form(src, dev, helmholtz_k, ifdipole=True) - 0.5 * eye(src.N)
     Naive_SLP = lambda src, trg: df.modhelm_form(src, trg, dev, helmholtz_k, ifcharge=True)
-    A = K(bdy, bdy)
-    qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [lambda src, trg: A, ], Naive_SLP, on_surface=True, form_b2c=False)
-    Alu = DenseSolver(A)
-    targets = ShardedTargets(ebdyc.grid_and_radial_pts, owned=getattr(ue, 'owned', None))
+    correction = HomogeneousCorrection(
+        solver, bdy, ebdy, bc, K, Naive_SLP,
+        lambda src, trg, ch: Modified_Helmholtz_Layer_Apply(src, trg, k=helmholtz_k, charge=ch),
+        owned=getattr(ue, 'owned', None), far=correction_far)
     T['homogeneous_form_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    bv = solver.get_boundary_values(ue.get_radial_value_list())
-    tau = Alu.solve(np.concatenate((bc - bv).bdy_value_list))
-    sigma = qfs([tau, ])
-    out = Modified_Helmholtz_Layer_Apply(ebdyc.bdy_inward_sources, targets, k=helmholtz_k,
-                                         charge=sigma).cpu().numpy()
-    gslp, rslpl = ebdyc.divide_grid_and_radial(out)
-    ue[0] += rslpl[0].reshape(ebdyc[0].radial_shape)
-    ue['grid'] += gslp
+    ue = correction(ue)
     T['homogeneous_apply_s'] = time.perf_counter() - t0
+    T['correction'] = correction
+    if resident:
+        ue = ue.to_host()
     err = np.abs(np.asarray(ue) - np.asarray(ua))
     if getattr(ue, 'owned', None) is not None:      # a sharded answer: this rank's entries, then the max over the ranks
         from ipde_amd.sharding import global_max

@@ -14,6 +14,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from ipde_amd.ebdy_collection import EmbeddedBoundaryCollection  # noqa: E402
 from ipde_amd.embedded_boundary import EmbeddedBoundary  # noqa: E402
@@ -21,7 +22,7 @@ from ipde_amd.embedded_function import EmbeddedFunction, BoundaryFunction  # noq
 from ipde_amd.heavisides import SlepianMollifier  # noqa: E402
 from ipde_amd.layer_potentials import Laplace_Layer_Apply, DeviceTargets, ShardedTargets  # noqa: E402
 from ipde_amd.pybie2d_compat import star, Global_Smooth_Boundary as GSB  # noqa: E402
-from ipde_amd.qfs import QFS_Evaluator, DenseSolver  # noqa: E402
+from homogeneous_correction import HomogeneousCorrection  # noqa: E402  (examples/homogeneous_correction.py)
 from ipde_amd.solvers.multi_boundary.poisson import PoissonSolver  # noqa: E402
 
 
@@ -38,7 +39,8 @@ def _forms():
 
 
 def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, grid_upsample=1,
-        Ns=None, verbose=False, timings=None, grid_backend=None, h=None, sharded_result=False):
+        Ns=None, verbose=False, timings=None, grid_backend=None, h=None, sharded_result=False,
+        resident=False, correction_far=True):
     T = {} if timings is None else timings
     t0 = time.perf_counter()
     MOL = SlepianMollifier(1.5 * M)
@@ -53,6 +55,10 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
     # the reference's set-up bracket (examples/poisson_for_paper.py:60-64) ends with the solver's
     # construction: geometry, grid registration, solver.  The manufactured problem is defined after it.
     solver = PoissonSolver(ebdyc, solver_type=solver_type, grid_backend=grid_backend)
+    from ipde_amd.sharding import is_distributed
+    if not sharded_result and not is_distributed():
+        # grid_and_radial_pts resident for the correction stage: its patch plan is cut by a background thread
+        ebdyc.resident_grid_and_radial_pts(far=correction_far)
     T['setup_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     if problem == 'easy':
@@ -75,27 +81,26 @@ def run(nb=800, M=20, problem='easy', solver_type='spectral', solver_tol=1e-14, 
     t0 = time.perf_counter()
     # sharded_result (torch.distributed): the answer stays sharded through the solve and the correction
     # below, `ue.owned` marks the entries complete on this rank (ipde_amd/solvers/multi_boundary/scalar.py)
+    if resident:        # right-hand side and answer stay in HBM (hostio.DeviceFunction)
+        from ipde_amd.hostio import DeviceFunction
+        T['f'] = f = DeviceFunction.from_host(f)
     ue = solver(f, tol=solver_tol, verbose=verbose, maxiter=100, restart=20, sharded_result=sharded_result)
     T['inhomogeneous_solve_s'] = time.perf_counter() - t0
 
     # homogeneous correction: double-layer density on the boundary, evaluated through QFS
     t0 = time.perf_counter()
     Singular_DLP, Naive_SLP = _forms()
-    A = Singular_DLP(bdy, bdy)
-    qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [lambda src, trg: A, ], Naive_SLP, on_surface=True, form_b2c=False)
-    Alu = DenseSolver(A)
-    targets = ShardedTargets(ebdyc.grid_and_radial_pts, owned=getattr(ue, 'owned', None))
+    correction = HomogeneousCorrection(solver, bdy, ebdy, bc, Singular_DLP, Naive_SLP,
+                                       lambda src, trg, ch: Laplace_Layer_Apply(src, trg, charge=ch),
+                                       owned=getattr(ue, 'owned', None), far=correction_far)
     T['homogeneous_form_s'] = time.perf_counter() - t0
 
     t0 = time.perf_counter()
-    bv = solver.get_boundary_values(ue.get_radial_value_list())
-    tau = Alu.solve(np.concatenate((bc - bv).bdy_value_list))
-    sigma = qfs([tau, ])
-    out = Laplace_Layer_Apply(ebdyc.bdy_inward_sources, targets, charge=sigma).cpu().numpy()
-    gslp, rslpl = ebdyc.divide_grid_and_radial(out)
-    ue[0] += rslpl[0].reshape(ebdyc[0].radial_shape)
-    ue['grid'] += gslp
+    ue = correction(ue)
     T['homogeneous_apply_s'] = time.perf_counter() - t0
+    T['correction'] = correction
+    if resident:
+        ue = ue.to_host()
 
     err = np.abs(np.asarray(ue) - np.asarray(ua))
     if getattr(ue, 'owned', None) is not None:      # a sharded answer: this rank's entries, then the max over the ranks

@@ -95,8 +95,9 @@ def run(nb=400, M=16, helmholtz_k=2.0, verbose=False, return_solution=False):
         qfs = QFS_Evaluator(ebdy.bdy_qfs, ebdy.interior, [K, ], Naive_SLP, on_surface=True, form_b2c=False)
         sigmal.append(qfs([t, ]))
     sigmav = np.concatenate(sigmal)
-    out = Modified_Helmholtz_Layer_Apply(ebdyc.bdy_inward_sources, ShardedTargets(ebdyc.grid_and_radial_pts),
-                                         k=k, charge=sigmav).cpu().numpy()
+    from ipde_amd.sharding import is_distributed
+    targets = ShardedTargets(ebdyc.grid_and_radial_pts) if is_distributed() else ebdyc.resident_grid_and_radial_pts()
+    out = Modified_Helmholtz_Layer_Apply(ebdyc.bdy_inward_sources, targets, k=k, charge=sigmav).cpu().numpy()
     gslp, rslpl = ebdyc.divide_grid_and_radial(out)
     for i in range(len(ebdys)):
         ue[i] += rslpl[i].reshape(ebdys[i].radial_shape)

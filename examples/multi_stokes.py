@@ -141,7 +141,16 @@ def run(nb=800, M=14, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes
         sources.add(qfs.source, 'i' if qfs.interior else 'e')
     sources.amass_information()
     sigmav = np.column_stack([v2f(s) for s in sigmal])
-    out = Stokes_Layer_Apply(sources, ShardedTargets(ebdyc.grid_and_radial_pts), forces=sigmav)
+    # the one big sum of the correction (reference :179): onto grid_and_radial_pts resident in HBM in the form its
+    # sums are fastest in — grid points in padded 4 x 4 patch blocks, radial grids as columns, far sources block
+    # by block in local expansions (ipde_stokes_apply_patches_far / _columns_far); target-sharded under
+    # torch.distributed
+    from ipde_amd.sharding import is_distributed
+    targets = ShardedTargets(ebdyc.grid_and_radial_pts) if is_distributed() else ebdyc.resident_grid_and_radial_pts()
+    t1 = time.perf_counter()
+    out = Stokes_Layer_Apply(sources, targets, forces=sigmav)
+    torch.cuda.synchronize()
+    T['homogeneous_sum_s'] = time.perf_counter() - t1
     for f, o in zip((uc, vc, pc), out):
         f += o.cpu().numpy()
     T['homogeneous_s'] = time.perf_counter() - t0

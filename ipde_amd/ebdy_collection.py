@@ -171,6 +171,27 @@ class EmbeddedBoundaryCollection(object):
         self.radial_dof = int(np.sum(self.radial_dof_list))
         self.dof = self.grid_dof + self.radial_dof
 
+    def resident_grid_and_radial_pts(self, far=True):
+        """`grid_and_radial_pts` (reference :426-429) resident in HBM for the example scripts' homogeneous
+        correction (reference examples/interior_poisson.py:84-92, its largest timed stage): the physical grid
+        points as 4 x 4 patches in padded blocks, every boundary's radial grid as columns — sums onto the set
+        take the far-field forms (layer_potentials.CompositeTargets).  Built once per registered grid; the
+        patch plan is cut in a background thread that the first sum joins.  far=False: plain resident lists,
+        every pair directly (the A/B reference of the tests)."""
+        from .layer_potentials import DeviceTargets, CompositeTargets
+        cache = self.__dict__.setdefault('_resident_garp', {})
+        if cache.get('grid') is not self.grid:      # a new registration: new point sets
+            cache.clear()
+            cache['grid'] = self.grid
+        key = bool(far)
+        if key not in cache:
+            parts = [DeviceTargets(self.grid_phys, plan=key, far=key)]
+            for e in self:
+                parts.append(DeviceTargets(e.radial_x.ravel(), e.radial_y.ravel(),
+                                           columns=tuple(e.radial_shape) if key else None))
+            cache[key] = CompositeTargets(parts)
+        return cache[key]
+
     # -- splitters (reference :528-570) -----------------------------------------------
     def v2l(self, v):
         if type(v).__module__.startswith('torch'):      # device vectors stay where they are

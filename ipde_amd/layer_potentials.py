@@ -21,7 +21,7 @@ from .device import get_context, location_of, as_f64, ptr, empty_like_loc, to_de
 __all__ = [
     "laplace_apply", "modified_helmholtz_apply", "stokes_apply",
     "Laplace_Layer_Apply", "Modified_Helmholtz_Layer_Apply", "Stokes_Layer_Apply",
-    "DeviceTargets", "ShardedTargets", "make_laplace_layer_apply", "make_modified_helmholtz_layer_apply",
+    "DeviceTargets", "ShardedTargets", "CompositeTargets", "make_laplace_layer_apply", "make_modified_helmholtz_layer_apply",
     "make_stokes_layer_apply",
 ]
 
@@ -166,6 +166,36 @@ class ShardedTargets:
         return full if isinstance(out, tuple) else full[0]
 
 
+class CompositeTargets:
+    """Resident target sets end to end, each in the form its sums are fastest in — what
+    `ebdyc.grid_and_radial_pts` is (reference ipde/ebdy_collection.py:426-429): the physical grid points
+    (a lattice: 4 x 4 patches in padded blocks, far sources block by block in local expansions) followed by
+    every boundary's (M, N) radial grid (blocks of 64 radial lines, the column far-field forms).  The
+    high-level *_Layer_Apply functions evaluate part by part into ONE device tensor in the list's order,
+    which is the storage order of an EmbeddedFunction / hostio.DeviceFunction: the example scripts'
+    homogeneous correction (reference examples/interior_poisson.py:84-92) adds it onto the solution where it
+    lies.  Built once per geometry (`EmbeddedBoundaryCollection.resident_grid_and_radial_pts`)."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.N = int(sum(p.N for p in self.parts))
+        self.ctx = self.parts[0].ctx
+
+    def evaluate(self, apply_part):
+        """apply_part(DeviceTargets) -> tensor or tuple of tensors; -> the same over the whole list"""
+        outs = [apply_part(p) for p in self.parts]
+        if isinstance(outs[0], tuple):
+            return tuple(None if c[0] is None else (torch.cat([torch.as_tensor(a) for a in c]) if len(c) > 1
+                                                    else torch.as_tensor(c[0])) for c in zip(*outs))
+        return torch.cat([torch.as_tensor(a) for a in outs]) if len(outs) > 1 else torch.as_tensor(outs[0])
+
+    def wait(self):
+        """join the background threads that cut the parts' patch plans"""
+        for p in self.parts:
+            p.plan()
+        return self
+
+
 def _match(a, loc, ctx):
     """Bring a (small) source-side array to the location of the targets."""
     if a is None:
@@ -293,7 +323,7 @@ def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=N
     """out = SLP[charge] + DLP[dipstr] evaluated at target (pybie2d call shape;
     reference ipde/solvers/internals/poisson.py:35, examples/interior_poisson.py:89).
     target None: source onto itself, the coincident pairs skipped."""
-    if isinstance(target, ShardedTargets):
+    if isinstance(target, (ShardedTargets, CompositeTargets)):
         return target.evaluate(lambda t: Laplace_Layer_Apply(source, t, charge=charge, dipstr=dipstr))
     self_eval = target is None
     trg = source if self_eval else target
@@ -331,7 +361,7 @@ def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=N
 def Modified_Helmholtz_Layer_Apply(source, target=None, k=1.0, charge=None, dipstr=None,
                                    backend=None, **kwargs):
     """(reference ipde/solvers/internals/modified_helmholtz.py:37)"""
-    if isinstance(target, ShardedTargets):
+    if isinstance(target, (ShardedTargets, CompositeTargets)):
         return target.evaluate(lambda t: Modified_Helmholtz_Layer_Apply(source, t, k=k, charge=charge,
                                                                         dipstr=dipstr))
     self_eval = target is None
@@ -366,7 +396,7 @@ def Modified_Helmholtz_Layer_Apply(source, target=None, k=1.0, charge=None, dips
 def Stokes_Layer_Apply(source, target=None, forces=None, dipstr=None, pressure=True, **kwargs):
     """Returns (u, v, p) like the reference's Stokes Layer_Apply closure
     (ipde/solvers/internals/stokes.py:25-35).  forces / dipstr have shape (2, N)."""
-    if isinstance(target, ShardedTargets):
+    if isinstance(target, (ShardedTargets, CompositeTargets)):
         return target.evaluate(lambda t: Stokes_Layer_Apply(source, t, forces=forces, dipstr=dipstr,
                                                             pressure=pressure))
     self_eval = target is None

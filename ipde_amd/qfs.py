@@ -487,6 +487,8 @@ class DenseSolver(object):
         if self._dev is None:
             return scipy.linalg.lu_solve(self._lu, np.asarray(b, dtype=float))
         import torch
+        if isinstance(b, torch.Tensor):        # device in, device out (the examples' resident correction)
+            return self._fact.solve(self._A, b.to(device=self._dev, dtype=torch.float64).reshape(-1), steps=1)
         bd = torch.as_tensor(np.ascontiguousarray(b, dtype=float), device=self._dev)
         return self._fact.solve(self._A, bd, steps=1).cpu().numpy()
 
@@ -685,15 +687,18 @@ class QFS_Evaluator(object):
             import torch
             self._A = torch.as_tensor(A, device=self._dev)
             self._fact = _lu_async(self._A)
-            self.b2c_mats = [torch.as_tensor(B, device=self._dev) for B in self.b2c_mats]
+            self.b2c_mats = [torch.as_tensor(B, device=self._dev).contiguous() for B in self.b2c_mats]
         else:
             self._lu = scipy.linalg.lu_factor(A)
 
     def __call__(self, densities):
         if self._dev is not None:
             import torch
-            u = sum(_gemv(B.contiguous(), torch.as_tensor(np.ascontiguousarray(d, dtype=float), device=self._dev))
-                    for B, d in zip(self.b2c_mats, densities))
-            return self._fact.solve(self._A, u).cpu().numpy()
+            on_dev = _wants_device(densities)
+            u = None
+            for B, d in zip(self.b2c_mats, densities):
+                u = _gemv(B if B.is_contiguous() else B.contiguous(), _on_device(d, self._dev), u)
+            x = self._fact.solve(self._A, u)
+            return x if on_dev else x.cpu().numpy()
         u = sum(B @ np.asarray(d) for B, d in zip(self.b2c_mats, densities))
         return scipy.linalg.lu_solve(self._lu, u)
