@@ -1,5 +1,7 @@
 """The boundary-condition (homogeneous) correction shared by the single-boundary scalar examples —
 reference examples/interior_poisson.py:84-92, examples/interior_modified_helmholtz.py:66-84."""
+import os
+
 import numpy as np
 
 from ipde_amd.layer_potentials import ShardedTargets
@@ -28,7 +30,7 @@ class HomogeneousCorrection(object):
         A = singular_dlp(bdy, bdy)
         self.qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [lambda src, trg: A, ], naive_slp, on_surface=True,
                                  form_b2c=False)
-        self.Alu = DenseSolver(A)
+        self.Alu = DenseSolver(A, refine=int(os.environ.get('IPDE_CORRECTION_REFINE', '1')))
         from ipde_amd.sharding import is_distributed
         if owned is not None or is_distributed():
             self.targets = ShardedTargets(self.ebdyc.grid_and_radial_pts, owned=owned)
@@ -48,6 +50,7 @@ class HomogeneousCorrection(object):
         return torch.cat([e @ ur for e, ur in zip(self._est, ue.get_radial_value_list())])
 
     def __call__(self, ue):
+        import torch
         from ipde_amd.hostio import DeviceFunction
         if isinstance(ue, DeviceFunction):
             tau = self.Alu.solve(self.bc_dev - self.boundary_values(ue))
@@ -57,8 +60,14 @@ class HomogeneousCorrection(object):
         bv = self.solver.get_boundary_values(ue.get_radial_value_list())
         tau = self.Alu.solve(self.bc_host - np.concatenate(bv.bdy_value_list))
         sigma = self.qfs([tau, ])
-        out = self.layer_apply(self.ebdyc.bdy_inward_sources, self.targets, sigma).cpu().numpy()
-        gslp, rslpl = self.ebdyc.divide_grid_and_radial(out)
+        out = self.layer_apply(self.ebdyc.bdy_inward_sources, self.targets, sigma)
+        if self.owned is None and isinstance(out, torch.Tensor) and out.is_cuda and ue.flags.c_contiguous:
+            # grid_and_radial_pts is the container's own storage order (reference ipde/embedded_function.py:24-31):
+            # the sum is added onto it where it lies, copy and additions overlapped (hostio.add_from_device)
+            from ipde_amd import hostio
+            self._pin = hostio.add_from_device(np.asarray(ue).view(np.ndarray), out, getattr(self, '_pin', None))
+            return ue
+        gslp, rslpl = self.ebdyc.divide_grid_and_radial(out.cpu().numpy())
         for i, r in enumerate(rslpl):
             ue[i] += r.reshape(self.ebdyc[i].radial_shape)
         ue['grid'] += gslp

@@ -45,6 +45,10 @@ def run(nb=400, M=16, helmholtz_k=2.0, verbose=False, return_solution=False):
     ebdyc.register_grid(grid)
     # set-up bracket as in the reference's examples/poisson_for_paper.py:60-64: geometry, grid, solver
     solver = ModifiedHelmholtzSolver(ebdyc, k=helmholtz_k)
+    from ipde_amd.sharding import is_distributed
+    if not is_distributed():
+        # grid_and_radial_pts resident for the correction stage: its patch plan is cut by a background thread
+        ebdyc.resident_grid_and_radial_pts()
     T['setup_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     kk = 2 * np.pi / 7
@@ -95,7 +99,6 @@ def run(nb=400, M=16, helmholtz_k=2.0, verbose=False, return_solution=False):
         qfs = QFS_Evaluator(ebdy.bdy_qfs, ebdy.interior, [K, ], Naive_SLP, on_surface=True, form_b2c=False)
         sigmal.append(qfs([t, ]))
     sigmav = np.concatenate(sigmal)
-    from ipde_amd.sharding import is_distributed
     targets = ShardedTargets(ebdyc.grid_and_radial_pts) if is_distributed() else ebdyc.resident_grid_and_radial_pts()
     out = Modified_Helmholtz_Layer_Apply(ebdyc.bdy_inward_sources, targets, k=k, charge=sigmav).cpu().numpy()
     gslp, rslpl = ebdyc.divide_grid_and_radial(out)

@@ -69,6 +69,10 @@ def run(nb=800, M=14, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes
     esin = lambda x: np.exp(sin(x))
     # set-up bracket as in the reference's examples/poisson_for_paper.py:60-64: geometry, grid, solver
     solver = StokesSolver(ebdyc, solver_type=solver_type, grid_backend=grid_backend)
+    from ipde_amd.sharding import is_distributed
+    if not is_distributed():
+        # grid_and_radial_pts resident for the correction stage: its patch plan is cut by a background thread
+        ebdyc.resident_grid_and_radial_pts()
     T['setup_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     psix = lambda x, y: esin(a * x) * cos(b * y)

@@ -88,6 +88,8 @@ const char* ipde_last_error(ipde_ctx* ctx);
    Names: "laplace_variant", "stokes_variant", "dense_pairs", "annular_grouped",
    "fft2d" (1: hand-written 2-D FFT pipeline on power-of-two grids, 0: rocFFT),
    "interp_shifted" (1: ipde_grid_interp through four shifted coarse transforms at any size),
+   "interp_band" (1, default: ipde_grid_interp / _fields in the band form — oversampled transform along x only
+   for the kept columns, exact sums along y per point; 0: full oversampled fine grids and a 2-D window gather),
    "dense_persistent", "annular_fused_fft", "gmres_graphs", "gmres_lookahead" (1: inner iteration
    j + 1 of the annular GMRES enters the stream before the host has read column j; same bits),
    "gmres_fused_scale" (1: the Arnoldi normalisation inside the preconditioner's kernel; same bits),

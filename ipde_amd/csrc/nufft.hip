@@ -22,6 +22,19 @@
 // transforms of i k F: differentiating the window instead would amplify the aliasing error by
 // N_fine / k.
 // Roofline: HBM (the fine-grid passes); the gather touches 3 w^2 doubles per point.
+//
+// BAND form (round 4; context option "interp_band", default 1).  The points sit in a band around a few curves,
+// so a whole fine grid per field is transformed to read w^2 values per point of it.  Instead: the oversampled
+// transform along x ONLY — for the kept columns ky = 0 .. ny/2, two half-cell-shifted length-nx column passes
+// (power-of-two grids, packed spectra; no zeros moved) or one zero-padded length-nfx pass (other sizes) — gives
+// g[x_fine][ky], and a point's value is  sum over its w fine rows of psi_x * Re sum_ky eps_ky g[row][ky] e^{i ky y}:
+// the sum along y is EXACT (no window, no oversampling in y, any ny).  The points are bucketed by their first
+// fine row on the device (one small kernel), a workgroup takes a fine row with up to 16 of the points whose
+// windows cover it, holds the row in registers and forms the dense sums with phases e^{2 pi i k f} =
+// table[k f * 256] x (short Taylor polynomial), k f reduced exactly (fma), advanced by recurrence over k += 256.
+// Every (point, row) pair is written once and the w partials of a point are added in order: results are
+// reproducible bit for bit.  Traffic per field at 4096^2 x 8192 points: 134 MB of spectrum in, 2 x 269 MB
+// through the column pass, 269 MB read by the gather — against twelve full 4096^2 inverse transforms.
 #include "ipde_common.h"
 #include "fft2d.h"
 #include <cmath>
@@ -334,6 +347,219 @@ __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restri
     }
 }
 
+
+// ---- the band form ----------------------------------------------------------------------------------
+// Packed coarse spectra -> D, the fine-row-interleaved layout (2 nx rows of `pitch` complex, row 2 i + a =
+// sample (i + a / 2) h): for wavenumber kx of coarse row i, the pad kernel's value (same Nyquist rules, the
+// y window factor 1) goes to row 2 i as it is and to row 2 i + 1 times e^{i pi kx / nx}; the x Nyquist row
+// holds +nx/2 and -nx/2 together.  A length-nx inverse transform of the columns of the a = 0 rows and of the
+// a = 1 rows (one launch: the layout is (nx, 2 pitch)) then IS the 2x oversampled transform along x.
+__global__ __launch_bounds__(256) void band_shift_kernel(Combo cb, cd* __restrict__ D, int nx, int ny, int pitch,
+                                                         const double* __restrict__ rx, double dkx, double dky) {
+    const int H = ny / 2, ncol = H + 1;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)nx * ncol) return;
+    const int i = (int)(idx / ncol), j = (int)(idx - (int64_t)i * ncol);
+    auto value = [&](int kx) -> cd {
+        const int akx = kx < 0 ? -kx : kx;
+        const int ci = (kx + nx) % nx;
+        double wgt = rx[akx];
+        const bool nyqx = 2 * akx == nx, nyqy = (j == H);
+        if (nyqx && nyqy)
+            wgt = kx > 0 ? 0.5 * wgt : 0.0;
+        else if (nyqx || nyqy)
+            wgt *= 0.5;
+        cd acc{0.0, 0.0};
+        for (int t = 0; t < cb.n; ++t) {
+            const cd* S = cb.src[t];
+            cd v;
+            if (j == 0 || j == H) {
+                cd g = S[(int64_t)ci * H], gm = S[(int64_t)((nx - ci) % nx) * H];
+                v = (j == 0) ? cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)} : cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
+            } else {
+                v = S[(int64_t)ci * H + j];
+            }
+            const double c = wgt * cb.coef[t];
+            v.x *= c;
+            v.y *= c;
+            if (cb.der[t] == 1) v = cd{-v.y * (kx * dkx), v.x * (kx * dkx)};
+            if (cb.der[t] == 2) v = cd{-v.y * (j * dky), v.x * (j * dky)};
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+        return acc;
+    };
+    cd v0, v1;
+    if (2 * i == nx) {
+        const cd vp = value(nx / 2), vm = value(-(nx / 2));
+        v0 = cd{vp.x + vm.x, vp.y + vm.y};
+        v1 = cd{-(vp.y - vm.y), vp.x - vm.x};      // i (vp - vm): e^{+- i pi / 2}
+    } else {
+        const int kx = (i < nx / 2) ? i : i - nx;
+        v0 = value(kx);
+        v1 = cmulz(v0, cis_pi((double)kx / nx));
+    }
+    D[(int64_t)(2 * i) * pitch + j] = v0;
+    D[(int64_t)(2 * i + 1) * pitch + j] = v1;
+}
+
+// Bucket the points by the first fine row of their x window (one workgroup; a few 10^4 points): r0[j] = first
+// row + 16 (>= 0 also for windows that wrap below 0), perm = the points in bucket order, start = the buckets'
+// offsets (nrows_ext + 1 entries).  The order INSIDE a bucket depends on the atomics; nothing downstream does.
+__global__ __launch_bounds__(1024) void band_sort_kernel(const double* __restrict__ px, int64_t np, int nfx, int W,
+                                                         int nrows_ext, int* __restrict__ cnt,
+                                                         int* __restrict__ start, int* __restrict__ perm,
+                                                         int* __restrict__ r0v, int* __restrict__ rank) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const double TWO_PI = 6.283185307179586476925286766559;
+    const double hfx = TWO_PI / nfx;
+    for (int i = tid; i <= nrows_ext; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int64_t j = tid; j < np; j += 1024) {
+        double x = px[j];
+        x -= TWO_PI * floor(x / TWO_PI);
+        const int r0 = (int)ceil(x / hfx - 0.5 * W) + 16;
+        r0v[j] = r0;
+        rank[j] = atomicAdd(&cnt[r0], 1);
+    }
+    __syncthreads();
+    const int per = (nrows_ext + 1023) / 1024;
+    const int a = tid * per;
+    int s = 0;
+    for (int i = a; i < a + per && i < nrows_ext; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {       // inclusive scan of the 1024 partial sums
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int i = a; i < a + per && i < nrows_ext; ++i) {
+        start[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 1023) start[nrows_ext] = (int)np;
+    __syncthreads();
+    for (int64_t j = tid; j < np; j += 1024) perm[start[r0v[j]] + rank[j]] = (int)j;
+}
+
+// e^{2 pi i k f}, k >= 0 an integer, f in [0, 1): k f = p + e exactly (fma), frac(p) exact, the 8 leading bits
+// of the fraction index a table of the 256th roots of unity, the rest (< 1/256 of a turn) goes through
+// Taylor polynomials: |error| ~ 2e-16 whatever k.
+__device__ __forceinline__ cd unit_kf(int k, double f, const cd* __restrict__ T) {
+    const double p = (double)k * f;
+    const double e = fma((double)k, f, -p);
+    const double s = (p - floor(p)) * 256.0;
+    const int idx = (int)s;
+    const double z = 6.283185307179586476925286766559 * ((s - (double)idx) * 0.00390625 + e);
+    const double z2 = z * z;
+    const double c = fma(z2, fma(z2, fma(z2, fma(z2, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
+    const double sn = z * fma(z2, fma(z2, fma(z2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+    const cd t = T[idx & 255];
+    return cd{t.x * c - t.y * sn, t.x * sn + t.y * c};
+}
+
+// One fine row (blockIdx.x, in the extended numbering of band_sort_kernel) with the points whose windows
+// cover it, 16 at a time: thread t holds columns k = t + 256 q of the row (nf fields), forms
+// Re sum_k eps_k g[k] e^{i k y} for every point, the wave sums go through LDS, and the (point, row) partial —
+// times the x window's weight — is written to its own slot partial[(f np + j) 16 + s].
+template <int Q>
+__global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__ D0, const cd* __restrict__ D1,
+                                                          const cd* __restrict__ D2, int nf, int64_t pitch,
+                                                          int ncol, int nfx, const double* __restrict__ px,
+                                                          const double* __restrict__ py, int64_t np,
+                                                          const int* __restrict__ start,
+                                                          const int* __restrict__ perm,
+                                                          const int* __restrict__ r0v, double beta,
+                                                          double* __restrict__ partial) {
+    constexpr int W = 16, PTS = 16;
+    const int r_ext = blockIdx.x;
+    const int lo = start[r_ext - (W - 1) > 0 ? r_ext - (W - 1) : 0], hi = start[r_ext + 1];
+    const int cnt = hi - lo;
+    if ((int)blockIdx.y * PTS >= cnt) return;      // (uniform over the workgroup, before any barrier)
+    __shared__ cd T[256];
+    __shared__ double wsum[3][PTS][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double TWO_PI = 6.283185307179586476925286766559;
+    {
+        double sn, cs;
+        sincospi((double)tid * 0.0078125, &sn, &cs);
+        T[tid] = cd{cs, sn};
+    }
+    const int phys = ((r_ext - 16) % nfx + nfx) % nfx;
+    const cd* Dp[3] = {D0, D1, D2};
+    cd g[3][Q];
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int k = tid + 256 * q;
+            g[f][q] = (f < nf && k < ncol) ? Dp[f][(int64_t)phys * pitch + k] : cd{0.0, 0.0};
+            if (k == 0) g[f][q] = cd{0.5 * g[f][q].x, 0.5 * g[f][q].y};      // eps_0 = 1/2 (see row_c2r)
+        }
+    __syncthreads();
+    const double hfx = TWO_PI / nfx;
+    for (int c = blockIdx.y; c * PTS < cnt; c += gridDim.y) {
+        const int npt = cnt - c * PTS < PTS ? cnt - c * PTS : PTS;
+        for (int p = 0; p < npt; ++p) {
+            const int j = perm[lo + c * PTS + p];
+            double fy = py[j] * (1.0 / TWO_PI);
+            fy -= floor(fy);
+            cd ph = unit_kf(tid, fy, T);
+            const cd step = unit_kf(256, fy, T);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                a0 = fma(g[0][q].x, ph.x, fma(-g[0][q].y, ph.y, a0));
+                a1 = fma(g[1][q].x, ph.x, fma(-g[1][q].y, ph.y, a1));
+                a2 = fma(g[2][q].x, ph.x, fma(-g[2][q].y, ph.y, a2));
+                ph = cmulz(ph, step);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                a0 += __shfl_xor(a0, m);
+                a1 += __shfl_xor(a1, m);
+                a2 += __shfl_xor(a2, m);
+            }
+            if (lane == 0) {
+                wsum[0][p][wave] = a0;
+                wsum[1][p][wave] = a1;
+                wsum[2][p][wave] = a2;
+            }
+        }
+        __syncthreads();
+        if (tid < 3 * PTS) {
+            const int f = tid / PTS, p = tid % PTS;
+            if (f < nf && p < npt) {
+                const int j = perm[lo + c * PTS + p];
+                const double sum = ((wsum[f][p][0] + wsum[f][p][1]) + wsum[f][p][2]) + wsum[f][p][3];
+                const int r0 = r0v[j], sidx = r_ext - r0;
+                double x = px[j];
+                x -= TWO_PI * floor(x / TWO_PI);
+                const double zq = (x - (double)(r0 - 16 + sidx) * hfx) / (0.5 * W * hfx);
+                const double qq = 1.0 - zq * zq;
+                const double wx = qq > 0.0 ? exp(beta * (sqrt(qq) - 1.0)) : 0.0;
+                partial[((int64_t)f * np + j) * W + sidx] = wx * sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void band_reduce_kernel(const double* __restrict__ partial, int64_t n,
+                                                          double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* p = partial + i * 16;
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) s += p[m];
+    out[i] = s;
+}
+
 }  // namespace
 
 struct GridInterp {
@@ -352,6 +578,15 @@ struct GridInterp {
     void* spec[3] = {nullptr, nullptr, nullptr};  // packed spectra of input fields (grid_interp_fields)
     double* stage = nullptr;      // host-call staging (points, results)
     size_t stage_bytes = 0;
+    double hx = 0, hy = 0;
+    bool legacy_ready = false;    // the full-fine-grid form's buffers (fine plan of the packed variant, g[])
+    // band form
+    cd* bandD[3] = {nullptr, nullptr, nullptr};   // packed variant: (2 nx, band_pitch) fine-row-interleaved
+    int64_t band_pitch = 0;
+    double* d_ones = nullptr;     // the y window factor of the pad kernels: 1
+    int* ibuf = nullptr;          // cnt, start (nfx + 33 each), perm, r0, rank (np each)
+    int64_t ibuf_np = -1;
+    double* partial = nullptr;    // (3, np, 16)
 };
 
 bool grid_interp_supported(int64_t nx, int64_t ny) { return fft2d_supported(nx, ny); }
@@ -383,6 +618,11 @@ void grid_interp_destroy(GridInterp* gi) {
         if (g) (void)hipFree(g);
     for (auto& q : gi->spec)
         if (q) (void)hipFree(q);
+    for (auto& q : gi->bandD)
+        if (q) (void)hipFree(q);
+    if (gi->d_ones) (void)hipFree(gi->d_ones);
+    if (gi->ibuf) (void)hipFree(gi->ibuf);
+    if (gi->partial) (void)hipFree(gi->partial);
     if (gi->stage) (void)hipFree(gi->stage);
     delete gi;
 }
@@ -410,8 +650,12 @@ int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double 
     gi->betax = general ? beta_of((double)gi->nfx / nx) : 2.30 * gi->w;
     gi->betay = general ? beta_of((double)gi->nfy / ny) : 2.30 * gi->w;
     gi->beta = gi->betax;
-    int st = gi->shifted ? IPDE_OK
-                         : fft2d_plan_init(ctx, gi->fine, gi->nfx, gi->nfy, hx * nx / gi->nfx, hy * ny / gi->nfy);
+    gi->hx = hx;
+    gi->hy = hy;
+    // (general sizes: the zero-padded fine spectra serve both forms; the packed variant's fine plan and the
+    // fine real grids belong to the full-fine-grid form alone and are created when it first runs)
+    int st = general ? fft2d_plan_init(ctx, gi->fine, gi->nfx, gi->nfy, hx * nx / gi->nfx, hy * ny / gi->nfy)
+                     : IPDE_OK;
     std::vector<double> rx, ry;
     window_factors(gi->nfx, gi->w, gi->betax, nx / 2 + 1, rx);
     window_factors(gi->nfy, gi->w, gi->betay, ny / 2 + 1, ry);
@@ -422,12 +666,10 @@ int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double 
     };
     up(&gi->d_rx, rx);
     up(&gi->d_ry, ry);
-    const size_t gbytes = (size_t)gi->nfx * gi->nfy * sizeof(double);
-    for (auto& g : gi->g)
-        if (st == IPDE_OK && hipMalloc((void**)&g, gbytes) != hipSuccess) st = IPDE_ERR_ALLOC;
+    up(&gi->d_ones, std::vector<double>((size_t)ny / 2 + 2, 1.0));
     // the columns of the fine half spectra beyond the coarse band are never written: zero once
     for (auto& w : gi->fine.W)
-        if (!gi->shifted && st == IPDE_OK && w &&
+        if (general && st == IPDE_OK && w &&
             hipMemset(w, 0, (size_t)gi->nfx * (gi->nfy / 2) * 2 * sizeof(double)) != hipSuccess)
             st = IPDE_ERR_HIP;
     if (st != IPDE_OK) {
@@ -438,6 +680,126 @@ int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double 
     return IPDE_OK;
 }
 
+// the full-fine-grid form's own buffers, at its first use
+static int ensure_legacy(GridInterp* gi) {
+    if (gi->legacy_ready) return IPDE_OK;
+    ipde_ctx* ctx = gi->ctx;
+    if (!gi->general && !gi->shifted && !gi->fine.ready) {
+        IPDE_TRY(fft2d_plan_init(ctx, gi->fine, gi->nfx, gi->nfy, gi->hx * gi->nx / gi->nfx, gi->hy * gi->ny / gi->nfy));
+        for (auto& w : gi->fine.W)
+            IPDE_HIP_CHECK(ctx, hipMemset(w, 0, (size_t)gi->nfx * (gi->nfy / 2) * 2 * sizeof(double)));
+    }
+    const size_t gbytes = (size_t)gi->nfx * gi->nfy * sizeof(double);
+    for (auto& g : gi->g)
+        if (!g) IPDE_HIP_CHECK(ctx, hipMalloc((void**)&g, gbytes));
+    gi->legacy_ready = true;
+    return IPDE_OK;
+}
+
+static int ensure_band(GridInterp* gi, int64_t np) {
+    ipde_ctx* ctx = gi->ctx;
+    if (!gi->general && !gi->bandD[0]) {
+        const int64_t ncol = gi->ny / 2 + 1;
+        gi->band_pitch = (ncol + 3) / 4 * 4;
+        const size_t bytes = (size_t)2 * gi->nx * gi->band_pitch * sizeof(cd);
+        for (auto& d : gi->bandD) {
+            IPDE_HIP_CHECK(ctx, hipMalloc((void**)&d, bytes));
+            IPDE_HIP_CHECK(ctx, hipMemset(d, 0, bytes));     // (the padding columns go through the column pass too)
+        }
+    }
+    if (np > gi->ibuf_np) {
+        if (gi->ibuf) (void)hipFree(gi->ibuf);
+        if (gi->partial) (void)hipFree(gi->partial);
+        gi->ibuf = nullptr;
+        gi->partial = nullptr;
+        gi->ibuf_np = -1;
+        const int64_t cap = np + np / 4 + 64;
+        IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->ibuf, (size_t)(2 * (gi->nfx + 33) + 3 * cap) * sizeof(int)));
+        IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->partial, (size_t)3 * cap * 16 * sizeof(double)));
+        gi->ibuf_np = cap;
+    }
+    return IPDE_OK;
+}
+
+template <int Q>
+static void launch_band_gather(GridInterp* gi, const cd* const* D, int nf, int64_t pitch, int ncol, const double* d_px,
+                               const double* d_py, int64_t np, const int* start, const int* perm, const int* r0v) {
+    hipLaunchKernelGGL(band_gather_kernel<Q>, dim3((unsigned)(gi->nfx + 32), 4), dim3(256), 0, gi->ctx->stream, D[0],
+                       D[1], D[2], nf, pitch, ncol, (int)gi->nfx, d_px, d_py, np, start, perm, r0v, gi->betax,
+                       gi->partial);
+}
+
+// The band form of interp_combos (see the head of the file).
+static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout, const Combo* combos, int64_t np,
+                              const double* d_px, const double* d_py, double dkx, double dky, double* d_out) {
+    ipde_ctx* ctx = gi->ctx;
+    const int64_t nx = gi->nx, ny = gi->ny;
+    if (np < 1) return IPDE_OK;
+    if (np >= (1LL << 30)) return IPDE_ERR_INVALID;
+    IPDE_TRY(ensure_band(gi, np));
+    const int nrows_ext = (int)gi->nfx + 32;
+    int* cnt = gi->ibuf;
+    int* start = cnt + (gi->nfx + 33);
+    int* perm = start + (gi->nfx + 33);
+    int* r0v = perm + gi->ibuf_np;
+    int* rank = r0v + gi->ibuf_np;
+    hipLaunchKernelGGL(band_sort_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_px, np, (int)gi->nfx, gi->w, nrows_ext, cnt,
+                       start, perm, r0v, rank);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    const int ncol = (int)(ny / 2 + 1);
+    for (int f0 = 0; f0 < nout; f0 += 3) {
+        const int nf = nout - f0 < 3 ? nout - f0 : 3;
+        const cd* D[3] = {nullptr, nullptr, nullptr};
+        int64_t pitch = 0;
+        for (int f = 0; f < nf; ++f) {
+            const Combo& cb = combos[f0 + f];
+            if (gi->general) {
+                const int64_t nthreads = gi->nfx * (ny / 2 + 1);
+                hipLaunchKernelGGL(nufft_pad_general_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0,
+                                   ctx->stream, cb, (cd*)gi->fine.W[f], (int)nx, (int)ny, (int)gi->nfx, (int)gi->nfy,
+                                   (const double*)gi->d_rx, (const double*)gi->d_ones, dkx, dky);
+                IPDE_HIP_CHECK(ctx, hipGetLastError());
+                IPDE_TRY(fft2d_cols(ctx, gi->fine, f, FFT2D_SYM_NONE, 2, 0.0, 1.0, -1, ny / 2 + 1));
+                D[f] = (const cd*)gi->fine.W[f];
+                pitch = gi->fine.pitch;
+            } else {
+                const int64_t nthreads = nx * ncol;
+                hipLaunchKernelGGL(band_shift_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0, ctx->stream,
+                                   cb, gi->bandD[f], (int)nx, (int)ny, (int)gi->band_pitch, (const double*)gi->d_rx, dkx,
+                                   dky);
+                IPDE_HIP_CHECK(ctx, hipGetLastError());
+                // rows 2 i (a = 0) and 2 i + 1 (a = 1) as the two halves of a (nx, 2 pitch) array: one column pass
+                Fft2dPlan both = coarse;
+                both.W[0] = gi->bandD[f];
+                both.pitch = 2 * gi->band_pitch;
+                IPDE_TRY(fft2d_cols(ctx, both, 0, FFT2D_SYM_NONE, 2, 0.0, 1.0, -1, gi->band_pitch + ncol));
+                D[f] = gi->bandD[f];
+                pitch = gi->band_pitch;
+            }
+        }
+        if (ncol <= 256)
+            launch_band_gather<1>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+        else if (ncol <= 512)
+            launch_band_gather<2>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+        else if (ncol <= 768)
+            launch_band_gather<3>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+        else if (ncol <= 1280)
+            launch_band_gather<5>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+        else if (ncol <= 2304)
+            launch_band_gather<9>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+        else if (ncol <= 4352)
+            launch_band_gather<17>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+        else
+            return IPDE_ERR_INVALID;
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+        const int64_t n = (int64_t)nf * np;
+        hipLaunchKernelGGL(band_reduce_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream,
+                           (const double*)gi->partial, n, d_out + (int64_t)f0 * np);
+        IPDE_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return IPDE_OK;
+}
+
 // The core: nout output fields, each a Combo over packed coarse spectra, at np points.
 // d_px, d_py, d_out: device; out (nout, np).  Three fields per sweep (the g buffers).
 static int interp_combos(GridInterp* gi, const Fft2dPlan& coarse, int nout, const Combo* combos,
@@ -445,6 +807,8 @@ static int interp_combos(GridInterp* gi, const Fft2dPlan& coarse, int nout, cons
                          double* d_out) {
     ipde_ctx* ctx = gi->ctx;
     const int64_t nx = gi->nx, ny = gi->ny;
+    if (ctx->opt_interp_band) return interp_combos_band(gi, coarse, nout, combos, np, d_px, d_py, dkx, dky, d_out);
+    IPDE_TRY(ensure_legacy(gi));
     for (int f0 = 0; f0 < nout; f0 += 3) {
         const int nf = nout - f0 < 3 ? nout - f0 : 3;
         for (int f = 0; f < nf; ++f) {

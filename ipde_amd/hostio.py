@@ -55,6 +55,40 @@ def upload(dst, src, pin):
         dst[edges[k]:edges[k + 1]].copy_(pin[edges[k]:edges[k + 1]], non_blocking=True)
 
 
+def add_from_device(dst, src, pin=None):
+    """dst (numpy, 1-D fp64, n) += src (device tensor, n): the device->host copy goes chunk by chunk into a
+    pinned buffer and worker threads add each chunk onto `dst` as soon as it has landed (numpy's add
+    releases the GIL), so the DMA and the host's additions overlap — the host-container form of the
+    examples' homogeneous correction (17.6 MB at 2048^2: one blocking copy + one numpy add took ~2 ms).
+    Complete on return."""
+    dst = np.asarray(dst).reshape(-1)
+    n = dst.shape[0]
+    assert src.numel() == n and dst.dtype == np.float64 and dst.flags.c_contiguous
+    src = src.reshape(-1)
+    if pin is None or pin.numel() < n:
+        pin = torch.empty(n, dtype=torch.float64, pin_memory=True)
+    host = pin.numpy()
+    nchunk = max(1, min(4 * STAGE_THREADS, n // _MIN_CHUNK))
+    edges = [n * k // nchunk for k in range(nchunk + 1)]
+    events = []
+    for k in range(nchunk):
+        pin[edges[k]:edges[k + 1]].copy_(src[edges[k]:edges[k + 1]], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        events.append(ev)
+
+    def add(k):
+        events[k].synchronize()
+        a, b = edges[k], edges[k + 1]
+        np.add(dst[a:b], host[a:b], out=dst[a:b])
+    if nchunk == 1:
+        add(0)
+        return pin
+    for fut in [_stage_pool().submit(add, k) for k in range(nchunk)]:
+        fut.result()
+    return pin
+
+
 def pinned_function(ebdyc):
     """(EmbeddedFunction whose storage is one pinned host block, the block as a tensor).
     The numpy view keeps the tensor alive; when the caller drops the function the block

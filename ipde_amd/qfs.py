@@ -473,8 +473,9 @@ class DenseSolver(object):
     equations of the example scripts) — on the GPU through torch with one refinement
     step, host LAPACK without a GPU.  solve(b) -> numpy."""
 
-    def __init__(self, A):
+    def __init__(self, A, refine=1):
         self._dev = _device()
+        self.refine = int(refine)      # refinement steps on top of the substitution
         if self._dev is not None:
             import torch
             self._A = A.to(self._dev) if isinstance(A, torch.Tensor) \
@@ -488,9 +489,10 @@ class DenseSolver(object):
             return scipy.linalg.lu_solve(self._lu, np.asarray(b, dtype=float))
         import torch
         if isinstance(b, torch.Tensor):        # device in, device out (the examples' resident correction)
-            return self._fact.solve(self._A, b.to(device=self._dev, dtype=torch.float64).reshape(-1), steps=1)
+            return self._fact.solve(self._A, b.to(device=self._dev, dtype=torch.float64).reshape(-1),
+                                    steps=self.refine)
         bd = torch.as_tensor(np.ascontiguousarray(b, dtype=float), device=self._dev)
-        return self._fact.solve(self._A, bd, steps=1).cpu().numpy()
+        return self._fact.solve(self._A, bd, steps=self.refine).cpu().numpy()
 
 
 def _device():

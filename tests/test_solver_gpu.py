@@ -504,21 +504,21 @@ def test_homogeneous_correction_far_form_equals_pair_by_pair_and_resident_equals
     import interior_poisson
     import interior_modified_helmholtz as imh
     from ipde_amd.layer_potentials import CompositeTargets
-    e_far, scale, solver, u_far, T = interior_poisson.run(nb=1400, M=16, solver_tol=1e-13)
+    e_far, scale, solver, u_far, T = interior_poisson.run(nb=2000, M=16, solver_tol=1e-13)
     tg = T['correction'].targets
     assert isinstance(tg, CompositeTargets) and tg.parts[0].plan() is not None and tg.parts[0].plan().padded_blocks
     assert tg.parts[1].columns == tuple(solver.ebdyc[0].radial_shape)
-    e_dir, _, _, u_dir, T2 = interior_poisson.run(nb=1400, M=16, solver_tol=1e-13, correction_far=False)
+    e_dir, _, _, u_dir, T2 = interior_poisson.run(nb=2000, M=16, solver_tol=1e-13, correction_far=False)
     assert T2['correction'].targets.parts[0].plan() is None
-    e_res, _, _, u_res, _ = interior_poisson.run(nb=1400, M=16, solver_tol=1e-13, resident=True)
+    e_res, _, _, u_res, _ = interior_poisson.run(nb=2000, M=16, solver_tol=1e-13, resident=True)
     print(e_far / scale, e_dir / scale, e_res / scale)
     assert e_far / scale < 1e-12 and e_res / scale < 1e-12
     assert np.abs(np.asarray(u_far) - np.asarray(u_dir)).max() < 1e-13 * scale
     assert np.abs(np.asarray(u_res) - np.asarray(u_far)).max() < 1e-13 * scale
     # modified Helmholtz: the same stage through ipde_modhelm_apply_patches_far / _columns_far
-    e_far, scale, _, u_far, _ = imh.run(nb=1400, M=16, helmholtz_k=10.0, solver_tol=1e-13)
-    e_dir, _, _, u_dir, _ = imh.run(nb=1400, M=16, helmholtz_k=10.0, solver_tol=1e-13, correction_far=False)
-    e_res, _, _, u_res, _ = imh.run(nb=1400, M=16, helmholtz_k=10.0, solver_tol=1e-13, resident=True)
+    e_far, scale, _, u_far, _ = imh.run(nb=2000, M=16, helmholtz_k=10.0, solver_tol=1e-13)
+    e_dir, _, _, u_dir, _ = imh.run(nb=2000, M=16, helmholtz_k=10.0, solver_tol=1e-13, correction_far=False)
+    e_res, _, _, u_res, _ = imh.run(nb=2000, M=16, helmholtz_k=10.0, solver_tol=1e-13, resident=True)
     print(e_far / scale, e_dir / scale, e_res / scale)
     assert e_far / scale < 1e-12 and e_res / scale < 1e-12
     assert np.abs(np.asarray(u_far) - np.asarray(u_dir)).max() < 1e-13 * scale

@@ -170,12 +170,17 @@ def test_hand_written_fft_pipeline_against_oracle(ctx, shape):
                                                 # of two >= 2 n (oversampling 2 .. 4), odd sizes too
                                                 ((48, 40), 300, 0), ((301, 255), 500, 0),
                                                 ((600, 900), 800, 0), ((1370, 1370), 2000, 0)])
-def test_grid_interp_against_dense_fourier_sums(ctx, shape, npts, shifted):
+@pytest.mark.parametrize("band", [1, 0])
+def test_grid_interp_against_dense_fourier_sums(ctx, shape, npts, shifted, band):
     """Values and gradient of the grid solution at scattered points: the oversampled-FFT
     interpolation of csrc/nufft.hip (what the solvers use on power-of-two grids) against the
     exact dense Fourier sums of ipde_amd.interp (the checker), <= 1e-13 of each field's
     maximum; timing of both printed.  shifted = 1 forces the variant that grids of 4096 points
-    a side use by themselves (four half-cell-shifted coarse transforms instead of one fine one)."""
+    a side use by themselves (four half-cell-shifted coarse transforms instead of one fine one).
+    band = 1 (the default): the oversampled transform along x only, exact sums along y per point;
+    band = 0: full oversampled fine grids and the 2-D window gather."""
+    if band and shifted:
+        pytest.skip("the band form has one variant for the packed spectra")
     import time
     import torch
     from ipde_amd.spectral import GridPlan
@@ -191,6 +196,7 @@ def test_grid_interp_against_dense_fourier_sums(ctx, shape, npts, shifted):
         + 1e-3 * torch.randn(nx, ny, dtype=torch.float64, device="cuda", generator=g)
     f -= f.mean()
     ctx.set_option("interp_shifted", shifted)
+    ctx.set_option("interp_band", band)
     plan = GridPlan(nx, ny, hx, hy)
     assert plan.keep_spectrum(True)
     u = plan.poisson_solve(f)
@@ -215,7 +221,8 @@ def test_grid_interp_against_dense_fourier_sums(ctx, shape, npts, shifted):
     ref = periodic_interp2d_gradient(uh, px, py, 1j * kx[:, None], 1j * ky)
     torch.cuda.synchronize()
     t_gemm = time.perf_counter() - t0
-    print("grid %s, %d points: oversampled FFT %.3f ms, dense sums %.3f ms" % (shape, npts, 1e3 * t_fft, 1e3 * t_gemm))
+    print("grid %s, %d points: %s %.3f ms, dense sums %.3f ms"
+          % (shape, npts, "band form" if band else "oversampled FFT", 1e3 * t_fft, 1e3 * t_gemm))
     for k in range(3):
         err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
         assert err < 1e-13, (k, err)
@@ -253,10 +260,13 @@ def test_grid_interp_needs_a_kept_spectrum_and_a_supported_grid():
 @pytest.mark.parametrize("shape,npts,shifted", [((512, 1024), 500, 0), ((1024, 1024), 900, 1),
                                                 ((2048, 2048), 3000, 0), ((301, 255), 400, 0),
                                                 ((1370, 1370), 1500, 0)])
-def test_grid_interp_fields_against_dense_fourier_sums(ctx, shape, npts, shifted):
+@pytest.mark.parametrize("band", [1, 0])
+def test_grid_interp_fields_against_dense_fourier_sums(ctx, shape, npts, shifted, band):
     """ipde_grid_interp_fields: the five interface fields of the Stokes solver (u, v and the
     stress T = grad u + grad u^T - p I of three real grid fields) against the dense Fourier sums
     of ipde_amd.interp on the same multiplied spectra (reference multi_boundary/vector.py:66-82)."""
+    if band and shifted:
+        pytest.skip("the band form has one variant for the packed spectra")
     import torch
     from ipde_amd.spectral import GridPlan
     from ipde_amd.interp import periodic_interp2d
@@ -278,6 +288,7 @@ def test_grid_interp_fields_against_dense_fourier_sums(ctx, shape, npts, shifted
     px = torch.as_tensor(rng.uniform(0, 2 * np.pi, npts), device="cuda")
     py = torch.as_tensor(rng.uniform(0, 2 * np.pi, npts), device="cuda")
     ctx.set_option("interp_shifted", shifted)
+    ctx.set_option("interp_band", band)
     plan = GridPlan(nx, ny, hx, hy)
     got = plan.interp_fields([u, v, p], VectorSolver._STRESS_FIELDS, px, py)
     ikx = torch.as_tensor(1j * np.fft.fftfreq(nx, hx / (2 * np.pi)), device="cuda")[:, None]
@@ -374,3 +385,58 @@ def test_host_io_staged_upload_and_pinned_result():
     block.copy_(torch.as_tensor(np.asarray(ue), device="cuda"), non_blocking=False)
     assert np.array_equal(np.asarray(f), np.asarray(ue))
     assert np.array_equal(f[0], ue[0])        # the radial block of boundary 0 through the container
+
+
+@pytest.mark.parametrize("shape,npts", [((2048, 2048), 4096), ((4096, 4096), 8192), ((1024, 8192), 3000)])
+def test_grid_interp_band_form_on_points_along_a_curve(ctx, shape, npts):
+    """The band form where it is used: points along a closed curve (the interface nodes of a solve — many points
+    share fine rows where the curve runs along y, few where it runs along x), at the sizes of BASELINE configs[2]
+    and configs[3], against the full-fine-grid form on the same kept spectrum (1e-13) and, on a sample, the dense
+    Fourier sums; results of two calls identical bit for bit; timings of both forms printed."""
+    import time
+    import torch
+    from ipde_amd.spectral import GridPlan
+    from ipde_amd.interp import periodic_interp2d_gradient
+    nx, ny = shape
+    hx, hy = 3.0 / nx, 3.0 / ny
+    x = torch.arange(nx, dtype=torch.float64, device="cuda") * hx
+    y = torch.arange(ny, dtype=torch.float64, device="cuda") * hy
+    X, Y = torch.meshgrid(x, y, indexing="ij")
+    f = torch.exp(torch.sin(2 * np.pi * X / 3.0)) * torch.cos(4 * np.pi * Y / 3.0) + torch.sin(2 * np.pi * (3 * X + Y) / 3.0)
+    f -= f.mean()
+    del X, Y
+    th = 2 * np.pi * np.arange(npts) / npts
+    r = 1.0 + 0.2 * np.cos(5 * th)
+    px = torch.as_tensor((1.5 + r * np.cos(th)) * 2 * np.pi / 3.0, device="cuda")
+    py = torch.as_tensor((1.5 + r * np.sin(th)) * 2 * np.pi / 3.0, device="cuda")
+    out, ms = {}, {}
+    for band in (1, 0):
+        ctx.set_option("interp_band", band)
+        plan = GridPlan(nx, ny, hx, hy)
+        assert plan.keep_spectrum(True)
+        plan.poisson_solve(f)
+        a = plan.interp_gradient(px, py)
+        b = plan.interp_gradient(px, py)
+        assert torch.equal(a, b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            plan.interp_gradient(px, py)
+        torch.cuda.synchronize()
+        ms[band] = 1e3 * (time.perf_counter() - t0) / 5
+        out[band] = a
+        if band == 0:
+            plan.keep_spectrum(False)
+            uh, _ = plan.poisson_solve(f, want_uhat=True)
+        plan.close()
+        del plan
+        torch.cuda.empty_cache()
+    print("grid %s, %d curve points: band form %.3f ms, full fine grids %.3f ms" % (shape, npts, ms[1], ms[0]))
+    for k in range(3):
+        assert float((out[1][k] - out[0][k]).abs().max()) < 1e-13 * float(out[0][k].abs().max()), k
+    idx = torch.as_tensor(np.random.default_rng(2).choice(npts, 400, replace=False), device="cuda")
+    kx = torch.as_tensor(np.fft.fftfreq(nx, hx / (2 * np.pi)), device="cuda")
+    ky = torch.as_tensor(np.fft.fftfreq(ny, hy / (2 * np.pi)), device="cuda")
+    ref = periodic_interp2d_gradient(uh, px[idx], py[idx], 1j * kx[:, None], 1j * ky)
+    for k in range(3):
+        assert float((out[1][k][idx] - ref[k]).abs().max()) < 1e-13 * float(ref[k].abs().max()), k
