@@ -30,7 +30,10 @@ class HomogeneousCorrection(object):
         A = singular_dlp(bdy, bdy)
         self.qfs = QFS_Evaluator(ebdy.bdy_qfs, True, [lambda src, trg: A, ], naive_slp, on_surface=True,
                                  form_b2c=False)
-        self.Alu = DenseSolver(A, refine=int(os.environ.get('IPDE_CORRECTION_REFINE', '1')))
+        # (second-kind system, condition O(10): the plain substitution already has LAPACK's residual — measured at
+        # 2048^2 / 4096 nodes, tools/ab_correction.py: error 1.2553e-14 without the refinement step, 1.2733e-14 with
+        # it, 0.27 ms of the stage saved; IPDE_CORRECTION_REFINE=1 puts it back)
+        self.Alu = DenseSolver(A, refine=int(os.environ.get('IPDE_CORRECTION_REFINE', '0')))
         from ipde_amd.sharding import is_distributed
         if owned is not None or is_distributed():
             self.targets = ShardedTargets(self.ebdyc.grid_and_radial_pts, owned=owned)

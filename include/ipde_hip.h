@@ -220,14 +220,16 @@ int ipde_laplace_apply_patches_far(ipde_ctx* ctx,
  * doubles each), column j = the M points of one radial line, neighbouring columns neighbouring lines
  * (ipde/embedded_boundary.py:280-358 `radial_x`, `radial_y` raveled).  Single layer; blocks of 64 columns, a
  * block's far sources in its local expansion, near batches pair by pair: the radial sums of correct()
- * (ipde/solvers/internals/scalar.py:113-114).  out: DEVICE, M * N doubles.  Any (M, N) array gives correct sums
+ * (ipde/solvers/internals/scalar.py:113-114); w_sigma and / or (nx, ny, w_tau) as in ipde_laplace_apply (either may be
+ * NULL).  out: DEVICE, M * N doubles.  Any (M, N) array gives correct sums
  * (a block's disc is the bounding box of its 64 columns over ALL rows); the form is FAST when neighbouring
  * columns are neighbouring lines.  Modified Helmholtz: sources beyond k d > 45 of a block are dropped
  * (K0(45) = 5e-21: an ABSOLUTE bound — a target with only such sources gets 0, not a relatively accurate value).
  */
 int ipde_laplace_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
-                                   const double* w_sigma, int M, int64_t N, const double* tx, const double* ty,
-                                   double* out);
+                                   const double* w_sigma,
+                                   const double* nx, const double* ny, const double* w_tau,
+                                   int M, int64_t N, const double* tx, const double* ty, double* out);
 
 /*
  * The cut of a target list (HOST arrays x, y of nt points) into those patches, on the host — no
@@ -283,11 +285,14 @@ int ipde_modhelm_apply(ipde_ctx* ctx, int loc, double k,
  * nearer batches of eight sources are summed pair by pair through the table of ipde_modhelm_apply.
  * Blocks whose half-diagonal exceeds 1/k keep every source pair by pair.  The place of the
  * reference's grid_backend='fmm2d' branch (fmm2dpy.hfmm2d with zk = i k,
- * ipde/solvers/internals/modified_helmholtz.py:29-35).  DEVICE pointers.
+ * ipde/solvers/internals/modified_helmholtz.py:29-35).  Single layer (w_sigma) and / or double layer
+ * (nx, ny, w_tau; either may be NULL): the dipole's coefficients follow from the single layer's by the ladder
+ * relations of K_m (the double layer is the source-side directional derivative), one family for both.  DEVICE pointers.
  */
 int ipde_modhelm_apply_patches_far(ipde_ctx* ctx, double k, int64_t ns, const double* sx, const double* sy,
-                                   const double* w_sigma, int64_t np, const double* pxy, const int32_t* pout,
-                                   double* out);
+                                   const double* w_sigma,
+                                   const double* nx, const double* ny, const double* w_tau,
+                                   int64_t np, const double* pxy, const int32_t* pout, double* out);
 
 /*
  * The same far-field form for the radial grid of an annulus: targets (M, N) row-major (tx, ty: DEVICE,
@@ -297,8 +302,9 @@ int ipde_modhelm_apply_patches_far(ipde_ctx* ctx, double k, int64_t ns, const do
  * (ipde/solvers/internals/scalar.py:113-114).  out: DEVICE, M * N doubles.
  */
 int ipde_modhelm_apply_columns_far(ipde_ctx* ctx, double k, int64_t ns, const double* sx, const double* sy,
-                                   const double* w_sigma, int M, int64_t N, const double* tx, const double* ty,
-                                   double* out);
+                                   const double* w_sigma,
+                                   const double* nx, const double* ny, const double* w_tau,
+                                   int M, int64_t N, const double* tx, const double* ty, double* out);
 
 /*
  * Stokes (mu=1) Stokeslet + stresslet with pressure:
@@ -326,11 +332,15 @@ int ipde_stokes_apply(ipde_ctx* ctx, int loc,
  * radii through local expansions (three families of 27 complex coefficients: log|d|, d/conj(d) and
  * 1/d about the block's centre, 26 terms at ratio <= 1/4), the nearer batches of eight sources pair
  * by pair.  The place of the reference's FMM call for this sum (pyfmmlib2d SFMM,
- * ipde/solvers/internals/stokes.py:25-35).  DEVICE pointers; values agree with ipde_stokes_apply to
- * a few roundings of the largest partial sum.
+ * ipde/solvers/internals/stokes.py:25-35).  The stresslet (nx, ny, wdx, wdy; reference
+ * ipde/solvers/internals/stokes_save.py:41-54,77-81) takes the same route: with A = (n_x + i n_y)(g_x + i g_y),
+ * U = sum [A / delta + 2 (n.g) / conj(delta) + conj(A) delta / conj(delta)^2] / 4, p / 2 = Re sum A / (2 delta^2),
+ * three more coefficient families feeding the SAME three chains per target; either density pair may be NULL.
+ * DEVICE pointers; values agree with ipde_stokes_apply to a few roundings of the largest partial sum.
  */
 int ipde_stokes_apply_patches_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
                                   const double* wfx, const double* wfy,
+                                  const double* nx, const double* ny, const double* wdx, const double* wdy,
                                   int64_t np, const double* pxy, const int32_t* pout,
                                   double* out_u, double* out_v, double* out_p);
 
@@ -342,8 +352,10 @@ int ipde_stokes_apply_patches_far(ipde_ctx* ctx, int64_t ns, const double* sx, c
  * doubles; out_p may be NULL.
  */
 int ipde_stokes_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
-                                  const double* wfx, const double* wfy, int M, int64_t N,
-                                  const double* tx, const double* ty, double* out_u, double* out_v, double* out_p);
+                                  const double* wfx, const double* wfy,
+                                  const double* nx, const double* ny, const double* wdx, const double* wdy,
+                                  int M, int64_t N, const double* tx, const double* ty,
+                                  double* out_u, double* out_v, double* out_p);
 
 /* ------------------------------------------------------------------------- */
 /* periodic spectral grid operators                  */

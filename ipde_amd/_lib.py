@@ -77,11 +77,13 @@ SIGNATURES = {
                                   _vp, _int]),
     "ipde_laplace_apply_patches": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ipde_laplace_apply_patches_far": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "ipde_modhelm_apply_patches_far": (_int, [_vp, _dbl, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "ipde_laplace_apply_columns_far": (_int, [_vp, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp]),
-    "ipde_modhelm_apply_columns_far": (_int, [_vp, _dbl, _i64, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp]),
-    "ipde_stokes_apply_columns_far": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "ipde_stokes_apply_patches_far": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ipde_modhelm_apply_patches_far": (_int, [_vp, _dbl, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "ipde_laplace_apply_columns_far": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp]),
+    "ipde_modhelm_apply_columns_far": (_int, [_vp, _dbl, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp]),
+    "ipde_stokes_apply_columns_far": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp,
+                                             _vp, _vp]),
+    "ipde_stokes_apply_patches_far": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                             _vp]),
     "ipde_target_plan_build": (_int, [_i64, _vp, _vp, _int, _int, _dbl, _i64, _int, _c_void_pp]),
     "ipde_target_plan_build_blocks": (_int, [_i64, _vp, _vp, _int, _int, _dbl, _i64, _int, _int, _c_void_pp]),
     "ipde_target_plan_sizes": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),

@@ -828,12 +828,12 @@ __global__ __launch_bounds__(256) void laplace_columns_as_patches_kernel(const d
     }
 }
 
-template <int NT>
+template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void laplace_cols_far_kernel(
     const double* __restrict__ rec, int ns_pad, const double* __restrict__ tx, const double* __restrict__ ty, int M,
     int64_t N, double* __restrict__ out, const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab,
-    unsigned key_lo, unsigned nkeys, const double* __restrict__ head, const double* __restrict__ cs, int nslice,
-    const unsigned* __restrict__ near, int nch) {
+    unsigned key_lo, unsigned nkeys, const double* __restrict__ head, const double* __restrict__ cs,
+    const double* __restrict__ cdl, int nslice, const unsigned* __restrict__ near, int nch) {
     extern __shared__ double2 ltab[];
     for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
     __syncthreads();
@@ -844,16 +844,22 @@ __global__ __launch_bounds__(NT) void laplace_cols_far_kernel(
     const int64_t g = wid / nrc;
     const int r0 = 4 * (int)(wid - g * nrc);
     if (g * 64 >= N) return;                           // (whole waves, after the only barrier)
-    // B_k = -(2/k) S_k (B_0 = S_0), the slices' sums added up, parked in LDS behind the table
+    // B_k = -(2/k) S_k - D_(k+1) (B_0 = S_0 - Re D_1), the slices' sums added up, parked in LDS behind the table
     double2* B = ltab + nkeys + wv * (FAR_P + 1);
     if (ln <= FAR_P) {
         double br = 0.0, bi = 0.0;
         for (int sl = 0; sl < nslice; ++sl) {
-            br += cs[(g * nslice + sl) * FAR_NCOEF + 2 * ln];
-            bi += cs[(g * nslice + sl) * FAR_NCOEF + 2 * ln + 1];
+            if (MODE & MODE_SLP) {
+                const double f = ln == 0 ? 1.0 : -2.0 / (double)ln;
+                br += f * cs[(g * nslice + sl) * FAR_NCOEF + 2 * ln];
+                if (ln) bi += f * cs[(g * nslice + sl) * FAR_NCOEF + 2 * ln + 1];
+            }
+            if (MODE & MODE_DLP) {
+                br -= cdl[(g * nslice + sl) * FAR_NCOEF + 2 * (ln + 1)];
+                if (ln) bi -= cdl[(g * nslice + sl) * FAR_NCOEF + 2 * (ln + 1) + 1];
+            }
         }
-        const double f = ln == 0 ? 1.0 : -2.0 / (double)ln;
-        B[ln] = double2{f * br, ln == 0 ? 0.0 : f * bi};
+        B[ln] = double2{br, bi};
     }
     __builtin_amdgcn_wave_barrier();
     const double* h = head + g * FAR_HDR;
@@ -873,36 +879,45 @@ __global__ __launch_bounds__(NT) void laplace_cols_far_kernel(
         while (m) {
             const int bt = __builtin_ctz(m);
             m &= m - 1;
-            SrcRow sx, sy, sq;
+            SrcRow sx, sy, sq, sax, say;
             sx.load(rec, 8 * c + bt, 0);
             sy.load(rec, 8 * c + bt, 1);
-            sq.load(rec, 8 * c + bt, 2);
+            if (MODE & MODE_SLP) sq.load(rec, 8 * c + bt, 2);
+            if (MODE & MODE_DLP) {
+                sax.load(rec, 8 * c + bt, 3);
+                say.load(rec, 8 * c + bt, 4);
+            }
 #pragma unroll
             for (int u = 0; u < IPDE_SRC_PAD; ++u) {
-                double d2[4];
+                double d2[4], ad[4];
                 double2 e[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const double dx = x[i] - sx.v[u], dy = y[i] - sy.v[u];
                     d2[i] = fma(dy, dy, dx * dx);
+                    if (MODE & MODE_DLP) ad[i] = fma(say.v[u], dy, sax.v[u] * dx);
                     e[i] = ta.lookup(ltab, d2[i]);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = fma(sq.v[u], log_from_y(tab_y(d2[i], e[i].x), e[i].y), acc[i]);
+                for (int i = 0; i < 4; ++i) {
+                    const double yy = tab_y(d2[i], e[i].x);
+                    if (MODE & MODE_SLP) acc[i] = fma(sq.v[u], log_from_y(yy, e[i].y), acc[i]);
+                    if (MODE & MODE_DLP) acc[i] = fma(ad[i], rcp_from_y_fast(e[i].x, yy), acc[i]);
+                }
             }
         }
     }
     if (!ta.all_inside(key_lo) || prm->pad) {
         double gs[4] = {0.0, 0.0, 0.0, 0.0};
         if (prm->pad) {
-            laplace_generic_loop<MODE_SLP, false, 4>(rec, 0, ns_pad, x, y, gs);
+            laplace_generic_loop<MODE, false, 4>(rec, 0, ns_pad, x, y, gs);
         } else {
             for (int c = 0; c < nch; ++c) {
                 unsigned m = nm[c];
                 while (m) {
                     const int bt = __builtin_ctz(m);
                     m &= m - 1;
-                    laplace_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, x, y, gs);
+                    laplace_generic_loop<MODE, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, x, y, gs);
                 }
             }
         }
@@ -931,7 +946,7 @@ __global__ __launch_bounds__(NT) void laplace_cols_far_kernel(
         for (int i = 0; i < 4; ++i) acc[i] += vre[i] + b0;
     }
     if (j < N) {
-        const double corr = prm->corr;
+        const double corr = (MODE & MODE_SLP) ? prm->corr : 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (r0 + i < M) out[(int64_t)(r0 + i) * N + j] = acc[i] + corr;
@@ -1183,56 +1198,87 @@ extern "C" int ipde_laplace_apply_patches_far(ipde_ctx* ctx, int64_t ns, const d
     return launch_laplace_patches_far<MODE_BOTH>(ctx, rec, ns, pxy, np, pout, out, prm);
 }
 
-// Single-layer sums onto an (M, N) radial grid (row-major DEVICE arrays; column j = one radial line): the
-// radial sums of the solvers' correct() (reference ipde/solvers/internals/scalar.py:113-114) with the far
-// sources of every block of 64 lines in a local expansion.
-extern "C" int ipde_laplace_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
-                                              const double* w_sigma, int M, int64_t N, const double* tx,
-                                              const double* ty, double* out) {
-    if (!ctx) return IPDE_ERR_INVALID;
-    IPDE_CHECK_ARG(ctx, ns >= 0 && N >= 0 && M >= 1 && ns < (1LL << 30) && N < (1LL << 30) && (int64_t)M * N < (1LL << 40));
-    if (N == 0) return IPDE_OK;
-    IPDE_CHECK_ARG(ctx, tx && ty && out);
-    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && w_sigma);
-    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    PackArgs pa{};
+// the records of an apply: q = -w_sigma / 4 pi (times log d^2), a = n w_tau / 2 pi (scaled with the coordinates)
+static void laplace_pack_args(ipde_ctx* ctx, PackArgs& pa, const double* sx, const double* sy, const double* w_sigma,
+                              const double* nx, const double* ny, const double* w_tau) {
     pa.sx = sx;
     pa.sy = sy;
     pa.ch[0] = w_sigma;
     pa.mul[0] = -0.25 / M_PI;
+    pa.ch[1] = w_tau ? nx : nullptr;
+    pa.mulby[1] = w_tau;
+    pa.mul[1] = 0.5 / M_PI;
+    pa.pw[1] = 1;
+    pa.ch[2] = w_tau ? ny : nullptr;
+    pa.mulby[2] = w_tau;
+    pa.mul[2] = 0.5 / M_PI;
+    pa.pw[2] = 1;
     pa.corr_ch = 0;
     pa.corr2_ch = -1;
     pa.use_scale = 1;
     pa.exp_hi = ctx->logtab.exp_hi;
-    const double* rec;
-    const ApplyParams* prm;
-    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, tx, ty, (int64_t)M * N, &rec, &prm));
+}
+
+// Single- and / or double-layer sums onto an (M, N) radial grid (row-major DEVICE arrays; column j = one radial
+// line): the radial sums of the solvers' correct() (reference ipde/solvers/internals/scalar.py:113-114) with the far
+// sources of every block of 64 lines in a local expansion.
+template <int MODE>
+static int launch_laplace_columns_far(ipde_ctx* ctx, const double* rec, int64_t ns, int M, int64_t N, const double* tx,
+                                      const double* ty, double* out, const ApplyParams* prm) {
     constexpr int NT = 256, NSL = 8;
     const LogTable& lt = ctx->logtab;
     const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
     const int64_t ng = ceil_div64(N, 64);
     const int nch = (int)ceil_div64(ns_pad, 64);
-    const size_t nd = (size_t)8 * N + (size_t)ng * (FAR_HDR + NSL * FAR_NCOEF);
+    const size_t nd = (size_t)8 * N + (size_t)ng * (FAR_HDR + 2 * NSL * FAR_NCOEF);
     IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
     double* pxy = (double*)ctx->partial.p;
     double* head = pxy + (size_t)8 * N;
     double* cs = head + (size_t)ng * FAR_HDR;
-    unsigned* near = (unsigned*)(cs + (size_t)ng * NSL * FAR_NCOEF);
+    double* cdl = cs + (size_t)ng * NSL * FAR_NCOEF;
+    unsigned* near = (unsigned*)(cdl + (size_t)ng * NSL * FAR_NCOEF);
     ipde_time_begin(ctx);
     hipLaunchKernelGGL(laplace_columns_as_patches_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, ctx->stream,
                        tx, ty, M, N, pxy);
-    hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_SLP, 1>), dim3((unsigned)ceil_div64(ng * NSL, 4)), dim3(256), 0,
-                       ctx->stream, rec, ns_pad, (const double*)pxy, N, prm, head, cs, near, nch, 1,
-                       (const unsigned*)nullptr, NSL);
+    const unsigned gb = (unsigned)ceil_div64(ng * NSL, 4);
+    if (MODE & MODE_SLP)
+        hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_SLP, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
+                           (const double*)pxy, N, prm, head, cs, near, nch, 1, (const unsigned*)nullptr, NSL);
+    if (MODE & MODE_DLP)
+        hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_DLP, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
+                           (const double*)pxy, N, prm, head, cdl, near, nch, (MODE & MODE_SLP) ? 0 : 1,
+                           (const unsigned*)nullptr, NSL);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     const size_t lds = ((size_t)lt.nkeys + (size_t)(NT / 64) * (FAR_P + 1)) * sizeof(double2);
-    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_cols_far_kernel<NT>,
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_cols_far_kernel<MODE, NT>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((laplace_cols_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng * ((M + 3) / 4), NT)), dim3(NT),
+    hipLaunchKernelGGL((laplace_cols_far_kernel<MODE, NT>), dim3((unsigned)ceil_div64(64 * ng * ((M + 3) / 4), NT)), dim3(NT),
                        lds, ctx->stream, rec, ns_pad, tx, ty, M, N, out, prm, (const double2*)lt.d_tab,
-                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)cs, NSL,
-                       (const unsigned*)near, nch);
+                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)cs, (const double*)cdl,
+                       NSL, (const unsigned*)near, nch);
     ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
+}
+
+extern "C" int ipde_laplace_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                              const double* w_sigma, const double* nx, const double* ny,
+                                              const double* w_tau, int M, int64_t N, const double* tx,
+                                              const double* ty, double* out) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ns >= 0 && N >= 0 && M >= 1 && ns < (1LL << 30) && N < (1LL << 30) && (int64_t)M * N < (1LL << 40));
+    if (N == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, tx && ty && out);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && (w_sigma || w_tau));
+    IPDE_CHECK_ARG(ctx, w_tau == nullptr || (nx != nullptr && ny != nullptr));
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    PackArgs pa{};
+    laplace_pack_args(ctx, pa, sx, sy, w_sigma, nx, ny, w_tau);
+    const double* rec;
+    const ApplyParams* prm;
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, tx, ty, (int64_t)M * N, &rec, &prm));
+    const int mode = (w_sigma ? MODE_SLP : 0) | (w_tau ? MODE_DLP : 0);
+    if (mode == MODE_SLP) return launch_laplace_columns_far<MODE_SLP>(ctx, rec, ns, M, N, tx, ty, out, prm);
+    if (mode == MODE_DLP) return launch_laplace_columns_far<MODE_DLP>(ctx, rec, ns, M, N, tx, ty, out, prm);
+    return launch_laplace_columns_far<MODE_BOTH>(ctx, rec, ns, M, N, tx, ty, out, prm);
 }

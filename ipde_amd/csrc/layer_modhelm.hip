@@ -234,7 +234,15 @@ constexpr int MFAR_HDR = 4;      // cx, cy, 1/r, r^2/4
 // Two levels as in layer_laplace.hip: PPL = 16 first, `nslice` waves (slices of the sources) per parent
 // block of sixteen consecutive blocks, `bits` = the batches the parent takes or drops; PPL = 1 then per
 // block with `skip` = those bits, `bits` = its near batches.
-template <int PPL>
+// WHICH: MODE_SLP, MODE_DLP or both — ONE family of coefficients either way.  The double layer is the source-side
+// directional derivative of the single layer, (a . grad_{z_j}) K0(|z - z_j|) = (a . d) K1(|d|) / |d|, and with
+// (d_x +- i d_y)[K_m(rho) e^{i m phi}] = -K_{m+-1}(rho) e^{i (m+-1) phi} the derivative of Graf's coefficient
+// function is a ladder step:  (a . grad)[K_m e^{-i m phi_j}] = -(a K_{m+1} e^{-i(m+1) phi_j} + conj(a) K_{m-1}
+// e^{-i(m-1) phi_j}) / 2, a = a_x + i a_y.  In the scaled quantities Kh_m = K_m (r/2)^m / m! a source adds
+//     C_{m-1} += -(2 m / r) a Kh_m e^{-i m phi_j}   (m = 1 .. P + 1; C_0: twice the real part, its own mirror term),
+//     C_{m+1} += -(r / (2 (m + 1))) conj(a) Kh_m e^{-i m phi_j}   (m = 0 .. P - 1),
+// one more step of the K recurrence than the single layer needs; the targets' side is unchanged.
+template <int PPL, int WHICH>
 __global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __restrict__ rec, int ns_pad,
                                                                const double* __restrict__ pxy, int64_t np,
                                                                const ApplyParams* __restrict__ prm,
@@ -284,27 +292,52 @@ __global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __
         }
         if (__ballot(far && !negligible) == 0) continue;              // (wave-uniform)
         const double y = far ? d2 : 1.0;
-        const double q = (far && !negligible) ? rec[ipde_rec_index(jj, 2)] : 0.0;
+        const bool live = far && !negligible;
+        const double q = ((WHICH & MODE_SLP) && live) ? rec[ipde_rec_index(jj, 2)] : 0.0;
+        const double ax = ((WHICH & MODE_DLP) && live) ? rec[ipde_rec_index(jj, 3)] : 0.0;
+        const double ay = ((WHICH & MODE_DLP) && live) ? rec[ipde_rec_index(jj, 4)] : 0.0;
         double k0 = 0.0, k1x = 0.0;
         bessel_k01<3>(y, k0, k1x);
         const double rho = sqrt(y), irho = 1.0 / rho;
         const double ere = dx * irho, eim = -dy * irho;        // e^{-i phi_j} (near lanes: weight 0)
         const double rr = r * irho;
         double km1 = k0, km = k1x * y * (0.5 * r) * irho;      // Kh_0, Kh_1 = K1(rho) r / 2
-        sre[0] = fma(q, km1, sre[0]);
+        if (WHICH & MODE_SLP) sre[0] = fma(q, km1, sre[0]);
+        // -(2 / r) a and -(r / 2) conj(a)
+        const double apx = -2.0 / r * ax, apy = -2.0 / r * ay, aqx = -0.5 * r * ax, aqy = 0.5 * r * ay;
+        if (WHICH & MODE_DLP) {                                 // m = 0: Kh_0, phase 1, into C_1
+            sre[1] = fma(aqx, km1, sre[1]);
+            sim[1] = fma(aqy, km1, sim[1]);
+        }
         double pre = ere, pim = eim;                            // e^{-i m phi_j}
         const double q2 = 2.0 * q;
+        constexpr int MTOP = (WHICH & MODE_DLP) ? MFAR_P + 1 : MFAR_P;
 #pragma unroll
-        for (int mm = 1; mm <= MFAR_P; ++mm) {
-            const double wq = q2 * km;
-            sre[mm] = fma(wq, pre, sre[mm]);
-            sim[mm] = fma(wq, pim, sim[mm]);
-            const double kn = fma(km1, r2q * (1.0 / ((double)mm * (mm + 1))), km * (((double)mm / (mm + 1)) * rr));
-            km1 = km;
-            km = kn;
-            const double nre = pre * ere - pim * eim;
-            pim = fma(pre, eim, pim * ere);
-            pre = nre;
+        for (int mm = 1; mm <= MTOP; ++mm) {
+            if ((WHICH & MODE_SLP) && mm <= MFAR_P) {
+                const double wq = q2 * km;
+                sre[mm] = fma(wq, pre, sre[mm]);
+                sim[mm] = fma(wq, pim, sim[mm]);
+            }
+            if (WHICH & MODE_DLP) {
+                const double vr = km * pre, vi = km * pim;      // Kh_m e^{-i m phi_j}
+                const double tr = apx * vr - apy * vi, ti = fma(apx, vi, apy * vr);
+                sre[mm - 1] = fma((double)mm, tr, sre[mm - 1]);
+                sim[mm - 1] = fma((double)mm, ti, sim[mm - 1]);
+                if (mm + 1 <= MFAR_P) {
+                    const double ur = aqx * vr - aqy * vi, ui = fma(aqx, vi, aqy * vr);
+                    sre[mm + 1] = fma(1.0 / (double)(mm + 1), ur, sre[mm + 1]);
+                    sim[mm + 1] = fma(1.0 / (double)(mm + 1), ui, sim[mm + 1]);
+                }
+            }
+            if (mm < MTOP) {
+                const double kn = fma(km1, r2q * (1.0 / ((double)mm * (mm + 1))), km * (((double)mm / (mm + 1)) * rr));
+                km1 = km;
+                km = kn;
+                const double nre = pre * ere - pim * eim;
+                pim = fma(pre, eim, pim * ere);
+                pre = nre;
+            }
         }
     }
 #pragma unroll
@@ -328,7 +361,10 @@ __global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __
     }
 }
 
-template <int NT>
+// MODE: the near pairs' kernel (single or double layer; the table of that kind in LDS); FAR: add the block's
+// expansion (whose coefficients hold whatever layers the coefficient pass was given); ACC: add to `out`.  Both
+// layers in one apply: <SLP, true, false> then <DLP, false, true>.
+template <int NT, int MODE, bool FAR, bool ACC>
 __global__ __launch_bounds__(NT) void modhelm_patch_far_kernel(
     const double* __restrict__ rec, int ns_pad, const double* __restrict__ pxy, int64_t np,
     const int* __restrict__ pout, double* __restrict__ out, const ApplyParams* __restrict__ prm,
@@ -363,18 +399,23 @@ __global__ __launch_bounds__(NT) void modhelm_patch_far_kernel(
             while (m) {
                 const int bt = __builtin_ctz(m);
                 m &= m - 1;
-                SrcRow sx, sy, sq;
+                SrcRow sx, sy, sq, sa;
                 sx.load(rec, 8 * c + bt, 0);
                 sy.load(rec, 8 * c + bt, 1);
-                sq.load(rec, 8 * c + bt, 2);
+                sq.load(rec, 8 * c + bt, MODE == MODE_SLP ? 2 : 3);      // q, or a_x
+                if (MODE == MODE_DLP) sa.load(rec, 8 * c + bt, 4);       // a_y
 #pragma unroll
                 for (int u = 0; u < IPDE_SRC_PAD; ++u) {
-                    double dx2[4], dy2[4];
+                    double dx2[4], dy2[4], adx[4], ady[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const double dx = xs[a] - sx.v[u], dy = ys[a] - sy.v[u];
                         dx2[a] = dx * dx;
                         dy2[a] = dy * dy;
+                        if (MODE == MODE_DLP) {
+                            adx[a] = sq.v[u] * dx;
+                            ady[a] = sa.v[u] * dy;
+                        }
                     }
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
@@ -401,7 +442,7 @@ __global__ __launch_bounds__(NT) void modhelm_patch_far_kernel(
                             p = fma(p, z, e[b][1].x);
                             p = fma(p, z, e[b][0].y);
                             p = fma(p, z, e[b][0].x);
-                            acc[4 * a + b] = fma(sq.v[u], p, acc[4 * a + b]);
+                            acc[4 * a + b] = fma(MODE == MODE_SLP ? sq.v[u] : adx[a] + ady[b], p, acc[4 * a + b]);
                         }
                     }
                 }
@@ -420,7 +461,7 @@ __global__ __launch_bounds__(NT) void modhelm_patch_far_kernel(
                 while (m) {
                     const int bt = __builtin_ctz(m);
                     m &= m - 1;
-                    modhelm_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, xa, ys, gs);
+                    modhelm_generic_loop<MODE, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, xa, ys, gs);
                 }
             }
 #pragma unroll
@@ -428,7 +469,7 @@ __global__ __launch_bounds__(NT) void modhelm_patch_far_kernel(
         }
     }
     // far sources: Re sum_m C_m zeta^m T_m(w), Horner downwards with T's recurrence alongside
-    {
+    if (FAR) {
         const double* h = head + g * MFAR_HDR;
         const double cx = h[0], cy = h[1], rinv = h[2], r2q = h[3];
         const double* C = coef + g * MFAR_NCOEF;
@@ -476,7 +517,7 @@ __global__ __launch_bounds__(NT) void modhelm_patch_far_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = pout[(int64_t)r * np + t];
-        if (i >= 0) out[i] = acc[r];
+        if (i >= 0) out[i] = ACC ? out[i] + acc[r] : acc[r];
     }
 }
 
@@ -546,8 +587,9 @@ __global__ __launch_bounds__(1024) void modhelm_far_parent_kernel(const double* 
     }
 }
 
+// which: MODE_SLP, MODE_DLP or both (the densities present in the records)
 int launch_modhelm_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, const double* pxy, int64_t np,
-                               const int* pout, double* out, const ApplyParams* prm) {
+                               const int* pout, double* out, const ApplyParams* prm, int which) {
     constexpr int NT = 1024;
     constexpr int NSL = 8;                             // waves (slices of the sources) per parent block
     const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
@@ -564,17 +606,35 @@ int launch_modhelm_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, con
     unsigned* near = (unsigned*)(coef2 + (size_t)ng2 * NSL * MFAR_NCOEF);
     unsigned* taken = near + (size_t)ng * nch;
     ipde_time_begin(ctx);
-    hipLaunchKernelGGL(modhelm_far_coeff_kernel<16>, dim3((unsigned)ceil_div64(ng2 * NSL, 4)), dim3(256), 0, ctx->stream,
-                       rec, ns_pad, pxy, np, prm, head2, coef2, taken, nch, (const unsigned*)nullptr, NSL);
-    hipLaunchKernelGGL(modhelm_far_coeff_kernel<1>, dim3((unsigned)ceil_div64(ng, 4)), dim3(256), 0, ctx->stream, rec,
-                       ns_pad, pxy, np, prm, head, coef, near, nch, (const unsigned*)taken, 1);
+    auto coeffs = [&](auto parent, auto block) {
+        hipLaunchKernelGGL(parent, dim3((unsigned)ceil_div64(ng2 * NSL, 4)), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np,
+                           prm, head2, coef2, taken, nch, (const unsigned*)nullptr, NSL);
+        hipLaunchKernelGGL(block, dim3((unsigned)ceil_div64(ng, 4)), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
+                           head, coef, near, nch, (const unsigned*)taken, 1);
+    };
+    if (which == MODE_SLP)
+        coeffs(modhelm_far_coeff_kernel<16, MODE_SLP>, modhelm_far_coeff_kernel<1, MODE_SLP>);
+    else if (which == MODE_DLP)
+        coeffs(modhelm_far_coeff_kernel<16, MODE_DLP>, modhelm_far_coeff_kernel<1, MODE_DLP>);
+    else
+        coeffs(modhelm_far_coeff_kernel<16, MODE_SLP | MODE_DLP>, modhelm_far_coeff_kernel<1, MODE_SLP | MODE_DLP>);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     const size_t lds = (size_t)KT_NKEYS * KT_ENTRY * sizeof(double);
-    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)modhelm_patch_far_kernel<NT>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((modhelm_patch_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds,
-                       ctx->stream, rec, ns_pad, pxy, np, pout, out, prm, (const double2*)ctx->d_ktab,
-                       (const double*)head, (const double*)coef, (const unsigned*)near, nch);
+    const double* tab_s = ctx->d_ktab;
+    const double* tab_d = ctx->d_ktab + (size_t)KT_NWIN * KT_NKEYS * KT_ENTRY;
+    auto patches = [&](auto kern, const double* tab) -> int {
+        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds, ctx->stream, rec, ns_pad, pxy, np,
+                           pout, out, prm, (const double2*)tab, (const double*)head, (const double*)coef,
+                           (const unsigned*)near, nch);
+        return IPDE_OK;
+    };
+    if (which & MODE_SLP) {
+        IPDE_TRY(patches(modhelm_patch_far_kernel<NT, MODE_SLP, true, false>, tab_s));
+        if (which & MODE_DLP) IPDE_TRY(patches(modhelm_patch_far_kernel<NT, MODE_DLP, false, true>, tab_d));
+    } else {
+        IPDE_TRY(patches(modhelm_patch_far_kernel<NT, MODE_DLP, true, false>, tab_d));
+    }
     hipLaunchKernelGGL(modhelm_far_parent_kernel, dim3((unsigned)ng2), dim3(1024), 0, ctx->stream, pxy, np, pout, out,
                        prm, (const double*)head2, (const double*)coef2, NSL);
     ipde_time_end(ctx);
@@ -613,7 +673,8 @@ __global__ __launch_bounds__(256) void columns_as_patches_kernel(const double* _
     }
 }
 
-template <int NT>
+// (MODE, FAR, ACC as for modhelm_patch_far_kernel)
+template <int NT, int MODE, bool FAR, bool ACC>
 __global__ __launch_bounds__(NT) void modhelm_cols_far_kernel(
     const double* __restrict__ rec, int ns_pad, const double* __restrict__ tx, const double* __restrict__ ty, int M,
     int64_t N, double* __restrict__ out, const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab,
@@ -665,18 +726,20 @@ __global__ __launch_bounds__(NT) void modhelm_cols_far_kernel(
                 while (m) {
                     const int bt = __builtin_ctz(m);
                     m &= m - 1;
-                    SrcRow sx, sy, sq;
+                    SrcRow sx, sy, sq, sa;
                     sx.load(rec, 8 * c + bt, 0);
                     sy.load(rec, 8 * c + bt, 1);
-                    sq.load(rec, 8 * c + bt, 2);
+                    sq.load(rec, 8 * c + bt, MODE == MODE_SLP ? 2 : 3);      // q, or a_x
+                    if (MODE == MODE_DLP) sa.load(rec, 8 * c + bt, 4);       // a_y
 #pragma unroll
                     for (int u = 0; u < IPDE_SRC_PAD; ++u) {
-                        double d2[4];
+                        double d2[4], ad[4];
                         double2 e[4][KT_READS];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const double dx = x[i] - sx.v[u], dy = y[i] - sy.v[u];
                             d2[i] = fma(dy, dy, dx * dx);
+                            if (MODE == MODE_DLP) ad[i] = fma(sa.v[u], dy, sq.v[u] * dx);
                             const unsigned hi = (unsigned)__double2hiint(d2[i]);
                             hmin = min(hmin, hi);
                             unsigned idx;
@@ -695,7 +758,7 @@ __global__ __launch_bounds__(NT) void modhelm_cols_far_kernel(
                             p = fma(p, z, e[i][1].x);
                             p = fma(p, z, e[i][0].y);
                             p = fma(p, z, e[i][0].x);
-                            acc[i] = fma(sq.v[u], p, acc[i]);
+                            acc[i] = fma(MODE == MODE_SLP ? sq.v[u] : ad[i], p, acc[i]);
                         }
                     }
                 }
@@ -708,7 +771,7 @@ __global__ __launch_bounds__(NT) void modhelm_cols_far_kernel(
                 while (m) {
                     const int bt = __builtin_ctz(m);
                     m &= m - 1;
-                    modhelm_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, x, y, gs);
+                    modhelm_generic_loop<MODE, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, x, y, gs);
                 }
             }
 #pragma unroll
@@ -731,24 +794,29 @@ __global__ __launch_bounds__(NT) void modhelm_cols_far_kernel(
             tm[i] = s0p;
             vr[i] = vi[i] = 0.0;
         }
+        if (FAR) {
 #pragma unroll 2
-        for (int m = MFAR_P; m >= 0; --m) {
-            const double2 c = C[m];
-            const double f = m >= 1 ? 1.0 / ((double)m * (m + 1)) : 0.0;
+            for (int m = MFAR_P; m >= 0; --m) {
+                const double2 c = C[m];
+                const double f = m >= 1 ? 1.0 / ((double)m * (m + 1)) : 0.0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const double nr = vr[i] * zx[i] - vi[i] * zy[i];
-                vi[i] = fma(vr[i], zy[i], vi[i] * zx[i]) + c.y * tm[i];
-                vr[i] = nr + c.x * tm[i];
-                const double tn = fma(w[i] * f, tp[i], tm[i]);
-                tp[i] = tm[i];
-                tm[i] = tn;
+                for (int i = 0; i < 4; ++i) {
+                    const double nr = vr[i] * zx[i] - vi[i] * zy[i];
+                    vi[i] = fma(vr[i], zy[i], vi[i] * zx[i]) + c.y * tm[i];
+                    vr[i] = nr + c.x * tm[i];
+                    const double tn = fma(w[i] * f, tp[i], tm[i]);
+                    tp[i] = tm[i];
+                    tm[i] = tn;
+                }
             }
         }
         if (j < N) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (r0 + i < M) out[(int64_t)(r0 + i) * N + j] = acc[i] + vr[i];
+                if (r0 + i < M) {
+                    double* o = out + (int64_t)(r0 + i) * N + j;
+                    *o = ACC ? *o + acc[i] + vr[i] : acc[i] + vr[i];
+                }
         }
     }
 }
@@ -978,62 +1046,74 @@ extern "C" int ipde_modhelm_apply(ipde_ctx* ctx, int loc, double k, int64_t ns, 
     return ipde_stage_finish(ctx, loc, 7, out, nt);
 }
 
-// Single-layer sums K0(k r) w_sigma / (2 pi) onto a patch list whose 64-patch groups are 8 x 8 blocks of
-// tiles (ipde_target_plan_build_blocks, pad_blocks = 1): far sources block by block in local expansions
-// (Graf's addition theorem), near batches through the table.
+// The records of an apply: q' = w_sigma / 2 pi, a' = n w_tau k / 2 pi, coordinates scaled by k (see the file's head).
+static void modhelm_pack_args(PackArgs& pa, double k, const double* sx, const double* sy, const double* w_sigma,
+                              const double* nx, const double* ny, const double* w_tau) {
+    pa.sx = sx;
+    pa.sy = sy;
+    pa.ch[0] = w_sigma;
+    pa.mul[0] = 0.5 / M_PI;
+    pa.ch[1] = w_tau ? nx : nullptr;
+    pa.mulby[1] = w_tau;
+    pa.mul[1] = 0.5 * k / M_PI;
+    pa.ch[2] = w_tau ? ny : nullptr;
+    pa.mulby[2] = w_tau;
+    pa.mul[2] = 0.5 * k / M_PI;
+    pa.corr_ch = -1;
+    pa.corr2_ch = -1;
+    pa.use_scale = 1;
+    pa.fixed_scale = k;
+}
+
+// Single- and / or double-layer sums (K0(k r) w_sigma + k K1(k r) (n . d) / r w_tau) / (2 pi) onto a patch list whose
+// 64-patch groups are 8 x 8 blocks of tiles (ipde_target_plan_build_blocks, pad_blocks = 1): far sources block by
+// block in local expansions (Graf's addition theorem; the double layer by the ladder relations of K_m), near
+// batches through the tables.
 extern "C" int ipde_modhelm_apply_patches_far(ipde_ctx* ctx, double k, int64_t ns, const double* sx,
-                                              const double* sy, const double* w_sigma, int64_t np,
+                                              const double* sy, const double* w_sigma, const double* nx,
+                                              const double* ny, const double* w_tau, int64_t np,
                                               const double* pxy, const int32_t* pout, double* out) {
     if (!ctx) return IPDE_ERR_INVALID;
     IPDE_CHECK_ARG(ctx, ns >= 0 && np >= 0 && ns < (1LL << 30) && np < (1LL << 27));
     IPDE_CHECK_ARG(ctx, k > 0.0);
     if (np == 0) return IPDE_OK;
     IPDE_CHECK_ARG(ctx, pxy && pout && out);
-    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && w_sigma);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && (w_sigma || w_tau));
+    IPDE_CHECK_ARG(ctx, w_tau == nullptr || (nx != nullptr && ny != nullptr));
     IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_ktab) IPDE_TRY(ipde_build_k_table(ctx));
     PackArgs pa{};
-    pa.sx = sx;
-    pa.sy = sy;
-    pa.ch[0] = w_sigma;
-    pa.mul[0] = 0.5 / M_PI;
-    pa.corr_ch = -1;
-    pa.corr2_ch = -1;
-    pa.use_scale = 1;
-    pa.fixed_scale = k;
+    modhelm_pack_args(pa, k, sx, sy, w_sigma, nx, ny, w_tau);
     const double* rec;
     const ApplyParams* prm;
     IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, pxy, pxy + 4 * np, 4 * np, &rec, &prm));
-    return launch_modhelm_patches_far(ctx, rec, ns, pxy, np, pout, out, prm);
+    return launch_modhelm_patches_far(ctx, rec, ns, pxy, np, pout, out, prm,
+                                      (w_sigma ? MODE_SLP : 0) | (w_tau ? MODE_DLP : 0));
 }
 
-// Single-layer sums onto an (M, N) radial grid (row-major DEVICE arrays tx, ty: column j = the M points of
+// The same sums onto an (M, N) radial grid (row-major DEVICE arrays tx, ty: column j = the M points of
 // one radial line, neighbouring columns neighbouring lines): blocks of 64 columns, far sources in the
-// block's local expansion, near batches through the table — the radial sums of the solvers' correct()
+// block's local expansion, near batches through the tables — the radial sums of the solvers' correct()
 // (reference ipde/solvers/internals/scalar.py:113-114).
 extern "C" int ipde_modhelm_apply_columns_far(ipde_ctx* ctx, double k, int64_t ns, const double* sx,
-                                              const double* sy, const double* w_sigma, int M, int64_t N,
+                                              const double* sy, const double* w_sigma, const double* nx,
+                                              const double* ny, const double* w_tau, int M, int64_t N,
                                               const double* tx, const double* ty, double* out) {
     if (!ctx) return IPDE_ERR_INVALID;
     IPDE_CHECK_ARG(ctx, ns >= 0 && N >= 0 && M >= 1 && ns < (1LL << 30) && N < (1LL << 30) && (int64_t)M * N < (1LL << 40));
     IPDE_CHECK_ARG(ctx, k > 0.0);
     if (N == 0) return IPDE_OK;
     IPDE_CHECK_ARG(ctx, tx && ty && out);
-    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && w_sigma);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && (w_sigma || w_tau));
+    IPDE_CHECK_ARG(ctx, w_tau == nullptr || (nx != nullptr && ny != nullptr));
     IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_ktab) IPDE_TRY(ipde_build_k_table(ctx));
     PackArgs pa{};
-    pa.sx = sx;
-    pa.sy = sy;
-    pa.ch[0] = w_sigma;
-    pa.mul[0] = 0.5 / M_PI;
-    pa.corr_ch = -1;
-    pa.corr2_ch = -1;
-    pa.use_scale = 1;
-    pa.fixed_scale = k;
+    modhelm_pack_args(pa, k, sx, sy, w_sigma, nx, ny, w_tau);
     const double* rec;
     const ApplyParams* prm;
     IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, tx, ty, (int64_t)M * N, &rec, &prm));
+    const int which = (w_sigma ? MODE_SLP : 0) | (w_tau ? MODE_DLP : 0);
     constexpr int NT = 256, NSL = 8;
     const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
     const int64_t ng = ceil_div64(N, 64);
@@ -1047,15 +1127,33 @@ extern "C" int ipde_modhelm_apply_columns_far(ipde_ctx* ctx, double k, int64_t n
     ipde_time_begin(ctx);
     hipLaunchKernelGGL(columns_as_patches_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, ctx->stream, tx, ty,
                        M, N, pxy);
-    hipLaunchKernelGGL(modhelm_far_coeff_kernel<1>, dim3((unsigned)ceil_div64(ng * NSL, 4)), dim3(256), 0, ctx->stream,
-                       rec, ns_pad, (const double*)pxy, N, prm, head, coef, near, nch, (const unsigned*)nullptr, NSL);
+    auto coeffs = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div64(ng * NSL, 4)), dim3(256), 0, ctx->stream, rec, ns_pad,
+                           (const double*)pxy, N, prm, head, coef, near, nch, (const unsigned*)nullptr, NSL);
+    };
+    if (which == MODE_SLP)
+        coeffs(modhelm_far_coeff_kernel<1, MODE_SLP>);
+    else if (which == MODE_DLP)
+        coeffs(modhelm_far_coeff_kernel<1, MODE_DLP>);
+    else
+        coeffs(modhelm_far_coeff_kernel<1, MODE_SLP | MODE_DLP>);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     const size_t lds = (size_t)KT_NKEYS * KT_ENTRY * sizeof(double) + (size_t)(NT / 64) * (MFAR_P + 1) * sizeof(double2);
-    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)modhelm_cols_far_kernel<NT>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((modhelm_cols_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng * ((M + 3) / 4), NT)), dim3(NT), lds,
-                       ctx->stream, rec, ns_pad, tx, ty, M, N, out, prm, (const double2*)ctx->d_ktab,
-                       (const double*)head, (const double*)coef, NSL, (const unsigned*)near, nch);
+    const double* tab_s = ctx->d_ktab;
+    const double* tab_d = ctx->d_ktab + (size_t)KT_NWIN * KT_NKEYS * KT_ENTRY;
+    auto cols = [&](auto kern, const double* tab) -> int {
+        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div64(64 * ng * ((M + 3) / 4), NT)), dim3(NT), lds, ctx->stream, rec,
+                           ns_pad, tx, ty, M, N, out, prm, (const double2*)tab, (const double*)head, (const double*)coef,
+                           NSL, (const unsigned*)near, nch);
+        return IPDE_OK;
+    };
+    if (which & MODE_SLP) {
+        IPDE_TRY(cols(modhelm_cols_far_kernel<NT, MODE_SLP, true, false>, tab_s));
+        if (which & MODE_DLP) IPDE_TRY(cols(modhelm_cols_far_kernel<NT, MODE_DLP, false, true>, tab_d));
+    } else {
+        IPDE_TRY(cols(modhelm_cols_far_kernel<NT, MODE_DLP, true, false>, tab_d));
+    }
     ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;

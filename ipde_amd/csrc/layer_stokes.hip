@@ -347,6 +347,19 @@ __global__ __launch_bounds__(NT) void stokes_rowrun_kernel(
 //     sum_j (f'.d)/d^2 = -Re S2 / r.
 // Three coefficient launches (a family fills the register file), then the patch kernel: expansion
 // values first, then the near batches pair by pair through the table.
+//
+// The stresslet (round 4).  With N = n_x + i n_y, G = g'_x + i g'_y:  (d.n)(d.g') = [delta^2 conj(N G) + conj(delta)^2
+// N G + |delta|^2 2 (n.g')] / 4, so with A = N G and the real C = 2 n.g'
+//     U = sum_j (d.n)(d.g') delta / |delta|^4 = (1/4) sum_j [ A / delta + C / conj(delta) + conj(A) delta / conj(delta)^2 ],
+//     p / 2 = sum_j [ -(n.g') / (2 |delta|^2) + (d.n)(d.g') / |delta|^4 ] = (1/2) Re sum_j A / delta^2,
+// and with 1/delta^2 = (vt^2 / r^2) sum_k (k + 1) (zeta vt)^k three more families, stored by slot k = power - 1,
+//     Y1_k = sum_j A vt^(k+1) (k = 0..P+1),   Y2_k = sum_j C vt^(k+1),   Y4_k = sum_j (A vt / conj(vt)) vt^(k+1)   (k = 0..P),
+// give, T2 = sum_k (k + 1) Y1_(k+1) zeta^k,
+//     U = -(1/4r) sum_k Y1_k zeta^k - (1/4r) sum_k [conj(Y2_k) + (k + 1) conj(Y4_k)] conj(zeta)^k + (1/4r) zeta conj(T2),
+//     p / 2 = Re T2 / (2 r^2)
+// — the stokeslet's three chains with other coefficients: a1_k += -Y1_k / 4r, a2_k += -(k + 1) Y1_(k+1) / 2r,
+// b_k += -[conj(Y2_k) + (k + 1) conj(Y4_k)] / 4r.  The targets' side is the stokeslet's, unchanged; both layers in one
+// apply share it.
 constexpr int SFAR_P = 26;
 constexpr double SFAR_RHO = 0.25;
 constexpr int SFAR_NCOEF = 2 * (SFAR_P + 2);
@@ -354,14 +367,17 @@ constexpr int SFAR_HDR = 4;
 
 // Two levels as in layer_laplace.hip: PPL = 16 first, `nslice` waves (slices of the sources) per parent
 // block of sixteen consecutive blocks, `bits` = the batches the parent takes; PPL = 1 then per block with
-// `skip` = those bits, `bits` = its near batches.
+// `skip` = those bits, `bits` = its near batches.  WHICH = 1, 2, 3: the stokeslet's families X1, X2, X3;
+// 4, 5, 6: the stresslet's Y1, Y2, Y4 (slot k = power k + 1).  `lead`: this launch writes the block headers and
+// the batch bits (the first family of an apply).
 template <int WHICH, int PPL>
 __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __restrict__ rec, int ns_pad,
                                                               const double* __restrict__ pxy, int64_t np,
                                                               const ApplyParams* __restrict__ prm,
                                                               double* __restrict__ head, double* __restrict__ coef,
                                                               unsigned* __restrict__ near, int nch,
-                                                              const unsigned* __restrict__ skip, int nslice) {
+                                                              const unsigned* __restrict__ skip, int nslice,
+                                                              int lead) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t g = gw / nslice;
@@ -374,8 +390,9 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
     blk.init<PPL>(pxy, np, g, lane, s1);
     const double cx = blk.cx, cy = blk.cy, r = blk.r, r2 = blk.r2;
     const double thr = r2 * (1.0 / (SFAR_RHO * SFAR_RHO)) * (1.0 + 0x1p-40);
-    constexpr int K0 = WHICH == 3 ? 0 : 1;
-    constexpr int K1 = WHICH == 1 ? SFAR_P + 1 : SFAR_P;
+    constexpr bool DL = WHICH >= 4;
+    constexpr int K0 = (WHICH == 3 || DL) ? 0 : 1;
+    constexpr int K1 = (WHICH == 1 || WHICH == 4) ? SFAR_P + 1 : SFAR_P;
     double sre[K1 + 1], sim[K1 + 1];
 #pragma unroll
     for (int k = 0; k <= K1; ++k) sre[k] = sim[k] = 0.0;
@@ -399,15 +416,30 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
             const unsigned long long mv = __ballot(valid);
             const bool far = mine && ((m >> (lane & ~7)) & 0xFFull) == 0;
             anyfar = anyfar || far;
-            if (WHICH == 1 && lane == 0 && jb < ns_pad) {
+            if (lead && lane == 0 && jb < ns_pad) {
                 const unsigned nearbits = far_batch_bits(m);
                 near[g * nch + (jb >> 6)] = PPL == 1 ? nearbits : (far_batch_bits(mv) & ~nearbits);
             }
             const double inv = far ? r / d2 : 0.0;
             vre[h] = dx * inv;
             vim[h] = -dy * inv;                            // vt = r / (z_j - c)
-            const double fx = far ? rec[ipde_rec_index(jj, 2)] : 0.0, fy = far ? rec[ipde_rec_index(jj, 3)] : 0.0;
-            if (WHICH == 1) {
+            double fx, fy;
+            if (!DL) {
+                fx = far ? rec[ipde_rec_index(jj, 2)] : 0.0;
+                fy = far ? rec[ipde_rec_index(jj, 3)] : 0.0;
+            } else if (WHICH == 5) {
+                fx = far ? 2.0 * rec[ipde_rec_index(jj, 8)] : 0.0;        // C = 2 n.g'
+                fy = 0.0;
+            } else {
+                const double gx = far ? rec[ipde_rec_index(jj, 4)] : 0.0, gy = far ? rec[ipde_rec_index(jj, 5)] : 0.0;
+                const double nx = rec[ipde_rec_index(jj, 6)], ny = rec[ipde_rec_index(jj, 7)];
+                fx = nx * gx - ny * gy;                                     // A = N G
+                fy = nx * gy + ny * gx;
+            }
+            if (WHICH == 4 || WHICH == 5) {
+                wre[h] = fx;
+                wim[h] = fy;
+            } else if (WHICH == 1) {
                 wre[h] = fx;
                 wim[h] = fy;
                 const double hl = fma(-0.5, log(far ? d2 : 1.0), 0.5);     // 1/2 - log|c - z_j|
@@ -428,8 +460,8 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
         double pre[2], pim[2];                             // vt^k
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            pre[h] = K0 == 0 ? 1.0 : vre[h];
-            pim[h] = K0 == 0 ? 0.0 : vim[h];
+            pre[h] = (K0 == 0 && !DL) ? 1.0 : vre[h];
+            pim[h] = (K0 == 0 && !DL) ? 0.0 : vim[h];
         }
 #pragma unroll
         for (int k = K0; k <= K1; ++k) {
@@ -449,7 +481,7 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
         sim[k] = wave_sum(sim[k]);
     }
     if (lane == 0) {
-        if (WHICH == 1 && slice == 0) {
+        if (lead && slice == 0) {
             head[g * SFAR_HDR + 0] = cx;
             head[g * SFAR_HDR + 1] = cy;
             head[g * SFAR_HDR + 2] = 1.0 / r;
@@ -466,34 +498,57 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
 
 // Entry k of the combined coefficients the Horner loops read (the three families summed over `nslice`
 // rows each):  [3k] a1_k = X1_k / (2k) (k = 0: C0),  [3k+1] a2_k = X1_(k+1),  [3k+2] b_k = conj(X3_k)/2 + conj(X2_k)/(2k)
+// ALL: the layers in this apply (MODE_SLP: X1..X3; MODE_DLP: D1, D2, D4 = the stresslet's Y1, Y2, Y4, see the head of
+// the section; rinv = 1 / r of the block).
+template <int ALL>
 __device__ __forceinline__ void sfar_combine(double2* __restrict__ W, int k, const double* __restrict__ X1,
                                              const double* __restrict__ X2, const double* __restrict__ X3,
-                                             int nslice) {
+                                             const double* __restrict__ D1, const double* __restrict__ D2,
+                                             const double* __restrict__ D4, double rinv, int nslice) {
     double a1r = 0.0, a1i = 0.0, a2r = 0.0, a2i = 0.0, br = 0.0, bi = 0.0;
     const double hk = k >= 1 ? 0.5 / (double)k : 1.0;
+    const double q4 = -0.25 * rinv, q2 = -0.5 * rinv * (double)(k + 1), q4k = q4 * (double)(k + 1);
     for (int sl = 0; sl < nslice; ++sl) {
-        const double* Y1 = X1 + (size_t)sl * SFAR_NCOEF;
-        const double* Y2 = X2 + (size_t)sl * SFAR_NCOEF;
-        const double* Y3 = X3 + (size_t)sl * SFAR_NCOEF;
-        a1r += hk * Y1[2 * k];
-        a1i += hk * Y1[2 * k + 1];
-        a2r += Y1[2 * (k + 1)];
-        a2i += Y1[2 * (k + 1) + 1];
-        br += 0.5 * Y3[2 * k] + (k >= 1 ? hk * Y2[2 * k] : 0.0);
-        bi -= 0.5 * Y3[2 * k + 1] + (k >= 1 ? hk * Y2[2 * k + 1] : 0.0);
+        if (ALL & MODE_SLP) {
+            const double* Y1 = X1 + (size_t)sl * SFAR_NCOEF;
+            const double* Y2 = X2 + (size_t)sl * SFAR_NCOEF;
+            const double* Y3 = X3 + (size_t)sl * SFAR_NCOEF;
+            a1r += hk * Y1[2 * k];
+            a1i += hk * Y1[2 * k + 1];
+            a2r += Y1[2 * (k + 1)];
+            a2i += Y1[2 * (k + 1) + 1];
+            br += 0.5 * Y3[2 * k] + (k >= 1 ? hk * Y2[2 * k] : 0.0);
+            bi -= 0.5 * Y3[2 * k + 1] + (k >= 1 ? hk * Y2[2 * k + 1] : 0.0);
+        }
+        if (ALL & MODE_DLP) {
+            const double* Z1 = D1 + (size_t)sl * SFAR_NCOEF;
+            const double* Z2 = D2 + (size_t)sl * SFAR_NCOEF;
+            const double* Z4 = D4 + (size_t)sl * SFAR_NCOEF;
+            a1r += q4 * Z1[2 * k];
+            a1i += q4 * Z1[2 * k + 1];
+            a2r += q2 * Z1[2 * (k + 1)];
+            a2i += q2 * Z1[2 * (k + 1) + 1];
+            br += q4 * Z2[2 * k] + q4k * Z4[2 * k];
+            bi -= q4 * Z2[2 * k + 1] + q4k * Z4[2 * k + 1];
+        }
     }
     W[3 * k] = double2{a1r, a1i};
     W[3 * k + 1] = double2{a2r, a2i};
     W[3 * k + 2] = double2{br, bi};
 }
 
-template <int NT>
+// MODE: the layer of the near pairs this launch sums (MODE_SLP or MODE_DLP); ALL: the layers of the apply (what the
+// coefficients hold, what a table miss recomputes); FAR: this launch starts from the block's expansion and STORES;
+// !FAR: it ADDS its near pairs to what is stored.  Both layers: <SLP, 3, true> then <DLP, 3, false> (one launch with
+// both near bodies would not fit the register file).
+template <int NT, int MODE, int ALL, bool FAR>
 __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
     const double* __restrict__ rec, int ns_pad, const double* __restrict__ pxy, int64_t np,
     const int* __restrict__ pout, double* __restrict__ ou, double* __restrict__ ov, double* __restrict__ op,
     const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab, unsigned key_lo, unsigned nkeys,
     const double* __restrict__ head, const double* __restrict__ c1, const double* __restrict__ c2,
-    const double* __restrict__ c3, const unsigned* __restrict__ near, int nch,
+    const double* __restrict__ c3, const double* __restrict__ c4, const double* __restrict__ c5,
+    const double* __restrict__ c6, const unsigned* __restrict__ near, int nch,
     const unsigned* __restrict__ taken) {
     extern __shared__ double2 ltab[];
     for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
@@ -509,8 +564,9 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
     // the block's combined coefficients, parked in LDS behind the table (lane k stages entry k)
     constexpr int WCL = 3 * (SFAR_P + 1);
     double2* wc = ltab + nkeys + wv * WCL;
-    if ((threadIdx.x & 63) <= SFAR_P)
-        sfar_combine(wc, threadIdx.x & 63, c1 + g * SFAR_NCOEF, c2 + g * SFAR_NCOEF, c3 + g * SFAR_NCOEF, 1);
+    if (FAR && (threadIdx.x & 63) <= SFAR_P)
+        sfar_combine<ALL>(wc, threadIdx.x & 63, c1 + g * SFAR_NCOEF, c2 + g * SFAR_NCOEF, c3 + g * SFAR_NCOEF,
+                          c4 + g * SFAR_NCOEF, c5 + g * SFAR_NCOEF, c6 + g * SFAR_NCOEF, head[g * SFAR_HDR + 2], 1);
     __builtin_amdgcn_wave_barrier();
     double xs[4], ys[4];
 #pragma unroll
@@ -519,9 +575,11 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
         ys[a] = pxy[(int64_t)(4 + a) * np + t] * s1;
     }
     StokesAcc acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = StokesAcc{0.0, 0.0, 0.0, 0.0, 0.0};
     // far sources first: the block's expansion values are the accumulators' starting values (the parent's
     // expansion is added by stokes_far_parent_kernel afterwards: this kernel is at its register limit)
-    {
+    if (FAR) {
         const double* h = head + g * SFAR_HDR;
         const double cx = h[0], cy = h[1], rinv = h[2];
         const double2* W = wc;
@@ -574,32 +632,63 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
 #pragma unroll
             for (int u = 0; u < IPDE_SRC_PAD; ++u) {
                 const double sx = row[u], sy = row[IPDE_SRC_PAD + u];
-                const double fx = row[2 * IPDE_SRC_PAD + u], fy = row[3 * IPDE_SRC_PAD + u];
-                double dy[4], dy2[4], fydy[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    dy[b] = ys[b] - sy;
-                    dy2[b] = dy[b] * dy[b];
-                    fydy[b] = fy * dy[b];
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const double dx = xs[a] - sx;
-                    const double dx2 = dx * dx, fxdx = fx * dx;
+                if (MODE == MODE_SLP) {
+                    const double fx = row[2 * IPDE_SRC_PAD + u], fy = row[3 * IPDE_SRC_PAD + u];
+                    double dy[4], dy2[4], fydy[4];
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const double d2 = dx2 + dy2[b];
-                        const double2 e = ta.lookup(ltab, d2);
-                        const double yy = tab_y(d2, e.x);
-                        const double ri = rcp_from_y_fast(e.x, yy);
-                        const double L = log_from_y(yy, e.y);
-                        const double tt = (fxdx + fydy[b]) * ri;
-                        StokesAcc& A = acc[4 * a + b];
-                        A.uL = fma(fx, L, A.uL);
-                        A.vL = fma(fy, L, A.vL);
-                        A.u = fma(tt, dx, A.u);
-                        A.v = fma(tt, dy[b], A.v);
-                        A.p += tt;
+                        dy[b] = ys[b] - sy;
+                        dy2[b] = dy[b] * dy[b];
+                        fydy[b] = fy * dy[b];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const double dx = xs[a] - sx;
+                        const double dx2 = dx * dx, fxdx = fx * dx;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const double d2 = dx2 + dy2[b];
+                            const double2 e = ta.lookup(ltab, d2);
+                            const double yy = tab_y(d2, e.x);
+                            const double ri = rcp_from_y_fast(e.x, yy);
+                            const double L = log_from_y(yy, e.y);
+                            const double tt = (fxdx + fydy[b]) * ri;
+                            StokesAcc& A = acc[4 * a + b];
+                            A.uL = fma(fx, L, A.uL);
+                            A.vL = fma(fy, L, A.vL);
+                            A.u = fma(tt, dx, A.u);
+                            A.v = fma(tt, dy[b], A.v);
+                            A.p += tt;
+                        }
+                    }
+                } else {
+                    // stresslet: w = (d.n)(d.g') / d2^2;  u += w dx, v += w dy, p/2 += w - (n.g') / (2 d2)
+                    const double gx = row[4 * IPDE_SRC_PAD + u], gy = row[5 * IPDE_SRC_PAD + u];
+                    const double nx = row[6 * IPDE_SRC_PAD + u], ny = row[7 * IPDE_SRC_PAD + u];
+                    const double hng = -0.5 * row[8 * IPDE_SRC_PAD + u];
+                    double dy[4], dy2[4], nydy[4], gydy[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        dy[b] = ys[b] - sy;
+                        dy2[b] = dy[b] * dy[b];
+                        nydy[b] = ny * dy[b];
+                        gydy[b] = gy * dy[b];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const double dx = xs[a] - sx;
+                        const double dx2 = dx * dx, nxdx = nx * dx, gxdx = gx * dx;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const double d2 = dx2 + dy2[b];
+                            const double2 e = ta.lookup(ltab, d2);
+                            const double ri = rcp_from_y_fast(e.x, tab_y(d2, e.x));
+                            const double w = (nxdx + nydy[b]) * (gxdx + gydy[b]) * (ri * ri);
+                            StokesAcc& A = acc[4 * a + b];
+                            A.u = fma(w, dx, A.u);
+                            A.v = fma(w, dy[b], A.v);
+                            A.p += fma(hng, ri, w);
+                        }
                     }
                 }
             }
@@ -607,8 +696,10 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
     }
     if (!ta.all_inside(key_lo) || prm->pad) {
         // a near pair of this patch left the table (or the scaling failed: then nothing is in an
-        // expansion): all sources of its targets again with the generic math — all but the batches the
-        // parent block took (stokes_far_parent_kernel adds those to whatever is stored here)
+        // expansion): all sources of its targets again with the generic math, every layer of the apply — all
+        // but the batches the parent block took (stokes_far_parent_kernel adds those to whatever is stored
+        // here).  The launch that only adds near pairs sees the same misses (same pairs, same table) and then
+        // adds nothing: the storing launch has recomputed everything.
         const unsigned* tk = taken + (g >> 4) * nch;
         const int nbatch = ns_pad / IPDE_SRC_PAD;
 #pragma unroll
@@ -617,13 +708,15 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
             StokesAcc gs[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) gs[b] = StokesAcc{0, 0, 0, 0, 0};
-            for (int c = 0; c < nch; ++c) {
-                unsigned m = ~tk[c] & 0xFFu;
-                while (m) {
-                    const int bt = __builtin_ctz(m);
-                    m &= m - 1;
-                    if (8 * c + bt < nbatch)
-                        stokes_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, xa, ys, gs);
+            if (FAR) {
+                for (int c = 0; c < nch; ++c) {
+                    unsigned m = ~tk[c] & 0xFFu;
+                    while (m) {
+                        const int bt = __builtin_ctz(m);
+                        m &= m - 1;
+                        if (8 * c + bt < nbatch)
+                            stokes_generic_loop<ALL, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, xa, ys, gs);
+                    }
                 }
             }
 #pragma unroll
@@ -631,21 +724,28 @@ __global__ __launch_bounds__(NT) void stokes_patch_far_kernel(
         }
     }
     if (lane >= np) return;
-    const double cu = prm->corr, cv = prm->corr2;
+    const double cu = (ALL & MODE_SLP) ? prm->corr : 0.0, cv = (ALL & MODE_SLP) ? prm->corr2 : 0.0;
     const double ps = 2.0 * s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = pout[(int64_t)r * np + t];
         if (i >= 0) {
-            ou[i] = fma(-0.5, acc[r].uL + cu, acc[r].u);
-            ov[i] = fma(-0.5, acc[r].vL + cv, acc[r].v);
-            if (op) op[i] = ps * acc[r].p;
+            if (FAR) {
+                ou[i] = fma(-0.5, acc[r].uL + cu, acc[r].u);
+                ov[i] = fma(-0.5, acc[r].vL + cv, acc[r].v);
+                if (op) op[i] = ps * acc[r].p;
+            } else {
+                ou[i] += fma(-0.5, acc[r].uL, acc[r].u);
+                ov[i] += fma(-0.5, acc[r].vL, acc[r].v);
+                if (op) op[i] += ps * acc[r].p;
+            }
         }
     }
 }
 
 // The parent blocks' expansions added to the stored values (one lane per patch, all of the parent's
 // sixteen blocks read the same 3 x 27 combined coefficients: staged in LDS by the workgroup = one parent).
+template <int ALL>
 __global__ __launch_bounds__(1024) void stokes_far_parent_kernel(const double* __restrict__ pxy, int64_t np,
                                                                  const int* __restrict__ pout, double* __restrict__ ou,
                                                                  double* __restrict__ ov, double* __restrict__ op,
@@ -653,13 +753,18 @@ __global__ __launch_bounds__(1024) void stokes_far_parent_kernel(const double* _
                                                                  const double* __restrict__ head2,
                                                                  const double* __restrict__ p1,
                                                                  const double* __restrict__ p2,
-                                                                 const double* __restrict__ p3, int nslice) {
+                                                                 const double* __restrict__ p3,
+                                                                 const double* __restrict__ p4,
+                                                                 const double* __restrict__ p5,
+                                                                 const double* __restrict__ p6, int nslice) {
     constexpr int WCL = 3 * (SFAR_P + 1);
     __shared__ double2 W[WCL];
     const int64_t par = blockIdx.x;                    // patches [1024 par, 1024 par + 1024)
-    if (threadIdx.x <= SFAR_P)
-        sfar_combine(W, threadIdx.x, p1 + par * nslice * SFAR_NCOEF, p2 + par * nslice * SFAR_NCOEF,
-                     p3 + par * nslice * SFAR_NCOEF, nslice);
+    if (threadIdx.x <= SFAR_P) {
+        const size_t o = (size_t)par * nslice * SFAR_NCOEF;
+        sfar_combine<ALL>(W, threadIdx.x, p1 + o, p2 + o, p3 + o, p4 + o, p5 + o, p6 + o, head2[par * SFAR_HDR + 2],
+                          nslice);
+    }
     __syncthreads();
     const int64_t t = par * 1024 + threadIdx.x;
     if (t >= np || prm->pad) return;
@@ -734,13 +839,15 @@ __global__ __launch_bounds__(256) void stokes_columns_as_patches_kernel(const do
     }
 }
 
-template <int NT>
+// ALL: the layers of the apply (both near bodies in one launch here: four targets per lane leave the room)
+template <int NT, int ALL>
 __global__ __launch_bounds__(NT) void stokes_cols_far_kernel(
     const double* __restrict__ rec, int ns_pad, const double* __restrict__ tx, const double* __restrict__ ty, int M,
     int64_t N, double* __restrict__ ou, double* __restrict__ ov, double* __restrict__ op,
     const ApplyParams* __restrict__ prm, const double2* __restrict__ gtab, unsigned key_lo, unsigned nkeys,
     const double* __restrict__ head, const double* __restrict__ c1, const double* __restrict__ c2,
-    const double* __restrict__ c3, int nslice, const unsigned* __restrict__ near, int nch) {
+    const double* __restrict__ c3, const double* __restrict__ c4, const double* __restrict__ c5,
+    const double* __restrict__ c6, int nslice, const unsigned* __restrict__ near, int nch) {
     extern __shared__ double2 ltab[];
     for (unsigned i = threadIdx.x; i < nkeys; i += NT) ltab[i] = gtab[i];
     __syncthreads();
@@ -753,9 +860,10 @@ __global__ __launch_bounds__(NT) void stokes_cols_far_kernel(
     if (g * 64 >= N) return;                           // (whole waves, after the only barrier)
     constexpr int WCL = 3 * (SFAR_P + 1);
     double2* W = ltab + nkeys + wv * WCL;
-    if (ln <= SFAR_P)
-        sfar_combine(W, ln, c1 + g * nslice * SFAR_NCOEF, c2 + g * nslice * SFAR_NCOEF, c3 + g * nslice * SFAR_NCOEF,
-                     nslice);
+    if (ln <= SFAR_P) {
+        const size_t o = (size_t)g * nslice * SFAR_NCOEF;
+        sfar_combine<ALL>(W, ln, c1 + o, c2 + o, c3 + o, c4 + o, c5 + o, c6 + o, head[g * SFAR_HDR + 2], nslice);
+    }
     __builtin_amdgcn_wave_barrier();
     const double* h = head + g * SFAR_HDR;
     const double cx = h[0], cy = h[1], rinv = h[2];
@@ -819,8 +927,17 @@ __global__ __launch_bounds__(NT) void stokes_cols_far_kernel(
 #pragma unroll
             for (int u = 0; u < IPDE_SRC_PAD; ++u) {
                 StokesSrc sr{};
-                sr.fx = row[2 * IPDE_SRC_PAD + u];
-                sr.fy = row[3 * IPDE_SRC_PAD + u];
+                if (ALL & MODE_SLP) {
+                    sr.fx = row[2 * IPDE_SRC_PAD + u];
+                    sr.fy = row[3 * IPDE_SRC_PAD + u];
+                }
+                if (ALL & MODE_DLP) {
+                    sr.gx = row[4 * IPDE_SRC_PAD + u];
+                    sr.gy = row[5 * IPDE_SRC_PAD + u];
+                    sr.nx = row[6 * IPDE_SRC_PAD + u];
+                    sr.ny = row[7 * IPDE_SRC_PAD + u];
+                    sr.ng = row[8 * IPDE_SRC_PAD + u];
+                }
                 const double sxu = row[u], syu = row[IPDE_SRC_PAD + u];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -828,7 +945,8 @@ __global__ __launch_bounds__(NT) void stokes_cols_far_kernel(
                     const double d2 = fma(dy, dy, dx * dx);
                     const double2 e = ta.lookup(ltab, d2);
                     const double yy = tab_y(d2, e.x);
-                    stokes_pair<MODE_SLP>(dx, dy, log_from_y(yy, e.y), rcp_from_y_fast(e.x, yy), sr, acc[i]);
+                    stokes_pair<ALL>(dx, dy, (ALL & MODE_SLP) ? log_from_y(yy, e.y) : 0.0, rcp_from_y_fast(e.x, yy), sr,
+                                     acc[i]);
                 }
             }
         }
@@ -838,14 +956,14 @@ __global__ __launch_bounds__(NT) void stokes_cols_far_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) gs[i] = StokesAcc{0, 0, 0, 0, 0};
         if (prm->pad) {
-            stokes_generic_loop<MODE_SLP, false, 4>(rec, 0, ns_pad, x, y, gs);
+            stokes_generic_loop<ALL, false, 4>(rec, 0, ns_pad, x, y, gs);
         } else {
             for (int c = 0; c < nch; ++c) {
                 unsigned m = nm[c];
                 while (m) {
                     const int bt = __builtin_ctz(m);
                     m &= m - 1;
-                    stokes_generic_loop<MODE_SLP, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, x, y, gs);
+                    stokes_generic_loop<ALL, false, 4>(rec, 8 * (8 * c + bt), 8 * (8 * c + bt) + 8, x, y, gs);
                 }
             }
         }
@@ -853,7 +971,7 @@ __global__ __launch_bounds__(NT) void stokes_cols_far_kernel(
         for (int i = 0; i < 4; ++i) acc[i] = gs[i];
     }
     if (j < N) {
-        const double cu = prm->corr, cv = prm->corr2;
+        const double cu = (ALL & MODE_SLP) ? prm->corr : 0.0, cv = (ALL & MODE_SLP) ? prm->corr2 : 0.0;
         const double ps = 2.0 * s1;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -866,6 +984,8 @@ __global__ __launch_bounds__(NT) void stokes_cols_far_kernel(
     }
 }
 
+// ALL: MODE_SLP, MODE_DLP or both (the densities present in the records)
+template <int ALL>
 int launch_stokes_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, const double* pxy, int64_t np,
                               const int* pout, double* ou, double* ov, double* op, const ApplyParams* prm) {
     constexpr int NT = 512;
@@ -875,46 +995,74 @@ int launch_stokes_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, cons
     const int64_t ng = ceil_div64(np, 64);
     const int64_t ng2 = ceil_div64(ng, 16);
     const int nch = (int)ceil_div64(ns_pad, 64);
-    const size_t nd = (size_t)ng * (SFAR_HDR + 3 * SFAR_NCOEF) + (size_t)ng2 * (SFAR_HDR + 3 * NSL * SFAR_NCOEF);
+    // block families 1..6 (stokeslet X1, X2, X3; stresslet Y1, Y2, Y4), the same per parent and source slice
+    const size_t nd = (size_t)ng * (SFAR_HDR + 6 * SFAR_NCOEF) + (size_t)ng2 * (SFAR_HDR + 6 * NSL * SFAR_NCOEF);
     IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial,
                                  nd * sizeof(double) + (size_t)(ng + ng2) * nch * sizeof(unsigned)));
     double* head = (double*)ctx->partial.p;
-    double* c1 = head + (size_t)ng * SFAR_HDR;
-    double* c2 = c1 + (size_t)ng * SFAR_NCOEF;
-    double* c3 = c2 + (size_t)ng * SFAR_NCOEF;
-    double* head2 = c3 + (size_t)ng * SFAR_NCOEF;
-    double* p1 = head2 + (size_t)ng2 * SFAR_HDR;
-    double* p2 = p1 + (size_t)ng2 * NSL * SFAR_NCOEF;
-    double* p3 = p2 + (size_t)ng2 * NSL * SFAR_NCOEF;
-    unsigned* near = (unsigned*)(p3 + (size_t)ng2 * NSL * SFAR_NCOEF);
+    double* c[6];
+    c[0] = head + (size_t)ng * SFAR_HDR;
+    for (int f = 1; f < 6; ++f) c[f] = c[f - 1] + (size_t)ng * SFAR_NCOEF;
+    double* head2 = c[5] + (size_t)ng * SFAR_NCOEF;
+    double* q[6];
+    q[0] = head2 + (size_t)ng2 * SFAR_HDR;
+    for (int f = 1; f < 6; ++f) q[f] = q[f - 1] + (size_t)ng2 * NSL * SFAR_NCOEF;
+    unsigned* near = (unsigned*)(q[5] + (size_t)ng2 * NSL * SFAR_NCOEF);
     unsigned* taken = near + (size_t)ng * nch;
     const unsigned gb = (unsigned)ceil_div64(ng, 4), gb2 = (unsigned)ceil_div64(ng2 * NSL, 4);
     const unsigned* none = nullptr;
     ipde_time_begin(ctx);
-    hipLaunchKernelGGL((stokes_far_coeff_kernel<1, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
-                       head2, p1, taken, nch, none, NSL);
-    hipLaunchKernelGGL((stokes_far_coeff_kernel<2, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
-                       head2, p2, taken, nch, none, NSL);
-    hipLaunchKernelGGL((stokes_far_coeff_kernel<3, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
-                       head2, p3, taken, nch, none, NSL);
-    hipLaunchKernelGGL((stokes_far_coeff_kernel<1, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
-                       head, c1, near, nch, (const unsigned*)taken, 1);
-    hipLaunchKernelGGL((stokes_far_coeff_kernel<2, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
-                       head, c2, near, nch, (const unsigned*)taken, 1);
-    hipLaunchKernelGGL((stokes_far_coeff_kernel<3, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, prm,
-                       head, c3, near, nch, (const unsigned*)taken, 1);
+    // parents first (their bits steer the blocks' pass); the first family of the apply writes headers and bits
+    constexpr int L1 = (ALL & MODE_SLP) ? 1 : 0;
+#define SFAR_PARENT(WHICH, F, LEAD)                                                                                    \
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<WHICH, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np, \
+                       prm, head2, q[F], taken, nch, none, NSL, LEAD)
+#define SFAR_BLOCK(WHICH, F, LEAD)                                                                                     \
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<WHICH, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad, pxy, np,   \
+                       prm, head, c[F], near, nch, (const unsigned*)taken, 1, LEAD)
+    if (ALL & MODE_SLP) {
+        SFAR_PARENT(1, 0, 1);
+        SFAR_PARENT(2, 1, 0);
+        SFAR_PARENT(3, 2, 0);
+    }
+    if (ALL & MODE_DLP) {
+        SFAR_PARENT(4, 3, 1 - L1);
+        SFAR_PARENT(5, 4, 0);
+        SFAR_PARENT(6, 5, 0);
+    }
+    if (ALL & MODE_SLP) {
+        SFAR_BLOCK(1, 0, 1);
+        SFAR_BLOCK(2, 1, 0);
+        SFAR_BLOCK(3, 2, 0);
+    }
+    if (ALL & MODE_DLP) {
+        SFAR_BLOCK(4, 3, 1 - L1);
+        SFAR_BLOCK(5, 4, 0);
+        SFAR_BLOCK(6, 5, 0);
+    }
+#undef SFAR_PARENT
+#undef SFAR_BLOCK
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     // the table, then 27 x 3 combined coefficients for each of the workgroup's waves
     const size_t lds = ((size_t)lt.nkeys + (size_t)(NT / 64) * 3 * (SFAR_P + 1)) * sizeof(double2);
-    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stokes_patch_far_kernel<NT>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((stokes_patch_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds,
-                       ctx->stream, rec, ns_pad, pxy, np, pout, ou, ov, op, prm, (const double2*)lt.d_tab,
-                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)c1,
-                       (const double*)c2, (const double*)c3, (const unsigned*)near, nch, (const unsigned*)taken);
-    hipLaunchKernelGGL(stokes_far_parent_kernel, dim3((unsigned)ng2), dim3(1024), 0, ctx->stream, pxy, np, pout, ou,
-                       ov, op, prm, (const double*)head2, (const double*)p1, (const double*)p2, (const double*)p3,
-                       NSL);
+    auto patches = [&](auto kern) -> int {
+        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div64(64 * ng, NT)), dim3(NT), lds, ctx->stream, rec, ns_pad, pxy, np,
+                           pout, ou, ov, op, prm, (const double2*)lt.d_tab, (unsigned)lt.key_lo, (unsigned)lt.nkeys,
+                           (const double*)head, (const double*)c[0], (const double*)c[1], (const double*)c[2],
+                           (const double*)c[3], (const double*)c[4], (const double*)c[5], (const unsigned*)near, nch,
+                           (const unsigned*)taken);
+        return IPDE_OK;
+    };
+    if (ALL & MODE_SLP) {
+        IPDE_TRY(patches(stokes_patch_far_kernel<NT, MODE_SLP, ALL, true>));
+        if (ALL & MODE_DLP) IPDE_TRY(patches(stokes_patch_far_kernel<NT, MODE_DLP, ALL, false>));
+    } else {
+        IPDE_TRY(patches(stokes_patch_far_kernel<NT, MODE_DLP, ALL, true>));
+    }
+    hipLaunchKernelGGL(stokes_far_parent_kernel<ALL>, dim3((unsigned)ng2), dim3(1024), 0, ctx->stream, pxy, np, pout, ou,
+                       ov, op, prm, (const double*)head2, (const double*)q[0], (const double*)q[1], (const double*)q[2],
+                       (const double*)q[3], (const double*)q[4], (const double*)q[5], NSL);
     ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
@@ -1066,98 +1214,139 @@ extern "C" int ipde_stokes_apply(ipde_ctx* ctx, int loc, int64_t ns, const doubl
     return IPDE_OK;
 }
 
-// Stokeslet sums (with pressure) onto a patch list whose 64-patch groups are 8 x 8 blocks of tiles
+// the records of an apply (see the head of the file)
+static void stokes_pack_args(ipde_ctx* ctx, PackArgs& pa, const double* sx, const double* sy, const double* wfx,
+                             const double* wfy, const double* nx, const double* ny, const double* wdx,
+                             const double* wdy) {
+    const bool slp = wfx && wfy, dlp = wdx && wdy;
+    pa.sx = sx;
+    pa.sy = sy;
+    pa.ch[0] = slp ? wfx : nullptr;
+    pa.mul[0] = 0.25 / M_PI;
+    pa.ch[1] = slp ? wfy : nullptr;
+    pa.mul[1] = 0.25 / M_PI;
+    pa.ch[2] = dlp ? wdx : nullptr;
+    pa.mul[2] = 1.0 / M_PI;
+    pa.pw[2] = 1;
+    pa.ch[3] = dlp ? wdy : nullptr;
+    pa.mul[3] = 1.0 / M_PI;
+    pa.pw[3] = 1;
+    pa.ch[4] = dlp ? nx : nullptr;
+    pa.mul[4] = 1.0;
+    pa.ch[5] = dlp ? ny : nullptr;
+    pa.mul[5] = 1.0;
+    pa.stokes_ng = dlp ? 1 : 0;
+    pa.corr_ch = slp ? 0 : -1;
+    pa.corr2_ch = slp ? 1 : -1;
+    pa.use_scale = 1;
+    pa.exp_hi = ctx->logtab.exp_hi;
+}
+
+// Stokeslet and / or stresslet sums (with pressure) onto a patch list whose 64-patch groups are 8 x 8 blocks of tiles
 // (ipde_target_plan_build_blocks, pad_blocks = 1): far sources block by block in local expansions.
 extern "C" int ipde_stokes_apply_patches_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
-                                             const double* wfx, const double* wfy, int64_t np,
+                                             const double* wfx, const double* wfy, const double* nx,
+                                             const double* ny, const double* wdx, const double* wdy, int64_t np,
                                              const double* pxy, const int32_t* pout, double* out_u,
                                              double* out_v, double* out_p) {
     if (!ctx) return IPDE_ERR_INVALID;
     IPDE_CHECK_ARG(ctx, ns >= 0 && np >= 0 && ns < (1LL << 30) && np < (1LL << 27));
+    const bool slp = wfx != nullptr && wfy != nullptr, dlp = wdx != nullptr && wdy != nullptr;
+    IPDE_CHECK_ARG(ctx, (wfx == nullptr) == (wfy == nullptr));
+    IPDE_CHECK_ARG(ctx, (wdx == nullptr) == (wdy == nullptr));
+    IPDE_CHECK_ARG(ctx, slp || dlp);
+    IPDE_CHECK_ARG(ctx, !dlp || (nx != nullptr && ny != nullptr));
     if (np == 0) return IPDE_OK;
     IPDE_CHECK_ARG(ctx, pxy && pout && out_u && out_v);
-    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && wfx && wfy);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy);
     IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     PackArgs pa{};
-    pa.sx = sx;
-    pa.sy = sy;
-    pa.ch[0] = wfx;
-    pa.mul[0] = 0.25 / M_PI;
-    pa.ch[1] = wfy;
-    pa.mul[1] = 0.25 / M_PI;
-    pa.stokes_ng = 0;
-    pa.corr_ch = 0;
-    pa.corr2_ch = 1;
-    pa.use_scale = 1;
-    pa.exp_hi = ctx->logtab.exp_hi;
+    stokes_pack_args(ctx, pa, sx, sy, wfx, wfy, nx, ny, wdx, wdy);
     const double* rec;
     const ApplyParams* prm;
     IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, pxy, pxy + 4 * np, 4 * np, &rec, &prm));
-    return launch_stokes_patches_far(ctx, rec, ns, pxy, np, pout, out_u, out_v, out_p, prm);
+    if (slp && dlp) return launch_stokes_patches_far<3>(ctx, rec, ns, pxy, np, pout, out_u, out_v, out_p, prm);
+    if (slp) return launch_stokes_patches_far<MODE_SLP>(ctx, rec, ns, pxy, np, pout, out_u, out_v, out_p, prm);
+    return launch_stokes_patches_far<MODE_DLP>(ctx, rec, ns, pxy, np, pout, out_u, out_v, out_p, prm);
 }
 
-// Stokeslet sums (with pressure when out_p != NULL) onto an (M, N) radial grid (row-major DEVICE arrays;
-// column j = one radial line): the radial sums of the Stokes helpers' correct()
-// (reference ipde/solvers/internals/vector.py:140-162) with the far sources of every block of 64 lines in
-// local expansions.
-extern "C" int ipde_stokes_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
-                                             const double* wfx, const double* wfy, int M, int64_t N,
-                                             const double* tx, const double* ty, double* out_u, double* out_v,
-                                             double* out_p) {
-    if (!ctx) return IPDE_ERR_INVALID;
-    IPDE_CHECK_ARG(ctx, ns >= 0 && N >= 0 && M >= 1 && ns < (1LL << 30) && N < (1LL << 30) && (int64_t)M * N < (1LL << 40));
-    if (N == 0) return IPDE_OK;
-    IPDE_CHECK_ARG(ctx, tx && ty && out_u && out_v);
-    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy && wfx && wfy);
-    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    PackArgs pa{};
-    pa.sx = sx;
-    pa.sy = sy;
-    pa.ch[0] = wfx;
-    pa.mul[0] = 0.25 / M_PI;
-    pa.ch[1] = wfy;
-    pa.mul[1] = 0.25 / M_PI;
-    pa.stokes_ng = 0;
-    pa.corr_ch = 0;
-    pa.corr2_ch = 1;
-    pa.use_scale = 1;
-    pa.exp_hi = ctx->logtab.exp_hi;
-    const double* rec;
-    const ApplyParams* prm;
-    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, tx, ty, (int64_t)M * N, &rec, &prm));
+template <int ALL>
+static int launch_stokes_columns_far(ipde_ctx* ctx, const double* rec, int64_t ns, int M, int64_t N, const double* tx,
+                                     const double* ty, double* out_u, double* out_v, double* out_p,
+                                     const ApplyParams* prm) {
     constexpr int NT = 256, NSL = 8;
     const LogTable& lt = ctx->logtab;
     const int ns_pad = (int)(ceil_div64(ns, IPDE_SRC_PAD) * IPDE_SRC_PAD);
     const int64_t ng = ceil_div64(N, 64);
     const int nch = (int)ceil_div64(ns_pad, 64);
-    const size_t nd = (size_t)8 * N + (size_t)ng * (SFAR_HDR + 3 * NSL * SFAR_NCOEF);
+    const size_t nd = (size_t)8 * N + (size_t)ng * (SFAR_HDR + 6 * NSL * SFAR_NCOEF);
     IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->partial, nd * sizeof(double) + (size_t)ng * nch * sizeof(unsigned)));
     double* pxy = (double*)ctx->partial.p;
     double* head = pxy + (size_t)8 * N;
-    double* c1 = head + (size_t)ng * SFAR_HDR;
-    double* c2 = c1 + (size_t)ng * NSL * SFAR_NCOEF;
-    double* c3 = c2 + (size_t)ng * NSL * SFAR_NCOEF;
-    unsigned* near = (unsigned*)(c3 + (size_t)ng * NSL * SFAR_NCOEF);
+    double* c[6];
+    c[0] = head + (size_t)ng * SFAR_HDR;
+    for (int f = 1; f < 6; ++f) c[f] = c[f - 1] + (size_t)ng * NSL * SFAR_NCOEF;
+    unsigned* near = (unsigned*)(c[5] + (size_t)ng * NSL * SFAR_NCOEF);
     const unsigned gb = (unsigned)ceil_div64(ng * NSL, 4);
     const unsigned* none = nullptr;
     ipde_time_begin(ctx);
     hipLaunchKernelGGL(stokes_columns_as_patches_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, ctx->stream,
                        tx, ty, M, N, pxy);
-    hipLaunchKernelGGL((stokes_far_coeff_kernel<1, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
-                       (const double*)pxy, N, prm, head, c1, near, nch, none, NSL);
-    hipLaunchKernelGGL((stokes_far_coeff_kernel<2, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
-                       (const double*)pxy, N, prm, head, c2, near, nch, none, NSL);
-    hipLaunchKernelGGL((stokes_far_coeff_kernel<3, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
-                       (const double*)pxy, N, prm, head, c3, near, nch, none, NSL);
+    constexpr int L1 = (ALL & MODE_SLP) ? 1 : 0;
+#define SFAR_COLS(WHICH, F, LEAD)                                                                                  \
+    hipLaunchKernelGGL((stokes_far_coeff_kernel<WHICH, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,          \
+                       (const double*)pxy, N, prm, head, c[F], near, nch, none, NSL, LEAD)
+    if (ALL & MODE_SLP) {
+        SFAR_COLS(1, 0, 1);
+        SFAR_COLS(2, 1, 0);
+        SFAR_COLS(3, 2, 0);
+    }
+    if (ALL & MODE_DLP) {
+        SFAR_COLS(4, 3, 1 - L1);
+        SFAR_COLS(5, 4, 0);
+        SFAR_COLS(6, 5, 0);
+    }
+#undef SFAR_COLS
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     const size_t lds = ((size_t)lt.nkeys + (size_t)(NT / 64) * 3 * (SFAR_P + 1)) * sizeof(double2);
-    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stokes_cols_far_kernel<NT>,
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stokes_cols_far_kernel<NT, ALL>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((stokes_cols_far_kernel<NT>), dim3((unsigned)ceil_div64(64 * ng * ((M + 3) / 4), NT)), dim3(NT),
+    hipLaunchKernelGGL((stokes_cols_far_kernel<NT, ALL>), dim3((unsigned)ceil_div64(64 * ng * ((M + 3) / 4), NT)), dim3(NT),
                        lds, ctx->stream, rec, ns_pad, tx, ty, M, N, out_u, out_v, out_p, prm, (const double2*)lt.d_tab,
-                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)c1,
-                       (const double*)c2, (const double*)c3, NSL, (const unsigned*)near, nch);
+                       (unsigned)lt.key_lo, (unsigned)lt.nkeys, (const double*)head, (const double*)c[0],
+                       (const double*)c[1], (const double*)c[2], (const double*)c[3], (const double*)c[4],
+                       (const double*)c[5], NSL, (const unsigned*)near, nch);
     ipde_time_end(ctx);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
+}
+
+// Stokeslet and / or stresslet sums (with pressure when out_p != NULL) onto an (M, N) radial grid (row-major DEVICE
+// arrays; column j = one radial line): the radial sums of the Stokes helpers' correct()
+// (reference ipde/solvers/internals/vector.py:140-162) with the far sources of every block of 64 lines in
+// local expansions.
+extern "C" int ipde_stokes_apply_columns_far(ipde_ctx* ctx, int64_t ns, const double* sx, const double* sy,
+                                             const double* wfx, const double* wfy, const double* nx,
+                                             const double* ny, const double* wdx, const double* wdy, int M,
+                                             int64_t N, const double* tx, const double* ty, double* out_u,
+                                             double* out_v, double* out_p) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, ns >= 0 && N >= 0 && M >= 1 && ns < (1LL << 30) && N < (1LL << 30) && (int64_t)M * N < (1LL << 40));
+    const bool slp = wfx != nullptr && wfy != nullptr, dlp = wdx != nullptr && wdy != nullptr;
+    IPDE_CHECK_ARG(ctx, (wfx == nullptr) == (wfy == nullptr));
+    IPDE_CHECK_ARG(ctx, (wdx == nullptr) == (wdy == nullptr));
+    IPDE_CHECK_ARG(ctx, slp || dlp);
+    IPDE_CHECK_ARG(ctx, !dlp || (nx != nullptr && ny != nullptr));
+    if (N == 0) return IPDE_OK;
+    IPDE_CHECK_ARG(ctx, tx && ty && out_u && out_v);
+    IPDE_CHECK_ARG(ctx, ns > 0 && sx && sy);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    PackArgs pa{};
+    stokes_pack_args(ctx, pa, sx, sy, wfx, wfy, nx, ny, wdx, wdy);
+    const double* rec;
+    const ApplyParams* prm;
+    IPDE_TRY(ipde_layer_prepare(ctx, pa, ns, tx, ty, (int64_t)M * N, &rec, &prm));
+    if (slp && dlp) return launch_stokes_columns_far<3>(ctx, rec, ns, M, N, tx, ty, out_u, out_v, out_p, prm);
+    if (slp) return launch_stokes_columns_far<MODE_SLP>(ctx, rec, ns, M, N, tx, ty, out_u, out_v, out_p, prm);
+    return launch_stokes_columns_far<MODE_DLP>(ctx, rec, ns, M, N, tx, ty, out_u, out_v, out_p, prm);
 }

@@ -340,15 +340,18 @@ def Laplace_Layer_Apply(source, target=None, charge=None, dipstr=None, backend=N
                                          ny=None if dipstr is None else src.normal_y,
                                          w_tau=_weighted(dipstr, src.weights), ctx=target.ctx,
                                          far=target.far and plan.padded_blocks)
-    if dipstr is None and not self_eval and isinstance(target, DeviceTargets) and target.columns is not None \
+    if not self_eval and isinstance(target, DeviceTargets) and target.columns is not None \
             and target.columns[1] >= COLUMNS_FAR_MIN:
         # a radial grid: blocks of 64 radial lines, far sources in the blocks' local expansions
         ctx = target.ctx
         M, N = target.columns
-        sxd, syd, wd = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (src.x, src.y, _weighted(charge, src.weights)))
+        sxd, syd, wd, nxd, nyd, td = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (
+            src.x, src.y, _weighted(charge, src.weights), None if dipstr is None else src.normal_x,
+            None if dipstr is None else src.normal_y, _weighted(dipstr, src.weights)))
         out = torch.empty(target.N, dtype=torch.float64, device=target.x.device)
-        ctx.check(ctx.lib.ipde_laplace_apply_columns_far(ctx.handle, int(sxd.shape[0]), ptr(sxd), ptr(syd), ptr(wd), M,
-                                                         N, ptr(target.x), ptr(target.y), ptr(out)))
+        ctx.check(ctx.lib.ipde_laplace_apply_columns_far(ctx.handle, int(sxd.shape[0]), ptr(sxd), ptr(syd), ptr(wd),
+                                                         ptr(nxd), ptr(nyd), ptr(td), M, N, ptr(target.x),
+                                                         ptr(target.y), ptr(out)))
         return out
     return laplace_apply(src.x, src.y, tx, ty,
                          w_sigma=_weighted(charge, src.weights),
@@ -370,20 +373,26 @@ def Modified_Helmholtz_Layer_Apply(source, target=None, k=1.0, charge=None, dips
     if charge is None and dipstr is None:
         raise ValueError("need a charge and/or a dipstr density")
     src = _source_side(source, trg)
-    if dipstr is None and not self_eval and isinstance(target, DeviceTargets) and target.far:
+    if not self_eval and isinstance(target, DeviceTargets) and target.far:
         plan = target.plan()
         if plan is not None and plan.padded_blocks:      # far sources block by block in local expansions
             from . import target_plan
-            return target_plan.modhelm_apply(plan, k, src.x, src.y, _weighted(charge, src.weights), ctx=target.ctx)
-    if dipstr is None and not self_eval and isinstance(target, DeviceTargets) and target.columns is not None \
+            return target_plan.modhelm_apply(plan, k, src.x, src.y, w_sigma=_weighted(charge, src.weights),
+                                             nx=None if dipstr is None else src.normal_x,
+                                             ny=None if dipstr is None else src.normal_y,
+                                             w_tau=_weighted(dipstr, src.weights), ctx=target.ctx)
+    if not self_eval and isinstance(target, DeviceTargets) and target.columns is not None \
             and target.columns[1] >= COLUMNS_FAR_MIN:
         # a radial grid: blocks of 64 radial lines, far sources in the blocks' local expansions
         ctx = target.ctx
         M, N = target.columns
-        sxd, syd, wd = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (src.x, src.y, _weighted(charge, src.weights)))
+        sxd, syd, wd, nxd, nyd, td = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (
+            src.x, src.y, _weighted(charge, src.weights), None if dipstr is None else src.normal_x,
+            None if dipstr is None else src.normal_y, _weighted(dipstr, src.weights)))
         out = torch.empty(target.N, dtype=torch.float64, device=target.x.device)
         ctx.check(ctx.lib.ipde_modhelm_apply_columns_far(ctx.handle, float(k), int(sxd.shape[0]), ptr(sxd), ptr(syd),
-                                                         ptr(wd), M, N, ptr(target.x), ptr(target.y), ptr(out)))
+                                                         ptr(wd), ptr(nxd), ptr(nyd), ptr(td), M, N, ptr(target.x),
+                                                         ptr(target.y), ptr(out)))
         return out
     return modified_helmholtz_apply(src.x, src.y, tx, ty, k,
                                     w_sigma=_weighted(charge, src.weights),
@@ -407,24 +416,32 @@ def Stokes_Layer_Apply(source, target=None, forces=None, dipstr=None, pressure=T
     src = _source_side(source, trg)
     f = _weighted(forces, src.weights, rows=2)
     g = _weighted(dipstr, src.weights, rows=2)
-    if g is None and not self_eval and isinstance(target, DeviceTargets) and target.far:
+    if not self_eval and isinstance(target, DeviceTargets) and target.far:
         plan = target.plan()
         if plan is not None and plan.padded_blocks:      # far sources block by block in local expansions
             from . import target_plan
-            return target_plan.stokes_apply(plan, src.x, src.y, f[0], f[1], pressure=pressure, ctx=target.ctx)
-    if g is None and not self_eval and isinstance(target, DeviceTargets) and target.columns is not None \
+            return target_plan.stokes_apply(plan, src.x, src.y, wfx=None if f is None else f[0],
+                                            wfy=None if f is None else f[1],
+                                            nx=None if g is None else src.normal_x,
+                                            ny=None if g is None else src.normal_y,
+                                            wdx=None if g is None else g[0], wdy=None if g is None else g[1],
+                                            pressure=pressure, ctx=target.ctx)
+    if not self_eval and isinstance(target, DeviceTargets) and target.columns is not None \
             and target.columns[1] >= COLUMNS_FAR_MIN:
         # a radial grid: blocks of 64 radial lines, far sources in the blocks' local expansions
         ctx = target.ctx
         M, N = target.columns
-        sxd, syd, fxd, fyd = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (src.x, src.y, f[0], f[1]))
+        sxd, syd, fxd, fyd, nxd, nyd, gxd, gyd = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (
+            src.x, src.y, None if f is None else f[0], None if f is None else f[1],
+            None if g is None else src.normal_x, None if g is None else src.normal_y,
+            None if g is None else g[0], None if g is None else g[1]))
         dev = target.x.device
         u = torch.empty(target.N, dtype=torch.float64, device=dev)
         v = torch.empty(target.N, dtype=torch.float64, device=dev)
         p = torch.empty(target.N, dtype=torch.float64, device=dev) if pressure else None
         ctx.check(ctx.lib.ipde_stokes_apply_columns_far(ctx.handle, int(sxd.shape[0]), ptr(sxd), ptr(syd), ptr(fxd),
-                                                        ptr(fyd), M, N, ptr(target.x), ptr(target.y), ptr(u), ptr(v),
-                                                        ptr(p)))
+                                                        ptr(fyd), ptr(nxd), ptr(nyd), ptr(gxd), ptr(gyd), M, N,
+                                                        ptr(target.x), ptr(target.y), ptr(u), ptr(v), ptr(p)))
         return u, v, p
     return stokes_apply(src.x, src.y, tx, ty,
                         wfx=None if f is None else f[0], wfy=None if f is None else f[1],

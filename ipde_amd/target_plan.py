@@ -161,48 +161,50 @@ def laplace_apply(plan, sx, sy, w_sigma=None, nx=None, ny=None, w_tau=None, ctx=
     return out
 
 
-def stokes_apply(plan, sx, sy, wfx, wfy, pressure=True, ctx=None):
-    """Stokeslet sums (u, v, p) over a planned list with padded blocks: the patches through
+def stokes_apply(plan, sx, sy, wfx=None, wfy=None, nx=None, ny=None, wdx=None, wdy=None, pressure=True, ctx=None):
+    """Stokeslet and / or stresslet sums (u, v, p) over a planned list with padded blocks: the patches through
     ipde_stokes_apply_patches_far (every block's far sources in local expansions), the remainder
-    through ipde_stokes_apply.  Device tensors; wfx, wfy weight-multiplied."""
+    through ipde_stokes_apply.  Device tensors; wfx, wfy / wdx, wdy weight-multiplied."""
     from . import _lib
     from .layer_potentials import _match, stokes_apply as list_apply
     ctx = ctx or get_context()
     if not plan.padded_blocks:
         raise ValueError("the far-field form needs a plan built with pad_blocks=True")
-    sx, sy, wfx, wfy = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (sx, sy, wfx, wfy))
+    sx, sy, wfx, wfy, nx, ny, wdx, wdy = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (sx, sy, wfx, wfy, nx, ny, wdx, wdy))
     dev = plan.pxy.device
     u = torch.empty(plan.n, dtype=torch.float64, device=dev)
     v = torch.empty(plan.n, dtype=torch.float64, device=dev)
     p = torch.empty(plan.n, dtype=torch.float64, device=dev) if pressure else None
     if plan.nrest:
-        ru, rv, rp = list_apply(sx, sy, plan.rest_x, plan.rest_y, wfx=wfx, wfy=wfy, pressure=pressure, ctx=ctx)
+        ru, rv, rp = list_apply(sx, sy, plan.rest_x, plan.rest_y, wfx=wfx, wfy=wfy, nx=nx, ny=ny, wdx=wdx, wdy=wdy,
+                                pressure=pressure, ctx=ctx)
         u[plan.rest] = ru
         v[plan.rest] = rv
         if pressure:
             p[plan.rest] = rp
     ctx.check(ctx.lib.ipde_stokes_apply_patches_far(ctx.handle, int(sx.shape[0]), ptr(sx), ptr(sy), ptr(wfx),
-                                                    ptr(wfy), plan.np, ptr(plan.pxy), ptr(plan.pout), ptr(u),
-                                                    ptr(v), ptr(p)))
+                                                    ptr(wfy), ptr(nx), ptr(ny), ptr(wdx), ptr(wdy), plan.np,
+                                                    ptr(plan.pxy), ptr(plan.pout), ptr(u), ptr(v), ptr(p)))
     return u, v, p
 
 
-def modhelm_apply(plan, k, sx, sy, w_sigma, ctx=None, out=None):
-    """Modified Helmholtz single-layer sums over a planned list with padded blocks: the patches
-    through ipde_modhelm_apply_patches_far (far sources block by block in local expansions), the
-    remainder through ipde_modhelm_apply.  Device tensors; w_sigma weight-multiplied."""
+def modhelm_apply(plan, k, sx, sy, w_sigma=None, nx=None, ny=None, w_tau=None, ctx=None, out=None):
+    """Modified Helmholtz single- and / or double-layer sums over a planned list with padded blocks: the
+    patches through ipde_modhelm_apply_patches_far (far sources block by block in local expansions), the
+    remainder through ipde_modhelm_apply.  Device tensors; w_sigma, w_tau weight-multiplied."""
     from . import _lib
     from .layer_potentials import _match, modified_helmholtz_apply as list_apply
     ctx = ctx or get_context()
     if not plan.padded_blocks:
         raise ValueError("the far-field form needs a plan built with pad_blocks=True")
-    sx, sy, w_sigma = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (sx, sy, w_sigma))
+    sx, sy, w_sigma, nx, ny, w_tau = (_match(a, _lib.IPDE_DEVICE, ctx) for a in (sx, sy, w_sigma, nx, ny, w_tau))
     if out is None:
         out = torch.empty(plan.n, dtype=torch.float64, device=plan.pxy.device)
     assert out.is_contiguous() and out.dtype == torch.float64 and out.numel() == plan.n
     if plan.nrest:
-        out[plan.rest] = list_apply(sx, sy, plan.rest_x, plan.rest_y, float(k), w_sigma=w_sigma, ctx=ctx)
+        out[plan.rest] = list_apply(sx, sy, plan.rest_x, plan.rest_y, float(k), w_sigma=w_sigma, nx=nx, ny=ny,
+                                    w_tau=w_tau, ctx=ctx)
     ctx.check(ctx.lib.ipde_modhelm_apply_patches_far(ctx.handle, float(k), int(sx.shape[0]), ptr(sx), ptr(sy),
-                                                     ptr(w_sigma), plan.np, ptr(plan.pxy), ptr(plan.pout),
-                                                     ptr(out)))
+                                                     ptr(w_sigma), ptr(nx), ptr(ny), ptr(w_tau), plan.np,
+                                                     ptr(plan.pxy), ptr(plan.pout), ptr(out)))
     return out

@@ -769,6 +769,36 @@ def test_stokes_far_expansion_against_oracle_and_list_kernel(lp, ngrid, nb):
     assert p2 is None and np.array_equal(u2.cpu().numpy(), u) and np.array_equal(v2.cpu().numpy(), v)
 
 
+@pytest.mark.parametrize("ngrid,nb", [(200, 192), (640, 512), (1024, 1500)])
+def test_stresslet_far_expansion_against_oracle_and_list_kernel(lp, ngrid, nb):
+    """Stresslet sums with pressure through ipde_stokes_apply_patches_far — U = sum [A / delta + 2 (n.g) / conj(delta)
+    + conj(A) delta / conj(delta)^2] / 4, A = N G, three more coefficient families on the stokeslet's three chains —
+    alone and together with the stokeslet, against the C oracle on a sample and the list kernel everywhere
+    (reference formulas: ipde/solvers/internals/stokes_save.py:41-54,77-81)."""
+    from ipde_amd import target_plan
+    c = Curve(nb, a=0.2, f=5)
+    trg, h = grid_targets(c, ngrid, clearance=2.0)
+    rng = np.random.default_rng(ngrid + nb + 7)
+    fx, fy = rng.standard_normal(c.N) * c.weights, rng.standard_normal(c.N) * c.weights
+    gx, gy = rng.standard_normal(c.N) * c.weights, rng.standard_normal(c.N) * c.weights
+    dev = lp.get_context().torch_device()
+    plan = target_plan.build_host(trg.x, trg.y, device=dev, pad_blocks=True)
+    idx = rng.choice(trg.N, min(trg.N, 5000), replace=False)
+    for ff in ((None, None), (fx, fy)):
+        u, v, p = (a.cpu().numpy() for a in target_plan.stokes_apply(plan, c.x, c.y, ff[0], ff[1], nx=c.normal_x,
+                                                                     ny=c.normal_y, wdx=gx, wdy=gy))
+        lu, lv, lpp = lp.stokes_apply(c.x, c.y, trg.x, trg.y, wfx=ff[0], wfy=ff[1], nx=c.normal_x, ny=c.normal_y,
+                                      wdx=gx, wdy=gy)
+        for got, lst in ((u, lu), (v, lv), (p, lpp)):
+            assert np.abs(got - lst).max() < 2e-13 * np.abs(lst).max()
+        ru, rv, rp = oracle.c_stokes_apply(c.x, c.y, trg.x[idx], trg.y[idx], wfx=ff[0], wfy=ff[1], nx=c.normal_x,
+                                           ny=c.normal_y, wdx=gx, wdy=gy)
+        assert rel_err(u[idx], ru) < TOL and rel_err(v[idx], rv) < TOL and rel_err(p[idx], rp) < 10 * TOL
+        u2, v2, p2 = target_plan.stokes_apply(plan, c.x, c.y, ff[0], ff[1], nx=c.normal_x, ny=c.normal_y, wdx=gx,
+                                              wdy=gy, pressure=False)
+        assert p2 is None and np.array_equal(u2.cpu().numpy(), u) and np.array_equal(v2.cpu().numpy(), v)
+
+
 def test_stokes_far_expansion_table_miss_and_high_level_call(lp):
     """A source 1e-10 from a grid target (that patch's sums are redone with the generic math over
     all sources) and the route the Stokes solver takes: DeviceTargets(plan=True, far=True) ->
@@ -810,12 +840,25 @@ def test_stokes_far_expansion_table_miss_and_high_level_call(lp):
     b = lp.Stokes_Layer_Apply(c, plain, forces=f)
     for x, y in zip(a, b):
         assert float((torch.as_tensor(x) - torch.as_tensor(y)).abs().max()) < 2e-13 * float(torch.as_tensor(y).abs().max())
-    # a stresslet density keeps the list kernel (no expansion form): same call, same numbers
+    # a stresslet density takes its own expansion form (alone, and together with the stokeslet)
     g = rng.standard_normal((2, c.N))
-    a = lp.Stokes_Layer_Apply(c, far, forces=f, dipstr=g)
-    b = lp.Stokes_Layer_Apply(c, plain, forces=f, dipstr=g)
-    for x, y in zip(a, b):
-        assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
+    for ff in (f, None):
+        a = lp.Stokes_Layer_Apply(c, far, forces=ff, dipstr=g)
+        b = lp.Stokes_Layer_Apply(c, plain, forces=ff, dipstr=g)
+        for x, y in zip(a, b):
+            x, y = torch.as_tensor(x), torch.as_tensor(y)
+            assert float((x - y).abs().max()) < 2e-13 * float(y.abs().max())
+    # ... also where a source sits 1e-10 from a target: the storing launch redoes that patch with the generic
+    # math for BOTH layers and the adding launch leaves it alone
+    gx, gy = rng.standard_normal(c.N) * c.weights, rng.standard_normal(c.N) * c.weights
+    nrm = np.stack([np.cos(np.arange(c.N) * 0.3), np.sin(np.arange(c.N) * 0.3)])
+    u, v, p = (a.cpu().numpy() for a in target_plan.stokes_apply(plan, sx, sy, fx, fy, nx=nrm[0], ny=nrm[1], wdx=gx,
+                                                                 wdy=gy))
+    ru, rv, rp = oracle.c_stokes_apply(sx, sy, trg.x, trg.y, wfx=fx, wfy=fy, nx=nrm[0], ny=nrm[1], wdx=gx, wdy=gy)
+    for got, ref in ((u, ru), (v, rv)):
+        # (at the six targets the stresslet's 1/d^2 factors carry the distance's own 1e-6 relative rounding)
+        assert np.all(np.isfinite(got)) and np.abs(got - ref)[far_pts].max() < TOL * np.abs(ref[far_pts]).max()
+    assert np.abs(p - rp)[far_pts].max() < 10 * TOL * np.abs(rp[far_pts]).max()
 
 
 @pytest.mark.parametrize("k", [0.7, 10.0, 40.0, 300.0])
@@ -840,10 +883,34 @@ def test_modhelm_far_expansion_against_oracle_and_list_kernel(lp, k, ngrid, nb):
     assert np.abs(far[idx] - ref).max() < TOL * np.abs(lst).max()
 
 
+@pytest.mark.parametrize("k", [0.7, 10.0, 40.0, 300.0])
+@pytest.mark.parametrize("ngrid,nb", [(200, 192), (640, 512), (1024, 1500)])
+def test_modhelm_double_layer_far_expansion_against_oracle_and_list_kernel(lp, k, ngrid, nb):
+    """The modified Helmholtz DOUBLE layer (and both layers in one apply) through ipde_modhelm_apply_patches_far:
+    the dipole's coefficients by the ladder relations of K_m on the single layer's Graf expansion — against the
+    list kernel everywhere and the scipy oracle on a sample, relative to max|u|."""
+    from ipde_amd import target_plan
+    c = Curve(nb, a=0.2, f=5)
+    trg, h = grid_targets(c, ngrid, clearance=2.0)
+    rng = np.random.default_rng(ngrid + nb + 1)
+    w = rng.standard_normal(c.N) * c.weights
+    t = rng.standard_normal(c.N) * c.weights
+    dev = lp.get_context().torch_device()
+    plan = target_plan.build_host(trg.x, trg.y, device=dev, pad_blocks=True)
+    idx = rng.choice(trg.N, min(trg.N, 1500), replace=False)
+    for ws in (None, w):
+        far = target_plan.modhelm_apply(plan, k, c.x, c.y, w_sigma=ws, nx=c.normal_x, ny=c.normal_y, w_tau=t).cpu().numpy()
+        lst = lp.modified_helmholtz_apply(c.x, c.y, trg.x, trg.y, k, w_sigma=ws, nx=c.normal_x, ny=c.normal_y, w_tau=t)
+        assert np.abs(far - lst).max() < 1e-13 * np.abs(lst).max()
+        ref = olp.modified_helmholtz_layer_apply(c.x, c.y, trg.x[idx], trg.y[idx], k, charge=ws, dipstr=t,
+                                                 nx=c.normal_x, ny=c.normal_y)
+        assert np.abs(far[idx] - ref).max() < TOL * np.abs(lst).max()
+
+
 def test_modhelm_far_expansion_near_misses_and_high_level_call(lp):
     """Sources 1e-9 from grid targets (below the table window: those patches' near batches are redone
     with the series code), and the route the solver takes: DeviceTargets(plan=True, far=True) ->
-    Modified_Helmholtz_Layer_Apply; a dipole density keeps the list kernel."""
+    Modified_Helmholtz_Layer_Apply, with a dipole density too (the double layer's far-field form)."""
     import torch
     from ipde_amd import target_plan
     c = Curve(600, a=0.2, f=5)
@@ -867,9 +934,18 @@ def test_modhelm_far_expansion_near_misses_and_high_level_call(lp):
     a = lp.Modified_Helmholtz_Layer_Apply(c, far, k=10.0, charge=s)
     b = lp.Modified_Helmholtz_Layer_Apply(c, plain, k=10.0, charge=s)
     assert float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max()) < 1e-13 * float(torch.as_tensor(b).abs().max())
-    a = lp.Modified_Helmholtz_Layer_Apply(c, far, k=10.0, charge=s, dipstr=s[::-1].copy())
-    b = lp.Modified_Helmholtz_Layer_Apply(c, plain, k=10.0, charge=s, dipstr=s[::-1].copy())
-    assert torch.equal(torch.as_tensor(a), torch.as_tensor(b))
+    for ch in (s, None):
+        a = torch.as_tensor(lp.Modified_Helmholtz_Layer_Apply(c, far, k=10.0, charge=ch, dipstr=s[::-1].copy()))
+        b = torch.as_tensor(lp.Modified_Helmholtz_Layer_Apply(c, plain, k=10.0, charge=ch, dipstr=s[::-1].copy()))
+        assert float((a - b).abs().max()) < 1e-13 * float(b.abs().max())
+    # near misses with a dipole density: the patches below the table window redo their near batches with the series
+    nrm = np.stack([np.cos(np.arange(c.N) * 0.7), np.sin(np.arange(c.N) * 0.7)])
+    for k in (2.0, 25.0):
+        got = target_plan.modhelm_apply(plan, k, sx, sy, nx=nrm[0], ny=nrm[1], w_tau=w).cpu().numpy()
+        idx = rng.choice(trg.N, 1500, replace=False)
+        idx = idx[~np.isin(idx, hit)]
+        ref = olp.modified_helmholtz_layer_apply(sx, sy, trg.x[idx], trg.y[idx], k, dipstr=w, nx=nrm[0], ny=nrm[1])
+        assert np.all(np.isfinite(got)) and np.abs(got[idx] - ref).max() < TOL * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
@@ -911,10 +987,19 @@ def test_far_forms_on_ragged_rectangular_lattices_with_scattered_sources(lp, see
         got = target_plan.modhelm_apply(plan, k, sx, sy, w1).cpu().numpy()
         want = lp.modified_helmholtz_apply(sx, sy, tx, ty, k, w_sigma=w1)
         assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
+        for ws in (None, w1):
+            got = target_plan.modhelm_apply(plan, k, sx, sy, w_sigma=ws, nx=nrm[0], ny=nrm[1], w_tau=w2).cpu().numpy()
+            want = lp.modified_helmholtz_apply(sx, sy, tx, ty, k, w_sigma=ws, nx=nrm[0], ny=nrm[1], w_tau=w2)
+            assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
     gu, gv, gp = (a.cpu().numpy() for a in target_plan.stokes_apply(plan, sx, sy, w1, w2))
     wu, wv, wp = lp.stokes_apply(sx, sy, tx, ty, wfx=w1, wfy=w2)
     for g_, w_ in ((gu, wu), (gv, wv), (gp, wp)):
         assert np.abs(g_ - w_).max() < 2e-13 * np.abs(w_).max()
+    for ff in ((None, None), (w1, w2)):        # the stresslet alone, and both layers
+        got = target_plan.stokes_apply(plan, sx, sy, ff[0], ff[1], nx=nrm[0], ny=nrm[1], wdx=w2, wdy=w1)
+        want = lp.stokes_apply(sx, sy, tx, ty, wfx=ff[0], wfy=ff[1], nx=nrm[0], ny=nrm[1], wdx=w2, wdy=w1)
+        for g_, w_ in zip(got, want):
+            assert np.abs(g_.cpu().numpy() - w_).max() < 2e-13 * np.abs(w_).max()
 
 
 def _radial_grid(c, M, width):
@@ -942,11 +1027,12 @@ def test_modhelm_column_far_form_on_a_radial_grid(lp, k, nb, M):
     src.x, src.y, src.weights, src.N = sx, sy, c.weights, c.N
     cols = lp.DeviceTargets(tx.ravel(), ty.ravel(), columns=(M, nb))
     plain = lp.DeviceTargets(tx.ravel(), ty.ravel())
-    a = lp.Modified_Helmholtz_Layer_Apply(src, cols, k=k, charge=s)
-    b = lp.Modified_Helmholtz_Layer_Apply(src, plain, k=k, charge=s)
     import torch
-    a, b = torch.as_tensor(a), torch.as_tensor(b)
-    assert a.shape == b.shape and float((a - b).abs().max()) < 1e-13 * float(b.abs().max())
+    src.normal_x, src.normal_y = c.normal_x, c.normal_y
+    for ch, dp in ((s, None), (None, s[::-1].copy()), (s, s[::-1].copy())):       # single, double, both layers
+        a = torch.as_tensor(lp.Modified_Helmholtz_Layer_Apply(src, cols, k=k, charge=ch, dipstr=dp))
+        b = torch.as_tensor(lp.Modified_Helmholtz_Layer_Apply(src, plain, k=k, charge=ch, dipstr=dp))
+        assert a.shape == b.shape and float((a - b).abs().max()) < 1e-13 * float(b.abs().max())
     with pytest.raises(ValueError):
         lp.DeviceTargets(tx.ravel(), ty.ravel(), columns=(M + 1, nb))
 
@@ -954,7 +1040,7 @@ def test_modhelm_column_far_form_on_a_radial_grid(lp, k, nb, M):
 @pytest.mark.parametrize("nb,M", [(2048, 20), (3000, 14), (4096, 24)])
 def test_laplace_column_far_form_on_a_radial_grid(lp, nb, M):
     """ipde_laplace_apply_columns_far on the (M, N) radial grid of an annulus against the list kernel and,
-    on a sample, the C oracle; a dipole density keeps the list kernel."""
+    on a sample, the C oracle; single layer, double layer and both."""
     import torch
     c = Curve(nb, a=0.2, f=5)
     h = 2 * np.pi / nb
@@ -975,15 +1061,19 @@ def test_laplace_column_far_form_on_a_radial_grid(lp, nb, M):
     idx = rng.choice(M * nb, 3000, replace=False)
     ref = oracle.c_laplace_apply(src.x, src.y, tx.ravel()[idx], ty.ravel()[idx], w_sigma=s * c.weights)
     assert np.abs(a.cpu().numpy()[idx] - ref).max() < TOL * np.abs(ref).max()
-    a = torch.as_tensor(lp.Laplace_Layer_Apply(src, cols, charge=s, dipstr=s))
-    b = torch.as_tensor(lp.Laplace_Layer_Apply(src, plain, charge=s, dipstr=s))
-    assert torch.equal(a, b)
+    for ch in (s, None):
+        a = torch.as_tensor(lp.Laplace_Layer_Apply(src, cols, charge=ch, dipstr=s[::-1].copy()))
+        b = torch.as_tensor(lp.Laplace_Layer_Apply(src, plain, charge=ch, dipstr=s[::-1].copy()))
+        assert float((a - b).abs().max()) < 1e-13 * float(b.abs().max())
+    ref = oracle.c_laplace_apply(src.x, src.y, tx.ravel()[idx], ty.ravel()[idx], w_sigma=None,
+                                 nx=src.normal_x, ny=src.normal_y, w_tau=s[::-1] * c.weights)
+    assert np.abs(a.cpu().numpy()[idx] - ref).max() < TOL * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("nb,M", [(2048, 20), (3000, 14), (4096, 24)])
 def test_stokes_column_far_form_on_a_radial_grid(lp, nb, M):
     """ipde_stokes_apply_columns_far (u, v, p) on the (M, N) radial grid of an annulus against the list kernel;
-    without the pressure too; a stresslet density keeps the list kernel."""
+    without the pressure too; stokeslet, stresslet and both."""
     import torch
     c = Curve(nb, a=0.2, f=5)
     h = 2 * np.pi / nb
@@ -1005,10 +1095,12 @@ def test_stokes_column_far_form_on_a_radial_grid(lp, nb, M):
         assert float((x - y).abs().max()) < 2e-13 * float(y.abs().max())
     a2 = lp.Stokes_Layer_Apply(src, cols, forces=f, pressure=False)
     assert a2[2] is None and torch.equal(torch.as_tensor(a2[0]), torch.as_tensor(a[0]))
-    a = lp.Stokes_Layer_Apply(src, cols, forces=f, dipstr=f)
-    b = lp.Stokes_Layer_Apply(src, plain, forces=f, dipstr=f)
-    for x, y in zip(a, b):
-        assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
+    for ff in (f, None):                       # both layers, and the stresslet alone
+        a = lp.Stokes_Layer_Apply(src, cols, forces=ff, dipstr=f[::-1].copy())
+        b = lp.Stokes_Layer_Apply(src, plain, forces=ff, dipstr=f[::-1].copy())
+        for x, y in zip(a, b):
+            x, y = torch.as_tensor(x), torch.as_tensor(y)
+            assert float((x - y).abs().max()) < 2e-13 * float(y.abs().max())
 
 
 def test_column_far_forms_on_columns_that_are_not_straight(lp):
