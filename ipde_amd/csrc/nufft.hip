@@ -37,6 +37,7 @@
 // through the column pass, 269 MB read by the gather — against twelve full 4096^2 inverse transforms.
 #include "ipde_common.h"
 #include "fft2d.h"
+#include "fft_core.h"
 #include <cmath>
 
 namespace {
@@ -349,58 +350,105 @@ __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restri
 
 
 // ---- the band form ----------------------------------------------------------------------------------
-// Packed coarse spectra -> D, the fine-row-interleaved layout (2 nx rows of `pitch` complex, row 2 i + a =
-// sample (i + a / 2) h): for wavenumber kx of coarse row i, the pad kernel's value (same Nyquist rules, the
-// y window factor 1) goes to row 2 i as it is and to row 2 i + 1 times e^{i pi kx / nx}; the x Nyquist row
-// holds +nx/2 and -nx/2 together.  A length-nx inverse transform of the columns of the a = 0 rows and of the
-// a = 1 rows (one launch: the layout is (nx, 2 pitch)) then IS the 2x oversampled transform along x.
-__global__ __launch_bounds__(256) void band_shift_kernel(Combo cb, cd* __restrict__ D, int nx, int ny, int pitch,
-                                                         const double* __restrict__ rx, double dkx, double dky) {
-    const int H = ny / 2, ncol = H + 1;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)nx * ncol) return;
-    const int i = (int)(idx / ncol), j = (int)(idx - (int64_t)i * ncol);
-    auto value = [&](int kx) -> cd {
-        const int akx = kx < 0 ? -kx : kx;
-        const int ci = (kx + nx) % nx;
-        double wgt = rx[akx];
-        const bool nyqx = 2 * akx == nx, nyqy = (j == H);
-        if (nyqx && nyqy)
-            wgt = kx > 0 ? 0.5 * wgt : 0.0;
-        else if (nyqx || nyqy)
-            wgt *= 0.5;
-        cd acc{0.0, 0.0};
-        for (int t = 0; t < cb.n; ++t) {
-            const cd* S = cb.src[t];
-            cd v;
-            if (j == 0 || j == H) {
-                cd g = S[(int64_t)ci * H], gm = S[(int64_t)((nx - ci) % nx) * H];
-                v = (j == 0) ? cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)} : cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
-            } else {
-                v = S[(int64_t)ci * H + j];
-            }
-            const double c = wgt * cb.coef[t];
-            v.x *= c;
-            v.y *= c;
-            if (cb.der[t] == 1) v = cd{-v.y * (kx * dkx), v.x * (kx * dkx)};
-            if (cb.der[t] == 2) v = cd{-v.y * (j * dky), v.x * (j * dky)};
-            acc.x += v.x;
-            acc.y += v.y;
+// The pad kernel's value at fine wavenumber kx (|kx| <= nx/2), column j (0 .. ny/2) of a Combo over PACKED coarse
+// spectra, with the y window factor 1: the same Nyquist rules (see nufft_pad_kernel).
+__device__ __forceinline__ cd band_value(const Combo& cb, int kx, int j, int nx, int H, const double* __restrict__ rx,
+                                         double dkx, double dky) {
+    const int akx = kx < 0 ? -kx : kx;
+    const int ci = (kx + nx) % nx;
+    double wgt = rx[akx];
+    const bool nyqx = 2 * akx == nx, nyqy = (j == H);
+    if (nyqx && nyqy)
+        wgt = kx > 0 ? 0.5 * wgt : 0.0;
+    else if (nyqx || nyqy)
+        wgt *= 0.5;
+    cd acc{0.0, 0.0};
+    for (int t = 0; t < cb.n; ++t) {
+        const cd* S = cb.src[t];
+        cd v;
+        if (j == 0 || j == H) {
+            cd g = S[(int64_t)ci * H], gm = S[(int64_t)((nx - ci) % nx) * H];
+            v = (j == 0) ? cd{0.5 * (g.x + gm.x), 0.5 * (g.y - gm.y)} : cd{0.5 * (g.y + gm.y), -0.5 * (g.x - gm.x)};
+        } else {
+            v = S[(int64_t)ci * H + j];
         }
-        return acc;
-    };
-    cd v0, v1;
-    if (2 * i == nx) {
-        const cd vp = value(nx / 2), vm = value(-(nx / 2));
-        v0 = cd{vp.x + vm.x, vp.y + vm.y};
-        v1 = cd{-(vp.y - vm.y), vp.x - vm.x};      // i (vp - vm): e^{+- i pi / 2}
-    } else {
-        const int kx = (i < nx / 2) ? i : i - nx;
-        v0 = value(kx);
-        v1 = cmulz(v0, cis_pi((double)kx / nx));
+        const double c = wgt * cb.coef[t];
+        v.x *= c;
+        v.y *= c;
+        if (cb.der[t] == 1) v = cd{-v.y * (kx * dkx), v.x * (kx * dkx)};
+        if (cb.der[t] == 2) v = cd{-v.y * (j * dky), v.x * (j * dky)};
+        acc.x += v.x;
+        acc.y += v.y;
     }
-    D[(int64_t)(2 * i) * pitch + j] = v0;
-    D[(int64_t)(2 * i + 1) * pitch + j] = v1;
+    return acc;
+}
+
+// The 2x oversampled inverse transform along x of columns j0 .. j0 + C - 1, straight from the packed coarse
+// spectra: D, the fine-row-interleaved layout (2 nx rows of `pitch` complex, row 2 i + a = sample (i + a / 2) h_x),
+// gets the length-nx inverse transform of value(kx, j) (a = 0) and of value(kx, j) e^{i pi kx / nx} (a = 1; the x
+// Nyquist row holds +nx/2 and -nx/2 together: v+ + v- and i (v+ - v-)).  The workgroup is col_kernel's (fft2d.hip):
+// thread = (column, t), its values rows t + T q — the transform's own register layout, 64-byte row segments in
+// and out, XCD-aware hand-out of the column blocks.  Nothing padded or shifted ever goes through HBM.
+template <int NX, int C>
+__global__ __launch_bounds__(C* fftcore::Cfg<NX>::T) void band_col_kernel(Combo cb, cd* __restrict__ D, int ny, int pitch,
+                                                                         int nblocks, const double* __restrict__ rx,
+                                                                         double dkx, double dky,
+                                                                         const fftcore::cd* __restrict__ tw_x) {
+    using namespace fftcore;
+    using G = Cfg<NX>;
+    constexpr int T = G::T, P = G::P, NPC = lds_slots<NX>() + 4;
+    extern __shared__ double2 lds_raw[];
+    fftcore::cd* lds = (fftcore::cd*)lds_raw;
+    const int per = (nblocks + 7) / 8;
+    const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (blk >= nblocks) return;
+    const int tid = threadIdx.x;
+    const int col = tid % C, t = tid / C;
+    const int H = ny / 2;
+    const int j = blk * C + col;
+    const bool live = j <= H;
+    const PassTw<NX> pw = load_pass_twiddles<NX>(t, tw_x);
+    fftcore::cd* buf = lds + col * NPC;
+    // e^{i pi (t + T q) / nx} = e^{i pi t / nx} (e^{i pi T / nx})^q
+    double sn, cs;
+    sincospi((double)t / NX, &sn, &cs);
+    const fftcore::cd e0{cs, sn};
+    sincospi((double)T / NX, &sn, &cs);
+    const fftcore::cd est{cs, sn};
+#pragma unroll 1
+    for (int a = 0; a < 2; ++a) {
+        fftcore::cd v[P];
+        fftcore::cd ph = e0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int i = t + T * q;
+            fftcore::cd val{0.0, 0.0};
+            if (live) {
+                if (2 * i == NX) {
+                    const ::cd vp = band_value(cb, NX / 2, j, NX, H, rx, dkx, dky);
+                    const ::cd vm = band_value(cb, -(NX / 2), j, NX, H, rx, dkx, dky);
+                    val = a == 0 ? fftcore::cd{vp.x + vm.x, vp.y + vm.y} : fftcore::cd{-(vp.y - vm.y), vp.x - vm.x};
+                } else {
+                    const int kx = (i < NX / 2) ? i : i - NX;
+                    const ::cd w = band_value(cb, kx, j, NX, H, rx, dkx, dky);
+                    val = fftcore::cd{w.x, w.y};
+                    if (a == 1) {
+                        val = cmul(val, ph);
+                        if (i > NX / 2) val = fftcore::cd{-val.x, -val.y};      // e^{i pi (i - nx) / nx} = -e^{i pi i / nx}
+                    }
+                }
+            }
+            v[q] = val;
+            ph = cmul(ph, est);
+        }
+        fft_regs<NX, +1, false>(v, t, pw, buf);
+        if (live) {
+            fftcore::cd* base = (fftcore::cd*)D + j;
+#pragma unroll
+            for (int q = 0; q < P; ++q) base[(int64_t)(2 * (t + T * q) + a) * pitch] = v[q];
+        }
+        __syncthreads();
+    }
 }
 
 // Bucket the points by the first fine row of their x window (one workgroup; a few 10^4 points): r0[j] = first
@@ -462,18 +510,34 @@ __device__ __forceinline__ cd unit_kf(int k, double f, const cd* __restrict__ T)
     return cd{t.x * c - t.y * sn, t.x * sn + t.y * c};
 }
 
+// What a gather launch produces from its (up to three) transformed arrays: output `out` (a row of the partial
+// buffer) = sum over its entries of coef * (plain sum | y-derivative sum) of array `arr`; acc: add to what an
+// earlier launch left in the row.
+struct BandOut {
+    int out, n, acc;
+    int arr[2], kind[2];      // kind 0: Re sum_k eps_k g e^{i k y};  1: d/dy = Re sum_k (i k dky) g e^{i k y}
+    double coef[2];
+};
+struct BandRecipe {
+    int nout;
+    int need_dy[3];
+    BandOut o[8];
+};
+
 // One fine row (blockIdx.x, in the extended numbering of band_sort_kernel) with the points whose windows
-// cover it, 16 at a time: thread t holds columns k = t + 256 q of the row (nf fields), forms
-// Re sum_k eps_k g[k] e^{i k y} for every point, the wave sums go through LDS, and the (point, row) partial —
-// times the x window's weight — is written to its own slot partial[(f np + j) 16 + s].
+// cover it, 16 at a time: thread t holds columns k = t + 256 q of the row (na arrays), forms for every point
+// P = Re sum_k eps_k g[k] e^{i k y} and, where asked, Dy = -dky sum_k k Im(g[k] e^{i k y}); the wave sums go through
+// LDS, and the (output, point, row) partial — times the x window's weight — is written to its own slot
+// partial[(out np + j) 16 + s].
 template <int Q>
 __global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__ D0, const cd* __restrict__ D1,
-                                                          const cd* __restrict__ D2, int nf, int64_t pitch,
-                                                          int ncol, int nfx, const double* __restrict__ px,
+                                                          const cd* __restrict__ D2, int na, BandRecipe rc,
+                                                          int64_t pitch, int ncol, int nfx,
+                                                          const double* __restrict__ px,
                                                           const double* __restrict__ py, int64_t np,
                                                           const int* __restrict__ start,
                                                           const int* __restrict__ perm,
-                                                          const int* __restrict__ r0v, double beta,
+                                                          const int* __restrict__ r0v, double beta, double dky,
                                                           double* __restrict__ partial) {
     constexpr int W = 16, PTS = 16;
     const int r_ext = blockIdx.x;
@@ -481,7 +545,7 @@ __global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__
     const int cnt = hi - lo;
     if ((int)blockIdx.y * PTS >= cnt) return;      // (uniform over the workgroup, before any barrier)
     __shared__ cd T[256];
-    __shared__ double wsum[3][PTS][4];
+    __shared__ double wsum[6][PTS][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double TWO_PI = 6.283185307179586476925286766559;
     {
@@ -497,7 +561,7 @@ __global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int k = tid + 256 * q;
-            g[f][q] = (f < nf && k < ncol) ? Dp[f][(int64_t)phys * pitch + k] : cd{0.0, 0.0};
+            g[f][q] = (f < na && k < ncol) ? Dp[f][(int64_t)phys * pitch + k] : cd{0.0, 0.0};
             if (k == 0) g[f][q] = cd{0.5 * g[f][q].x, 0.5 * g[f][q].y};      // eps_0 = 1/2 (see row_c2r)
         }
     __syncthreads();
@@ -510,39 +574,46 @@ __global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__
             fy -= floor(fy);
             cd ph = unit_kf(tid, fy, T);
             const cd step = unit_kf(256, fy, T);
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                a0 = fma(g[0][q].x, ph.x, fma(-g[0][q].y, ph.y, a0));
-                a1 = fma(g[1][q].x, ph.x, fma(-g[1][q].y, ph.y, a1));
-                a2 = fma(g[2][q].x, ph.x, fma(-g[2][q].y, ph.y, a2));
+                const double kq = (double)(tid + 256 * q);
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    s[f] = fma(g[f][q].x, ph.x, fma(-g[f][q].y, ph.y, s[f]));
+                    if (rc.need_dy[f]) s[3 + f] = fma(kq, fma(g[f][q].x, ph.y, g[f][q].y * ph.x), s[3 + f]);
+                }
                 ph = cmulz(ph, step);
             }
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                a0 += __shfl_xor(a0, m);
-                a1 += __shfl_xor(a1, m);
-                a2 += __shfl_xor(a2, m);
-            }
+            for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                for (int f = 0; f < 6; ++f) s[f] += __shfl_xor(s[f], m);
             if (lane == 0) {
-                wsum[0][p][wave] = a0;
-                wsum[1][p][wave] = a1;
-                wsum[2][p][wave] = a2;
+#pragma unroll
+                for (int f = 0; f < 6; ++f) wsum[f][p][wave] = s[f];
             }
         }
         __syncthreads();
-        if (tid < 3 * PTS) {
-            const int f = tid / PTS, p = tid % PTS;
-            if (f < nf && p < npt) {
+        if (tid < 8 * PTS) {
+            const int o = tid / PTS, p = tid % PTS;
+            if (o < rc.nout && p < npt) {
+                const BandOut& bo = rc.o[o];
                 const int j = perm[lo + c * PTS + p];
-                const double sum = ((wsum[f][p][0] + wsum[f][p][1]) + wsum[f][p][2]) + wsum[f][p][3];
+                double val = 0.0;
+                for (int e = 0; e < bo.n; ++e) {
+                    const int f = bo.arr[e] + 3 * bo.kind[e];
+                    const double sum = ((wsum[f][p][0] + wsum[f][p][1]) + wsum[f][p][2]) + wsum[f][p][3];
+                    val += bo.coef[e] * (bo.kind[e] ? -dky * sum : sum);
+                }
                 const int r0 = r0v[j], sidx = r_ext - r0;
                 double x = px[j];
                 x -= TWO_PI * floor(x / TWO_PI);
                 const double zq = (x - (double)(r0 - 16 + sidx) * hfx) / (0.5 * W * hfx);
                 const double qq = 1.0 - zq * zq;
                 const double wx = qq > 0.0 ? exp(beta * (sqrt(qq) - 1.0)) : 0.0;
-                partial[((int64_t)f * np + j) * W + sidx] = wx * sum;
+                double* dst = partial + ((int64_t)bo.out * np + j) * W + sidx;
+                *dst = bo.acc ? *dst + wx * val : wx * val;
             }
         }
         __syncthreads();
@@ -586,7 +657,7 @@ struct GridInterp {
     double* d_ones = nullptr;     // the y window factor of the pad kernels: 1
     int* ibuf = nullptr;          // cnt, start (nfx + 33 each), perm, r0, rank (np each)
     int64_t ibuf_np = -1;
-    double* partial = nullptr;    // (3, np, 16)
+    double* partial = nullptr;    // (8, np, 16)
 };
 
 bool grid_interp_supported(int64_t nx, int64_t ny) { return fft2d_supported(nx, ny); }
@@ -701,7 +772,7 @@ static int ensure_band(GridInterp* gi, int64_t np) {
     if (!gi->general && !gi->bandD[0]) {
         const int64_t ncol = gi->ny / 2 + 1;
         gi->band_pitch = (ncol + 3) / 4 * 4;
-        const size_t bytes = (size_t)2 * gi->nx * gi->band_pitch * sizeof(cd);
+        const size_t bytes = (size_t)2 * gi->nx * gi->band_pitch * sizeof(cd);      // (fine-row-interleaved)
         for (auto& d : gi->bandD) {
             IPDE_HIP_CHECK(ctx, hipMalloc((void**)&d, bytes));
             IPDE_HIP_CHECK(ctx, hipMemset(d, 0, bytes));     // (the padding columns go through the column pass too)
@@ -715,18 +786,61 @@ static int ensure_band(GridInterp* gi, int64_t np) {
         gi->ibuf_np = -1;
         const int64_t cap = np + np / 4 + 64;
         IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->ibuf, (size_t)(2 * (gi->nfx + 33) + 3 * cap) * sizeof(int)));
-        IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->partial, (size_t)3 * cap * 16 * sizeof(double)));
+        IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->partial, (size_t)8 * cap * 16 * sizeof(double)));
         gi->ibuf_np = cap;
     }
     return IPDE_OK;
 }
 
 template <int Q>
-static void launch_band_gather(GridInterp* gi, const cd* const* D, int nf, int64_t pitch, int ncol, const double* d_px,
-                               const double* d_py, int64_t np, const int* start, const int* perm, const int* r0v) {
+static void launch_band_gather(GridInterp* gi, const cd* const* D, int na, const BandRecipe& rc, int64_t pitch, int ncol,
+                               const double* d_px, const double* d_py, int64_t np, const int* start, const int* perm,
+                               const int* r0v, double dky) {
     hipLaunchKernelGGL(band_gather_kernel<Q>, dim3((unsigned)(gi->nfx + 32), 4), dim3(256), 0, gi->ctx->stream, D[0],
-                       D[1], D[2], nf, pitch, ncol, (int)gi->nfx, d_px, d_py, np, start, perm, r0v, gi->betax,
+                       D[1], D[2], na, rc, pitch, ncol, (int)gi->nfx, d_px, d_py, np, start, perm, r0v, gi->betax, dky,
                        gi->partial);
+}
+
+template <int NX>
+static int launch_band_cols(GridInterp* gi, const Fft2dPlan& coarse, const Combo& cb, cd* D, double dkx, double dky) {
+    using namespace fftcore;
+    constexpr int C = NX >= 4096 ? 2 : 4, T = Cfg<NX>::T;
+    ipde_ctx* ctx = gi->ctx;
+    const size_t lds = (size_t)C * (lds_slots<NX>() + 4) * sizeof(fftcore::cd);
+    const int ncol = (int)(gi->ny / 2 + 1);
+    const int nblocks = (ncol + C - 1) / C;
+    auto k = band_col_kernel<NX, C>;
+    if (lds > 48 * 1024)
+        IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)(((nblocks + 7) / 8) * 8)), dim3(C * T), lds, ctx->stream, cb, D, (int)gi->ny,
+                       (int)gi->band_pitch, nblocks, (const double*)gi->d_rx, dkx, dky, (const fftcore::cd*)coarse.tw_x);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
+// An output combo's x part (terms D^der, der in {0, 1}) and its y-derivative part (der == 2, with the i ky left to
+// the gather) are arrays to transform; equal arrays up to a scalar are transformed once (the scalar solvers'
+// u, du/dx, du/dy: two arrays; the Stokes solver's five fields: five).
+struct BandArray {
+    Combo cb;
+};
+static int band_find_or_add(std::vector<BandArray>& arrs, const Combo& c, double* scale) {
+    for (size_t i = 0; i < arrs.size(); ++i) {
+        const Combo& a = arrs[i].cb;
+        if (a.n != c.n) continue;
+        bool same = true;
+        const double sc = c.coef[0] / a.coef[0];
+        for (int t = 0; t < c.n && same; ++t)
+            same = a.src[t] == c.src[t] && a.der[t] == c.der[t] &&
+                   fabs(c.coef[t] - sc * a.coef[t]) <= 4e-16 * fabs(c.coef[t]);
+        if (same) {
+            *scale = sc;
+            return (int)i;
+        }
+    }
+    arrs.push_back(BandArray{c});
+    *scale = 1.0;
+    return (int)arrs.size() - 1;
 }
 
 // The band form of interp_combos (see the head of the file).
@@ -735,7 +849,7 @@ static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout,
     ipde_ctx* ctx = gi->ctx;
     const int64_t nx = gi->nx, ny = gi->ny;
     if (np < 1) return IPDE_OK;
-    if (np >= (1LL << 30)) return IPDE_ERR_INVALID;
+    if (np >= (1LL << 30) || nout > 8) return IPDE_ERR_INVALID;
     IPDE_TRY(ensure_band(gi, np));
     const int nrows_ext = (int)gi->nfx + 32;
     int* cnt = gi->ibuf;
@@ -746,13 +860,41 @@ static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout,
     hipLaunchKernelGGL(band_sort_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_px, np, (int)gi->nfx, gi->w, nrows_ext, cnt,
                        start, perm, r0v, rank);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
+    // arrays and recipes
+    std::vector<BandArray> arrs;
+    struct Use {
+        int arr[2], kind[2], n;
+        double coef[2];
+    } use[8];
+    for (int f = 0; f < nout; ++f) {
+        Combo P{0, {nullptr, nullptr, nullptr}, {0, 0, 0}, {0.0, 0.0, 0.0}}, Qd = P;
+        for (int t = 0; t < combos[f].n; ++t) {
+            Combo& dst = combos[f].der[t] == 2 ? Qd : P;
+            dst.src[dst.n] = combos[f].src[t];
+            dst.der[dst.n] = combos[f].der[t] == 2 ? 0 : combos[f].der[t];
+            dst.coef[dst.n] = combos[f].coef[t];
+            ++dst.n;
+        }
+        use[f].n = 0;
+        for (int kind = 0; kind < 2; ++kind) {
+            const Combo& c = kind ? Qd : P;
+            if (c.n == 0) continue;
+            double sc;
+            const int a = band_find_or_add(arrs, c, &sc);
+            use[f].arr[use[f].n] = a;
+            use[f].kind[use[f].n] = kind;
+            use[f].coef[use[f].n] = sc;
+            ++use[f].n;
+        }
+    }
     const int ncol = (int)(ny / 2 + 1);
-    for (int f0 = 0; f0 < nout; f0 += 3) {
-        const int nf = nout - f0 < 3 ? nout - f0 : 3;
+    bool started[8] = {false, false, false, false, false, false, false, false};
+    for (int a0 = 0; a0 < (int)arrs.size(); a0 += 3) {
+        const int na = (int)arrs.size() - a0 < 3 ? (int)arrs.size() - a0 : 3;
         const cd* D[3] = {nullptr, nullptr, nullptr};
         int64_t pitch = 0;
-        for (int f = 0; f < nf; ++f) {
-            const Combo& cb = combos[f0 + f];
+        for (int f = 0; f < na; ++f) {
+            const Combo& cb = arrs[a0 + f].cb;
             if (gi->general) {
                 const int64_t nthreads = gi->nfx * (ny / 2 + 1);
                 hipLaunchKernelGGL(nufft_pad_general_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0,
@@ -763,40 +905,57 @@ static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout,
                 D[f] = (const cd*)gi->fine.W[f];
                 pitch = gi->fine.pitch;
             } else {
-                const int64_t nthreads = nx * ncol;
-                hipLaunchKernelGGL(band_shift_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0, ctx->stream,
-                                   cb, gi->bandD[f], (int)nx, (int)ny, (int)gi->band_pitch, (const double*)gi->d_rx, dkx,
-                                   dky);
-                IPDE_HIP_CHECK(ctx, hipGetLastError());
-                // rows 2 i (a = 0) and 2 i + 1 (a = 1) as the two halves of a (nx, 2 pitch) array: one column pass
-                Fft2dPlan both = coarse;
-                both.W[0] = gi->bandD[f];
-                both.pitch = 2 * gi->band_pitch;
-                IPDE_TRY(fft2d_cols(ctx, both, 0, FFT2D_SYM_NONE, 2, 0.0, 1.0, -1, gi->band_pitch + ncol));
+                int st = IPDE_ERR_INVALID;
+                switch (nx) {
+                    case 512: st = launch_band_cols<512>(gi, coarse, cb, gi->bandD[f], dkx, dky); break;
+                    case 1024: st = launch_band_cols<1024>(gi, coarse, cb, gi->bandD[f], dkx, dky); break;
+                    case 2048: st = launch_band_cols<2048>(gi, coarse, cb, gi->bandD[f], dkx, dky); break;
+                    case 4096: st = launch_band_cols<4096>(gi, coarse, cb, gi->bandD[f], dkx, dky); break;
+                }
+                IPDE_TRY(st);
                 D[f] = gi->bandD[f];
                 pitch = gi->band_pitch;
             }
         }
+        BandRecipe rc{};
+        for (int f = 0; f < nout; ++f) {
+            BandOut bo{};
+            bo.out = f;
+            for (int e = 0; e < use[f].n; ++e) {
+                const int a = use[f].arr[e];
+                if (a < a0 || a >= a0 + na) continue;
+                bo.arr[bo.n] = a - a0;
+                bo.kind[bo.n] = use[f].kind[e];
+                bo.coef[bo.n] = use[f].coef[e];
+                if (use[f].kind[e]) rc.need_dy[a - a0] = 1;
+                ++bo.n;
+            }
+            if (bo.n == 0) continue;
+            bo.acc = started[f] ? 1 : 0;
+            started[f] = true;
+            rc.o[rc.nout++] = bo;
+        }
+        if (rc.nout == 0) continue;
         if (ncol <= 256)
-            launch_band_gather<1>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+            launch_band_gather<1>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
         else if (ncol <= 512)
-            launch_band_gather<2>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+            launch_band_gather<2>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
         else if (ncol <= 768)
-            launch_band_gather<3>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+            launch_band_gather<3>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
         else if (ncol <= 1280)
-            launch_band_gather<5>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+            launch_band_gather<5>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
         else if (ncol <= 2304)
-            launch_band_gather<9>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+            launch_band_gather<9>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
         else if (ncol <= 4352)
-            launch_band_gather<17>(gi, D, nf, pitch, ncol, d_px, d_py, np, start, perm, r0v);
+            launch_band_gather<17>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
         else
             return IPDE_ERR_INVALID;
         IPDE_HIP_CHECK(ctx, hipGetLastError());
-        const int64_t n = (int64_t)nf * np;
-        hipLaunchKernelGGL(band_reduce_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream,
-                           (const double*)gi->partial, n, d_out + (int64_t)f0 * np);
-        IPDE_HIP_CHECK(ctx, hipGetLastError());
     }
+    const int64_t n = (int64_t)nout * np;
+    hipLaunchKernelGGL(band_reduce_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream,
+                       (const double*)gi->partial, n, d_out);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }
 
