@@ -77,6 +77,50 @@ def cpu_baseline(c, trg, sigma, budget_s=15.0):
     }
 
 
+def far_form_work(plan, c):
+    """Pairs by kind of one far-field apply, counted on the host with the kernels' own rules (csrc/layer_common.h
+    FarBlock, csrc/layer_laplace.hip laplace_far_coeff_kernel): blocks = 64 consecutive patches, parents = 16
+    consecutive blocks, discs = bounding-box centre and half-diagonal, batches of eight consecutive sources."""
+    pxy = plan.pxy.cpu().numpy()                     # (8, np)
+    npch = pxy.shape[1]
+    ng = (npch + 63) // 64
+    pad = ng * 64 - npch
+    if pad:
+        pxy = np.concatenate([pxy, np.repeat(pxy[:, -1:], pad, axis=1)], axis=1)
+    xs, ys = pxy[:4].T.reshape(ng, 256), pxy[4:].T.reshape(ng, 256)
+
+    def discs(x, y):
+        cx, cy = 0.5 * (x.min(1) + x.max(1)), 0.5 * (y.min(1) + y.max(1))
+        r2 = (0.5 * (x.max(1) - x.min(1))) ** 2 + (0.5 * (y.max(1) - y.min(1))) ** 2
+        return cx, cy, r2
+    bcx, bcy, br2 = discs(xs, ys)
+    ng2 = (ng + 15) // 16
+    padg = ng2 * 16 - ng
+    xs2 = np.concatenate([xs, np.repeat(xs[-1:], padg, axis=0)]).reshape(ng2, -1)
+    ys2 = np.concatenate([ys, np.repeat(ys[-1:], padg, axis=0)]).reshape(ng2, -1)
+    pcx, pcy, pr2 = discs(xs2, ys2)
+    ns = c.N
+    nb = (ns + 7) // 8
+    sxp = np.concatenate([c.x, np.repeat(c.x[-1:], nb * 8 - ns)])
+    syp = np.concatenate([c.y, np.repeat(c.y[-1:], nb * 8 - ns)])
+    # parents: a batch is taken if all eight of its sources are beyond 4 parent radii
+    d2p = (sxp[None, :] - pcx[:, None]) ** 2 + (syp[None, :] - pcy[:, None]) ** 2          # (ng2, ns_pad)
+    taken = (d2p >= 16.0 * pr2[:, None]).reshape(ng2, nb, 8).all(axis=2)                   # (ng2, nb)
+    far_p = int(taken.sum()) * 8
+    far_b = near = 0
+    for g0 in range(0, ng, 4096):                    # blocks in slabs (memory)
+        g1 = min(ng, g0 + 4096)
+        d2 = (sxp[None, :] - bcx[g0:g1, None]) ** 2 + (syp[None, :] - bcy[g0:g1, None]) ** 2
+        farb = (d2 >= 16.0 * br2[g0:g1, None]).reshape(g1 - g0, nb, 8).all(axis=2)
+        mine = ~taken[np.arange(g0, g1) // 16]
+        far_b += int((farb & mine).sum()) * 8
+        near += int((~farb & mine).sum()) * 8
+    return {"blocks": int(ng), "parents": int(ng2), "targets": int(16 * npch),
+            "far_pairs_parents": float(far_p), "far_pairs_blocks": float(far_b),
+            "near_pairs": float(near) * 1024.0,
+            "near_fraction_of_all_pairs": float(near) * 1024.0 / (float(ns) * 16.0 * npch)}
+
+
 def f_like(solver, EmbeddedFunction):
     f = EmbeddedFunction(solver.ebdyc)
     f.define_via_function(lambda x, y: (2.0 * np.cos(x) + 3.0 * np.cos(x) * np.sin(x) - np.cos(x) ** 3)
@@ -528,6 +572,7 @@ def main():
     # uses for its sum onto grid_pnai): a separate, labelled figure — `value` and `roofline` above are the
     # pair-by-pair kernel's
     expansion = None
+    layers = None
     if plan is not None and world == 1:
         dtf = lp.DeviceTargets(trg.x[sl], trg.y[sl], ctx=ctx, plan=True, far=True)
         planf = dtf.plan()
@@ -544,6 +589,31 @@ def main():
         msf = 1e3 * (time.perf_counter() - tf0) / nf
         kmsf = float(np.mean(ctx.kernel_ms_history()[-nf:]))       # parents + blocks + patches, by the library's events
         ctx.enable_timing(False)
+        # the three stages apart (option timing_split: an event pair each), with the work each does counted on the
+        # host from the plan's blocks by the kernels' own rule — a batch of eight sources enters a parent's expansion
+        # if all eight lie beyond 4 parent radii, else a block's if all beyond 4 block radii, else it is summed pair
+        # by pair for that block — and priced against the fp64 vector peak
+        ctx.set_option("timing_split", 1)
+        ctx.enable_timing(True)
+        for _ in range(nf):
+            target_plan.laplace_apply(planf, sx, sy, w_sigma=sig_full * w, ctx=ctx, out=outf, far=True)
+        torch.cuda.synchronize()
+        hist3 = np.asarray(ctx.kernel_ms_history()[-3 * nf:]).reshape(nf, 3).mean(axis=0)
+        ctx.enable_timing(False)
+        ctx.set_option("timing_split", 0)
+        work = far_form_work(planf, c)
+        P1 = 27                      # coefficients k = 0 .. 26
+        flop_cfma = 8.0
+        stage = {}
+        for name, ms_, flops, what in (
+                ("parent_coefficients", hist3[0], work["far_pairs_parents"] * P1 * flop_cfma,
+                 "far (source, parent) pairs x 27 complex FMAs"),
+                ("block_coefficients", hist3[1], work["far_pairs_blocks"] * P1 * flop_cfma,
+                 "far (source, block) pairs x 27 complex FMAs"),
+                ("patches", hist3[2], work["near_pairs"] * FLOPS_PER_PAIR_ALGO + 2.0 * work["targets"] * 26 * flop_cfma,
+                 "near pairs x 8 flop + targets x 2 levels x 26 complex Horner steps")):
+            stage[name] = {"kernel_ms": float(ms_), "flops": float(flops), "flops_convention": what,
+                           "frac_of_fp64_vector_peak": float(flops / (ms_ * 1e-3) / 1e12 / PEAK_FP64_VECTOR_TFLOPS)}
         expansion = {"what": "ipde_laplace_apply_patches_far: sources beyond 4 block radii of a 32 x 32-point block "
                              "enter 27 complex local-expansion coefficients (truncation 3e-18 of sum|w|), nearer "
                              "batches of eight sources are summed pair by pair",
@@ -551,7 +621,43 @@ def main():
                      "effective_pair_interactions_per_s": float(NBDY) * float(dt.N) / (msf * 1e-3),
                      "max_abs_diff_vs_pair_by_pair": float((outf - out).abs().max()),
                      "max_abs_pair_by_pair": float(out.abs().max()),
-                     "padded_patches": planf.np}
+                     "padded_patches": planf.np,
+                     "stages": stage, "work": work,
+                     "roofline_note": "fp64 VALU bound like the pair-by-pair kernel; the coefficient passes visit every "
+                                      "source once per block and parent (O(N_s N_blocks)), of which only the far ones do "
+                                      "the 27-step power loop counted here"}
+        # the other layers of configs[1] ("Laplace SLP+DLP grid_evaluator"): double layer and both in one apply,
+        # pair by pair (4 x 4 patch kernel) and in the far-field form
+        nrm_x = torch.as_tensor(c.normal_x, device=dev)
+        nrm_y = torch.as_tensor(c.normal_y, device=dev)
+        tau = torch.as_tensor(np.random.default_rng(1).standard_normal(NBDY), device=dev)
+        layers = {}
+        for name, kw, fl in (("dlp", dict(nx=nrm_x, ny=nrm_y, w_tau=tau * w), 12),
+                             ("slp_dlp", dict(w_sigma=sig_full * w, nx=nrm_x, ny=nrm_y, w_tau=tau * w), 15)):
+            ctx.enable_timing(True)
+            ks = []
+            for _ in range(4):
+                target_plan.laplace_apply(plan, sx, sy, ctx=ctx, out=out, **kw)
+                ctx.sync()
+                ks.append(ctx.last_kernel_ms())
+            ref = out.clone()
+            kf = []
+            for _ in range(4):
+                target_plan.laplace_apply(planf, sx, sy, ctx=ctx, out=outf, far=True, **kw)
+                ctx.sync()
+                kf.append(ctx.last_kernel_ms())
+            ctx.enable_timing(False)
+            kms_ = float(np.mean(ks[1:]))
+            pairs = float(NBDY) * float(dt.N - plan.nrest)
+            layers[name] = {"kernel": "laplace_patch_kernel<%s>" % name.upper(), "kernel_ms": kms_,
+                            "pairs_per_s": pairs / (kms_ * 1e-3), "flops_per_pair_algorithmic": fl,
+                            "frac_of_fp64_vector_peak": pairs * fl / (kms_ * 1e-3) / 1e12 / PEAK_FP64_VECTOR_TFLOPS,
+                            "far_form_kernels_ms": float(np.mean(kf[1:])),
+                            "far_form_max_abs_diff": float((outf - ref).abs().max()),
+                            "max_abs": float(ref.abs().max())}
+        # `out` again from the timed route (parity check below)
+        target_plan.laplace_apply(plan, sx, sy, w_sigma=sig_full * w, ctx=ctx, out=out)
+        ctx.sync()
         del dtf, planf, outf
 
     def allreduce_max(x):
@@ -660,6 +766,7 @@ def main():
             },
         }
         result["expansion_form"] = expansion
+        result["other_layers"] = layers
         if not args.no_fft and world == 1:
             result["fft"] = fft_block()
         if not args.no_cpu_baseline and world == 1:

@@ -88,6 +88,8 @@ const char* ipde_last_error(ipde_ctx* ctx);
    Names: "laplace_variant", "stokes_variant", "dense_pairs", "annular_grouped",
    "fft2d" (1: hand-written 2-D FFT pipeline on power-of-two grids, 0: rocFFT),
    "interp_shifted" (1: ipde_grid_interp through four shifted coarse transforms at any size),
+   "timing_split" (1: ipde_laplace_apply_patches_far records one event pair per stage — parents' coefficients,
+   blocks' coefficients, patches — instead of one around the three),
    "interp_band" (1, default: ipde_grid_interp / _fields in the band form — oversampled transform along x only
    for the kept columns, exact sums along y per point; 0: full oversampled fine grids and a 2-D window gather),
    "dense_persistent", "annular_fused_fft", "gmres_graphs", "gmres_lookahead" (1: inner iteration

@@ -240,6 +240,7 @@ static int* option_slot(ipde_ctx* ctx, const char* name) {
     if (!strcmp(name, "fft2d")) return &ctx->opt_fft2d;
     if (!strcmp(name, "interp_shifted")) return &ctx->opt_interp_shifted;
     if (!strcmp(name, "interp_band")) return &ctx->opt_interp_band;
+    if (!strcmp(name, "timing_split")) return &ctx->opt_timing_split;
     return nullptr;
 }
 

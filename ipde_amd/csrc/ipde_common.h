@@ -73,6 +73,7 @@ struct ipde_ctx {
     int opt_modhelm_variant = 0;  // table kernel geometry: 0: 2 targets per lane, 1: 4, 2: 2 x two sources in flight, 3: 3
     int opt_stokes_variant = 1;   // 1: row-run stokeslet kernel (single layer), 0: strided table kernel
     int opt_interp_shifted = 0;   // 1: ipde_grid_interp always through four shifted coarse transforms (testing)
+    int opt_timing_split = 0;     // 1: ipde_laplace_apply_patches_far records an event pair per stage (parents, blocks, patches)
     int opt_interp_band = 1;      // 1: ipde_grid_interp in its band form (FFT along x only, exact sums along y: nufft.hip), 0: full fine grids
     int opt_fft2d = 1;            // 1: hand-written 2-D FFT pipeline on power-of-two grids (fft2d.hip), 0: rocFFT
 };

@@ -770,6 +770,9 @@ int launch_laplace_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, con
     unsigned* near = (unsigned*)(cdl2 + (size_t)ng2 * NSL * FAR_NCOEF);
     unsigned* taken = near + (size_t)ng * nch;
     const unsigned gb = (unsigned)ceil_div64(ng, 4), gb2 = (unsigned)ceil_div64(ng2 * NSL, 4);
+    // (option "timing_split": an event pair per stage — parents' coefficients, blocks' coefficients, patches —
+    // instead of one around the three; bench.py's per-kernel roofline figures)
+    const bool split = ctx->opt_timing_split != 0;
     ipde_time_begin(ctx);
     // parents first (their bits steer the blocks' pass)
     if (MODE & MODE_SLP)
@@ -779,6 +782,10 @@ int launch_laplace_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, con
         hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_DLP, 16>), dim3(gb2), dim3(256), 0, ctx->stream, rec, ns_pad,
                            pxy, np, prm, head2, cdl2, taken, nch, (MODE & MODE_SLP) ? 0 : 1, (const unsigned*)nullptr,
                            NSL);
+    if (split) {
+        ipde_time_end(ctx);
+        ipde_time_begin(ctx);
+    }
     if (MODE & MODE_SLP)
         hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_SLP, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
                            pxy, np, prm, head, cs, near, nch, 1, (const unsigned*)taken, 1);
@@ -786,6 +793,10 @@ int launch_laplace_patches_far(ipde_ctx* ctx, const double* rec, int64_t ns, con
         hipLaunchKernelGGL((laplace_far_coeff_kernel<MODE_DLP, 1>), dim3(gb), dim3(256), 0, ctx->stream, rec, ns_pad,
                            pxy, np, prm, head, cdl, near, nch, (MODE & MODE_SLP) ? 0 : 1, (const unsigned*)taken, 1);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
+    if (split) {
+        ipde_time_end(ctx);
+        ipde_time_begin(ctx);
+    }
     // the table, then 2 levels x 27 combined coefficients for each of the workgroup's waves
     const size_t lds = ((size_t)lt.nkeys + (size_t)(NT / 64) * 2 * (FAR_P + 1)) * sizeof(double2);
     IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)laplace_patch_far_kernel<MODE, NT>,

@@ -128,7 +128,7 @@ class Context:
 # every tuning knob of a context (ipde_ctx_set_option; csrc/ctx.hip option_slot)
 OPTION_NAMES = ("laplace_variant", "stokes_variant", "modhelm_variant", "dense_pairs", "dense_persistent",
                 "gmres_graphs", "gmres_persistent", "gmres_lookahead", "gmres_fused_scale", "annular_fused_fft",
-                "annular_grouped", "fft2d", "interp_shifted", "interp_band")
+                "annular_grouped", "fft2d", "interp_shifted", "interp_band", "timing_split")
 
 
 def snapshot_options():
