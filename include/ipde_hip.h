@@ -476,6 +476,11 @@ int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles, int* perm)
  */
 int ipde_dense_gemv(ipde_ctx* ctx, int64_t m, int64_t n, const double* A, const double* x, double* y,
                     int accumulate);
+/* r = b - A x (A: m x n row-major, DEVICE) with products and sum carried in double-double: the residual of an
+   iterative-refinement step of the QFS density solves (systems of condition ~1e15 and densities of 10^3 .. 10^4:
+   the plain fp64 residual's own rounding is as large as the residual).  HBM bound: the matrix once. */
+int ipde_dense_residual(ipde_ctx* ctx, int64_t m, int64_t n, const double* A, const double* x, const double* b,
+                        double* r);
 
 /* ------------------------------------------------------------------------- */
 /* Closest-point coordinates of points near a closed curve  */

@@ -43,56 +43,56 @@ class ChebyshevOperators(object):
         self.P10 = self.V0 @ _embed(M, M - 1) @ self.VI1
 
 
+NESTED = 3      # the radial collocation grids: M, M - 1 and M - 2 Chebyshev-Gauss nodes
+
+
 class ApproximateAnnularGeometry(object):
     """n tangential points, M radial Chebyshev modes, annulus of `width` around a
     circle of radius approx_r.  keep_nyquist=True is the reference's annular_full
-    (ns = n), False its annular (ns = n-1)."""
+    (ns = n), False its annular (ns = n-1).
+
+    The per-grid attributes the solvers read (`rv0..2`, `approx_psi0..2`, `approx_inv_psi0..2`: radial node
+    offsets, radii of the approximating circles and their reciprocals on the grids of M, M - 1, M - 2
+    nodes) are filled by one pass over the nested grids."""
 
     def __init__(self, n, M, width, approx_r, keep_nyquist=False):
-        self.n = n
-        self.M = M
-        self.radius = approx_r
-        self.width = width
-        self.radial_h = self.width / self.M
-        self.tangent_h = 2 * np.pi / n
-        self.n2 = int(self.n / 2)
-        self.k = np.fft.fftfreq(self.n, 1.0 / self.n)
-        if keep_nyquist:
-            self.ns = self.n
-            self.ks = self.k
-        else:
-            self.ns = self.n - 1
-            self.ks = np.concatenate([self.k[:self.n2], self.k[self.n2 + 1:]])
+        self.n, self.M = n, M
+        self.radius, self.width = approx_r, width
+        self.radial_h, self.tangent_h = width / M, 2 * np.pi / n
+        self.n2 = n // 2
+        self.k = np.fft.fftfreq(n, 1.0 / n)
+        drop = [] if keep_nyquist else [self.n2]           # tangential modes the solver keeps
+        self.ks = np.delete(self.k, drop)
+        self.ns = self.ks.shape[0]
         self.iks = 1j * self.ks
-        _, self.rv0, rat0 = get_chebyshev_nodes(-self.width, 0.0, self.M - 0)
-        _, self.rv1, rat1 = get_chebyshev_nodes(-self.width, 0.0, self.M - 1)
-        _, self.rv2, rat2 = get_chebyshev_nodes(-self.width, 0.0, self.M - 2)
-        self.ratio = -rat0
-        self.approx_psi0 = self.radius + self.rv0
-        self.approx_psi1 = self.radius + self.rv1
-        self.approx_psi2 = self.radius + self.rv2
-        self.approx_inv_psi0 = 1.0 / self.approx_psi0
-        self.approx_inv_psi1 = 1.0 / self.approx_psi1
-        self.approx_inv_psi2 = 1.0 / self.approx_psi2
+        for g in range(NESTED):
+            _, rv, rat = get_chebyshev_nodes(-width, 0.0, M - g)
+            if g == 0:
+                self.ratio = -rat
+            setattr(self, 'rv%d' % g, rv)
+            setattr(self, 'approx_psi%d' % g, approx_r + rv)
+            setattr(self, 'approx_inv_psi%d' % g, 1.0 / (approx_r + rv))
         self.CO = ChebyshevOperators(M, self.ratio)
 
 
 class RealAnnularGeometry(object):
-    """Metric fields psi_k = speed (1 + r_k curvature) of the true annulus."""
+    """Metric fields of the true annulus on the nested radial grids: psi_g = speed (1 + r_g curvature) and its
+    reciprocal for g = 0, 1, 2 (`psi0..2`, `inv_psi0..2`), and on the finest-but-two grid the derivative
+    terms of the Laplacian's cross part."""
 
     def __init__(self, speed, curvature, AAG):
         n = curvature.shape[0]
         k = np.fft.fftfreq(n, 1.0 / n)
         dt_curvature = np.fft.ifft(np.fft.fft(curvature) * 1j * k).real
-        rv0, rv1, rv2 = AAG.rv0, AAG.rv1, AAG.rv2
-        self.psi0 = speed * (1 + rv0[:, None] * curvature)
-        self.psi1 = speed * (1 + rv1[:, None] * curvature)
-        self.psi2 = speed * (1 + rv2[:, None] * curvature)
-        self.inv_psi0 = 1.0 / self.psi0
-        self.inv_psi1 = 1.0 / self.psi1
-        self.inv_psi2 = 1.0 / self.psi2
-        self.DR_psi2 = speed * curvature * np.ones(rv2[:, None].shape)
-        idenom2 = 1.0 / (speed * (1 + rv2[:, None] * curvature) ** 3)
-        # the reference computes two candidate forms and keeps these (annular.py:107-108)
-        self.ipsi_DR_ipsi_DT_psi2 = dt_curvature * idenom2
-        self.ipsi_DT_ipsi_DR_psi2 = dt_curvature * idenom2
+        for g in range(NESTED):
+            stretch = 1 + getattr(AAG, 'rv%d' % g)[:, None] * curvature
+            setattr(self, 'psi%d' % g, speed * stretch)
+            setattr(self, 'inv_psi%d' % g, 1.0 / (speed * stretch))
+        rows = AAG.rv2.shape[0]
+        self.DR_psi2 = np.tile(speed * curvature, (rows, 1)) if np.ndim(speed * curvature) else \
+            np.full((rows, 1), float(speed * curvature))
+        # the reference computes two candidate forms of the cross terms and keeps ONE expression for both
+        # (annular.py:103-108, "these are what work"): dt_curvature / (speed stretch_2^3)
+        cross = dt_curvature / (speed * stretch ** 3)
+        self.ipsi_DR_ipsi_DT_psi2 = cross
+        self.ipsi_DT_ipsi_DR_psi2 = cross.copy()

@@ -58,6 +58,7 @@ class _QFS(object):
 
     DEVICE_SOLVE = True
     REFINE_STEPS = 0
+    REFINE_DD = False      # refinement residuals in double-double (csrc/dense.hip: ipde_dense_residual)
 
     def __init__(self, bdy, interior, slp, dlp, qfs_boundary=None, eps=1e-12):
         self.bdy = bdy
@@ -119,7 +120,7 @@ class _QFS(object):
         import torch
         ud = u if isinstance(u, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(u, dtype=float),
                                                                   device=self._dev)
-        x = self._fact.solve(self._A, ud, steps=self.REFINE_STEPS)
+        x = self._fact.solve(self._A, ud, steps=self.REFINE_STEPS, dd=self.REFINE_DD)
         return x if isinstance(u, torch.Tensor) else x.cpu().numpy()
 
     def boundary_limit(self, densities):
@@ -177,6 +178,22 @@ def _gemv(A, x, y=None):
     return y
 
 
+def _residual(A, x, b, dd=False):
+    """b - A x on the device; dd: products and sum carried in double-double (csrc/dense.hip:
+    ipde_dense_residual) — the residual of a refinement step where the plain one's rounding,
+    eps |A| |x|, is as large as the residual itself (Stokes QFS: condition ~1e15, densities 1e3..1e4)"""
+    if not dd:
+        return b - _gemv(A, x)
+    import torch
+    from .device import get_context, ptr
+    ctx = get_context(A.device.index)
+    A = A if A.is_contiguous() else A.contiguous()
+    x, b = x.contiguous(), b.contiguous()
+    r = torch.empty_like(b)
+    ctx.check(ctx.lib.ipde_dense_residual(ctx.handle, A.shape[0], A.shape[1], ptr(A), ptr(x), ptr(b), ptr(r)))
+    return r
+
+
 def _on_device(d, dev):
     """density as a flat fp64 device tensor (device tensors pass through: the solvers keep
     their per-boundary vectors in HBM between the stages of a solve)"""
@@ -201,14 +218,14 @@ def call_many(requests):
     groups = {}
     for i, (q, d) in enumerate(requests):
         if q._dev is not None and hasattr(q, '_fact'):
-            groups.setdefault(q.REFINE_STEPS, []).append(i)
+            groups.setdefault((q.REFINE_STEPS, q.REFINE_DD), []).append(i)
         else:
             out[i] = q(d)
-    for steps, idx in groups.items():
+    for (steps, dd), idx in groups.items():
         qs = [requests[i][0] for i in idx]
         ds = [q._prepare(requests[i][1]) for q, i in zip(qs, idx)]
         us = [q.boundary_limit(d) for q, d in zip(qs, ds)]
-        xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps)
+        xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps, dd=dd)
         for i, q, d, x in zip(idx, qs, ds, xs):
             # device densities in -> device density out (no host round trip)
             out[i] = q._post(x if _wants_device(d) else x.cpu().numpy(), d)
@@ -227,13 +244,13 @@ def u2s_many(requests):
     groups = {}
     for i, (q, u) in enumerate(requests):
         if q._dev is not None and hasattr(q, '_fact'):
-            groups.setdefault(q.REFINE_STEPS, []).append(i)
+            groups.setdefault((q.REFINE_STEPS, q.REFINE_DD), []).append(i)
         else:
             out[i] = q.u2s(u)
-    for steps, idx in groups.items():
+    for (steps, dd), idx in groups.items():
         qs = [requests[i][0] for i in idx]
         us = [_on_device(requests[i][1], q._dev) for q, i in zip(qs, idx)]
-        xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps)
+        xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps, dd=dd)
         for i, x in zip(idx, xs):
             out[i] = x if isinstance(requests[i][1], torch.Tensor) else x.cpu().numpy()
     return out
@@ -431,12 +448,12 @@ class _DeviceLU(object):
                                                         ptr(self.perm), ptr(b), ptr(x)))
         return x
 
-    def solve(self, A, b, steps=0):
+    def solve(self, A, b, steps=0, dd=False):
         """substitution (+ `steps` of iterative refinement; the plain substitution already
-        has LAPACK's residual, so the QFS solves use none)"""
+        has LAPACK's residual, so the scalar QFS solves use none; dd: residuals in double-double)"""
         x = self._subst(b)
         for _ in range(steps):
-            x = x + self._subst(b - _gemv(A, x))
+            x = x + self._subst(_residual(A, x, b, dd))
         return x
 
     @staticmethod
@@ -459,11 +476,11 @@ class _DeviceLU(object):
         return xs
 
     @staticmethod
-    def solve_batch(facts, As, bs, steps=0):
+    def solve_batch(facts, As, bs, steps=0, dd=False):
         """solve() for several systems together; facts: _DeviceLU objects"""
         xs = _DeviceLU._subst_batch(facts, bs)
         for _ in range(steps):
-            ds = _DeviceLU._subst_batch(facts, [b - _gemv(A, x) for A, b, x in zip(As, bs, xs)])
+            ds = _DeviceLU._subst_batch(facts, [_residual(A, x, b, dd) for A, b, x in zip(As, bs, xs)])
             xs = [x + d for x, d in zip(xs, ds)]
         return xs
 
@@ -565,7 +582,8 @@ class Stokes_QFS(_QFS):
     # potentials lost four digits at condition 1e15 — 1e-8 vs 3e-13 — which is why this
     # class first ran on host LAPACK; plain substitution has LAPACK's residual)
     DEVICE_SOLVE = True
-    REFINE_STEPS = 1
+    REFINE_STEPS = int(os.environ.get("IPDE_STOKES_QFS_REFINE_STEPS", "1"))
+    REFINE_DD = os.environ.get("IPDE_STOKES_QFS_REFINE_DD", "1") != "0"
 
     def __init__(self, bdy, interior, slp=True, dlp=True, qfs_boundary=None, eps=1e-12):
         # Per Fourier mode k the stokeslet block from a curve at distance d is

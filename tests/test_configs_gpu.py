@@ -24,9 +24,36 @@ def _free():
     torch.cuda.empty_cache()
 
 
-def test_config1_slp_dlp_grid_evaluator_2048_is_covered_elsewhere():
-    """configs[1] at size: tests/test_layer_gpu.py::test_laplace_linearity_full_size (SLP),
-    ::test_laplace_dlp_and_fused_full_size (DLP, SLP+DLP) — this is only a pointer"""
+def test_config1_slp_dlp_grid_evaluator_2048():
+    """configs[1]: Laplace SLP + DLP grid evaluator, 2048^2 grid x 4096-node star, one GPU — both layers in one
+    apply onto the bench's target list, through the route the solvers take (resident targets cut into padded
+    4 x 4 patch blocks, far sources in local expansions), against the pair-by-pair patch kernel everywhere and
+    the C oracle on a sample; the double layer alone obeys Gauss' identity (-1 inside for tau = 1)."""
+    import torch
+    import oracle
+    from util import Curve, grid_targets
+    from ipde_amd import layer_potentials as lp
+    c = Curve(4096, a=0.2, f=5)
+    trg, h = grid_targets(c, 2048, lim=1.5, clearance=5.0)
+    assert trg.N == 4129988
+    rng = np.random.default_rng(0)
+    sig, tau = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    far = lp.DeviceTargets(trg, plan=True, far=True)
+    pair = lp.DeviceTargets(trg, plan=True)
+    assert far.plan().padded_blocks and not pair.plan().padded_blocks
+    a = lp.Laplace_Layer_Apply(c, far, charge=sig, dipstr=tau)
+    b = lp.Laplace_Layer_Apply(c, pair, charge=sig, dipstr=tau)
+    assert float((a - b).abs().max()) < 1e-13 * float(b.abs().max())
+    idx = rng.choice(trg.N, 4000, replace=False)
+    ref = oracle.c_laplace_apply(c.x, c.y, trg.x[idx], trg.y[idx], w_sigma=sig * c.weights, nx=c.normal_x,
+                                 ny=c.normal_y, w_tau=tau * c.weights)
+    assert np.abs(a.cpu().numpy()[idx] - ref).max() < 1e-12 * np.abs(ref).max()
+    one = lp.Laplace_Layer_Apply(c, far, dipstr=np.ones(c.N)).cpu().numpy()
+    inside = np.hypot(trg.x, trg.y) < 0.7            # (the star's inner radius is 0.8)
+    outside = np.hypot(trg.x, trg.y) > 1.3
+    assert np.abs(one[inside] + 1.0).max() < 1e-12 and np.abs(one[outside]).max() < 1e-12
+    del far, pair, a, b
+    _free()
 
 
 def test_config2_full_interior_poisson_2048():
