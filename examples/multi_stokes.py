@@ -39,7 +39,7 @@ def v2f(x):
 
 
 def run(nb=800, M=14, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes=True,
-        return_fields=False, simple=False, warm=False, grid_backend=None, ng=None):
+        return_fields=False, simple=False, warm=False, grid_backend=None, ng=None, tol=1e-12):
     T = {}
     t0 = time.perf_counter()
     MOL = SlepianMollifier(1.5 * M)
@@ -97,11 +97,11 @@ def run(nb=800, M=14, a=4.0, b=3.0, verbose=False, solver_type='spectral', holes
 
     T['problem_definition_s'] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    uc, vc, pc = solver(fu, fv, tol=1e-12, verbose=verbose, maxiter=200, restart=100)
+    uc, vc, pc = solver(fu, fv, tol=tol, verbose=verbose, maxiter=200, restart=100)
     T['inhomogeneous_solve_s'] = time.perf_counter() - t0
     if warm:
         t0 = time.perf_counter()
-        uc, vc, pc = solver(fu, fv, tol=1e-12, maxiter=200, restart=100)
+        uc, vc, pc = solver(fu, fv, tol=tol, maxiter=200, restart=100)
         T['warm_inhomogeneous_solve_s'] = time.perf_counter() - t0
 
     # block boundary-integral system for the homogeneous correction (reference :104-159)

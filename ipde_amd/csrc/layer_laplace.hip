@@ -527,6 +527,20 @@ __global__ __launch_bounds__(256) void laplace_far_coeff_kernel(const double* __
     for (int k = 0; k <= K1; ++k) sre[k] = sim[k] = 0.0;
     // two sources per lane and trip: two independent power chains in flight
     for (int j0 = jlo; j0 < jhi; j0 += 128) {
+        if (PPL == 1 && skip) {
+            // a trip whose sixteen batches the parent block took whole is nobody's here: the far arcs of the curve
+            // are long, so most trips of most blocks end at these two scalar loads (the blocks' pass visited every
+            // source once per block: O(N_s N_blocks) loads and distance tests for ~1 % of them in an expansion)
+            const unsigned t0 = skip[(g >> 4) * nch + (j0 >> 6)];
+            const unsigned t1 = j0 + 64 < ns_pad ? skip[(g >> 4) * nch + (j0 >> 6) + 1] : 0xFFu;
+            if ((t0 & 0xFFu) == 0xFFu && (t1 & 0xFFu) == 0xFFu) {
+                if (write_near && lane == 0) {
+                    near[g * nch + (j0 >> 6)] = 0u;
+                    if (j0 + 64 < ns_pad) near[g * nch + (j0 >> 6) + 1] = 0u;
+                }
+                continue;
+            }
+        }
         double vre[2], vim[2], wre[2], wim[2];
         bool anyfar = false;
 #pragma unroll

@@ -268,6 +268,14 @@ __global__ __launch_bounds__(256) void modhelm_far_coeff_kernel(const double* __
 #pragma unroll
     for (int k = 0; k <= MFAR_P; ++k) sre[k] = sim[k] = 0.0;
     for (int j0 = jlo; j0 < jhi; j0 += 64) {
+        if (PPL == 1 && skip) {
+            // (a trip whose eight batches the parent block took or dropped whole is nobody's here: see layer_laplace.hip)
+            const unsigned t0 = skip[(g >> 4) * nch + (j0 >> 6)];
+            if ((t0 & 0xFFu) == 0xFFu) {
+                if (lane == 0) near[g * nch + (j0 >> 6)] = 0u;
+                continue;
+            }
+        }
         const int j = j0 + lane;
         const bool valid = j < ns_pad;
         const int jj = valid ? j : ns_pad - 1;

@@ -399,6 +399,18 @@ __global__ __launch_bounds__(256) void stokes_far_coeff_kernel(const double* __r
     // two sources per lane and trip: two independent power chains in flight (the chain of complex
     // products is the critical path at two waves per SIMD)
     for (int j0 = jlo; j0 < jhi; j0 += 128) {
+        if (PPL == 1 && skip) {
+            // (a trip whose sixteen batches the parent block took whole is nobody's here: see layer_laplace.hip)
+            const unsigned t0 = skip[(g >> 4) * nch + (j0 >> 6)];
+            const unsigned t1 = j0 + 64 < ns_pad ? skip[(g >> 4) * nch + (j0 >> 6) + 1] : 0xFFu;
+            if ((t0 & 0xFFu) == 0xFFu && (t1 & 0xFFu) == 0xFFu) {
+                if (lead && lane == 0) {
+                    near[g * nch + (j0 >> 6)] = 0u;
+                    if (j0 + 64 < ns_pad) near[g * nch + (j0 >> 6) + 1] = 0u;
+                }
+                continue;
+            }
+        }
         double vre[2], vim[2], wre[2], wim[2];
         bool anyfar = false;
 #pragma unroll

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64) void nufft_gather_kernel(const double* __restri
 // ---- the band form ----------------------------------------------------------------------------------
 // The pad kernel's value at fine wavenumber kx (|kx| <= nx/2), column j (0 .. ny/2) of a Combo over PACKED coarse
 // spectra, with the y window factor 1: the same Nyquist rules (see nufft_pad_kernel).
-__device__ __forceinline__ cd band_value(const Combo& cb, int kx, int j, int nx, int H, const double* __restrict__ rx,
+__device__ __noinline__ cd band_value(const Combo& cb, int kx, int j, int nx, int H, const double* __restrict__ rx,
                                          double dkx, double dky) {
     const int akx = kx < 0 ? -kx : kx;
     const int ci = (kx + nx) % nx;
@@ -415,15 +415,21 @@ __global__ __launch_bounds__(C* fftcore::Cfg<NX>::T) void band_col_kernel(Combo 
     const fftcore::cd e0{cs, sn};
     sincospi((double)T / NX, &sn, &cs);
     const fftcore::cd est{cs, sn};
+    // Columns 0 and ny/2 are packed together in the coarse spectra (unpacked with the mirrored row): those two
+    // columns take the general routine, row by row (two of ny/2 + 1 columns); every other column reads its own
+    // entries.  Either way the values go through the transform's LDS slots in a ROLLED loop (eight rows at a time
+    // for the plain columns: eight loads per term in flight) — unrolled sixteen times next to the transform's own
+    // registers the loader spilled 1 KB per lane.
+    const bool special = live && (j == 0 || j == H);
+    const double wy = (j == H) ? 0.5 : 1.0;
 #pragma unroll 1
     for (int a = 0; a < 2; ++a) {
-        fftcore::cd v[P];
-        fftcore::cd ph = e0;
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const int i = t + T * q;
-            fftcore::cd val{0.0, 0.0};
-            if (live) {
+        if (special) {
+            fftcore::cd ph = e0;
+#pragma unroll 1
+            for (int q = 0; q < P; ++q) {
+                const int i = t + T * q;
+                fftcore::cd val;
                 if (2 * i == NX) {
                     const ::cd vp = band_value(cb, NX / 2, j, NX, H, rx, dkx, dky);
                     const ::cd vm = band_value(cb, -(NX / 2), j, NX, H, rx, dkx, dky);
@@ -434,13 +440,77 @@ __global__ __launch_bounds__(C* fftcore::Cfg<NX>::T) void band_col_kernel(Combo 
                     val = fftcore::cd{w.x, w.y};
                     if (a == 1) {
                         val = cmul(val, ph);
-                        if (i > NX / 2) val = fftcore::cd{-val.x, -val.y};      // e^{i pi (i - nx) / nx} = -e^{i pi i / nx}
+                        if (i > NX / 2) val = fftcore::cd{-val.x, -val.y};
                     }
                 }
+                buf[padpos(i)] = val;
+                ph = cmul(ph, est);
             }
-            v[q] = val;
-            ph = cmul(ph, est);
+        } else if (live) {
+            fftcore::cd ph = e0;
+            constexpr int LB = P >= 8 ? 8 : P;      // rows per batch of the loader
+            fftcore::cd estb = est;                 // est^LB
+#pragma unroll
+            for (int m = 1; m < LB; m <<= 1) estb = cmul(estb, estb);
+#pragma unroll 1
+            for (int q0 = 0; q0 < P; q0 += LB) {
+                fftcore::cd acc[LB];
+#pragma unroll
+                for (int q = 0; q < LB; ++q) acc[q] = fftcore::cd{0.0, 0.0};
+                for (int tm = 0; tm < cb.n; ++tm) {
+                    const fftcore::cd* S = (const fftcore::cd*)cb.src[tm] + j;
+                    const int der = cb.der[tm];
+                    const double cf = cb.coef[tm] * wy;
+                    fftcore::cd raw[LB];
+                    double wr[LB];
+#pragma unroll
+                    for (int q = 0; q < LB; ++q) {
+                        const int i = t + T * (q0 + q);
+                        const int kx = (i < NX / 2) ? i : i - NX;
+                        raw[q] = S[(int64_t)i * H];
+                        wr[q] = rx[kx < 0 ? -kx : kx];
+                    }
+#pragma unroll
+                    for (int q = 0; q < LB; ++q) {
+                        const int i = t + T * (q0 + q);
+                        const int kx = (i < NX / 2) ? i : i - NX;
+                        const double w = wr[q] * cf;
+                        fftcore::cd u{raw[q].x * w, raw[q].y * w};
+                        if (der == 1) u = fftcore::cd{-u.y * (kx * dkx), u.x * (kx * dkx)};
+                        if (der == 2) u = fftcore::cd{-u.y * (j * dky), u.x * (j * dky)};
+                        acc[q].x += u.x;
+                        acc[q].y += u.y;
+                    }
+                }
+                fftcore::cd pq = ph;
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {
+                    const int i = t + T * (q0 + q);
+                    fftcore::cd val = acc[q];
+                    if (a == 1) {
+                        val = cmul(val, pq);
+                        if (i > NX / 2) val = fftcore::cd{-val.x, -val.y};      // e^{i pi (i - nx) / nx} = -e^{i pi i / nx}
+                    }
+                    buf[padpos(i)] = val;
+                    pq = cmul(pq, est);
+                }
+                ph = cmul(ph, estb);
+            }
+            // the x Nyquist row (i = nx/2, thread t = 0) holds +nx/2 and -nx/2 together
+            if (t == 0) {
+                const ::cd vp = band_value(cb, NX / 2, j, NX, H, rx, dkx, dky);
+                const ::cd vm = band_value(cb, -(NX / 2), j, NX, H, rx, dkx, dky);
+                buf[padpos(NX / 2)] = a == 0 ? fftcore::cd{vp.x + vm.x, vp.y + vm.y}
+                                             : fftcore::cd{-(vp.y - vm.y), vp.x - vm.x};
+            }
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < P; ++q) buf[padpos(t + T * q)] = fftcore::cd{0.0, 0.0};
         }
+        fftcore::cd v[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = buf[padpos(t + T * q)];      // (its own slots: nobody else's)
+        __syncthreads();                                                  // (before anybody's exchange writes)
         fft_regs<NX, +1, false>(v, t, pw, buf);
         if (live) {
             fftcore::cd* base = (fftcore::cd*)D + j;
@@ -492,6 +562,26 @@ __global__ __launch_bounds__(1024) void band_sort_kernel(const double* __restric
     if (tid == 1023) start[nrows_ext] = (int)np;
     __syncthreads();
     for (int64_t j = tid; j < np; j += 1024) perm[start[r0v[j]] + rank[j]] = (int)j;
+}
+
+// wave-wide sum with DPP moves inside the 16-lane rows and four v_readlane across them (~30 instructions; the
+// shuffle form is six ds_bpermute round trips per operand, and the gather reduces six operands per point)
+template <int CTRL>
+__device__ __forceinline__ double band_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double band_rl(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double band_wave_sum(double v) {
+    v += band_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += band_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += band_dpp<0x141>(v);      // row_half_mirror
+    v += band_dpp<0x140>(v);      // row_mirror
+    return (band_rl(v, 0) + band_rl(v, 16)) + (band_rl(v, 32) + band_rl(v, 48));
 }
 
 // e^{2 pi i k f}, k >= 0 an integer, f in [0, 1): k f = p + e exactly (fma), frac(p) exact, the 8 leading bits
@@ -566,12 +656,21 @@ __global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__
         }
     __syncthreads();
     const double hfx = TWO_PI / nfx;
+    __shared__ int s_j[PTS];
+    __shared__ double s_fy[PTS];
     for (int c = blockIdx.y; c * PTS < cnt; c += gridDim.y) {
         const int npt = cnt - c * PTS < PTS ? cnt - c * PTS : PTS;
-        for (int p = 0; p < npt; ++p) {
-            const int j = perm[lo + c * PTS + p];
+        // the chunk's points first (index and y as a fraction of the period): fetched one after the other inside
+        // the loop, the two dependent loads were the longest thing a point did
+        if (tid < npt) {
+            const int j = perm[lo + c * PTS + tid];
             double fy = py[j] * (1.0 / TWO_PI);
-            fy -= floor(fy);
+            s_j[tid] = j;
+            s_fy[tid] = fy - floor(fy);
+        }
+        __syncthreads();
+        for (int p = 0; p < npt; ++p) {
+            const double fy = s_fy[p];
             cd ph = unit_kf(tid, fy, T);
             const cd step = unit_kf(256, fy, T);
             double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -586,9 +685,8 @@ __global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__
                 ph = cmulz(ph, step);
             }
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-                for (int f = 0; f < 6; ++f) s[f] += __shfl_xor(s[f], m);
+            for (int f = 0; f < 6; ++f)
+                if (f < na || (f >= 3 && f - 3 < na && rc.need_dy[f - 3])) s[f] = band_wave_sum(s[f]);
             if (lane == 0) {
 #pragma unroll
                 for (int f = 0; f < 6; ++f) wsum[f][p][wave] = s[f];
@@ -599,7 +697,7 @@ __global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__
             const int o = tid / PTS, p = tid % PTS;
             if (o < rc.nout && p < npt) {
                 const BandOut& bo = rc.o[o];
-                const int j = perm[lo + c * PTS + p];
+                const int j = s_j[p];
                 double val = 0.0;
                 for (int e = 0; e < bo.n; ++e) {
                     const int f = bo.arr[e] + 3 * bo.kind[e];
@@ -617,6 +715,268 @@ __global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__
             }
         }
         __syncthreads();
+    }
+}
+
+// The same gather with a WAVE per (fine row, quarter of its points): lane l holds columns k = l + 64 m of the row
+// (QW of them, na arrays), so a point's dense sums are the wave's own — no LDS exchange, no barrier, one DPP
+// reduction per sum — and the four waves of a row run on their own (the 256-thread form above: every point crossed
+// four waves and two barriers, and a row's sixteen points went one after the other: 180 us at 2048^2 x 4096 points
+// for 40 us of arithmetic).  Rows of up to 64 QW columns; wider ones (ny = 8192) keep the 256-thread form.
+template <int QW>
+__global__ __launch_bounds__(64) void band_gather_wave_kernel(const cd* __restrict__ D0, const cd* __restrict__ D1,
+                                                              const cd* __restrict__ D2, int na, BandRecipe rc,
+                                                              int64_t pitch, int ncol, int nfx,
+                                                              const double* __restrict__ px,
+                                                              const double* __restrict__ py, int64_t np,
+                                                              const int* __restrict__ start,
+                                                              const int* __restrict__ perm,
+                                                              const int* __restrict__ r0v, double beta, double dky,
+                                                              const cd* __restrict__ roots,
+                                                              double* __restrict__ partial) {
+    constexpr int W = 16;
+    const int r_ext = blockIdx.x;
+    const int lo = start[r_ext - (W - 1) > 0 ? r_ext - (W - 1) : 0], hi = start[r_ext + 1];
+    const int cnt = hi - lo;
+    const int sub = blockIdx.y, nsub = gridDim.y;
+    if (sub >= cnt) return;
+    const int lane = threadIdx.x;
+    __shared__ cd T[256];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T[lane + 64 * i] = roots[lane + 64 * i];
+    const double TWO_PI = 6.283185307179586476925286766559;
+    const int phys = ((r_ext - 16) % nfx + nfx) % nfx;
+    const cd* Dp[3] = {D0, D1, D2};
+    cd g[3][QW];
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int m = 0; m < QW; ++m) {
+            const int k = lane + 64 * m;
+            g[f][m] = (f < na && k < ncol) ? Dp[f][(int64_t)phys * pitch + k] : cd{0.0, 0.0};
+            if (k == 0) g[f][m] = cd{0.5 * g[f][m].x, 0.5 * g[f][m].y};      // eps_0 = 1/2 (see row_c2r)
+        }
+    __builtin_amdgcn_wave_barrier();
+    const double hfx = TWO_PI / nfx;
+    const int mine = (cnt - sub + nsub - 1) / nsub;          // points sub, sub + nsub, ...
+    for (int b0 = 0; b0 < mine; b0 += 64) {
+        // this batch's points, a lane each: index, y as a fraction of the period, the x window's weight
+        int jl = 0;
+        double fyl = 0.0, wxl = 0.0;
+        if (b0 + lane < mine) {
+            jl = perm[lo + sub + (b0 + lane) * nsub];
+            double fy = py[jl] * (1.0 / TWO_PI);
+            fyl = fy - floor(fy);
+            const int r0 = r0v[jl];
+            double x = px[jl];
+            x -= TWO_PI * floor(x / TWO_PI);
+            const double zq = (x - (double)(r_ext - 16) * hfx) / (0.5 * W * hfx);
+            const double qq = 1.0 - zq * zq;
+            wxl = qq > 0.0 ? exp(beta * (sqrt(qq) - 1.0)) : 0.0;
+            (void)r0;
+        }
+        const int nb = mine - b0 < 64 ? mine - b0 : 64;
+        for (int p = 0; p < nb; ++p) {
+            const double fy = __shfl(fyl, p);
+            cd ph = unit_kf(lane, fy, T);
+            const cd step = unit_kf(64, fy, T);
+            double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int m = 0; m < QW; ++m) {
+                const double kq = (double)(lane + 64 * m);
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    s[f] = fma(g[f][m].x, ph.x, fma(-g[f][m].y, ph.y, s[f]));
+                    if (rc.need_dy[f]) s[3 + f] = fma(kq, fma(g[f][m].x, ph.y, g[f][m].y * ph.x), s[3 + f]);
+                }
+                ph = cmulz(ph, step);
+            }
+#pragma unroll
+            for (int f = 0; f < 6; ++f)
+                if (f < na || (f >= 3 && f - 3 < na && rc.need_dy[f - 3])) s[f] = band_wave_sum(s[f]);
+            // (every lane holds the six sums now) lane o forms output o
+            const int j = __shfl(jl, p);
+            const double wx = __shfl(wxl, p);
+            if (lane < rc.nout) {
+                const BandOut& bo = rc.o[lane];
+                double val = 0.0;
+                for (int e = 0; e < bo.n; ++e) {
+                    const int f = bo.arr[e] + 3 * bo.kind[e];
+                    double sum = 0.0;
+#pragma unroll
+                    for (int ff = 0; ff < 6; ++ff) sum = f == ff ? s[ff] : sum;
+                    val += bo.coef[e] * (bo.kind[e] ? -dky * sum : sum);
+                }
+                const int sidx = r_ext - r0v[j];
+                double* dst = partial + ((int64_t)bo.out * np + j) * W + sidx;
+                *dst = bo.acc ? *dst + wx * val : wx * val;
+            }
+        }
+    }
+}
+
+// The gather as a block GEMM on the matrix cores.  For a tile of 16 consecutive fine rows and a chunk of 16 of the
+// points whose windows meet it,  P[row][point] = Re sum_k eps_k g[row][k] e^{i k y_point}  is a (16 x ncol) x (ncol x 16)
+// product: v_mfma_f64_16x16x4 with A = Re g / Im g of the rows (from LDS, staged 128 columns at a time with coalesced
+// loads) and B = cos / -sin of k y — the phases are formed ONCE per (k, point) and serve all sixteen rows (the
+// row-by-row forms above spend most of their time on them), each lane advancing its own point's phase by e^{4 i y}
+// and re-seeding it exactly at every staged tile (32 steps: 7e-15).  The y-derivative sums are two more products with
+// B = k sin, k cos.  A workgroup = a row tile, its four waves take four point chunks; the epilogue applies the x
+// window's weights and writes every (output, point, row) partial to its own slot, as before.
+typedef double band_d4 __attribute__((ext_vector_type(4)));
+
+template <int NA>
+__global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restrict__ D0, const cd* __restrict__ D1,
+                                                              const cd* __restrict__ D2, BandRecipe rc, int64_t pitch,
+                                                              int ncol, int nfx, int nrows_ext,
+                                                              const double* __restrict__ px,
+                                                              const double* __restrict__ py, int64_t np,
+                                                              const int* __restrict__ start,
+                                                              const int* __restrict__ perm,
+                                                              const int* __restrict__ r0v, double beta, double dky,
+                                                              const cd* __restrict__ roots,
+                                                              double* __restrict__ partial) {
+    // CH point chunks per round; the four waves SPLIT THE COLUMNS of every staged tile (wave w: steps w, w + 4, ...) and
+    // each carries all CH chunks — whatever the number of chunks of a tile (two, typically) all four SIMDs of the CU
+    // work; with a chunk per wave half of them idled and two workgroups on a CU queued on the same two.  The waves'
+    // partial products are added through LDS at the end of a round, in wave order.
+    constexpr int W = 16, KT = 128, RS = KT + 1;       // (row stride 129 slots: the sixteen rows of an A read hit 16 bank groups)
+    constexpr int CH = NA <= 2 ? 4 : 2;
+    constexpr int NACC = CH * NA * 2;                   // accumulator tiles (4 doubles per lane each)
+    __shared__ cd sG[NA][16][RS];
+    __shared__ cd T[256];
+    __shared__ int s_phys[16];
+    static_assert(sizeof(cd) * NA * 16 * RS >= sizeof(double) * 64 * 4 * NACC, "the reduction reuses the staging buffer");
+    double* sacc = (double*)&sG[0][0][0];               // [NACC][4][64] after the last tile of a round
+    const int R0 = 16 * (int)blockIdx.x;
+    const int first = R0 - (W - 1) > 0 ? R0 - (W - 1) : 0;
+    const int last = R0 + 16 < nrows_ext ? R0 + 16 : nrows_ext;
+    const int lo = start[first], cnt = start[last] - lo;
+    if (cnt <= 0) return;                               // (uniform over the workgroup)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, h4 = lane >> 4;
+    T[tid] = roots[tid];
+    if (tid < 16) s_phys[tid] = ((R0 + tid - 16) % nfx + nfx) % nfx;
+    const double TWO_PI = 6.283185307179586476925286766559;
+    const double hfx = TWO_PI / nfx;
+    const cd* Dp[3] = {D0, D1, D2};
+    const int nchunk = (cnt + 15) / 16;
+    // (blockIdx.y strides over the rounds: where the curve runs along a fine row hundreds of points meet one tile)
+    for (int round = blockIdx.y; round * CH < nchunk; round += gridDim.y) {
+        const int nact = nchunk - round * CH < CH ? nchunk - round * CH : CH;
+        // this lane's B column in every chunk of the round: point 16 (CH round + c) + l16
+        double fy[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int q = 16 * (round * CH + c) + l16;
+            double f = 0.0;
+            if (q < cnt) f = py[perm[lo + q]] * (1.0 / TWO_PI);
+            fy[c] = f - floor(f);
+        }
+        band_d4 acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = band_d4{0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < ncol; k0 += KT) {
+            __syncthreads();                            // (the previous tile has been consumed; T, s_phys are in place)
+            // (eight loads per thread in flight: rolled, every load waited for its own LDS store — 16 us per tile)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                cd st[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int e = tid + 256 * it, i = e / KT, kk = e % KT, k = k0 + kk;
+                    st[it] = k < ncol ? Dp[a][(int64_t)s_phys[i] * pitch + k] : cd{0.0, 0.0};
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int e = tid + 256 * it, i = e / KT, kk = e % KT;
+                    cd v = st[it];
+                    if (k0 + kk == 0) v = cd{0.5 * v.x, 0.5 * v.y};             // eps_0 = 1/2 (see row_c2r)
+                    sG[a][i][kk] = v;
+                }
+            }
+            __syncthreads();
+            // this wave's steps of the tile: k = k0 + 4 s + h4, s = wave, wave + 4, ...; phases re-seeded per tile
+            cd ph[CH], st16[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                ph[c] = unit_kf(k0 + 4 * wave + h4, fy[c], T);
+                st16[c] = unit_kf(16, fy[c], T);
+            }
+#pragma unroll 2
+            for (int it = 0; it < KT / 16; ++it) {
+                const int s4 = wave + 4 * it;
+                const int kk = 4 * s4 + h4;
+                const double kq = (double)(k0 + kk);
+                cd gv[NA];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) gv[a] = sG[a][l16][kk];   // A entries: row l16, k = k0 + 4 s + h4
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if (c >= nact) continue;            // (uniform: chunks of this round that exist)
+                    const double ky = kq * ph[c].y, kx = kq * ph[c].x, ms = -ph[c].y;
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        band_d4& P = acc[(c * NA + a) * 2];
+                        band_d4& Dy = acc[(c * NA + a) * 2 + 1];
+                        P = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[a].x, ph[c].x, P, 0, 0, 0);
+                        if (rc.need_dy[a]) Dy = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[a].x, ky, Dy, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        band_d4& P = acc[(c * NA + a) * 2];
+                        band_d4& Dy = acc[(c * NA + a) * 2 + 1];
+                        P = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[a].y, ms, P, 0, 0, 0);
+                        if (rc.need_dy[a]) Dy = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[a].y, kx, Dy, 0, 0, 0);
+                    }
+                    ph[c] = cmulz(ph[c], st16[c]);
+                }
+            }
+        }
+        // the four waves' partial products, added in wave order through the staging buffer
+        for (int w = 0; w < 4; ++w) {
+            __syncthreads();
+            if (wave == w) {
+#pragma unroll
+                for (int i = 0; i < NACC; ++i)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        double* slot = sacc + ((size_t)(i * 4 + v) * 64 + lane);
+                        *slot = w == 0 ? acc[i][v] : *slot + acc[i][v];
+                    }
+            }
+        }
+        __syncthreads();
+        // epilogue: wave c takes chunk c; lane (point l16, h4) holds rows h4 + 4 v of its point's column
+        if (wave < CH) {
+            const int c = wave;
+            const int q = 16 * (round * CH + c) + l16;
+            if (q < cnt) {
+                const int j = perm[lo + q];
+                const int r0 = r0v[j];
+                double x = px[j];
+                x -= TWO_PI * floor(x / TWO_PI);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r_ext = R0 + h4 + 4 * v;
+                    const int sidx = r_ext - r0;
+                    if (sidx < 0 || sidx >= W || r_ext >= nrows_ext) continue;
+                    const double zq = (x - (double)(r_ext - 16) * hfx) / (0.5 * W * hfx);
+                    const double qq = 1.0 - zq * zq;
+                    const double wx = qq > 0.0 ? exp(beta * (sqrt(qq) - 1.0)) : 0.0;
+                    for (int o = 0; o < rc.nout; ++o) {
+                        const BandOut& bo = rc.o[o];
+                        double val = 0.0;
+                        for (int e = 0; e < bo.n; ++e) {
+                            const int i = (c * NA + bo.arr[e]) * 2 + bo.kind[e];
+                            const double sum = sacc[(size_t)(i * 4 + v) * 64 + lane];
+                            val += bo.coef[e] * (bo.kind[e] ? -dky * sum : sum);
+                        }
+                        double* dst = partial + ((int64_t)bo.out * np + j) * W + sidx;
+                        *dst = bo.acc ? *dst + wx * val : wx * val;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -655,6 +1015,7 @@ struct GridInterp {
     cd* bandD[3] = {nullptr, nullptr, nullptr};   // packed variant: (2 nx, band_pitch) fine-row-interleaved
     int64_t band_pitch = 0;
     double* d_ones = nullptr;     // the y window factor of the pad kernels: 1
+    cd* d_roots = nullptr;        // the 256th roots of unity (the gather's phase table)
     int* ibuf = nullptr;          // cnt, start (nfx + 33 each), perm, r0, rank (np each)
     int64_t ibuf_np = -1;
     double* partial = nullptr;    // (8, np, 16)
@@ -692,6 +1053,7 @@ void grid_interp_destroy(GridInterp* gi) {
     for (auto& q : gi->bandD)
         if (q) (void)hipFree(q);
     if (gi->d_ones) (void)hipFree(gi->d_ones);
+    if (gi->d_roots) (void)hipFree(gi->d_roots);
     if (gi->ibuf) (void)hipFree(gi->ibuf);
     if (gi->partial) (void)hipFree(gi->partial);
     if (gi->stage) (void)hipFree(gi->stage);
@@ -738,6 +1100,17 @@ int grid_interp_create(ipde_ctx* ctx, int64_t nx, int64_t ny, double hx, double 
     up(&gi->d_rx, rx);
     up(&gi->d_ry, ry);
     up(&gi->d_ones, std::vector<double>((size_t)ny / 2 + 2, 1.0));
+    {
+        std::vector<double> roots(512);
+        for (int i = 0; i < 256; ++i) {
+            const long double a = 2.0L * 3.14159265358979323846264338327950288L * i / 256.0L;
+            roots[2 * i] = (double)cosl(a);
+            roots[2 * i + 1] = (double)sinl(a);
+        }
+        double* r = nullptr;
+        up(&r, roots);
+        gi->d_roots = (cd*)r;
+    }
     // the columns of the fine half spectra beyond the coarse band are never written: zero once
     for (auto& w : gi->fine.W)
         if (general && st == IPDE_OK && w &&
@@ -799,6 +1172,15 @@ static void launch_band_gather(GridInterp* gi, const cd* const* D, int na, const
     hipLaunchKernelGGL(band_gather_kernel<Q>, dim3((unsigned)(gi->nfx + 32), 4), dim3(256), 0, gi->ctx->stream, D[0],
                        D[1], D[2], na, rc, pitch, ncol, (int)gi->nfx, d_px, d_py, np, start, perm, r0v, gi->betax, dky,
                        gi->partial);
+}
+
+template <int QW>
+static void launch_band_gather_wave(GridInterp* gi, const cd* const* D, int na, const BandRecipe& rc, int64_t pitch,
+                                    int ncol, const double* d_px, const double* d_py, int64_t np, const int* start,
+                                    const int* perm, const int* r0v, double dky) {
+    hipLaunchKernelGGL(band_gather_wave_kernel<QW>, dim3((unsigned)(gi->nfx + 32), 4), dim3(64), 0, gi->ctx->stream, D[0],
+                       D[1], D[2], na, rc, pitch, ncol, (int)gi->nfx, d_px, d_py, np, start, perm, r0v, gi->betax, dky,
+                       (const cd*)gi->d_roots, gi->partial);
 }
 
 template <int NX>
@@ -936,20 +1318,21 @@ static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout,
             rc.o[rc.nout++] = bo;
         }
         if (rc.nout == 0) continue;
-        if (ncol <= 256)
-            launch_band_gather<1>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
-        else if (ncol <= 512)
-            launch_band_gather<2>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
-        else if (ncol <= 768)
-            launch_band_gather<3>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
-        else if (ncol <= 1280)
-            launch_band_gather<5>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
-        else if (ncol <= 2304)
-            launch_band_gather<9>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
-        else if (ncol <= 4352)
-            launch_band_gather<17>(gi, D, na, rc, pitch, ncol, d_px, d_py, np, start, perm, r0v, dky);
-        else
-            return IPDE_ERR_INVALID;
+        {
+            // the gather as a block GEMM on the matrix cores: a workgroup per tile of 16 fine rows
+            const unsigned ntiles = (unsigned)((nrows_ext + 15) / 16);
+#define BAND_MFMA(NA)                                                                                                  \
+    hipLaunchKernelGGL(band_gather_mfma_kernel<NA>, dim3(ntiles, 16), dim3(256), 0, ctx->stream, D[0], D[1], D[2], rc, pitch,  \
+                       ncol, (int)gi->nfx, nrows_ext, d_px, d_py, np, (const int*)start, (const int*)perm,                 \
+                       (const int*)r0v, gi->betax, dky, (const cd*)gi->d_roots, gi->partial)
+            if (na == 1)
+                BAND_MFMA(1);
+            else if (na == 2)
+                BAND_MFMA(2);
+            else
+                BAND_MFMA(3);
+#undef BAND_MFMA
+        }
         IPDE_HIP_CHECK(ctx, hipGetLastError());
     }
     const int64_t n = (int64_t)nout * np;

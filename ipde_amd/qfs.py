@@ -577,13 +577,13 @@ class Stokes_QFS(_QFS):
     (all the solver produces) it leaves the velocity untouched and selects the density
     with  int mu.n = 0, which also pins the pressure constant."""
 
-    MAX_ALPHA = 5.4
+    MAX_ALPHA = float(os.environ.get("IPDE_STOKES_QFS_MAX_ALPHA", "5.4"))
     # factor with rocSOLVER, substitute with csrc/dense.hip (with the library TRSM the
     # potentials lost four digits at condition 1e15 — 1e-8 vs 3e-13 — which is why this
     # class first ran on host LAPACK; plain substitution has LAPACK's residual)
     DEVICE_SOLVE = True
     REFINE_STEPS = int(os.environ.get("IPDE_STOKES_QFS_REFINE_STEPS", "1"))
-    REFINE_DD = os.environ.get("IPDE_STOKES_QFS_REFINE_DD", "1") != "0"
+    REFINE_DD = os.environ.get("IPDE_STOKES_QFS_REFINE_DD", "0") != "0"
 
     def __init__(self, bdy, interior, slp=True, dlp=True, qfs_boundary=None, eps=1e-12):
         # Per Fourier mode k the stokeslet block from a curve at distance d is
