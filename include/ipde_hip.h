@@ -463,7 +463,10 @@ int ipde_dense_lu_solve_batch(ipde_ctx* ctx, int nsys, const int64_t* n, const d
  * ipde/solvers/internals/poisson.py:18-25, stokes.py:21-24, examples/interior_poisson.py:87).
  * tiles: DEVICE, (n_pad/64)^2 tiles of 64 x 64 doubles, tile (I, J) at ((I nb + J) 4096), element
  * (r, c) of a tile at c*64 + r, the matrix padded with the identity to n_pad rows (a multiple of
- * 128, at most 8192).  perm: DEVICE, n_pad ints: row i of P A is row perm[i] of A.
+ * 128, at most 32768).  perm: DEVICE, n_pad ints: row i of P A is row perm[i] of A.
+ * Up to 8192 rows a panel is one workgroup's; beyond, the panels of more than 4096 rows are dealt out to
+ * up to 64 workgroups (a row per thread, one cross-workgroup exchange per column; a hand-off that times
+ * out sets the context's sticky abort word, reported by the next ipde_ctx_sync).
  * Asynchronous on the context's stream.
  */
 int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles, int* perm);

@@ -388,6 +388,230 @@ __global__ __launch_bounds__(NT) void lu_panel_kernel(double* __restrict__ T, in
     }
 }
 
+// ---- the panel across several CUs (systems beyond 8192 padded rows) --------------------------------------------
+// The single-workgroup panel above keeps W columns in registers and is left-looking over the rest: at 19 200 rows
+// (BASELINE configs[4]'s Stokes QFS systems) one CU would re-read 157 MB per panel, 0.85 s for the 300 panels.
+// Here the panel's rows are dealt out to G workgroups of 512 threads, a ROW PER THREAD with all 64 columns in
+// registers (128 VGPRs): plain right-looking elimination, nothing is re-read.  What crosses workgroups is the
+// pivot search — once per column every workgroup publishes its best candidate TOGETHER WITH that row's 64 values,
+// workgroup 0 the diagonal row; wave 0 of every workgroup reads the G candidates, picks the winner by LAPACK's rule
+// (first row of maximal |a|) and fetches its row: one exchange per column, ~3 us.  Hand-off as in the substitution
+// kernels of dense.hip (cdna guide, Guideline 16: the data is the flag): every published value is one 8-byte
+// agent-scope relaxed atomic store into a slot of its own, every read an agent-scope relaxed atomic load polled until
+// the slot no longer holds the sentinel (a NaN pattern no arithmetic produces, filled by one memset per panel); every
+// spin is bounded, a time-out sets the context's sticky abort word and every waiter leaves.  All G <= 64 workgroups
+// are resident together (one per CU, 38 at 19 200 rows).
+constexpr unsigned long long LUX_SENTINEL = 0xFFF7A5A5FFF7A5A5ull;
+constexpr unsigned LUX_SENTINEL32 = 0xFFF7A5A5u;
+constexpr unsigned LUX_SPIN_LIMIT = 1u << 24;
+constexpr int LUX_REC = TB + 2;                 // a record: value, row, the row's 64 entries
+typedef __attribute__((address_space(1))) unsigned long long lux_u64;
+typedef __attribute__((address_space(1))) unsigned int lux_u32;
+
+__device__ __forceinline__ double lux_wait(const double* p, unsigned* abort_word) {
+    unsigned long long bits;
+    for (unsigned spins = 0;;) {
+        bits = __hip_atomic_load((lux_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bits != LUX_SENTINEL) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0) {
+            if (__hip_atomic_load((lux_u32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (spins >= LUX_SPIN_LIMIT) {
+                __hip_atomic_store((lux_u32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    return __longlong_as_double((long long)bits);
+}
+__device__ __forceinline__ void lux_publish(double* p, double v) {
+    __hip_atomic_store((lux_u64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// (the 64 column steps are a compile-time recursion: as a loop the optimizer would not unroll a body of this size,
+// and a[j] with a run-time j put the row into scratch memory)
+template <int NT>
+struct LuMultiPanel {
+    static constexpr int NW = NT / 64;
+    double a[TB];
+    int tid, lane, wave, g, G, q;
+    bool live;
+    double* xch;
+    unsigned* abort_word;
+    double* sh_cv;
+    int* sh_cq;
+    double* sh_prow;
+    double* sh_drow;
+    int* sh_p;
+    int* sh_piv;
+
+    template <int J>
+    __device__ __forceinline__ void step() {
+        constexpr int d = J;                           // diagonal position (panel row and column)
+        // this workgroup's candidate: first row of maximal |a| among its rows >= d
+        double bv = (live && q >= d) ? fabs(a[J]) : -1.0;
+        int bq = (live && q >= d && bv >= 0.0) ? q : 0x7fffffff;
+        if (bq == 0x7fffffff) bv = -1.0;               // (a NaN entry: never a candidate)
+        {
+            const double wmax = wave_max_f64(bv);
+            unsigned long long tie = __ballot(bv == wmax && bq != 0x7fffffff);
+            int wq = 0x7fffffff;
+            while (tie) {
+                const int l = __ffsll((long long)tie) - 1;
+                const int cq = __builtin_amdgcn_readlane(bq, l);
+                wq = cq < wq ? cq : wq;
+                tie &= tie - 1;
+            }
+            if (lane == 0) {
+                sh_cv[wave] = wq == 0x7fffffff ? -1.0 : wmax;
+                sh_cq[wave] = wq;
+            }
+        }
+        __syncthreads();
+        double gv = -1.0;
+        int gq = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const double cv = sh_cv[w];
+            const int cq = sh_cq[w];
+            if (cq != 0x7fffffff && (cv > gv || (cv == gv && cq < gq))) {
+                gv = cv;
+                gq = cq;
+            }
+        }
+        double* rec = xch + ((size_t)J * (G + 1) + g) * LUX_REC;
+        if (live && q == gq) {                         // the candidate row, by its owner, then its value (the flag last)
+#pragma unroll
+            for (int c = 0; c < TB; ++c) lux_publish(rec + 2 + c, a[c]);
+            lux_publish(rec + 1, (double)gq);
+            lux_publish(rec, gv);
+        }
+        if (gq == 0x7fffffff && tid == 0) {            // nothing to offer (all its rows above the diagonal, or NaN)
+            lux_publish(rec + 1, 2147483647.0);
+            lux_publish(rec, -1.0);
+        }
+        if (g == 0 && tid == d) {                      // the diagonal row as it is before the interchange
+            double* rd = xch + ((size_t)J * (G + 1) + G) * LUX_REC;
+#pragma unroll
+            for (int c = 0; c < TB; ++c) lux_publish(rd + 2 + c, a[c]);
+        }
+        if (wave == 0) {
+            double cv = -2.0;
+            int cq = 0x7fffffff;
+            if (lane < G) {
+                const double* r = xch + ((size_t)J * (G + 1) + lane) * LUX_REC;
+                cv = lux_wait(r, abort_word);
+                cq = (int)lux_wait(r + 1, abort_word);
+            }
+            const double gmax = wave_max_f64(cv);
+            unsigned long long tie = __ballot(cv == gmax && cq != 0x7fffffff && cv >= 0.0);
+            int p = 0x7fffffff, pw = 0;
+            while (tie) {
+                const int l = __ffsll((long long)tie) - 1;
+                const int c2 = __builtin_amdgcn_readlane(cq, l);
+                if (c2 < p) {
+                    p = c2;
+                    pw = l;
+                }
+                tie &= tie - 1;
+            }
+            const double dr = lux_wait(xch + ((size_t)J * (G + 1) + G) * LUX_REC + 2 + lane, abort_word);
+            double pr = dr;
+            if (p == 0x7fffffff)
+                p = d;                                 // (an all-NaN column: keep the diagonal)
+            else if (p != d)
+                pr = lux_wait(xch + ((size_t)J * (G + 1) + pw) * LUX_REC + 2 + lane, abort_word);
+            sh_prow[lane] = pr;
+            sh_drow[lane] = dr;
+            if (lane == 0) {
+                *sh_p = p;
+                if (g == 0) sh_piv[d] = p;
+            }
+        }
+        __syncthreads();
+        const int p = *sh_p;
+        if (p != d && live) {
+            if (q == d) {
+#pragma unroll
+                for (int c = 0; c < TB; ++c) a[c] = sh_prow[c];
+            } else if (q == p) {
+#pragma unroll
+                for (int c = 0; c < TB; ++c) a[c] = sh_drow[c];
+            }
+        }
+        const double pv = sh_prow[J];
+        const double rcp = pv != 0.0 ? 1.0 / pv : 0.0;
+        if (live && q > d) {
+            const double l = a[J] * rcp;
+            a[J] = l;
+#pragma unroll
+            for (int c = J + 1; c < TB; ++c) a[c] = fma(-l, sh_prow[c], a[c]);
+        }
+        if constexpr (J + 1 < TB) step<J + 1>();
+    }
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void lu_panel_multi_kernel(double* __restrict__ T, int nb, int K,
+                                                            int* __restrict__ perm, int* __restrict__ moves,
+                                                            double* __restrict__ xch, unsigned* abort_word) {
+    constexpr int NW = NT / 64;
+    __shared__ double sh_cv[NW];
+    __shared__ int sh_cq[NW];
+    __shared__ double sh_prow[TB], sh_drow[TB];
+    __shared__ int sh_p;
+    __shared__ int sh_piv[TB];
+    LuMultiPanel<NT> S;
+    S.tid = threadIdx.x;
+    S.lane = S.tid & 63;
+    S.wave = S.tid >> 6;
+    S.g = blockIdx.x;
+    S.G = gridDim.x;
+    const int R = (nb - K) * TB;
+    S.q = S.g * NT + S.tid;                            // this thread's row of the panel
+    S.live = S.q < R;
+    S.xch = xch;
+    S.abort_word = abort_word;
+    S.sh_cv = sh_cv;
+    S.sh_cq = sh_cq;
+    S.sh_prow = sh_prow;
+    S.sh_drow = sh_drow;
+    S.sh_p = &sh_p;
+    S.sh_piv = sh_piv;
+    double* __restrict__ P = T + ((size_t)K * nb + K) * TT;
+    const size_t tile_step = (size_t)nb * TT;
+    double* rowp = P + (size_t)(S.q >> 6) * tile_step + (S.q & 63);      // + c * TB: column c
+#pragma unroll
+    for (int c = 0; c < TB; ++c) S.a[c] = S.live ? rowp[(size_t)c * TB] : 0.0;
+    S.template step<0>();
+    if (S.live) {
+#pragma unroll
+        for (int c = 0; c < TB; ++c) rowp[(size_t)c * TB] = S.a[c];
+    }
+    // composed interchanges of this panel as row moves dst <- src, and the same moves on perm (workgroup 0)
+    if (S.g == 0) {
+        const int tid = S.tid;
+        __syncthreads();
+        if (tid < 2 * TB) {
+            const int qq = tid < TB ? tid : sh_piv[tid - TB];
+            int pos = qq;                              // backwards through the panel's 64 interchanges
+            for (int j = TB - 1; j >= 0; --j) {
+                const int pj = sh_piv[j];
+                pos = pos == j ? pj : (pos == pj ? j : pos);
+            }
+            const int dst = K * TB + qq, src = K * TB + pos;
+            moves[tid] = dst;
+            moves[2 * TB + tid] = src;
+            const int pv = perm[src];
+            __syncthreads();
+            perm[dst] = pv;
+        } else {
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(128) void lu_rowswap_kernel(double* __restrict__ T, int nb, int K,
                                                          const int* __restrict__ moves) {
     const int J = (int)blockIdx.x < K ? (int)blockIdx.x : (int)blockIdx.x + 1;     // every tile column but K
@@ -474,21 +698,41 @@ __global__ __launch_bounds__(256) void lu_update_kernel(double* __restrict__ T, 
 
 extern "C" int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles, int* perm) {
     if (!ctx) return IPDE_ERR_INVALID;
-    IPDE_CHECK_ARG(ctx, tiles && perm && n_pad >= 128 && n_pad % 128 == 0 && n_pad <= 8192);
+    constexpr int MNT = 512;                            // threads (= rows) per workgroup of the multi-CU panel
+    IPDE_CHECK_ARG(ctx, tiles && perm && n_pad >= 128 && n_pad % 128 == 0 && n_pad <= 64 * MNT);
     IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const int nb = (int)(n_pad / TB);
-    // scratch: row-major U tiles of the current block row, then the panel's row moves
-    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->lu_work, (size_t)nb * TT * sizeof(double) + 4 * TB * sizeof(int)));
+    const bool multi = n_pad > 8192;
+    const int Gmax = (int)((n_pad + MNT - 1) / MNT);
+    // scratch: row-major U tiles of the current block row, the panel's row moves, and (multi-CU panel) the exchange
+    // records of a panel: 64 columns x (G + 1) records
+    const size_t xch_doubles = multi ? (size_t)TB * (Gmax + 1) * LUX_REC : 0;
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->lu_work,
+                                 ((size_t)nb * TT + xch_doubles) * sizeof(double) + 4 * TB * sizeof(int)));
     double* Ur = (double*)ctx->lu_work.p;
-    int* moves = (int*)(Ur + (size_t)nb * TT);
+    double* xch = Ur + (size_t)nb * TT;
+    int* moves = (int*)(xch + xch_doubles);
+    if (multi && !ctx->d_lu_abort) {
+        IPDE_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_lu_abort, 16));
+        IPDE_HIP_CHECK(ctx, hipMemset(ctx->d_lu_abort, 0, 16));
+        *(volatile unsigned*)(ctx->h_pinned + ctx->h_pinned_bytes / sizeof(double) - 1) = 0;
+    }
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(lu_iota_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, perm, (int)n_pad);
     for (int K = 0; K < nb; ++K) {
-        // 1024 threads of 128 VGPRs: the sub-panel (rows per thread x W doubles) is half of that
-        if (n_pad <= 4096)
+        const int R = (nb - K) * TB;
+        if (multi && R > 4096) {
+            const int G = (R + MNT - 1) / MNT;
+            IPDE_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)xch, (int)LUX_SENTINEL32,
+                                                  (size_t)TB * (G + 1) * LUX_REC * 2, st));
+            hipLaunchKernelGGL((lu_panel_multi_kernel<MNT>), dim3(G), dim3(MNT), 0, st, tiles, nb, K, perm, moves, xch,
+                               ctx->d_lu_abort);
+        } else if (R <= 4096) {
+            // 1024 threads of 128 VGPRs: the sub-panel (rows per thread x W doubles) is half of that
             hipLaunchKernelGGL((lu_panel_kernel<1024, 4, 8>), dim3(1), dim3(1024), 0, st, tiles, nb, K, perm, moves);
-        else
+        } else {
             hipLaunchKernelGGL((lu_panel_kernel<1024, 8, 4>), dim3(1), dim3(1024), 0, st, tiles, nb, K, perm, moves);
+        }
         if (nb > 1) hipLaunchKernelGGL(lu_rowswap_kernel, dim3(nb - 1), dim3(128), 0, st, tiles, nb, K, moves);
         const int rest = nb - K - 1;
         if (rest > 0) {
@@ -496,6 +740,9 @@ extern "C" int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles,
             hipLaunchKernelGGL(lu_update_kernel, dim3(rest, rest), dim3(256), 0, st, tiles, nb, K, Ur);
         }
     }
+    if (multi)      // a waiter that gave up leaves the abort word set: the next library call reports it (ipde_ctx_sync)
+        IPDE_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_pinned + ctx->h_pinned_bytes / sizeof(double) - 1, ctx->d_lu_abort, 4,
+                                           hipMemcpyDeviceToHost, st));
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }

@@ -257,7 +257,7 @@ def u2s_many(requests):
 
 
 OWN_FACTORISATION = os.environ.get("IPDE_OWN_LU", "1") != "0"   # False: rocSOLVER getrf (torch.linalg.lu_factor) for every size
-OWN_FACTORISATION_MAX_ROWS = 8192
+OWN_FACTORISATION_MAX_ROWS = 32768      # (beyond 8192 padded rows: the panel across several CUs, csrc/lu_factor.hip)
 
 
 def _factor(A):

@@ -110,6 +110,43 @@ def test_own_factorisation_large_and_timing(n):
           % (n, t_own * 1e3, t_lib * 1e3, res, res_lib))
 
 
+@pytest.mark.parametrize("n", [8300, 9600, 19200])
+def test_own_factorisation_beyond_8192_rows_multi_cu_panel(n):
+    """Systems beyond 8192 padded rows: the panel dealt out to several workgroups, a row per thread, one exchange
+    per column (csrc/lu_factor.hip: lu_panel_multi_kernel); 19 200 = BASELINE configs[4]'s Stokes QFS systems
+    (reference ipde/solvers/internals/vector.py:124-125).  LAPACK's pivots (rocSOLVER getrf on the same matrix),
+    LAPACK's residual; timed against rocSOLVER."""
+    import torch
+    from ipde_amd import qfs
+    from ipde_amd.device import get_context
+    rng = np.random.default_rng(n)
+    A = torch.as_tensor(rng.standard_normal((n, n)), device="cuda")
+    b = torch.as_tensor(rng.standard_normal(n), device="cuda")
+    f = qfs._own_lu(A)
+    get_context().sync()            # (reports a hand-off time-out of the panel kernel, if there was one)
+    x = f._subst(b)
+    res = float((A @ x - b).abs().max())
+    lu, piv = torch.linalg.lu_factor(A)
+    g = qfs._DeviceLU(lu, piv)
+    assert torch.equal(f.perm, g.perm)
+    res_lib = float((A @ g._subst(b) - b).abs().max())
+    assert res < 20 * max(res_lib, 1e-12)
+    del lu, piv, g
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        qfs._own_lu(A)
+    torch.cuda.synchronize()
+    t_own = (time.perf_counter() - t0) / 2
+    t0 = time.perf_counter()
+    for _ in range(2):
+        torch.linalg.lu_factor(A)
+    torch.cuda.synchronize()
+    t_lib = (time.perf_counter() - t0) / 2
+    print("n = %d: own factorisation (incl. tiling) %.1f ms, rocSOLVER getrf %.1f ms; residuals %.1e / %.1e"
+          % (n, t_own * 1e3, t_lib * 1e3, res, res_lib))
+
+
 def test_lu_factor_argument_checks():
     import torch
     from ipde_amd.device import get_context, ptr
@@ -120,7 +157,7 @@ def test_lu_factor_argument_checks():
     assert call(ctx.handle, 128, ptr(T), ptr(p)) == 0
     assert call(ctx.handle, 64, ptr(T), ptr(p)) == 1          # not a multiple of 128
     assert call(ctx.handle, 192, ptr(T), ptr(p)) == 1
-    assert call(ctx.handle, 8192 + 128, ptr(T), ptr(p)) == 1   # beyond the panel kernel's reach
+    assert call(ctx.handle, 32768 + 128, ptr(T), ptr(p)) == 1  # beyond the multi-CU panel's 64 workgroups of 512 rows
     assert call(ctx.handle, 128, None, ptr(p)) == 1
     assert call(ctx.handle, 128, ptr(T), None) == 1
     assert call(None, 128, ptr(T), ptr(p)) == 1
