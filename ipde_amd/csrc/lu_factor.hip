@@ -702,7 +702,11 @@ extern "C" int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles,
     IPDE_CHECK_ARG(ctx, tiles && perm && n_pad >= 128 && n_pad % 128 == 0 && n_pad <= 64 * MNT);
     IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const int nb = (int)(n_pad / TB);
-    const bool multi = n_pad > 8192;
+    // (IPDE_LU_FORCE_MULTI: the multi-CU panel for every panel of more than 512 rows — the tests' way to run it
+    // against host LAPACK at small sizes)
+    static const bool force_multi = getenv("IPDE_LU_FORCE_MULTI") != nullptr;
+    const bool multi = n_pad > 8192 || force_multi;
+    const int multi_min_rows = force_multi ? 512 : 4096;
     const int Gmax = (int)((n_pad + MNT - 1) / MNT);
     // scratch: row-major U tiles of the current block row, the panel's row moves, and (multi-CU panel) the exchange
     // records of a panel: 64 columns x (G + 1) records
@@ -721,13 +725,13 @@ extern "C" int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles,
     hipLaunchKernelGGL(lu_iota_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, perm, (int)n_pad);
     for (int K = 0; K < nb; ++K) {
         const int R = (nb - K) * TB;
-        if (multi && R > 4096) {
+        if (multi && R > multi_min_rows) {
             const int G = (R + MNT - 1) / MNT;
             IPDE_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)xch, (int)LUX_SENTINEL32,
                                                   (size_t)TB * (G + 1) * LUX_REC * 2, st));
             hipLaunchKernelGGL((lu_panel_multi_kernel<MNT>), dim3(G), dim3(MNT), 0, st, tiles, nb, K, perm, moves, xch,
                                ctx->d_lu_abort);
-        } else if (R <= 4096) {
+        } else if (n_pad <= 4096 || R <= 4096) {
             // 1024 threads of 128 VGPRs: the sub-panel (rows per thread x W doubles) is half of that
             hipLaunchKernelGGL((lu_panel_kernel<1024, 4, 8>), dim3(1), dim3(1024), 0, st, tiles, nb, K, perm, moves);
         } else {

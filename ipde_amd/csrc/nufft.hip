@@ -564,26 +564,6 @@ __global__ __launch_bounds__(1024) void band_sort_kernel(const double* __restric
     for (int64_t j = tid; j < np; j += 1024) perm[start[r0v[j]] + rank[j]] = (int)j;
 }
 
-// wave-wide sum with DPP moves inside the 16-lane rows and four v_readlane across them (~30 instructions; the
-// shuffle form is six ds_bpermute round trips per operand, and the gather reduces six operands per point)
-template <int CTRL>
-__device__ __forceinline__ double band_dpp(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double band_rl(double v, int lane) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
-                            __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-__device__ __forceinline__ double band_wave_sum(double v) {
-    v += band_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
-    v += band_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
-    v += band_dpp<0x141>(v);      // row_half_mirror
-    v += band_dpp<0x140>(v);      // row_mirror
-    return (band_rl(v, 0) + band_rl(v, 16)) + (band_rl(v, 32) + band_rl(v, 48));
-}
-
 // e^{2 pi i k f}, k >= 0 an integer, f in [0, 1): k f = p + e exactly (fma), frac(p) exact, the 8 leading bits
 // of the fraction index a table of the 256th roots of unity, the rest (< 1/256 of a turn) goes through
 // Taylor polynomials: |error| ~ 2e-16 whatever k.
@@ -614,215 +594,15 @@ struct BandRecipe {
     BandOut o[8];
 };
 
-// One fine row (blockIdx.x, in the extended numbering of band_sort_kernel) with the points whose windows
-// cover it, 16 at a time: thread t holds columns k = t + 256 q of the row (na arrays), forms for every point
-// P = Re sum_k eps_k g[k] e^{i k y} and, where asked, Dy = -dky sum_k k Im(g[k] e^{i k y}); the wave sums go through
-// LDS, and the (output, point, row) partial — times the x window's weight — is written to its own slot
-// partial[(out np + j) 16 + s].
-template <int Q>
-__global__ __launch_bounds__(256) void band_gather_kernel(const cd* __restrict__ D0, const cd* __restrict__ D1,
-                                                          const cd* __restrict__ D2, int na, BandRecipe rc,
-                                                          int64_t pitch, int ncol, int nfx,
-                                                          const double* __restrict__ px,
-                                                          const double* __restrict__ py, int64_t np,
-                                                          const int* __restrict__ start,
-                                                          const int* __restrict__ perm,
-                                                          const int* __restrict__ r0v, double beta, double dky,
-                                                          double* __restrict__ partial) {
-    constexpr int W = 16, PTS = 16;
-    const int r_ext = blockIdx.x;
-    const int lo = start[r_ext - (W - 1) > 0 ? r_ext - (W - 1) : 0], hi = start[r_ext + 1];
-    const int cnt = hi - lo;
-    if ((int)blockIdx.y * PTS >= cnt) return;      // (uniform over the workgroup, before any barrier)
-    __shared__ cd T[256];
-    __shared__ double wsum[6][PTS][4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double TWO_PI = 6.283185307179586476925286766559;
-    {
-        double sn, cs;
-        sincospi((double)tid * 0.0078125, &sn, &cs);
-        T[tid] = cd{cs, sn};
-    }
-    const int phys = ((r_ext - 16) % nfx + nfx) % nfx;
-    const cd* Dp[3] = {D0, D1, D2};
-    cd g[3][Q];
-#pragma unroll
-    for (int f = 0; f < 3; ++f)
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int k = tid + 256 * q;
-            g[f][q] = (f < na && k < ncol) ? Dp[f][(int64_t)phys * pitch + k] : cd{0.0, 0.0};
-            if (k == 0) g[f][q] = cd{0.5 * g[f][q].x, 0.5 * g[f][q].y};      // eps_0 = 1/2 (see row_c2r)
-        }
-    __syncthreads();
-    const double hfx = TWO_PI / nfx;
-    __shared__ int s_j[PTS];
-    __shared__ double s_fy[PTS];
-    for (int c = blockIdx.y; c * PTS < cnt; c += gridDim.y) {
-        const int npt = cnt - c * PTS < PTS ? cnt - c * PTS : PTS;
-        // the chunk's points first (index and y as a fraction of the period): fetched one after the other inside
-        // the loop, the two dependent loads were the longest thing a point did
-        if (tid < npt) {
-            const int j = perm[lo + c * PTS + tid];
-            double fy = py[j] * (1.0 / TWO_PI);
-            s_j[tid] = j;
-            s_fy[tid] = fy - floor(fy);
-        }
-        __syncthreads();
-        for (int p = 0; p < npt; ++p) {
-            const double fy = s_fy[p];
-            cd ph = unit_kf(tid, fy, T);
-            const cd step = unit_kf(256, fy, T);
-            double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const double kq = (double)(tid + 256 * q);
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    s[f] = fma(g[f][q].x, ph.x, fma(-g[f][q].y, ph.y, s[f]));
-                    if (rc.need_dy[f]) s[3 + f] = fma(kq, fma(g[f][q].x, ph.y, g[f][q].y * ph.x), s[3 + f]);
-                }
-                ph = cmulz(ph, step);
-            }
-#pragma unroll
-            for (int f = 0; f < 6; ++f)
-                if (f < na || (f >= 3 && f - 3 < na && rc.need_dy[f - 3])) s[f] = band_wave_sum(s[f]);
-            if (lane == 0) {
-#pragma unroll
-                for (int f = 0; f < 6; ++f) wsum[f][p][wave] = s[f];
-            }
-        }
-        __syncthreads();
-        if (tid < 8 * PTS) {
-            const int o = tid / PTS, p = tid % PTS;
-            if (o < rc.nout && p < npt) {
-                const BandOut& bo = rc.o[o];
-                const int j = s_j[p];
-                double val = 0.0;
-                for (int e = 0; e < bo.n; ++e) {
-                    const int f = bo.arr[e] + 3 * bo.kind[e];
-                    const double sum = ((wsum[f][p][0] + wsum[f][p][1]) + wsum[f][p][2]) + wsum[f][p][3];
-                    val += bo.coef[e] * (bo.kind[e] ? -dky * sum : sum);
-                }
-                const int r0 = r0v[j], sidx = r_ext - r0;
-                double x = px[j];
-                x -= TWO_PI * floor(x / TWO_PI);
-                const double zq = (x - (double)(r0 - 16 + sidx) * hfx) / (0.5 * W * hfx);
-                const double qq = 1.0 - zq * zq;
-                const double wx = qq > 0.0 ? exp(beta * (sqrt(qq) - 1.0)) : 0.0;
-                double* dst = partial + ((int64_t)bo.out * np + j) * W + sidx;
-                *dst = bo.acc ? *dst + wx * val : wx * val;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// The same gather with a WAVE per (fine row, quarter of its points): lane l holds columns k = l + 64 m of the row
-// (QW of them, na arrays), so a point's dense sums are the wave's own — no LDS exchange, no barrier, one DPP
-// reduction per sum — and the four waves of a row run on their own (the 256-thread form above: every point crossed
-// four waves and two barriers, and a row's sixteen points went one after the other: 180 us at 2048^2 x 4096 points
-// for 40 us of arithmetic).  Rows of up to 64 QW columns; wider ones (ny = 8192) keep the 256-thread form.
-template <int QW>
-__global__ __launch_bounds__(64) void band_gather_wave_kernel(const cd* __restrict__ D0, const cd* __restrict__ D1,
-                                                              const cd* __restrict__ D2, int na, BandRecipe rc,
-                                                              int64_t pitch, int ncol, int nfx,
-                                                              const double* __restrict__ px,
-                                                              const double* __restrict__ py, int64_t np,
-                                                              const int* __restrict__ start,
-                                                              const int* __restrict__ perm,
-                                                              const int* __restrict__ r0v, double beta, double dky,
-                                                              const cd* __restrict__ roots,
-                                                              double* __restrict__ partial) {
-    constexpr int W = 16;
-    const int r_ext = blockIdx.x;
-    const int lo = start[r_ext - (W - 1) > 0 ? r_ext - (W - 1) : 0], hi = start[r_ext + 1];
-    const int cnt = hi - lo;
-    const int sub = blockIdx.y, nsub = gridDim.y;
-    if (sub >= cnt) return;
-    const int lane = threadIdx.x;
-    __shared__ cd T[256];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) T[lane + 64 * i] = roots[lane + 64 * i];
-    const double TWO_PI = 6.283185307179586476925286766559;
-    const int phys = ((r_ext - 16) % nfx + nfx) % nfx;
-    const cd* Dp[3] = {D0, D1, D2};
-    cd g[3][QW];
-#pragma unroll
-    for (int f = 0; f < 3; ++f)
-#pragma unroll
-        for (int m = 0; m < QW; ++m) {
-            const int k = lane + 64 * m;
-            g[f][m] = (f < na && k < ncol) ? Dp[f][(int64_t)phys * pitch + k] : cd{0.0, 0.0};
-            if (k == 0) g[f][m] = cd{0.5 * g[f][m].x, 0.5 * g[f][m].y};      // eps_0 = 1/2 (see row_c2r)
-        }
-    __builtin_amdgcn_wave_barrier();
-    const double hfx = TWO_PI / nfx;
-    const int mine = (cnt - sub + nsub - 1) / nsub;          // points sub, sub + nsub, ...
-    for (int b0 = 0; b0 < mine; b0 += 64) {
-        // this batch's points, a lane each: index, y as a fraction of the period, the x window's weight
-        int jl = 0;
-        double fyl = 0.0, wxl = 0.0;
-        if (b0 + lane < mine) {
-            jl = perm[lo + sub + (b0 + lane) * nsub];
-            double fy = py[jl] * (1.0 / TWO_PI);
-            fyl = fy - floor(fy);
-            const int r0 = r0v[jl];
-            double x = px[jl];
-            x -= TWO_PI * floor(x / TWO_PI);
-            const double zq = (x - (double)(r_ext - 16) * hfx) / (0.5 * W * hfx);
-            const double qq = 1.0 - zq * zq;
-            wxl = qq > 0.0 ? exp(beta * (sqrt(qq) - 1.0)) : 0.0;
-            (void)r0;
-        }
-        const int nb = mine - b0 < 64 ? mine - b0 : 64;
-        for (int p = 0; p < nb; ++p) {
-            const double fy = __shfl(fyl, p);
-            cd ph = unit_kf(lane, fy, T);
-            const cd step = unit_kf(64, fy, T);
-            double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int m = 0; m < QW; ++m) {
-                const double kq = (double)(lane + 64 * m);
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    s[f] = fma(g[f][m].x, ph.x, fma(-g[f][m].y, ph.y, s[f]));
-                    if (rc.need_dy[f]) s[3 + f] = fma(kq, fma(g[f][m].x, ph.y, g[f][m].y * ph.x), s[3 + f]);
-                }
-                ph = cmulz(ph, step);
-            }
-#pragma unroll
-            for (int f = 0; f < 6; ++f)
-                if (f < na || (f >= 3 && f - 3 < na && rc.need_dy[f - 3])) s[f] = band_wave_sum(s[f]);
-            // (every lane holds the six sums now) lane o forms output o
-            const int j = __shfl(jl, p);
-            const double wx = __shfl(wxl, p);
-            if (lane < rc.nout) {
-                const BandOut& bo = rc.o[lane];
-                double val = 0.0;
-                for (int e = 0; e < bo.n; ++e) {
-                    const int f = bo.arr[e] + 3 * bo.kind[e];
-                    double sum = 0.0;
-#pragma unroll
-                    for (int ff = 0; ff < 6; ++ff) sum = f == ff ? s[ff] : sum;
-                    val += bo.coef[e] * (bo.kind[e] ? -dky * sum : sum);
-                }
-                const int sidx = r_ext - r0v[j];
-                double* dst = partial + ((int64_t)bo.out * np + j) * W + sidx;
-                *dst = bo.acc ? *dst + wx * val : wx * val;
-            }
-        }
-    }
-}
-
 // The gather as a block GEMM on the matrix cores.  For a tile of 16 consecutive fine rows and a chunk of 16 of the
 // points whose windows meet it,  P[row][point] = Re sum_k eps_k g[row][k] e^{i k y_point}  is a (16 x ncol) x (ncol x 16)
 // product: v_mfma_f64_16x16x4 with A = Re g / Im g of the rows (from LDS, staged 128 columns at a time with coalesced
-// loads) and B = cos / -sin of k y — the phases are formed ONCE per (k, point) and serve all sixteen rows (the
-// row-by-row forms above spend most of their time on them), each lane advancing its own point's phase by e^{4 i y}
+// loads) and B = cos / -sin of k y — the phases are formed ONCE per (k, point) and serve all sixteen rows (a
+// row-by-row gather spends most of its time on them: 181 us against 62 at 2048^2 x 4096), each lane advancing its own point's phase by e^{4 i y}
 // and re-seeding it exactly at every staged tile (32 steps: 7e-15).  The y-derivative sums are two more products with
 // B = k sin, k cos.  A workgroup = a row tile, its four waves take four point chunks; the epilogue applies the x
-// window's weights and writes every (output, point, row) partial to its own slot, as before.
+// window's weights and writes every (output, point, row) partial to its own slot
+// partial[(out np + j) 16 + s], s = the row's place in the point's window; band_reduce_kernel adds the sixteen.
 typedef double band_d4 __attribute__((ext_vector_type(4)));
 
 template <int NA>
@@ -875,26 +655,33 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
         band_d4 acc[NACC];
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = band_d4{0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < ncol; k0 += KT) {
-            __syncthreads();                            // (the previous tile has been consumed; T, s_phys are in place)
-            // (eight loads per thread in flight: rolled, every load waited for its own LDS store — 16 us per tile)
+        // the staged tiles are double-buffered through registers: tile t + 1's loads are in flight under tile t's
+        // products (eight 16-byte loads per thread and array; waited for at the top of the next pass)
+        cd st[NA][8];
+        auto fetch = [&](int k0) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                cd st[8];
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int e = tid + 256 * it, i = e / KT, kk = e % KT, k = k0 + kk;
-                    st[it] = k < ncol ? Dp[a][(int64_t)s_phys[i] * pitch + k] : cd{0.0, 0.0};
+                    st[a][it] = k < ncol ? Dp[a][(int64_t)s_phys[i] * pitch + k] : cd{0.0, 0.0};
                 }
+        };
+        __syncthreads();                                // (T, s_phys are in place; the previous round's sums are read)
+        fetch(0);
+        for (int k0 = 0; k0 < ncol; k0 += KT) {
+            __syncthreads();                            // (the previous tile has been consumed)
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int e = tid + 256 * it, i = e / KT, kk = e % KT;
-                    cd v = st[it];
+                    cd v = st[a][it];
                     if (k0 + kk == 0) v = cd{0.5 * v.x, 0.5 * v.y};             // eps_0 = 1/2 (see row_c2r)
                     sG[a][i][kk] = v;
                 }
-            }
             __syncthreads();
+            if (k0 + KT < ncol) fetch(k0 + KT);
             // this wave's steps of the tile: k = k0 + 4 s + h4, s = wave, wave + 4, ...; phases re-seeded per tile
             cd ph[CH], st16[CH];
 #pragma unroll
@@ -1163,24 +950,6 @@ static int ensure_band(GridInterp* gi, int64_t np) {
         gi->ibuf_np = cap;
     }
     return IPDE_OK;
-}
-
-template <int Q>
-static void launch_band_gather(GridInterp* gi, const cd* const* D, int na, const BandRecipe& rc, int64_t pitch, int ncol,
-                               const double* d_px, const double* d_py, int64_t np, const int* start, const int* perm,
-                               const int* r0v, double dky) {
-    hipLaunchKernelGGL(band_gather_kernel<Q>, dim3((unsigned)(gi->nfx + 32), 4), dim3(256), 0, gi->ctx->stream, D[0],
-                       D[1], D[2], na, rc, pitch, ncol, (int)gi->nfx, d_px, d_py, np, start, perm, r0v, gi->betax, dky,
-                       gi->partial);
-}
-
-template <int QW>
-static void launch_band_gather_wave(GridInterp* gi, const cd* const* D, int na, const BandRecipe& rc, int64_t pitch,
-                                    int ncol, const double* d_px, const double* d_py, int64_t np, const int* start,
-                                    const int* perm, const int* r0v, double dky) {
-    hipLaunchKernelGGL(band_gather_wave_kernel<QW>, dim3((unsigned)(gi->nfx + 32), 4), dim3(64), 0, gi->ctx->stream, D[0],
-                       D[1], D[2], na, rc, pitch, ncol, (int)gi->nfx, d_px, d_py, np, start, perm, r0v, gi->betax, dky,
-                       (const cd*)gi->d_roots, gi->partial);
 }
 
 template <int NX>
