@@ -484,6 +484,17 @@ int ipde_dense_gemv(ipde_ctx* ctx, int64_t m, int64_t n, const double* A, const 
    the plain fp64 residual's own rounding is as large as the residual).  HBM bound: the matrix once. */
 int ipde_dense_residual(ipde_ctx* ctx, int64_t m, int64_t n, const double* A, const double* x, const double* b,
                         double* r);
+/* Noise cut of a periodic two-component QFS source density mu = [x(0..n-1) | y(0..n-1)] (DEVICE; out may be mu):
+   the density's spectrum decays, reaches a minimum where the amplified noise of the boundary data takes over
+   (collocation singular values ~ e^{-|k| alpha h} / |k|) and rises again; band maxima B_j of max(|z_k|, |z_-k|),
+   z = x + i y, running minimum m_j: the first band j below 0.9 Nyquist whose whole tail up to 0.9 Nyquist lies above
+   rise * m_{j-1}, with m_{j-1} < floor_rel * max B, marks the turnaround and every mode above the band of the
+   minimum is removed (no such band: nothing is).  max_keep: modes above max_keep x Nyquist are removed in any case
+   (>= 1: none).  kcut (DEVICE int, may be NULL) receives the last mode kept.  Restates what the reference's absent
+   third-party `qfs` package leaves to its caller; used by ipde_amd/qfs.py Stokes_QFS (reference call sites
+   ipde/solvers/internals/vector.py:124-125).  pack, FFT, cut (one workgroup), inverse FFT, unpack: five launches. */
+int ipde_density_noise_cut(ipde_ctx* ctx, int64_t n, const double* mu, double* out, double rise, double floor_rel,
+                           double max_keep, int* kcut);
 
 /* ------------------------------------------------------------------------- */
 /* Closest-point coordinates of points near a closed curve  */

@@ -118,6 +118,7 @@ SIGNATURES = {
     "ipde_grid_gather": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "ipde_dense_gemv": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _int]),
     "ipde_dense_residual": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "ipde_density_noise_cut": (_int, [_vp, _i64, _vp, _vp, _dbl, _dbl, _dbl, _vp]),
     "ipde_radial_to_grid": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ipde_curve_local_coordinates": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
     "ipde_grid_inside_scan": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),

@@ -181,6 +181,7 @@ extern "C" int ipde_ctx_destroy(ipde_ctx* ctx) {
     for (auto& b : ctx->fftwork) freebuf(b);
     for (auto& b : ctx->r2g) freebuf(b);
     freebuf(ctx->lu_work);
+    freebuf(ctx->cut_work);
     for (auto& kv : ctx->cheb_tab)
         if (kv.second) hipFree(kv.second);
     ctx->cheb_tab.clear();

@@ -39,6 +39,7 @@ struct ipde_ctx {
     DevBuf fftwork[8];
     DevBuf r2g[4];       // ipde_radial_to_grid: coefficient rows, spectra, oversampled rows
     DevBuf lu_work;      // ipde_dense_lu_factor: row-major U tiles of a block row, row moves of a panel
+    DevBuf cut_work;     // ipde_density_noise_cut: the density as a complex signal and its spectrum
     std::map<int, double*> cheb_tab;   // M -> device M x M analysis matrix of the Chebyshev-Gauss nodes
     double* h_pinned = nullptr;  // small pinned host buffer for scalars
     size_t h_pinned_bytes = 0;

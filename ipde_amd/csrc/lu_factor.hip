@@ -18,12 +18,18 @@
 //                      kernel, applied to every other tile column (read all, barrier, write all).
 //   lu_trsm_kernel     U(K, J) = L(K,K)^-1 A(K, J): a thread per column, L(K,K) broadcast from
 //                      LDS; also leaves a row-major copy for the update's operand loads.
+//   lu_panel_multi_kernel  panels of more than 4096 rows in systems beyond 8192 padded rows: the panel dealt out to
+//                      ceil(rows / 512) workgroups, a row per thread with its 64 columns in registers, right-looking,
+//                      one exchange per column through global slots (candidates, winner's row, diagonal row; the data
+//                      is the flag: NaN-sentinel slots, agent-scope relaxed atomics, bounded spins, sticky abort word).
 //   lu_update_kernel   A(I, J) -= L(I,K) U(K,J), one workgroup per tile, v_mfma_f64_16x16x4_f64:
 //                      the product is formed transposed (D = U^T L^T) so that both operands and
-//                      the read-modify-write of A(I, J) are contiguous per 16-lane group.
+//                      the read-modify-write of A(I, J) are contiguous per 16-lane group.  Since round 4 only for
+//                      the border of a panel PAIR (tile column and tile row K0 + 1);
+//   lu_update_pair_kernel  the trailing update of both panels of a pair in one pass (one read-modify-write of the
+//                      trailing matrix per 128 columns), a tile per wave, 2 x 2 tiles per workgroup, XCD-aware.
 //
-// Measured (MI355X, n = 4096): see DESIGN.md §3.  Sizes above 8192 padded rows are left to the
-// host library's caller (ipde_amd/qfs.py falls back to rocSOLVER and says so).
+// Measured (MI355X): see DESIGN.md §3.  Up to 32 768 padded rows (64 workgroups of 512 panel rows).
 #include "ipde_common.h"
 
 namespace {
@@ -663,9 +669,11 @@ __global__ __launch_bounds__(64) void lu_trsm_kernel(double* __restrict__ T, int
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// (I0, J0: the first tile row / column of the launch's tiles; the border launches of a panel pair run one tile
+// column and one tile row)
 __global__ __launch_bounds__(256) void lu_update_kernel(double* __restrict__ T, int nb, int K,
-                                                        const double* __restrict__ Ur) {
-    const int I = K + 1 + (int)blockIdx.y, J = K + 1 + (int)blockIdx.x;
+                                                        const double* __restrict__ Ur, int I0, int J0) {
+    const int I = I0 + (int)blockIdx.y, J = J0 + (int)blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     const double* __restrict__ L = T + ((size_t)I * nb + K) * TT;      // column-major: (i, k) at k*64 + i
@@ -694,6 +702,74 @@ __global__ __launch_bounds__(256) void lu_update_kernel(double* __restrict__ T, 
         for (int r = 0; r < 4; ++r) C[(size_t)(16 * jb + hi + 4 * r) * TB + 16 * w + lo] = acc[jb][r];
 }
 
+// The trailing update of a PAIR of panels K0, K0 + 1 in one pass:  A(I, J) -= L(I,K0) U(K0,J) + L(I,K0+1) U(K0+1,J)
+// for I, J > K0 + 1 — one read-modify-write of the trailing matrix per 128 columns instead of per 64 (at 19 200 rows
+// the single-panel form moved 590 GB of A per factorisation: the HBM floor of the whole factorisation), the same
+// MFMA chain per element (k ascending through both panels), hence the same bits as two single-panel updates.
+// A wave owns a whole 64 x 64 tile (16 accumulator blocks: eight operand loads feed sixteen MFMAs; the one-tile-per-
+// workgroup form above loads five for four), a workgroup 2 x 2 tiles.  Operands straight from L2, one k-step ahead
+// of the MFMAs.  The hand-out is XCD-aware: workgroup b runs on XCD b mod 8, which is given a contiguous band of the
+// tile-row pairs — its share of the two L panels (2.4 MB at 19 200 rows) stays in that XCD's L2 — and walks a column
+// pair's tiles band-first, so a U tile pair is fetched once per XCD.
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void lu_update_pair_kernel(double* __restrict__ T, int nb, int K0,
+                                                             const double* __restrict__ Ur, int gx, int gy) {
+    const int wg = (int)blockIdx.x, xcd = wg & 7, slot = wg >> 3;
+    const int iy0 = (xcd * gy) >> 3, nI = (((xcd + 1) * gy) >> 3) - iy0;
+    if (nI <= 0) return;
+    const int jx = slot / nI, iy = iy0 + slot % nI;
+    if (jx >= gx) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    const int I = K0 + 2 + 2 * iy + (w >> 1), J = K0 + 2 + 2 * jx + (w & 1);
+    if (I >= nb || J >= nb) return;                                     // (wave-uniform; no barriers below)
+    double* __restrict__ C = T + ((size_t)I * nb + J) * TT;
+    const double* __restrict__ L = T + ((size_t)I * nb + K0) * TT;     // panel p: + p TT (the next tile of the row)
+    const double* __restrict__ U = Ur + (size_t)J * TT;                // panel p: + p nb TT
+    const size_t ustep = (size_t)nb * TT;
+    // acc[ib][jb], reg r: C(16 ib + lo, 16 jb + hi + 4 r)
+    d4 acc[4][4];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ib][jb][r] = C[(size_t)(16 * jb + hi + 4 * r) * TB + 16 * ib + lo];
+    auto fetch = [&](int q, double (&a)[4], double (&b)[4]) {          // k-step q of 32: panel q / 16, k = 4 (q % 16) + hi
+        const int p = q >> 4, k = 4 * (q & 15) + hi;
+        const double* Lp = L + (size_t)p * TT + (size_t)k * TB + lo;
+        const double* Up = U + (size_t)p * ustep + (size_t)k * TB + lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b[i] = Lp[16 * i];
+            a[i] = Up[16 * i];
+        }
+    };
+    auto product = [&](const double (&a)[4], const double (&b)[4]) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const double nb_ = -b[ib];
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jb], nb_, acc[ib][jb], 0, 0, 0);
+        }
+    };
+    double a0[4], b0[4], a1[4], b1[4];
+    fetch(0, a0, b0);
+#pragma unroll 1
+    for (int q = 0; q < 32; q += 2) {
+        fetch(q + 1, a1, b1);
+        product(a0, b0);
+        if (q + 2 < 32) fetch(q + 2, a0, b0);
+        product(a1, b1);
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(16 * jb + hi + 4 * r) * TB + 16 * ib + lo] = acc[ib][jb][r];
+}
+
 }  // namespace
 
 extern "C" int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles, int* perm) {
@@ -712,9 +788,9 @@ extern "C" int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles,
     // records of a panel: 64 columns x (G + 1) records
     const size_t xch_doubles = multi ? (size_t)TB * (Gmax + 1) * LUX_REC : 0;
     IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->lu_work,
-                                 ((size_t)nb * TT + xch_doubles) * sizeof(double) + 4 * TB * sizeof(int)));
-    double* Ur = (double*)ctx->lu_work.p;
-    double* xch = Ur + (size_t)nb * TT;
+                                 (2 * (size_t)nb * TT + xch_doubles) * sizeof(double) + 4 * TB * sizeof(int)));
+    double* Ur = (double*)ctx->lu_work.p;               // two block rows: the panels of a pair
+    double* xch = Ur + 2 * (size_t)nb * TT;
     int* moves = (int*)(xch + xch_doubles);
     if (multi && !ctx->d_lu_abort) {
         IPDE_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_lu_abort, 16));
@@ -723,7 +799,7 @@ extern "C" int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles,
     }
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(lu_iota_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, perm, (int)n_pad);
-    for (int K = 0; K < nb; ++K) {
+    auto panel = [&](int K) -> int {
         const int R = (nb - K) * TB;
         if (multi && R > multi_min_rows) {
             const int G = (R + MNT - 1) / MNT;
@@ -738,10 +814,45 @@ extern "C" int ipde_dense_lu_factor(ipde_ctx* ctx, int64_t n_pad, double* tiles,
             hipLaunchKernelGGL((lu_panel_kernel<1024, 8, 4>), dim3(1), dim3(1024), 0, st, tiles, nb, K, perm, moves);
         }
         if (nb > 1) hipLaunchKernelGGL(lu_rowswap_kernel, dim3(nb - 1), dim3(128), 0, st, tiles, nb, K, moves);
-        const int rest = nb - K - 1;
-        if (rest > 0) {
-            hipLaunchKernelGGL(lu_trsm_kernel, dim3(rest), dim3(64), 0, st, tiles, nb, K, Ur);
-            hipLaunchKernelGGL(lu_update_kernel, dim3(rest, rest), dim3(256), 0, st, tiles, nb, K, Ur);
+        return IPDE_OK;
+    };
+    // Panels in pairs (nb is even): panel K0, its U block row, its update of tile column K0 + 1 only; panel K0 + 1 on
+    // the updated column; panel K0's update of tile row K0 + 1, that row's U blocks; then one update of the trailing
+    // matrix with both panels (lu_update_pair_kernel).  The interchanges of panel K0 + 1 permute rows of a trailing
+    // matrix that has not seen panel K0's update yet: they permute L(., K0) with it, so the update commutes — as long
+    // as every row gets it AFTER the interchanges, tile row K0 + 1 included.  Per element the same operations in the
+    // same order as panel-by-panel updates.
+    static const bool single_updates = getenv("IPDE_LU_SINGLE_UPDATES") != nullptr;      // (A/B: the round-3 schedule)
+    static const bool pair_occ2 = getenv("IPDE_LU_PAIR_OCC1") == nullptr;                // (two workgroups per CU: 243 against 262 ms at 19 200 rows, spills and all)
+    for (int K0 = 0; K0 < nb; K0 += 2) {
+        const int K1 = K0 + 1, rest0 = nb - K0 - 1, rest1 = nb - K1 - 1;
+        double* Ur0 = Ur;
+        double* Ur1 = Ur + (size_t)nb * TT;
+        IPDE_TRY(panel(K0));
+        hipLaunchKernelGGL(lu_trsm_kernel, dim3(rest0), dim3(64), 0, st, tiles, nb, K0, Ur0);
+        if (single_updates) {
+            hipLaunchKernelGGL(lu_update_kernel, dim3(rest0, rest0), dim3(256), 0, st, tiles, nb, K0, Ur0, K0 + 1, K0 + 1);
+            IPDE_TRY(panel(K1));
+            if (rest1 > 0) {
+                hipLaunchKernelGGL(lu_trsm_kernel, dim3(rest1), dim3(64), 0, st, tiles, nb, K1, Ur0);
+                hipLaunchKernelGGL(lu_update_kernel, dim3(rest1, rest1), dim3(256), 0, st, tiles, nb, K1, Ur0, K1 + 1, K1 + 1);
+            }
+            continue;
+        }
+        hipLaunchKernelGGL(lu_update_kernel, dim3(1, rest0), dim3(256), 0, st, tiles, nb, K0, Ur0, K0 + 1, K1);
+        IPDE_TRY(panel(K1));
+        if (rest1 > 0) {
+            // (tile row K1 takes panel K0's update only now: panel K1's interchanges bring rows up from below, and
+            // those have not seen it)
+            hipLaunchKernelGGL(lu_update_kernel, dim3(rest1, 1), dim3(256), 0, st, tiles, nb, K0, Ur0, K1, K1 + 1);
+            hipLaunchKernelGGL(lu_trsm_kernel, dim3(rest1), dim3(64), 0, st, tiles, nb, K1, Ur1);
+            const int g2 = (rest1 + 1) / 2, maxI = (g2 + 7) / 8;
+            if (pair_occ2)
+                hipLaunchKernelGGL(lu_update_pair_kernel<2>, dim3((unsigned)(8 * maxI * g2)), dim3(256), 0, st, tiles, nb,
+                                   K0, Ur, g2, g2);
+            else
+                hipLaunchKernelGGL(lu_update_pair_kernel<1>, dim3((unsigned)(8 * maxI * g2)), dim3(256), 0, st, tiles, nb,
+                                   K0, Ur, g2, g2);
         }
     }
     if (multi)      // a waiter that gave up leaves the abort word set: the next library call reports it (ipde_ctx_sync)

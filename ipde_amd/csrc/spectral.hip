@@ -767,6 +767,104 @@ void ipde_fft1_plans_destroy(ipde_ctx* ctx) {
     ctx->fft1_plans.clear();
 }
 
+// ---- noise cut of a QFS source density (ipde_amd/qfs.py: Stokes_QFS._lowpass) ------------------------------
+// The collocation's singular values fall like e^{-|k| alpha h} / |k|: the spectrum of a resolved density decays,
+// reaches a minimum where the amplified noise of the data takes over, and RISES again towards the Nyquist
+// frequency.  The rule: band maxima B_j of max(|z_k|, |z_{-k}|) (z = x + i y carries both components), m_j their
+// running minimum; the first band j <= top (0.9 Nyquist) whose whole tail up to top lies above rise * m_{j-1}, with
+// m_{j-1} < floor_rel * max B, marks the turnaround: every mode above the band where the minimum was reached is
+// removed.  No sustained rise after a deep minimum (an under-resolved density, an isolated high mode): nothing is.
+namespace {
+__global__ __launch_bounds__(256) void cut_pack_kernel(double2* __restrict__ z, const double* __restrict__ mu, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) z[i] = double2{mu[i], mu[n + i]};
+}
+__global__ __launch_bounds__(256) void cut_unpack_kernel(double* __restrict__ out, const double2* __restrict__ z, int64_t n,
+                                                         double s) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        out[i] = z[i].x * s;
+        out[n + i] = z[i].y * s;
+    }
+}
+constexpr int CUT_MAXB = 1024;
+__global__ __launch_bounds__(1024) void density_noise_cut_kernel(double2* __restrict__ Z, int n, int w, int nbands,
+                                                                 double rise, double floor_rel, int kcap,
+                                                                 int* __restrict__ kcut_out) {
+    __shared__ double B[CUT_MAXB], S[CUT_MAXB];
+    __shared__ int s_kc;
+    const int tid = threadIdx.x, H = n / 2;
+    for (int j = tid; j < nbands; j += 1024) {
+        double b = 0.0;
+        const int k1 = (j + 1) * w - 1 < H ? (j + 1) * w - 1 : H;
+        for (int k = j * w; k <= k1; ++k) {
+            const double2 p = Z[k], q = Z[(n - k) % n];
+            b = fmax(b, fmax(sqrt(p.x * p.x + p.y * p.y), sqrt(q.x * q.x + q.y * q.y)));
+        }
+        B[j] = b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int top = (int)(0.9 * H) / w;
+        if (top > nbands - 1) top = nbands - 1;
+        double gmax = 0.0;
+        for (int j = 0; j < nbands; ++j) gmax = fmax(gmax, B[j]);
+        double t = B[top];
+        for (int j = top; j >= 0; --j) {          // S_j = min of B over [j, top]
+            t = fmin(t, B[j]);
+            S[j] = t;
+        }
+        int kc = H;
+        double m = B[0];
+        int jmin = 0;
+        for (int j = 1; j <= top; ++j) {
+            if (m < floor_rel * gmax && S[j] > rise * m) {
+                kc = (jmin + 1) * w - 1;
+                break;
+            }
+            if (B[j] < m) {
+                m = B[j];
+                jmin = j;
+            }
+        }
+        if (kc > kcap) kc = kcap;
+        if (kc > H) kc = H;
+        s_kc = kc;
+        if (kcut_out) *kcut_out = kc;
+    }
+    __syncthreads();
+    const int kc = s_kc;
+    for (int k = kc + 1 + tid; k <= H; k += 1024) {
+        Z[k] = double2{0.0, 0.0};
+        Z[n - k] = double2{0.0, 0.0};
+    }
+}
+}  // namespace
+
+extern "C" int ipde_density_noise_cut(ipde_ctx* ctx, int64_t n, const double* mu, double* out, double rise,
+                                      double floor_rel, double max_keep, int* kcut) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_CHECK_ARG(ctx, mu && out && n >= 16 && n < (1ll << 30) && rise > 1.0 && floor_rel > 0.0 && max_keep > 0.0);
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    IPDE_TRY(ipde_devbuf_reserve(ctx, ctx->cut_work, 2 * (size_t)n * sizeof(double2)));
+    double2* z = (double2*)ctx->cut_work.p;
+    double2* zh = z + n;
+    const int H = (int)(n / 2);
+    int w = (H + 1 + 511) / 512;
+    if (w < 4) w = 4;
+    const int nbands = (H + w) / w;                       // bands cover k = 0 .. H
+    const int kcap = max_keep >= 1.0 ? H : (int)(max_keep * H);
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(cut_pack_kernel, dim3(nblk(n)), dim3(256), 0, st, z, mu, n);
+    IPDE_TRY(ipde_fft1_exec(ctx, 1, n, -1, z, zh));
+    hipLaunchKernelGGL(density_noise_cut_kernel, dim3(1), dim3(1024), 0, st, zh, (int)n, w, nbands, rise, floor_rel,
+                       kcap, kcut);
+    IPDE_TRY(ipde_fft1_exec(ctx, 1, n, +1, zh, z));
+    hipLaunchKernelGGL(cut_unpack_kernel, dim3(nblk(n)), dim3(256), 0, st, out, (const double2*)z, n, 1.0 / (double)n);
+    IPDE_HIP_CHECK(ctx, hipGetLastError());
+    return IPDE_OK;
+}
+
 extern "C" int ipde_fft1_c2c(ipde_ctx* ctx, int loc, int64_t batch, int64_t n, int direction,
                              const double* in_c, double* out_c) {
     if (!ctx) return IPDE_ERR_INVALID;

@@ -159,8 +159,11 @@ class _QFS(object):
     def _post(self, mu, densities):
         return mu
 
+    def _filter(self, mu):      # (what u2s applies to its result: Stokes_QFS low-passes the density)
+        return mu
+
     def u2s(self, u):
-        return self._solve(np.asarray(u, dtype=float))
+        return self._filter(self._solve(np.asarray(u, dtype=float)))
 
 
 def _gemv(A, x, y=None):
@@ -251,7 +254,8 @@ def u2s_many(requests):
         qs = [requests[i][0] for i in idx]
         us = [_on_device(requests[i][1], q._dev) for q, i in zip(qs, idx)]
         xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps, dd=dd)
-        for i, x in zip(idx, xs):
+        for q, i, x in zip(qs, idx, xs):
+            x = q._filter(x)
             out[i] = x if isinstance(requests[i][1], torch.Tensor) else x.cpu().numpy()
     return out
 
@@ -600,6 +604,9 @@ class Stokes_QFS(_QFS):
         super().__init__(bdy, interior, slp, dlp, qfs_boundary, eps)
         if interior:
             self._pressure_calibration()
+        if self._dev is not None and self.NOISE_CUT:
+            from .device import prewarm
+            prewarm(fft1=((1, int(self.source.N)),))      # the noise cut's transform plan, under the set-up
 
     def _s2b(self, src, trg):
         return Stokes_Layer_Form(src, trg, ifforce=True) + Stokes_Pressure_Fix(src, trg)
@@ -650,7 +657,69 @@ class Stokes_QFS(_QFS):
         # ... and its combined-layer call on a hole passes one tau for both layers (:171)
         return densities + [densities[-1]] * (want - len(densities))
 
+    # Noise cut of the source density.  The collocation's singular values fall like e^{-|k| alpha h} / |k|, so
+    # past the point where the boundary data have decayed to their noise floor the solve returns AMPLIFIED noise:
+    # measured on the 3-body example's outer boundary at configs[4] scale (N = 9560) the density's spectrum falls
+    # to 6e-9 of its mean by k ~ 700, then RISES again to a peak of 0.6 ... 5 at k = 3857 = 0.81 Nyquist — max|density|
+    # 57 or 90 depending on the boundary size — and that noise costs the solution up to a digit and a half next to
+    # the curve (n_b = 2390: 5.2e-10 with it, 2.6e-11 without; 2388: 7.3e-11 / 7.1e-12; 2386 ... 2400 all
+    # 5e-12 ... 2.6e-11 without: profiles/r04_stokes_nb_density_lowpass.log).  The cut is placed by the spectrum
+    # itself (ipde_density_noise_cut, csrc/spectral.hip; `_noise_cut_host` is the same rule in numpy): band maxima,
+    # running minimum, and where the whole tail up to 0.9 Nyquist lies RISE times above a minimum that is itself
+    # below FLOOR of the largest band, every mode above the minimum's band goes.  A density whose spectrum is still
+    # decaying at the Nyquist frequency (the example at its own size, N = 3200) is left alone: a fixed cut at
+    # 0.75 Nyquist cost THAT case a factor four (1.1e-10 -> 4.4e-10), measured.  NOISE_CUT = 0 switches it off.
+    NOISE_CUT = os.environ.get("IPDE_STOKES_QFS_NOISE_CUT", "1") != "0"
+    RISE, FLOOR = 30.0, 1e-5
+
+    @staticmethod
+    def _noise_cut_host(mu, rise=30.0, floor_rel=1e-5, max_keep=1.0):
+        """(filtered density, last mode kept) — the rule of ipde_density_noise_cut in numpy"""
+        mu = np.asarray(mu, dtype=float)
+        n = mu.shape[0] // 2
+        H = n // 2
+        z = np.fft.fft(mu[:n] + 1j * mu[n:])
+        k = np.arange(H + 1)
+        a = np.maximum(np.abs(z[k]), np.abs(z[(n - k) % n]))
+        w = max(4, (H + 1 + 511) // 512)
+        nbands = (H + w) // w
+        B = np.array([a[j * w:min((j + 1) * w, H + 1)].max() for j in range(nbands)])
+        top = min(nbands - 1, int(0.9 * H) // w)
+        S = np.minimum.accumulate(B[:top + 1][::-1])[::-1]
+        kc, m, jmin = H, B[0], 0
+        for j in range(1, top + 1):
+            if m < floor_rel * B.max() and S[j] > rise * m:
+                kc = (jmin + 1) * w - 1
+                break
+            if B[j] < m:
+                m, jmin = B[j], j
+        kc = min(kc, H if max_keep >= 1.0 else int(max_keep * H))
+        kk = np.minimum(np.arange(n), n - np.arange(n))       # |k| as integers
+        z[kk > kc] = 0.0
+        z = np.fft.ifft(z)
+        return np.concatenate([z.real, z.imag]), kc
+
+    def _lowpass(self, mu):
+        if not self.NOISE_CUT:
+            return mu
+        if type(mu).__module__.startswith('torch'):
+            import torch
+            from .device import get_context, ptr
+            ctx = get_context(mu.device.index)
+            mu = mu.contiguous()
+            out = torch.empty_like(mu)
+            ctx.check(ctx.lib.ipde_density_noise_cut(ctx.handle, int(mu.shape[0]) // 2, ptr(mu), ptr(out),
+                                                     float(self.RISE), float(self.FLOOR), 1.0, None))
+            return out
+        return self._noise_cut_host(mu, self.RISE, self.FLOOR)[0]
+
     def _post(self, mu, densities):
+        return self._lowpass(self._calibrate(mu, densities))
+
+    def _filter(self, mu):
+        return self._lowpass(mu)
+
+    def _calibrate(self, mu, densities):
         if self.interior:
             if type(mu).__module__.startswith('torch'):
                 # device densities (the solvers' device-resident flow): the same calibration with

@@ -203,6 +203,47 @@ def test_stokes_qfs_green_representation():
         assert np.abs(got[2] - pe).max() < 1e-8
 
 
+def _density_with_noise_turnaround(n, rng, k_floor, top_amp):
+    """a smooth two-component density whose spectrum decays to 1e-9 by k_floor and rises again (amplified noise)"""
+    t = 2 * np.pi * np.arange(n) / n
+    H = n // 2
+    k = np.arange(1, H)
+    amp = np.where(k <= k_floor, 10.0 ** (-9.0 * k / k_floor),
+                   1e-9 * (top_amp / 1e-9) ** ((k - k_floor) / (0.85 * H - k_floor)).clip(max=1.0))
+    comp = []
+    for _ in range(2):
+        ph = rng.uniform(0, 2 * np.pi, k.size)
+        comp.append(3.0 + (amp[:, None] * np.cos(k[:, None] * t[None, :] + ph[:, None])).sum(axis=0))
+    return np.concatenate(comp)
+
+
+def test_stokes_qfs_noise_cut_rule():
+    """Stokes_QFS._noise_cut_host (the numpy statement of ipde_density_noise_cut): a spectrum that decays to a
+    deep minimum and rises again is cut at the minimum, both components alike; a spectrum still decaying at the
+    Nyquist frequency, a flat one, and an isolated high mode over an empty spectrum are left alone."""
+    from ipde_amd.qfs import Stokes_QFS
+    rng = np.random.default_rng(5)
+    n = 1200
+    H = n // 2
+    mu = _density_with_noise_turnaround(n, rng, 150, 0.5)      # (9560: see tests/test_dense_gpu.py)
+    got, kc = Stokes_QFS._noise_cut_host(mu)
+    w = max(4, (H + 1 + 511) // 512)
+    assert 150 - 2 * w <= kc <= 150 + 2 * w
+    for comp, gcomp in ((mu[:n], got[:n]), (mu[n:], got[n:])):
+        h = np.fft.fft(comp)
+        h[np.minimum(np.arange(n), n - np.arange(n)) > kc] = 0.0
+        assert np.abs(np.fft.ifft(h).real - gcomp).max() < 1e-13
+    assert np.abs(got - mu).max() > 0.1                                   # (the rise was really there)
+    t = 2 * np.pi * np.arange(n) / n
+    k = np.arange(1, H)
+    decaying = np.concatenate([(10.0 ** (-7.0 * k / H))[:, None] * np.cos(k[:, None] * t[None, :])]).sum(axis=0)
+    for same in (np.concatenate([decaying, 2 * decaying]),                # under-resolved: still decaying at Nyquist
+                 rng.standard_normal(2 * n),                               # flat spectrum
+                 np.concatenate([np.cos(400 * t), np.sin(400 * t)])):      # one high mode, nothing below it
+        out, kc = Stokes_QFS._noise_cut_host(same)
+        assert kc == H and np.abs(out - same).max() < 1e-13 * max(1.0, np.abs(same).max())
+
+
 def test_kress_single_layer_for_odd_and_even_node_counts():
     """the log-singular quadrature has no Nyquist term for odd N"""
     for N in (300, 301):

@@ -41,40 +41,37 @@ for name, kw in (("slp", dict(charge=s1)), ("dlp", dict(dipstr=s2)), ("both", di
         torch.cuda.synchronize()
         print("   %-6s %.3f ms per apply (wall, %d applies)" % (tname, (time.perf_counter() - t0) / n * 1e3, n))
 
-# Stokeslet sums with pressure
-f = rng.standard_normal((2, c.N))
-a = lp.Stokes_Layer_Apply(c, lp.DeviceTargets(trg), forces=f)
-b = lp.Stokes_Layer_Apply(c, far, forces=f)
-torch.cuda.synchronize()
-for name, x, y in zip("uvp", a, b):
-    print("stokes %s max|direct| %.3e  max|far - direct| %.3e" % (name, float(x.abs().max()), float((x - y).abs().max())))
-plain_list = lp.DeviceTargets(trg)
-for tname, t in (("direct", plain_list), ("far", far)):
+def timed(call, n=10):
     for _ in range(3):
-        lp.Stokes_Layer_Apply(c, t, forces=f)
+        call()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 10
     for _ in range(n):
-        lp.Stokes_Layer_Apply(c, t, forces=f)
+        call()
     torch.cuda.synchronize()
-    print("   stokes %-6s %.3f ms per apply (wall, %d applies)" % (tname, (time.perf_counter() - t0) / n * 1e3, n))
+    return (time.perf_counter() - t0) / n * 1e3
 
-# modified Helmholtz single layer
-for k in (10.0, 100.0):
-    s = rng.standard_normal(c.N)
-    a = lp.Modified_Helmholtz_Layer_Apply(c, plain_list, k=k, charge=s)
-    b = lp.Modified_Helmholtz_Layer_Apply(c, far, k=k, charge=s)
+
+# Stokes sums with pressure: stokeslet, stresslet, both (round 4: the double layer has its far-field form too)
+plain_list = lp.DeviceTargets(trg)
+f, g = rng.standard_normal((2, c.N)), rng.standard_normal((2, c.N))
+for name, kw in (("stokeslet", dict(forces=f)), ("stresslet", dict(dipstr=g)), ("both", dict(forces=f, dipstr=g))):
+    a = lp.Stokes_Layer_Apply(c, plain_list, **kw)
+    b = lp.Stokes_Layer_Apply(c, far, **kw)
     torch.cuda.synchronize()
-    a, b = torch.as_tensor(a), torch.as_tensor(b)
-    print("modhelm k = %g  max|direct| %.3e  max|far - direct| %.3e" % (k, float(a.abs().max()), float((a - b).abs().max())))
-    for tname, t in (("direct", plain_list), ("far", far)):
-        for _ in range(3):
-            lp.Modified_Helmholtz_Layer_Apply(c, t, k=k, charge=s)
+    print("stokes %-9s " % name + "  ".join("%s: max %.2e diff %.2e" % (q, float(x.abs().max()), float((x - y).abs().max()))
+                                          for q, x, y in zip("uvp", a, b)))
+    print("   stokes %-9s direct %.3f ms   far %.3f ms per apply (wall)"
+          % (name, timed(lambda: lp.Stokes_Layer_Apply(c, plain_list, **kw)), timed(lambda: lp.Stokes_Layer_Apply(c, far, **kw))))
+
+# modified Helmholtz: single layer, double layer, both
+for k in (10.0, 100.0):
+    s_, d_ = rng.standard_normal(c.N), rng.standard_normal(c.N)
+    for name, kw in (("slp", dict(charge=s_)), ("dlp", dict(dipstr=d_)), ("both", dict(charge=s_, dipstr=d_))):
+        a = torch.as_tensor(lp.Modified_Helmholtz_Layer_Apply(c, plain_list, k=k, **kw))
+        b = torch.as_tensor(lp.Modified_Helmholtz_Layer_Apply(c, far, k=k, **kw))
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 10
-        for _ in range(n):
-            lp.Modified_Helmholtz_Layer_Apply(c, t, k=k, charge=s)
-        torch.cuda.synchronize()
-        print("   modhelm %-6s %.3f ms per apply (wall, %d applies)" % (tname, (time.perf_counter() - t0) / n * 1e3, n))
+        print("modhelm k = %g %-4s max|direct| %.3e  max|far - direct| %.3e" % (k, name, float(a.abs().max()), float((a - b).abs().max())))
+        print("   modhelm %-4s direct %.3f ms   far %.3f ms per apply (wall)"
+              % (name, timed(lambda: lp.Modified_Helmholtz_Layer_Apply(c, plain_list, k=k, **kw)),
+                 timed(lambda: lp.Modified_Helmholtz_Layer_Apply(c, far, k=k, **kw))))
