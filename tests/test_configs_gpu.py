@@ -119,7 +119,7 @@ def test_config4_multi_stokes_three_bodies_4096_grid():
     print(ue, ve, pe, scale, T)
     assert list(T['grid']) == [4096, 4096]
     assert max(ue, ve) < 1e-10 * scale
-    assert pe < 1e-7 * scale
+    assert pe < 1e-8 * scale          # (2.1e-9 measured; 2.7e-8 before the noise cut)
     _free()
 
 
