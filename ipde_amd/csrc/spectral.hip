@@ -791,7 +791,7 @@ constexpr int CUT_MAXB = 1024;
 __global__ __launch_bounds__(1024) void density_noise_cut_kernel(double2* __restrict__ Z, int n, int w, int nbands,
                                                                  double rise, double floor_rel, int kcap,
                                                                  int* __restrict__ kcut_out) {
-    __shared__ double B[CUT_MAXB], S[CUT_MAXB];
+    __shared__ double B[CUT_MAXB];
     __shared__ int s_kc;
     const int tid = threadIdx.x, H = n / 2;
     for (int j = tid; j < nbands; j += 1024) {
@@ -803,36 +803,39 @@ __global__ __launch_bounds__(1024) void density_noise_cut_kernel(double2* __rest
         }
         B[j] = b;
     }
+    if (tid == 0) s_kc = nbands;                 // (first band that meets the rule; nbands: none)
     __syncthreads();
-    if (tid == 0) {
-        int top = (int)(0.9 * H) / w;
-        if (top > nbands - 1) top = nbands - 1;
-        double gmax = 0.0;
-        for (int j = 0; j < nbands; ++j) gmax = fmax(gmax, B[j]);
-        double t = B[top];
-        for (int j = top; j >= 0; --j) {          // S_j = min of B over [j, top]
-            t = fmin(t, B[j]);
-            S[j] = t;
+    // Every band j evaluates the rule for itself (band = thread: nbands <= 1024): m = min B[0 .. j-1] and the first
+    // band attaining it, S = min B[j .. top], the largest band — loops over LDS with wave-uniform addresses
+    // (broadcast reads), a few microseconds; one thread walking the bands took 70-90 us of LDS latency per call.
+    int top = (int)(0.9 * H) / w;
+    if (top > nbands - 1) top = nbands - 1;
+    const int j = tid;
+    double gmax = 0.0, m = B[0], S = 1.0e300;
+    int jmin = 0;
+    for (int i = 0; i < nbands; ++i) {
+        const double b = B[i];
+        gmax = fmax(gmax, b);
+        if (i >= 1 && i < j && b < m) {
+            m = b;
+            jmin = i;
         }
-        int kc = H;
-        double m = B[0];
-        int jmin = 0;
-        for (int j = 1; j <= top; ++j) {
-            if (m < floor_rel * gmax && S[j] > rise * m) {
-                kc = (jmin + 1) * w - 1;
-                break;
-            }
-            if (B[j] < m) {
-                m = B[j];
-                jmin = j;
-            }
-        }
+        if (i >= j && i <= top) S = fmin(S, b);
+    }
+    if (j >= 1 && j <= top && m < floor_rel * gmax && S > rise * m) atomicMin(&s_kc, j);
+    __syncthreads();
+    const int jfirst = s_kc;
+    __syncthreads();
+    if (jfirst == nbands) {
+        if (tid == 0) s_kc = H < kcap ? H : kcap;
+    } else if (j == jfirst) {
+        int kc = (jmin + 1) * w - 1;
         if (kc > kcap) kc = kcap;
         if (kc > H) kc = H;
         s_kc = kc;
-        if (kcut_out) *kcut_out = kc;
     }
     __syncthreads();
+    if (tid == 0 && kcut_out) *kcut_out = s_kc;
     const int kc = s_kc;
     for (int k = kc + 1 + tid; k <= H; k += 1024) {
         Z[k] = double2{0.0, 0.0};
