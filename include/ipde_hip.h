@@ -83,6 +83,10 @@ void* ipde_ctx_get_stream(ipde_ctx* ctx);
    host framework allocates and fills the buffers it hands to a private context; the price is that a
    launch on the legacy stream waits for every such stream. */
 int ipde_ctx_use_legacy_stream(ipde_ctx* ctx);
+/* The context's own stream replaced by a non-blocking stream of the lowest priority the device offers (ordering
+   against other streams is then the caller's: events): for background work such as the factorisations of a set-up,
+   which must not make short kernels of the foreground streams queue behind it (ipde_amd/qfs.py: _OwnAsyncLU). */
+int ipde_ctx_use_background_stream(ipde_ctx* ctx);
 const char* ipde_last_error(ipde_ctx* ctx);
 /* Tuning knobs (kernel geometry variants); never changes results beyond rounding.
    Names: "laplace_variant", "stokes_variant", "dense_pairs", "annular_grouped",

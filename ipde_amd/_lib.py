@@ -56,6 +56,7 @@ SIGNATURES = {
     "ipde_ctx_set_stream": (_int, [_vp, _vp]),
     "ipde_ctx_get_stream": (_vp, [_vp]),
     "ipde_ctx_use_legacy_stream": (_int, [_vp]),
+    "ipde_ctx_use_background_stream": (_int, [_vp]),
     "ipde_last_error": (ctypes.c_char_p, [_vp]),
     "ipde_ctx_set_option": (_int, [_vp, ctypes.c_char_p, _int]),
     "ipde_ctx_get_option": (_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_int)]),

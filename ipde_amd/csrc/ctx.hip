@@ -222,6 +222,26 @@ extern "C" int ipde_ctx_set_stream(ipde_ctx* ctx, void* s) {
 
 extern "C" int ipde_ctx_use_legacy_stream(ipde_ctx* ctx) { return ipde_ctx_set_stream(ctx, (void*)hipStreamLegacy); }
 
+// The context's own stream replaced by a NON-blocking stream of the LOWEST priority the device offers: background
+// work (the QFS factorisations of a set-up) then yields the CUs to whatever the other streams submit, instead of
+// making a 50 us kernel and the host thread waiting for its result queue behind 0.5 s of trailing updates.
+extern "C" int ipde_ctx_use_background_stream(ipde_ctx* ctx) {
+    if (!ctx) return IPDE_ERR_INVALID;
+    IPDE_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    IPDE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    int least = 0, greatest = 0;
+    IPDE_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s = nullptr;
+    IPDE_HIP_CHECK(ctx, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+    if (ctx->own_stream) {
+        hipStreamSynchronize(ctx->own_stream);
+        hipStreamDestroy(ctx->own_stream);
+    }
+    ctx->own_stream = s;
+    ctx->stream = s;
+    return IPDE_OK;
+}
+
 extern "C" void* ipde_ctx_get_stream(ipde_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 extern "C" const char* ipde_last_error(ipde_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }

@@ -88,6 +88,12 @@ class Context:
         stream was a cross-queue dependency, ~17 us of idle GPU each (2048^2 Poisson: 7.3 -> 6.7 ms)."""
         self.check(self.lib.ipde_ctx_use_legacy_stream(self.handle))
 
+    def use_background_stream(self):
+        """The context's own stream becomes a non-blocking one of the device's lowest priority; returns it as a
+        torch stream (for the events that order it against the others)."""
+        self.check(self.lib.ipde_ctx_use_background_stream(self.handle))
+        return torch.cuda.ExternalStream(int(self.lib.ipde_ctx_get_stream(self.handle)), device=self.device)
+
     def set_option(self, name, value):
         self.check(self.lib.ipde_ctx_set_option(self.handle, name.encode(), int(value)))
 
