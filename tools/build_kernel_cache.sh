@@ -37,6 +37,7 @@ for n in (512, 1024, 2048, 4096, 8192, 16384):
     for batch in (16, 20, 24):
         for b in (batch, batch - 1, batch - 2):
             ctx.lib.ipde_fft1_prepare(ctx.handle, b, n)
+    ctx.lib.ipde_fft1_prepare(ctx.handle, 1, n)          # (the noise cut of a Stokes QFS density: one row)
     x = torch.ones((4, n), dtype=torch.complex128, device='cuda')
     torch.fft.fft(x, dim=1); torch.fft.ifft(x, dim=1)
     torch.fft.rfft(x.real, dim=1)
