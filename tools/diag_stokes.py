@@ -79,7 +79,7 @@ def one(nb, M, ng=None):
     sg = sg.cpu().numpy() if hasattr(sg, "cpu") else np.asarray(sg)
     sx = sg.reshape(2, -1)[0]
     sh = np.abs(np.fft.rfft(sx)) / sx.size
-    edges = [0, 10, 100, 500, 1000, 2000, 3000, 4000, sh.size]
+    edges = sorted(set(min(e, sh.size) for e in (0, 10, 100, 500, 1000, 2000, 3000, 4000, sh.size)))
     out["sigma_g0_spectrum_band_max"] = [float(sh[a:b].max()) for a, b in zip(edges[:-1], edges[1:])]
     top = np.argsort(sh)[::-1][:6]
     out["sigma_g0_spectrum_peaks"] = [(int(k), float(sh[k])) for k in top]
