@@ -406,7 +406,7 @@ __global__ __launch_bounds__(C* fftcore::Cfg<NX>::T) void band_col_kernel(Combo 
     const int col = tid % C, t = tid / C;
     const int H = ny / 2;
     const int j = blk * C + col;
-    const bool live = j <= H;
+    const bool live = j < H;                  // (column H rides in column 0, see below: H columns, H / C whole blocks)
     const PassTw<NX> pw = load_pass_twiddles<NX>(t, tw_x);
     fftcore::cd* buf = lds + col * NPC;
     // e^{i pi (t + T q) / nx} = e^{i pi t / nx} (e^{i pi T / nx})^q
@@ -415,38 +415,32 @@ __global__ __launch_bounds__(C* fftcore::Cfg<NX>::T) void band_col_kernel(Combo 
     const fftcore::cd e0{cs, sn};
     sincospi((double)T / NX, &sn, &cs);
     const fftcore::cd est{cs, sn};
-    // Columns 0 and ny/2 are packed together in the coarse spectra (unpacked with the mirrored row): those two
-    // columns take the general routine, row by row (two of ny/2 + 1 columns); every other column reads its own
-    // entries.  Either way the values go through the transform's LDS slots in a ROLLED loop (eight rows at a time
-    // for the plain columns: eight loads per term in flight) — unrolled sixteen times next to the transform's own
-    // registers the loader spilled 1 KB per lane.
-    const bool special = live && (j == 0 || j == H);
-    const double wy = (j == H) ? 0.5 : 1.0;
+    // Columns 0 and ny/2 are packed together in the coarse spectra (unpacked with the mirrored row), and they leave
+    // this kernel packed together again: both are spectra of REAL sequences along x (the combos' terms are fields
+    // and their x derivatives with real coefficients; y derivatives are left to the gather), so their transforms
+    // D_0 and D_H are real and ONE transform of value(kx, 0) + i value(kx, H) carries them as Re and Im of column 0
+    // — the gather reads them back as such.  H columns instead of H + 1: at 2048^2 that is 256 workgroups of four
+    // columns on 256 CUs where 257 took two rounds (73 -> 40 us), at 4096^2 1024 instead of 1025 (five rounds -> four).
+    // The values go through the transform's LDS slots in a ROLLED loop (eight rows at a time: eight loads per term in
+    // flight; the packed column loads each row's mirror as well) — unrolled sixteen times next to the transform's
+    // own registers the loader spilled 1 KB per lane.  (A first version sent the packed column through band_value
+    // row by row: its workgroup then took 110 us where the others take 40.)
+    // One mode of column H is not Hermitian: the corner (kx, ky) = (+nx/2, ny/2) carries its whole weight on kx > 0
+    // (the convention of the dense sums this interpolation reproduces).  It stays out of the packed transform; its
+    // own transform is known in closed form — v_c e^{i pi r / 2} on fine row r — and is stored in the spare slot
+    // D[r][H], which the gather adds to D_H.
+    const bool special = live && j == 0;
+    auto packed = [&](int kx) {
+        const ::cd v0 = band_value(cb, kx, 0, NX, H, rx, dkx, dky);
+        ::cd vh{0.0, 0.0};
+        if (2 * kx != NX && 2 * kx != -NX) vh = band_value(cb, kx, H, NX, H, rx, dkx, dky);
+        return ::cd{v0.x - vh.y, v0.y + vh.x};
+    };
+    ::cd vcorner{0.0, 0.0};
+    if (special) vcorner = band_value(cb, NX / 2, H, NX, H, rx, dkx, dky);
 #pragma unroll 1
     for (int a = 0; a < 2; ++a) {
-        if (special) {
-            fftcore::cd ph = e0;
-#pragma unroll 1
-            for (int q = 0; q < P; ++q) {
-                const int i = t + T * q;
-                fftcore::cd val;
-                if (2 * i == NX) {
-                    const ::cd vp = band_value(cb, NX / 2, j, NX, H, rx, dkx, dky);
-                    const ::cd vm = band_value(cb, -(NX / 2), j, NX, H, rx, dkx, dky);
-                    val = a == 0 ? fftcore::cd{vp.x + vm.x, vp.y + vm.y} : fftcore::cd{-(vp.y - vm.y), vp.x - vm.x};
-                } else {
-                    const int kx = (i < NX / 2) ? i : i - NX;
-                    const ::cd w = band_value(cb, kx, j, NX, H, rx, dkx, dky);
-                    val = fftcore::cd{w.x, w.y};
-                    if (a == 1) {
-                        val = cmul(val, ph);
-                        if (i > NX / 2) val = fftcore::cd{-val.x, -val.y};
-                    }
-                }
-                buf[padpos(i)] = val;
-                ph = cmul(ph, est);
-            }
-        } else if (live) {
+        if (live) {
             fftcore::cd ph = e0;
             constexpr int LB = P >= 8 ? 8 : P;      // rows per batch of the loader
             fftcore::cd estb = est;                 // est^LB
@@ -460,7 +454,7 @@ __global__ __launch_bounds__(C* fftcore::Cfg<NX>::T) void band_col_kernel(Combo 
                 for (int tm = 0; tm < cb.n; ++tm) {
                     const fftcore::cd* S = (const fftcore::cd*)cb.src[tm] + j;
                     const int der = cb.der[tm];
-                    const double cf = cb.coef[tm] * wy;
+                    const double cf = cb.coef[tm];
                     fftcore::cd raw[LB];
                     double wr[LB];
 #pragma unroll
@@ -469,6 +463,17 @@ __global__ __launch_bounds__(C* fftcore::Cfg<NX>::T) void band_col_kernel(Combo 
                         const int kx = (i < NX / 2) ? i : i - NX;
                         raw[q] = S[(int64_t)i * H];
                         wr[q] = rx[kx < 0 ? -kx : kx];
+                    }
+                    if (special) {
+                        // the packed column: value(kx, 0) + i value(kx, H) = w (X_0 + i X_H / 2) — column H carries
+                        // its Nyquist half — with X_0 = (P + conj P-) / 2, i X_H = (P - conj P-) / 2 of the packed entry
+                        // P(kx) and its mirror P- = P(-kx):  3/4 P + 1/4 conj P-
+#pragma unroll
+                        for (int q = 0; q < LB; ++q) {
+                            const int i = t + T * (q0 + q);
+                            const fftcore::cd m = S[(int64_t)((NX - i) & (NX - 1)) * H];
+                            raw[q] = fftcore::cd{0.75 * raw[q].x + 0.25 * m.x, 0.75 * raw[q].y - 0.25 * m.y};
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < LB; ++q) {
@@ -498,8 +503,8 @@ __global__ __launch_bounds__(C* fftcore::Cfg<NX>::T) void band_col_kernel(Combo 
             }
             // the x Nyquist row (i = nx/2, thread t = 0) holds +nx/2 and -nx/2 together
             if (t == 0) {
-                const ::cd vp = band_value(cb, NX / 2, j, NX, H, rx, dkx, dky);
-                const ::cd vm = band_value(cb, -(NX / 2), j, NX, H, rx, dkx, dky);
+                const ::cd vp = special ? packed(NX / 2) : band_value(cb, NX / 2, j, NX, H, rx, dkx, dky);
+                const ::cd vm = special ? packed(-(NX / 2)) : band_value(cb, -(NX / 2), j, NX, H, rx, dkx, dky);
                 buf[padpos(NX / 2)] = a == 0 ? fftcore::cd{vp.x + vm.x, vp.y + vm.y}
                                              : fftcore::cd{-(vp.y - vm.y), vp.x - vm.x};
             }
@@ -516,6 +521,14 @@ __global__ __launch_bounds__(C* fftcore::Cfg<NX>::T) void band_col_kernel(Combo 
             fftcore::cd* base = (fftcore::cd*)D + j;
 #pragma unroll
             for (int q = 0; q < P; ++q) base[(int64_t)(2 * (t + T * q) + a) * pitch] = v[q];
+            if (special) {                               // the corner mode's transform: v_c i^r on fine row r
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    const int r = 2 * (t + T * q) + a;
+                    const fftcore::cd c = (r & 1) ? fftcore::cd{-vcorner.y, vcorner.x} : fftcore::cd{vcorner.x, vcorner.y};
+                    base[(int64_t)r * pitch + H] = (r & 2) ? fftcore::cd{-c.x, -c.y} : c;
+                }
+            }
         }
         __syncthreads();
     }
@@ -608,7 +621,7 @@ typedef double band_d4 __attribute__((ext_vector_type(4)));
 template <int NA>
 __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restrict__ D0, const cd* __restrict__ D1,
                                                               const cd* __restrict__ D2, BandRecipe rc, int64_t pitch,
-                                                              int ncol, int nfx, int nrows_ext,
+                                                              int ncol, int packed0, int nfx, int nrows_ext,
                                                               const double* __restrict__ px,
                                                               const double* __restrict__ py, int64_t np,
                                                               const int* __restrict__ start,
@@ -626,6 +639,7 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
     __shared__ cd sG[NA][16][RS];
     __shared__ cd T[256];
     __shared__ int s_phys[16];
+    __shared__ cd sNyq[NA][16];                         // packed0: the rows' column-ny/2 values (Im of column 0 + corner)
     static_assert(sizeof(cd) * NA * 16 * RS >= sizeof(double) * 64 * 4 * NACC, "the reduction reuses the staging buffer");
     double* sacc = (double*)&sG[0][0][0];               // [NACC][4][64] after the last tile of a round
     const int R0 = 16 * (int)blockIdx.x;
@@ -677,7 +691,17 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
                 for (int it = 0; it < 8; ++it) {
                     const int e = tid + 256 * it, i = e / KT, kk = e % KT;
                     cd v = st[a][it];
-                    if (k0 + kk == 0) v = cd{0.5 * v.x, 0.5 * v.y};             // eps_0 = 1/2 (see row_c2r)
+                    if (k0 + kk == 0) {
+                        // eps_0 = 1/2 (see row_c2r).  packed0: column 0 holds D_0 + i D_H, both real, and slot ncol the
+                        // one non-Hermitian mode of column H (band_col_kernel): D_0 goes through the product, D_H —
+                        // one column, frequency ncol — is added by the epilogue
+                        if (packed0) {
+                            const cd cn = Dp[a][(int64_t)s_phys[i] * pitch + ncol];      // (the corner mode's part)
+                            sNyq[a][i] = cd{v.y + cn.x, cn.y};
+                            v.y = 0.0;
+                        }
+                        v = cd{0.5 * v.x, 0.5 * v.y};
+                    }
                     sG[a][i][kk] = v;
                 }
             __syncthreads();
@@ -742,6 +766,11 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
                 const int r0 = r0v[j];
                 double x = px[j];
                 x -= TWO_PI * floor(x / TWO_PI);
+                cd eH{0.0, 0.0};                        // e^{i ncol y} of this lane's point
+                if (packed0) {
+                    double f = py[j] * (1.0 / TWO_PI);
+                    eH = unit_kf(ncol, f - floor(f), T);
+                }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int r_ext = R0 + h4 + 4 * v;
@@ -755,7 +784,11 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
                         double val = 0.0;
                         for (int e = 0; e < bo.n; ++e) {
                             const int i = (c * NA + bo.arr[e]) * 2 + bo.kind[e];
-                            const double sum = sacc[(size_t)(i * 4 + v) * 64 + lane];
+                            double sum = sacc[(size_t)(i * 4 + v) * 64 + lane];
+                            if (packed0) {              // + Re / ncol Im of D_H e^{i ncol y}
+                                const cd dH = sNyq[bo.arr[e]][h4 + 4 * v];
+                                sum += bo.kind[e] ? (double)ncol * (dH.x * eH.y + dH.y * eH.x) : dH.x * eH.x - dH.y * eH.y;
+                            }
                             val += bo.coef[e] * (bo.kind[e] ? -dky * sum : sum);
                         }
                         double* dst = partial + ((int64_t)bo.out * np + j) * W + sidx;
@@ -958,7 +991,7 @@ static int launch_band_cols(GridInterp* gi, const Fft2dPlan& coarse, const Combo
     constexpr int C = NX >= 4096 ? 2 : 4, T = Cfg<NX>::T;
     ipde_ctx* ctx = gi->ctx;
     const size_t lds = (size_t)C * (lds_slots<NX>() + 4) * sizeof(fftcore::cd);
-    const int ncol = (int)(gi->ny / 2 + 1);
+    const int ncol = (int)(gi->ny / 2);                  // column ny/2 rides in column 0
     const int nblocks = (ncol + C - 1) / C;
     auto k = band_col_kernel<NX, C>;
     if (lds > 48 * 1024)
@@ -1038,7 +1071,9 @@ static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout,
             ++use[f].n;
         }
     }
-    const int ncol = (int)(ny / 2 + 1);
+    // (the packed path's column ny/2 rides in column 0 as its imaginary part: ny/2 columns there)
+    const int packed0 = gi->general ? 0 : 1;
+    const int ncol = (int)(ny / 2) + (packed0 ? 0 : 1);
     bool started[8] = {false, false, false, false, false, false, false, false};
     for (int a0 = 0; a0 < (int)arrs.size(); a0 += 3) {
         const int na = (int)arrs.size() - a0 < 3 ? (int)arrs.size() - a0 : 3;
@@ -1092,7 +1127,7 @@ static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout,
             const unsigned ntiles = (unsigned)((nrows_ext + 15) / 16);
 #define BAND_MFMA(NA)                                                                                                  \
     hipLaunchKernelGGL(band_gather_mfma_kernel<NA>, dim3(ntiles, 16), dim3(256), 0, ctx->stream, D[0], D[1], D[2], rc, pitch,  \
-                       ncol, (int)gi->nfx, nrows_ext, d_px, d_py, np, (const int*)start, (const int*)perm,                 \
+                       ncol, packed0, (int)gi->nfx, nrows_ext, d_px, d_py, np, (const int*)start, (const int*)perm,        \
                        (const int*)r0v, gi->betax, dky, (const cd*)gi->d_roots, gi->partial)
             if (na == 1)
                 BAND_MFMA(1);
