@@ -985,10 +985,14 @@ static int ensure_band(GridInterp* gi, int64_t np) {
     return IPDE_OK;
 }
 
+// (C: columns per workgroup — 64-byte row segments at 2048^2, 139 KB of LDS, one workgroup per CU; half of that,
+// two workgroups per CU, measured the same at 2048^2 (51.5 against 53.3 us) and worse at 4096^2 (273 against 253):
+// the phases of a workgroup do not wait for each other's CU)
 template <int NX>
 static int launch_band_cols(GridInterp* gi, const Fft2dPlan& coarse, const Combo& cb, cd* D, double dkx, double dky) {
+    constexpr int C = NX >= 4096 ? 2 : 4;
     using namespace fftcore;
-    constexpr int C = NX >= 4096 ? 2 : 4, T = Cfg<NX>::T;
+    constexpr int T = Cfg<NX>::T;
     ipde_ctx* ctx = gi->ctx;
     const size_t lds = (size_t)C * (lds_slots<NX>() + 4) * sizeof(fftcore::cd);
     const int ncol = (int)(gi->ny / 2);                  // column ny/2 rides in column 0
