@@ -706,7 +706,7 @@ class Stokes_QFS(_QFS):
         return np.concatenate([z.real, z.imag]), kc
 
     def _lowpass(self, mu):
-        if not self.NOISE_CUT:
+        if not self.NOISE_CUT or int(mu.shape[0]) < 64:      # (a curve of fewer than 32 nodes has no spectrum to speak of)
             return mu
         if type(mu).__module__.startswith('torch'):
             import torch
