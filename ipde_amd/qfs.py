@@ -83,12 +83,12 @@ class _QFS(object):
             as_dev = lambda M: (M if isinstance(M, torch.Tensor) else torch.as_tensor(M, device=self._dev)).contiguous()
             self._A = as_dev(A)
             self._fact = _lu_async(self._A)
+            # the on-surface forms are the curve's, shared by the two QFS objects of an interface (no copy of D with
+            # the jump folded into its diagonal: 2.95 GB per side at 19 200 rows); the one-sided limit is
+            # S sigma + D tau + jump tau, and its first two terms are computed once per interface (call_many)
             self._S = None if S is None else as_dev(S)
-            if D is not None:
-                D = as_dev(D)
-                self._D = D + jump * torch.eye(D.shape[0], dtype=torch.float64, device=self._dev)
-            else:
-                self._D = None
+            self._D = None if D is None else as_dev(D)
+            self._jump = jump
         else:
             self._dev = None
             to_np = lambda M: M.cpu().numpy() if hasattr(M, 'cpu') else M
@@ -123,20 +123,29 @@ class _QFS(object):
         x = self._fact.solve(self._A, ud, steps=self.REFINE_STEPS, dd=self.REFINE_DD)
         return x if isinstance(u, torch.Tensor) else x.cpu().numpy()
 
-    def boundary_limit(self, densities):
-        """one-sided limit on the curve of S[sigma] + D[tau]"""
+    def principal_value(self, densities):
+        """S[sigma] + D[tau] on the curve itself (device path): what the limits from either side share"""
+        import torch
+        densities = [_on_device(d, self._dev) for d in densities]
+        u = None
+        i = 0
+        if self.slp:
+            u = _gemv(self._S, densities[i])
+            i += 1
+        if self.dlp:
+            u = _gemv(self._D, densities[i], u)
+        return u if u is not None else torch.zeros(self._nrow, dtype=torch.float64, device=self._dev)
+
+    def boundary_limit(self, densities, pv=None):
+        """one-sided limit on the curve of S[sigma] + D[tau]; pv: principal_value(densities) when the caller has
+        it already (the other side's QFS object of the same interface asked for the same product)"""
         densities = list(densities)
         if self._dev is not None:
-            import torch
-            densities = [_on_device(d, self._dev) for d in densities]
-            u = None
-            i = 0
-            if self.slp:
-                u = _gemv(self._S, densities[i])
-                i += 1
-            if self.dlp:
-                u = _gemv(self._D, densities[i], u)
-            return u if u is not None else torch.zeros(self._nrow, dtype=torch.float64, device=self._dev)
+            if pv is None:
+                pv = self.principal_value(densities)
+            if not self.dlp:
+                return pv
+            return pv + self._jump * _on_device(densities[1 if self.slp else 0], self._dev)
         else:
             u = np.zeros(self._nrow)
         i = 0
@@ -227,7 +236,14 @@ def call_many(requests):
     for (steps, dd), idx in groups.items():
         qs = [requests[i][0] for i in idx]
         ds = [q._prepare(requests[i][1]) for q, i in zip(qs, idx)]
-        us = [q.boundary_limit(d) for q, d in zip(qs, ds)]
+        # the two sides of an interface ask for the limits of the same layers of the same densities: S sigma + D tau
+        # once (the matrices twice fewer through HBM: 2 x 2.95 GB at 19 200 rows)
+        pvs, us = {}, []
+        for q, d in zip(qs, ds):
+            key = (id(q._S), id(q._D), q.slp, q.dlp) + tuple(id(x) for x in d)
+            if key not in pvs:
+                pvs[key] = q.principal_value(d)
+            us.append(q.boundary_limit(d, pvs[key]))
         xs = _DeviceLU.solve_batch([q._fact for q in qs], [q._A for q in qs], us, steps=steps, dd=dd)
         for i, q, d, x in zip(idx, qs, ds, xs):
             # device densities in -> device density out (no host round trip)
