@@ -617,6 +617,7 @@ struct BandRecipe {
 // window's weights and writes every (output, point, row) partial to its own slot
 // partial[(out np + j) 16 + s], s = the row's place in the point's window; band_reduce_kernel adds the sixteen.
 typedef double band_d4 __attribute__((ext_vector_type(4)));
+constexpr int BAND_KSPLIT_MAX = 4;                      // column shares of a gather launch (slabs of the partial buffer)
 
 template <int NA>
 __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restrict__ D0, const cd* __restrict__ D1,
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
     // work; with a chunk per wave half of them idled and two workgroups on a CU queued on the same two.  The waves'
     // partial products are added through LDS at the end of a round, in wave order.
     constexpr int W = 16, KT = 128, RS = KT + 1;       // (row stride 129 slots: the sixteen rows of an A read hit 16 bank groups)
-    constexpr int CH = NA <= 2 ? 4 : 2;
+    constexpr int CH = 2;                               // (four per round for NA <= 2 left single CUs with twice the average work: 165 -> 127 us at 2048^2 x 4096)
     constexpr int NACC = CH * NA * 2;                   // accumulator tiles (4 doubles per lane each)
     __shared__ cd sG[NA][16][RS];
     __shared__ cd T[256];
@@ -681,9 +682,17 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
                     st[a][it] = k < ncol ? Dp[a][(int64_t)s_phys[i] * pitch + k] : cd{0.0, 0.0};
                 }
         };
+        // blockIdx.z takes a share of the staged column tiles (an A/B knob, one share by default: see the launch;
+        // the shares' sums go to slabs of their own)
+        const int ntile_k = (ncol + KT - 1) / KT;
+        const int kt0 = (int)(((int64_t)ntile_k * blockIdx.z) / gridDim.z), kt1 = (int)(((int64_t)ntile_k * (blockIdx.z + 1)) / gridDim.z);
+        const int kbeg = kt0 * KT, kend = kt1 * KT < ncol ? kt1 * KT : ncol;
         __syncthreads();                                // (T, s_phys are in place; the previous round's sums are read)
-        fetch(0);
-        for (int k0 = 0; k0 < ncol; k0 += KT) {
+        fetch(kbeg);
+        cd st16[CH];                                    // e^{16 i y}: the phase step of a wave's consecutive k
+#pragma unroll
+        for (int c = 0; c < CH; ++c) st16[c] = c < nact ? unit_kf(16, fy[c], T) : cd{1.0, 0.0};
+        for (int k0 = kbeg; k0 < kend; k0 += KT) {
             __syncthreads();                            // (the previous tile has been consumed)
 #pragma unroll
             for (int a = 0; a < NA; ++a)
@@ -705,14 +714,11 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
                     sG[a][i][kk] = v;
                 }
             __syncthreads();
-            if (k0 + KT < ncol) fetch(k0 + KT);
+            if (k0 + KT < kend) fetch(k0 + KT);
             // this wave's steps of the tile: k = k0 + 4 s + h4, s = wave, wave + 4, ...; phases re-seeded per tile
-            cd ph[CH], st16[CH];
+            cd ph[CH];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                ph[c] = unit_kf(k0 + 4 * wave + h4, fy[c], T);
-                st16[c] = unit_kf(16, fy[c], T);
-            }
+            for (int c = 0; c < CH; ++c) ph[c] = c < nact ? unit_kf(k0 + 4 * wave + h4, fy[c], T) : cd{1.0, 0.0};
 #pragma unroll 2
             for (int it = 0; it < KT / 16; ++it) {
                 const int s4 = wave + 4 * it;
@@ -785,13 +791,13 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
                         for (int e = 0; e < bo.n; ++e) {
                             const int i = (c * NA + bo.arr[e]) * 2 + bo.kind[e];
                             double sum = sacc[(size_t)(i * 4 + v) * 64 + lane];
-                            if (packed0) {              // + Re / ncol Im of D_H e^{i ncol y}
+                            if (packed0 && blockIdx.z == 0) {      // + Re / ncol Im of D_H e^{i ncol y} (with column 0's share)
                                 const cd dH = sNyq[bo.arr[e]][h4 + 4 * v];
                                 sum += bo.kind[e] ? (double)ncol * (dH.x * eH.y + dH.y * eH.x) : dH.x * eH.x - dH.y * eH.y;
                             }
                             val += bo.coef[e] * (bo.kind[e] ? -dky * sum : sum);
                         }
-                        double* dst = partial + ((int64_t)bo.out * np + j) * W + sidx;
+                        double* dst = partial + (((int64_t)blockIdx.z * 8 + bo.out) * np + j) * W + sidx;
                         *dst = bo.acc ? *dst + wx * val : wx * val;
                     }
                 }
@@ -800,14 +806,16 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void band_reduce_kernel(const double* __restrict__ partial, int64_t n,
-                                                          double* __restrict__ out) {
+__global__ __launch_bounds__(256) void band_reduce_kernel(const double* __restrict__ partial, int64_t n, int64_t np,
+                                                          int nslab, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double* p = partial + i * 16;
     double s = 0.0;
+    for (int z = 0; z < nslab; ++z) {               // (slab z: the column share of blockIdx.z, 8 outputs x np points each)
+        const double* p = partial + ((int64_t)z * 8 * np + i) * 16;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) s += p[m];
+        for (int m = 0; m < 16; ++m) s += p[m];
+    }
     out[i] = s;
 }
 
@@ -838,7 +846,7 @@ struct GridInterp {
     cd* d_roots = nullptr;        // the 256th roots of unity (the gather's phase table)
     int* ibuf = nullptr;          // cnt, start (nfx + 33 each), perm, r0, rank (np each)
     int64_t ibuf_np = -1;
-    double* partial = nullptr;    // (8, np, 16)
+    double* partial = nullptr;    // (column shares, 8, np, 16)
 };
 
 bool grid_interp_supported(int64_t nx, int64_t ny) { return fft2d_supported(nx, ny); }
@@ -979,7 +987,7 @@ static int ensure_band(GridInterp* gi, int64_t np) {
         gi->ibuf_np = -1;
         const int64_t cap = np + np / 4 + 64;
         IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->ibuf, (size_t)(2 * (gi->nfx + 33) + 3 * cap) * sizeof(int)));
-        IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->partial, (size_t)8 * cap * 16 * sizeof(double)));
+        IPDE_HIP_CHECK(ctx, hipMalloc((void**)&gi->partial, (size_t)BAND_KSPLIT_MAX * 8 * cap * 16 * sizeof(double)));
         gi->ibuf_np = cap;
     }
     return IPDE_OK;
@@ -1075,6 +1083,14 @@ static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout,
             ++use[f].n;
         }
     }
+    // column shares per gather launch (IPDE_BAND_KSPLIT, default 1): measured with two chunks per round at 2048^2 x 4096 /
+    // 4096^2 x 8192 points: 127 / 403 us with one share, 129 / 400 with two, 154 / 442 with four — the row tiles
+    // alone fill the CUs, and what a workgroup waits for is not hidden by a second one on its CU
+    static const int ks_env = getenv("IPDE_BAND_KSPLIT") ? atoi(getenv("IPDE_BAND_KSPLIT")) : 0;
+    const int ntile_k = (int)((ny / 2 + 1 + 127) / 128);
+    int ks = ks_env > 0 ? ks_env : 1;
+    if (ks > BAND_KSPLIT_MAX) ks = BAND_KSPLIT_MAX;
+    if (ks > ntile_k) ks = ntile_k;
     // (the packed path's column ny/2 rides in column 0 as its imaginary part: ny/2 columns there)
     const int packed0 = gi->general ? 0 : 1;
     const int ncol = (int)(ny / 2) + (packed0 ? 0 : 1);
@@ -1130,7 +1146,7 @@ static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout,
             // the gather as a block GEMM on the matrix cores: a workgroup per tile of 16 fine rows
             const unsigned ntiles = (unsigned)((nrows_ext + 15) / 16);
 #define BAND_MFMA(NA)                                                                                                  \
-    hipLaunchKernelGGL(band_gather_mfma_kernel<NA>, dim3(ntiles, 16), dim3(256), 0, ctx->stream, D[0], D[1], D[2], rc, pitch,  \
+    hipLaunchKernelGGL(band_gather_mfma_kernel<NA>, dim3(ntiles, 16, ks), dim3(256), 0, ctx->stream, D[0], D[1], D[2], rc, pitch,  \
                        ncol, packed0, (int)gi->nfx, nrows_ext, d_px, d_py, np, (const int*)start, (const int*)perm,        \
                        (const int*)r0v, gi->betax, dky, (const cd*)gi->d_roots, gi->partial)
             if (na == 1)
@@ -1145,7 +1161,7 @@ static int interp_combos_band(GridInterp* gi, const Fft2dPlan& coarse, int nout,
     }
     const int64_t n = (int64_t)nout * np;
     hipLaunchKernelGGL(band_reduce_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream,
-                       (const double*)gi->partial, n, d_out);
+                       (const double*)gi->partial, n, np, ks, d_out);
     IPDE_HIP_CHECK(ctx, hipGetLastError());
     return IPDE_OK;
 }
