@@ -641,6 +641,7 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
     __shared__ cd T[256];
     __shared__ int s_phys[16];
     __shared__ cd sNyq[NA][16];                         // packed0: the rows' column-ny/2 values (Im of column 0 + corner)
+    __shared__ cd sCorner[NA][16];                      // packed0: the corner mode's part of them (slot ncol of the rows)
     static_assert(sizeof(cd) * NA * 16 * RS >= sizeof(double) * 64 * 4 * NACC, "the reduction reuses the staging buffer");
     double* sacc = (double*)&sG[0][0][0];               // [NACC][4][64] after the last tile of a round
     const int R0 = 16 * (int)blockIdx.x;
@@ -654,6 +655,12 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
     const double TWO_PI = 6.283185307179586476925286766559;
     const double hfx = TWO_PI / nfx;
     const cd* Dp[3] = {D0, D1, D2};
+    // (read here, once per workgroup: inside the staging loop each of these sixteen loads was an exposed round trip —
+    // the compiler waits for a conditional load where it stands)
+    if (packed0 && tid < 16 * NA) {
+        const int pr = ((R0 + (tid & 15) - 16) % nfx + nfx) % nfx;
+        sCorner[tid >> 4][tid & 15] = Dp[tid >> 4][(int64_t)pr * pitch + ncol];
+    }
     const int nchunk = (cnt + 15) / 16;
     // (blockIdx.y strides over the rounds: where the curve runs along a fine row hundreds of points meet one tile)
     for (int round = blockIdx.y; round * CH < nchunk; round += gridDim.y) {
@@ -705,7 +712,7 @@ __global__ __launch_bounds__(256) void band_gather_mfma_kernel(const cd* __restr
                         // one non-Hermitian mode of column H (band_col_kernel): D_0 goes through the product, D_H —
                         // one column, frequency ncol — is added by the epilogue
                         if (packed0) {
-                            const cd cn = Dp[a][(int64_t)s_phys[i] * pitch + ncol];      // (the corner mode's part)
+                            const cd cn = sCorner[a][i];                                // (the corner mode's part)
                             sNyq[a][i] = cd{v.y + cn.x, cn.y};
                             v.y = 0.0;
                         }
