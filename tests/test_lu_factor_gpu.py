@@ -180,3 +180,36 @@ def test_factorisations_on_side_streams_equal_the_in_stream_one():
         assert torch.equal(f.perm, g.perm) and torch.equal(f.LU, g.LU)
         b = torch.as_tensor(rng.standard_normal(A.shape[0]), device="cuda")
         assert torch.equal(f._subst(b), g._subst(b))
+
+
+def test_paired_trailing_updates_give_the_bits_of_panel_by_panel_updates():
+    """One trailing update per PAIR of panels (lu_update_pair_kernel) runs the same MFMA chain per element as two
+    single-panel updates: factors and pivots bitwise equal.  The schedule is a process-wide switch
+    (IPDE_LU_SINGLE_UPDATES), so the two runs are child processes; sizes with an odd / even number of panel pairs and
+    one beyond 8192 rows (multi-workgroup panels)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, hashlib, numpy as np, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "from ipde_amd import qfs\n"
+            "out = {}\n"
+            "for n in (300, 1100, 2050, 8300):\n"
+            "    A = torch.as_tensor(np.random.default_rng(n).standard_normal((n, n)), device='cuda')\n"
+            "    f = qfs._own_lu(A)\n"
+            "    torch.cuda.synchronize()\n"
+            "    out[str(n)] = [hashlib.sha256(f.LU.cpu().numpy().tobytes()).hexdigest(),\n"
+            "                   hashlib.sha256(f.perm.cpu().numpy().tobytes()).hexdigest()]\n"
+            "print(json.dumps(out))\n" % root)
+    res = []
+    for single in (False, True):
+        env = dict(os.environ)
+        env.pop("IPDE_LU_SINGLE_UPDATES", None)
+        if single:
+            env["IPDE_LU_SINGLE_UPDATES"] = "1"
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append(json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1]))
+    assert res[0] == res[1]
