@@ -28,4 +28,4 @@ if __name__ == "__main__":
     t0 = time.perf_counter()
     solver(f, tol=1e-12, maxiter=100, restart=20)
     T['inhomogeneous_solve_warm_s'] = time.perf_counter() - t0
-    print(json.dumps(T))
+    print(json.dumps({k: v for k, v in T.items() if isinstance(v, (int, float, str, list, tuple))}))

@@ -34,7 +34,7 @@ t0 = time.perf_counter()
 for _ in range(10):
     solver(f, tol=1e-12, maxiter=100, restart=20)
 torch.cuda.synchronize()
-out = dict(T)
+out = {k: v for k, v in T.items() if isinstance(v, (int, float, str, list, tuple))}      # (not the resident objects)
 out.update(import_s=t_import, process_start_to_solution_s=t_end, rel_err=err / scale,
            warm_inhomogeneous_solve_ms=(time.perf_counter() - t0) / 10 * 1e3,
            rocfft_kernel_cache=os.environ.get('ROCFFT_RTC_CACHE_PATH'))
