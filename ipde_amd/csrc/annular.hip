@@ -1007,7 +1007,86 @@ int launch_fft_pair(ipde_ctx* ctx, cd* x, const void* tw, int rows, const double
     return IPDE_OK;
 }
 
-inline bool fft_pair_supported(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096; }
+// n = 8192 (BASELINE configs[3]'s boundary): the same stage as two 4096-point halves and one radix-2 level on either
+// side.  512 threads: group g = t / 256 owns the samples of parity g.  Inverse transform, decimation in time:
+// E = FFT(even samples), O = FFT(odd samples), X[k] = E[k] + w^k O[k], X[k + 4096] = E[k] - w^k O[k] — thread
+// (0, tt) and thread (1, tt) hold E and O at the SAME k = tt + 256 q, so the level is a pairwise exchange through
+// LDS, after which group g holds the physical samples j = 4096 g + k.  Forward transform, decimation in frequency:
+// a[j] = y[j] + y[j + 4096] -> X[2 m], b[j] = (y[j] - y[j + 4096]) w'^j -> X[2 m + 1]: the same exchange, then a
+// 4096-point transform per group, and group g stores the outputs of parity g.  tw: the 4096-point table.
+__global__ __launch_bounds__(512) void fft_pair8192_kernel(cd* __restrict__ x, const fftcore::cd* __restrict__ tw,
+                                                           const double* __restrict__ F0,
+                                                           const double* __restrict__ F1, int rows0, double s) {
+    constexpr int N = 8192, H = 4096, T = 256, P = 16;
+    extern __shared__ double2 pair_lds[];
+    const int t = threadIdx.x, g = t >> 8, tt = t & 255, row = blockIdx.x;
+    fftcore::cd* buf = (fftcore::cd*)pair_lds + (size_t)g * fftcore::lds_slots<H>();
+    fftcore::cd* other = (fftcore::cd*)pair_lds + (size_t)(1 - g) * fftcore::lds_slots<H>();
+    fftcore::cd* r = (fftcore::cd*)x + (size_t)row * N;
+    const double* F = row < rows0 ? F0 + (size_t)row * N : F1 + (size_t)(row - rows0) * N;
+    fftcore::cd v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) v[q] = r[2 * (tt + T * q) + g];
+    fftcore::fft_regs<H, +1, false>(v, tt, tw, buf);
+    // w^k = e^{+2 pi i k / 8192}, k = tt + 256 q: e^{i pi tt / 4096} (e^{i pi / 16})^q
+    double sn, cs;
+    sincospi((double)tt / 4096.0, &sn, &cs);
+    const fftcore::cd w0{cs, sn};
+    sincospi(1.0 / 16.0, &sn, &cs);
+    const fftcore::cd wst{cs, sn};
+    {
+        fftcore::cd w = w0;
+        __syncthreads();                                   // (the transforms' last exchange has been read)
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            if (g == 1) v[q] = fftcore::cmul(v[q], w);   // w^k O[k]
+            buf[fftcore::padpos(tt + T * q)] = v[q];
+            w = fftcore::cmul(w, wst);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const fftcore::cd o = other[fftcore::padpos(tt + T * q)];
+            v[q] = g == 0 ? v[q] + o : o - v[q];          // E + w O  |  E - w O
+        }
+    }
+    // physical sample j = 4096 g + tt + 256 q: the metric field, then the forward transform
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const double f = s * F[H * g + tt + T * q];
+        v[q] = fftcore::cd{v[q].x * f, v[q].y * f};
+    }
+    {
+        __syncthreads();                                   // (everybody has read the first exchange)
+#pragma unroll
+        for (int q = 0; q < P; ++q) buf[fftcore::padpos(tt + T * q)] = v[q];
+        __syncthreads();
+        fftcore::cd w = fftcore::cd{w0.x, -w0.y};         // w'^j = e^{-2 pi i j / 8192}, j = tt + 256 q
+        const fftcore::cd wstc{wst.x, -wst.y};
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const fftcore::cd o = other[fftcore::padpos(tt + T * q)];
+            v[q] = g == 0 ? v[q] + o : fftcore::cmul(o - v[q], w);      // y[j] + y[j + H]  |  (y[j] - y[j + H]) w'^j
+            w = fftcore::cmul(w, wstc);
+        }
+        __syncthreads();                                   // (before the transforms' exchanges reuse the buffers)
+    }
+    fftcore::fft_regs<H, -1, false>(v, tt, tw, buf);
+#pragma unroll
+    for (int q = 0; q < P; ++q) r[2 * (tt + T * q) + g] = v[q];
+}
+
+int launch_fft_pair8192(ipde_ctx* ctx, cd* x, const void* tw, int rows, const double* F0, const double* F1, int rows0,
+                        double s) {
+    const size_t lds = (size_t)2 * fftcore::lds_slots<4096>() * sizeof(fftcore::cd);
+    IPDE_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fft_pair8192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds));
+    hipLaunchKernelGGL(fft_pair8192_kernel, dim3((unsigned)rows), dim3(512), lds, ctx->stream, x, (const fftcore::cd*)tw,
+                       F0, F1, rows0, s);
+    return IPDE_OK;
+}
+
+inline bool fft_pair_supported(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192; }
 
 int fft_pair(ipde_ctx* ctx, int n, cd* x, const void* tw, int rows, const double* F0, const double* F1, int rows0,
              double s) {
@@ -1016,6 +1095,7 @@ int fft_pair(ipde_ctx* ctx, int n, cd* x, const void* tw, int rows, const double
         case 1024: return launch_fft_pair<1024>(ctx, x, tw, rows, F0, F1, rows0, s);
         case 2048: return launch_fft_pair<2048>(ctx, x, tw, rows, F0, F1, rows0, s);
         case 4096: return launch_fft_pair<4096>(ctx, x, tw, rows, F0, F1, rows0, s);
+        case 8192: return launch_fft_pair8192(ctx, x, tw, rows, F0, F1, rows0, s);
     }
     return IPDE_ERR_INVALID;
 }
@@ -1143,7 +1223,7 @@ int launch_gmres_persistent(ipde_ctx* ctx, const PgArgs& A) {
 // timed out (the caller then runs the whole solve the launch-per-stage way).
 int ipde_annular_scalar::persistent_cycle(const cd* b, double tol, int maxiter, int restart, int* iters,
                                           double* resid, int* converged) {
-    if (pg_disabled || !tw || !ctx->opt_gmres_persistent || !fft_pair_supported(n) || M < 3 ||
+    if (pg_disabled || !tw || !ctx->opt_gmres_persistent || !fft_pair_supported(n) || n > 4096 || M < 3 ||
         M > PG_RS * PG_MR_MAX || restart < 1 || restart > PG_RMAX)
         return IPDE_ERR_INVALID;
     const int TT = n >= 4096 ? 256 : n >= 2048 ? 128 : 64, CPB = TT / PG_RS, NW = (TT + 63) / 64;
@@ -1275,10 +1355,11 @@ extern "C" int ipde_annular_scalar_create(ipde_ctx* ctx, int M, int n, double he
                     Kt[((size_t)j * M + k) * n + i] = kinv[((size_t)i * M + j) * M + k];
         up(&h->Kt, Kt.data(), Kt.size());
     }
-    if (fft_pair_supported(n)) {   // twiddles of the fused transform pairs
-        std::vector<double> w(2 * (size_t)n);
-        for (int m = 0; m < n; ++m) {
-            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
+    if (fft_pair_supported(n)) {   // twiddles of the fused transform pairs (n = 8192: of its two 4096-point halves)
+        const int nt = n == 8192 ? 4096 : n;
+        std::vector<double> w(2 * (size_t)nt);
+        for (int m = 0; m < nt; ++m) {
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)nt;
             w[2 * m] = (double)cosl(a);
             w[2 * m + 1] = (double)sinl(a);
         }

@@ -401,9 +401,10 @@ def test_helper_jump_kernels_match_the_numpy_statements():
     ctx.sync()
 
 
-@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192])
 def test_fused_transform_pairs_equal_the_rocfft_stages(n):
-    """option "annular_fused_fft" (default on): for power-of-two n <= 4096 a stage of the scalar
+    """option "annular_fused_fft" (default on): for power-of-two n <= 8192 (8192 — BASELINE configs[3]'s boundary
+    — as two 4096-point halves and a radix-2 level) a stage of the scalar
     operator — inverse FFT, metric field, forward FFT — is one kernel on the fft_core.h transforms
     instead of two rocFFT calls around a pointwise kernel: the same operator to rounding, the same
     solution, on a non-circular annulus"""
